@@ -1,0 +1,111 @@
+/* yogo_hip.h -- C ABI of libyogo_hip.so, the MI355X (gfx950) implementation of the YOGO hot path.
+ *
+ * The reference (czbiohub-sf/yogo @ 2024_08_07) has no native code and no FFI: its "operators" are torch ATen /
+ * cuDNN / torchvision calls made from Python.  Each entry point below names the reference call site it replaces
+ * (file:line relative to the reference root).  How a maintainer binds them (ctypes) is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless noted; tensors are contiguous NCHW fp32 unless noted
+ *   - nothing is allocated or freed here: the caller passes outputs and workspaces (sizes from *_bytes / *_rows)
+ *   - hipStream_t is passed as an opaque pointer; all work is enqueued on it, no host synchronisation
+ *   - return value 0 = ok; non-zero = error, message from yogo_hip_last_error() (thread-local)
+ *   - re-entrant; one host thread per device
+ *   - activation codes: 0 none, 1 LeakyReLU(0.01), 2 SiLU
+ */
+#ifndef YOGO_HIP_H
+#define YOGO_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* yogo_stream_t; /* hipStream_t */
+
+const char* yogo_hip_last_error(void);
+int yogo_hip_abi_version(void);
+
+/* ---- convolution, fp32 matrix cores ---------------------------------------------------------------------------
+ * nn.Conv2d(cin, cout, 3, stride=1|2, padding=1) and nn.Conv2d(cin, cout, 1): yogo/model_defns.py:34-67,
+ * executed at yogo/model.py:275 (forward) and by loss.backward() at yogo/train.py:322 (dgrad / wgrad).          */
+
+/* bytes of the packed weight buffer. mode 0: forward, mode 1: dgrad */
+int yogo_conv_packed_bytes(int Cin, int Cout, int ksize, int stride, int mode, size_t* bytes);
+/* OIHW weights -> packed [tap][Kpad][Mpad] */
+int yogo_conv_pack_f32(const float* w_oihw, float* packed, int Cin, int Cout, int ksize, int stride, int mode,
+                       yogo_stream_t stream);
+/* rows / row stride (floats/2) of the BatchNorm partial-sum buffer a forward launch fills when stats_part != NULL */
+int yogo_conv2d_fwd_stats_shape(int B, int Cin, int Cout, int IH, int IW, int ksize, int stride, int* rows, int* mpad);
+/* out = chan_scale[b][c] * act(conv(in) + bias); out_pre (optional) receives conv(in)+bias;
+ * stats_part (optional) receives per-workgroup (sum, sumsq) per channel for BatchNorm training statistics.
+ * Fuses Conv2d + bias + LeakyReLU/SiLU + Dropout2d channel mask (model_defns.py:39-41 etc.).                      */
+int yogo_conv2d_fwd_f32(const float* in, const float* packed, const float* bias, float* out, float* out_pre,
+                        const float* chan_scale, float* stats_part, int B, int Cin, int Cout, int IH, int IW, int ksize,
+                        int stride, int act, yogo_stream_t stream);
+/* dx = conv_transpose(dy) * act'(act_ref) * chan_scale   (act_ref / chan_scale optional).
+ * (IH, IW) are the forward conv's INPUT dims.  act_ref: block output for LeakyReLU, pre-activation for SiLU.      */
+int yogo_conv2d_dgrad_f32(const float* dy, const float* packed_dgrad, float* dx, const float* act_ref, int ref_act,
+                          const float* chan_scale, int B, int Cin, int Cout, int IH, int IW, int ksize, int stride,
+                          yogo_stream_t stream);
+int yogo_conv2d_wgrad_workspace_bytes(int B, int Cin, int Cout, int IH, int IW, int ksize, int stride, size_t* bytes);
+/* dw (OIHW) and optional db from the layer input x and the gradient g w.r.t. the conv output; both are clamped to
+ * +-clip when clip > 0 (the per-parameter hook of yogo/model.py:76-77).  Deterministic (no float atomics).        */
+int yogo_conv2d_wgrad_f32(const float* x, const float* g, float* dw, float* db, void* workspace, int B, int Cin, int Cout,
+                          int IH, int IW, int ksize, int stride, float clip, yogo_stream_t stream);
+
+/* ---- first convolution: Cin = 1|3, uint8 or fp32 input (model_defns.py:34 + the cast at model.py:272-273) --------- */
+int yogo_conv_first_stats_rows(int B, int IH, int IW, int stride, int* rows);
+/* in_dtype: 0 = uint8, 1 = float32.  stats_part rows: [rows][Cout][2] */
+int yogo_conv_first_fwd(const void* in, int in_dtype, const float* w_oihw, const float* bias, float* out, float* out_pre,
+                        const float* chan_scale, float* stats_part, int B, int Cin, int Cout, int IH, int IW, int stride,
+                        int act, yogo_stream_t stream);
+/* partial gradients [rows][Cout][Cin*9 + 1] (last column = bias); finish with yogo_partials_reduce */
+int yogo_conv_first_wgrad(const void* in, int in_dtype, const float* dy, float* part, int B, int Cin, int Cout, int IH,
+                          int IW, int stride, yogo_stream_t stream);
+
+/* ---- BatchNorm2d (model_defns.py:35,55,60): batch statistics, apply + activation, backward ------------------------ */
+int yogo_bn_finalize(const float* part, int rows, int row_stride, int C, long long count, float eps, float momentum,
+                     float* mean_out, float* invstd_out, float* running_mean, float* running_var,
+                     long long* num_batches_tracked, yogo_stream_t stream);
+int yogo_bn_apply_act(const float* z, float* y, const float* mean, const float* invstd_or_var, int stat_is_var, float eps,
+                      const float* gamma, const float* beta, int B, int C, int HW, int act, yogo_stream_t stream);
+int yogo_bn_invstd(const float* var, float eps, float* invstd, int C, yogo_stream_t stream);
+int yogo_bn_bwd_rows(int B, int HW, int* rows);
+int yogo_bn_bwd(const float* g, const float* z, float* dz, const float* mean, const float* invstd, const float* gamma,
+                float* dgamma, float* dbeta, float* part, float* sums, int B, int C, int HW, int training, float clip,
+                yogo_stream_t stream);
+int yogo_partials_reduce(const float* part, int rows, int N, float clip, float* out, yogo_stream_t stream);
+int yogo_channel_sum(const float* g, int B, int C, int HW, float clip, float* out, yogo_stream_t stream);
+
+/* ---- box decode: YOGO.forward, yogo/model.py:277-313 ------------------------------------------------------------------ */
+int yogo_decode_fwd(const float* raw, float* out, const float* cxs, const float* cys, int B, int P, int Sy, int Sx,
+                    float anchor_w, float anchor_h, float width_multiplier, float height_multiplier, int inference,
+                    yogo_stream_t stream);
+int yogo_decode_bwd(const float* raw, const float* out, const float* gout, float* graw, int B, int P, int Sy, int Sx,
+                    int inference, yogo_stream_t stream);
+
+/* ---- loss: YOGOLoss.forward, yogo/yogo_loss.py:38-129 (+ its autograd) ------------------------------------------------- */
+int yogo_loss_workspace_bytes(int B, int Sy, int Sx, size_t* bytes);
+/* loss_out: 4 device floats {total, iou_loss, objectness_loss, classification_loss}; grad = d total / d pred */
+int yogo_loss_fwd_bwd(const float* pred, const float* label, float* grad, float* loss_out, void* workspace, int B, int P,
+                      int Sy, int Sx, float no_obj_weight, float iou_weight, float classify_weight, float label_smoothing,
+                      yogo_stream_t stream);
+
+/* ---- post-process: format_preds, yogo/utils/prediction_formatting.py:23-93, batched over images ------------------------ */
+int yogo_format_preds_workspace_bytes(int B, int Sy, int Sx, size_t* bytes);
+/* out_rows [B][cap][P], out_cells [B][cap] (int64 cell index y*Sx+x), out_count [B] (int32).
+ * box_format 0 = cxcywh, 1 = xyxy.  Row order per image is the reference's: descending max(class)*objectness
+ * (ties: lower cell first) when iou_thresh > 0, cell order otherwise.                                                    */
+int yogo_format_preds_batched(const float* pred, float* out_rows, long long* out_cells, int* out_count, void* workspace,
+                              int B, int P, int Sy, int Sx, int cap, double obj_thresh, double iou_thresh, int box_format,
+                              double min_class_confidence_threshold, yogo_stream_t stream);
+
+/* ---- optimiser: torch.optim.AdamW over one flat buffer, yogo/train.py:213-217,324 ---------------------------------------- */
+int yogo_adamw_step(float* p, const float* g, float* m, float* v, long long n, int step, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, float grad_scale, yogo_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOGO_HIP_H */

@@ -1,0 +1,285 @@
+// BatchNorm2d (training + eval) around the conv kernels, and the small deterministic reductions the backward
+// pass needs.  Replaces ATen batch_norm / batch_norm_backward behind nn.BatchNorm2d(…) in the reference
+// (yogo/model_defns.py:35,55,60).
+//
+// Training statistics: the conv epilogues write per-workgroup partial (sum, sumsq) rows; bn_finalize adds them
+// in fp64 in a fixed order (deterministic), producing mean / invstd and the momentum-0.1 running-stat update
+// (biased variance to normalise, unbiased into running_var -- torch semantics).
+// All element-wise kernels here are HBM-bound: one read + one write per element, float4 where the plane allows.
+#include "common.h"
+
+// ---- finalize: partial rows -> mean, invstd, running stats ---------------------------------------------------
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int rows, int row_stride, int C,
+                                                          double count, float eps, float momentum,
+                                                          float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                          long long* __restrict__ num_batches_tracked) {
+  __shared__ double sh[2][4];
+  const int c = blockIdx.x;
+  double s = 0.0, q = 0.0;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    const float* src = part + ((size_t)r * row_stride + c) * 2;
+    s += (double)src[0];
+    q += (double)src[1];
+  }
+  s = wave_sum_d(s);
+  q = wave_sum_d(q);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    sh[0][wave] = s;
+    sh[1][wave] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+    q = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mean_out[c] = (float)mean;
+    invstd_out[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean != nullptr) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+      running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+    }
+    if (c == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;
+  }
+}
+
+// ---- apply: y = act((z - mean) * (invstd * gamma) + beta) ------------------------------------------------------
+// stat_is_var != 0: `invstd_or_var` holds a variance (eval mode: running_var) and invstd is computed here.
+template <bool VEC4>
+__global__ __launch_bounds__(256) void bn_apply_act_kernel(const float* __restrict__ z, float* __restrict__ y,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd_or_var,
+                                                           int stat_is_var, float eps, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int C, int HW, int act) {
+  const int plane = blockIdx.y;
+  const int c = plane % C;
+  const float mu = mean[c];
+  const float is = stat_is_var ? 1.0f / sqrtf(invstd_or_var[c] + eps) : invstd_or_var[c];
+  const float sc = is * gamma[c];
+  const float sh = beta[c];
+  const float* zp = z + (size_t)plane * HW;
+  float* yp = y + (size_t)plane * HW;
+  if (VEC4) {
+    const int n4 = HW >> 2;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+      float4 v = reinterpret_cast<const float4*>(zp)[i];
+      v.x = act_fwd(fmaf(v.x - mu, sc, sh), act);
+      v.y = act_fwd(fmaf(v.y - mu, sc, sh), act);
+      v.z = act_fwd(fmaf(v.z - mu, sc, sh), act);
+      v.w = act_fwd(fmaf(v.w - mu, sc, sh), act);
+      reinterpret_cast<float4*>(yp)[i] = v;
+    }
+  } else {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) yp[i] = act_fwd(fmaf(zp[i] - mu, sc, sh), act);
+  }
+}
+
+// ---- backward reduce: per (plane chunk) partial sums of g and g * xhat -------------------------------------------
+// g is the gradient w.r.t. the BN output (activation derivative already applied by the producer).
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ z,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            float* __restrict__ part, int C, int HW) {
+  __shared__ float sh[2][4];
+  const int plane = blockIdx.y;  // b*C + c
+  const int c = plane % C;
+  const int b = plane / C;
+  const float mu = mean[c], is = invstd[c];
+  const float* gp = g + (size_t)plane * HW;
+  const float* zp = z + (size_t)plane * HW;
+  float s = 0.f, q = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+    const float gv = gp[i];
+    s += gv;
+    q += gv * ((zp[i] - mu) * is);
+  }
+  s = wave_sum(s);
+  q = wave_sum(q);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    sh[0][wave] = s;
+    sh[1][wave] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float* dst = part + ((size_t)(b * gridDim.x + blockIdx.x) * C + c) * 2;
+    dst[0] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+    dst[1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+  }
+}
+
+// dbeta = sum g, dgamma = sum g*xhat (fp64, fixed order), optionally clamped (the reference's per-parameter hook)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int rows, int C, float clip,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ sum_g, float* __restrict__ sum_gx) {
+  __shared__ double sh[2][4];
+  const int c = blockIdx.x;
+  double s = 0.0, q = 0.0;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    const float* src = part + ((size_t)r * C + c) * 2;
+    s += (double)src[0];
+    q += (double)src[1];
+  }
+  s = wave_sum_d(s);
+  q = wave_sum_d(q);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    sh[0][wave] = s;
+    sh[1][wave] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+    q = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    sum_g[c] = (float)s;
+    sum_gx[c] = (float)q;
+    float db = (float)s, dg = (float)q;
+    if (clip > 0.f) {
+      db = fminf(fmaxf(db, -clip), clip);
+      dg = fminf(fmaxf(dg, -clip), clip);
+    }
+    dbeta[c] = db;
+    dgamma[c] = dg;
+  }
+}
+
+// dz = gamma * invstd * (g - sum_g/n - xhat * sum_gx/n)   (training);  dz = gamma * invstd * g  (frozen stats)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ z,
+                                                           float* __restrict__ dz, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ sum_g, const float* __restrict__ sum_gx,
+                                                           float inv_count, int training, int C, int HW) {
+  const int plane = blockIdx.y;
+  const int c = plane % C;
+  const float mu = mean[c], is = invstd[c], gi = gamma[c] * is;
+  const float mg = training ? sum_g[c] * inv_count : 0.f;
+  const float mgx = training ? sum_gx[c] * inv_count : 0.f;
+  const float* gp = g + (size_t)plane * HW;
+  const float* zp = z + (size_t)plane * HW;
+  float* dp = dz + (size_t)plane * HW;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+    const float xh = (zp[i] - mu) * is;
+    dp[i] = gi * (gp[i] - mg - xh * mgx);
+  }
+}
+
+// eval-mode helper: invstd = 1/sqrt(var + eps)
+__global__ void bn_invstd_kernel(const float* __restrict__ var, float eps, float* __restrict__ invstd, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) invstd[c] = 1.0f / sqrtf(var[c] + eps);
+}
+
+// ---- generic deterministic reductions --------------------------------------------------------------------------
+// out[j] = clamp(sum_r part[r][j]) for j < N  (fp64 accumulate, fixed order)
+__global__ __launch_bounds__(256) void partials_reduce_kernel(const float* __restrict__ part, int rows, int N, float clip,
+                                                              float* __restrict__ out) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= N) return;
+  double s = 0.0;
+  for (int r = 0; r < rows; ++r) s += (double)part[(size_t)r * N + j];
+  float v = (float)s;
+  if (clip > 0.f) v = fminf(fmaxf(v, -clip), clip);
+  out[j] = v;
+}
+
+// per-channel sum over (b, h, w) of an NCHW tensor (bias gradients): one workgroup per channel, fixed order
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ g, int B, int C, int HW, float clip,
+                                                          float* __restrict__ out) {
+  __shared__ double sh[4];
+  const int c = blockIdx.x;
+  double s = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const float* gp = g + ((size_t)b * C + c) * HW;
+    float ps = 0.f;
+    for (int i = threadIdx.x; i < HW; i += 256) ps += gp[i];
+    s += (double)ps;
+  }
+  s = wave_sum_d(s);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) sh[wave] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float v = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
+    if (clip > 0.f) v = fminf(fmaxf(v, -clip), clip);
+    out[c] = v;
+  }
+}
+
+static inline int plane_blocks(int HW, int per_thread) { return max(1, min(64, cdiv(HW, 256 * per_thread))); }
+
+// =========================================================================================================
+// C ABI
+// =========================================================================================================
+extern "C" int yogo_bn_finalize(const float* part, int rows, int row_stride, int C, long long count, float eps,
+                                float momentum, float* mean_out, float* invstd_out, float* running_mean,
+                                float* running_var, long long* num_batches_tracked, hipStream_t stream) {
+  YOGO_CHECK_ARG(part && mean_out && invstd_out && C > 0 && rows > 0 && row_stride >= C && count > 0,
+                 "bn_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, stream, part, rows, row_stride, C, (double)count, eps,
+                     momentum, mean_out, invstd_out, running_mean, running_var, num_batches_tracked);
+  YOGO_CHECK_LAUNCH("bn_finalize");
+  return YOGO_OK;
+}
+
+extern "C" int yogo_bn_apply_act(const float* z, float* y, const float* mean, const float* invstd_or_var, int stat_is_var,
+                                 float eps, const float* gamma, const float* beta, int B, int C, int HW, int act,
+                                 hipStream_t stream) {
+  YOGO_CHECK_ARG(z && y && mean && invstd_or_var && gamma && beta && C > 0 && HW > 0 && B >= 0, "bn_apply_act: bad arguments");
+  if (B == 0) return YOGO_OK;
+  if ((HW & 3) == 0) {
+    dim3 grid(plane_blocks(HW, 8), B * C);
+    hipLaunchKernelGGL((bn_apply_act_kernel<true>), grid, dim3(256), 0, stream, z, y, mean, invstd_or_var, stat_is_var, eps,
+                       gamma, beta, C, HW, act);
+  } else {
+    dim3 grid(plane_blocks(HW, 4), B * C);
+    hipLaunchKernelGGL((bn_apply_act_kernel<false>), grid, dim3(256), 0, stream, z, y, mean, invstd_or_var, stat_is_var, eps,
+                       gamma, beta, C, HW, act);
+  }
+  YOGO_CHECK_LAUNCH("bn_apply_act");
+  return YOGO_OK;
+}
+
+extern "C" int yogo_bn_invstd(const float* var, float eps, float* invstd, int C, hipStream_t stream) {
+  YOGO_CHECK_ARG(var && invstd && C > 0, "bn_invstd: bad arguments");
+  hipLaunchKernelGGL(bn_invstd_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, var, eps, invstd, C);
+  YOGO_CHECK_LAUNCH("bn_invstd");
+  return YOGO_OK;
+}
+
+extern "C" int yogo_bn_bwd_rows(int B, int HW, int* rows) {
+  YOGO_CHECK_ARG(rows != nullptr, "bn_bwd_rows: null");
+  *rows = B * plane_blocks(HW, 8);
+  return YOGO_OK;
+}
+
+// g: grad w.r.t. BN output; z: saved conv output; part: workspace rows*C*2 floats (rows from yogo_bn_bwd_rows).
+// Writes dz (may alias g), dgamma, dbeta (clamped to +-clip when clip > 0).  sums: workspace 2*C floats.
+extern "C" int yogo_bn_bwd(const float* g, const float* z, float* dz, const float* mean, const float* invstd,
+                           const float* gamma, float* dgamma, float* dbeta, float* part, float* sums, int B, int C, int HW,
+                           int training, float clip, hipStream_t stream) {
+  YOGO_CHECK_ARG(g && z && dz && mean && invstd && gamma && dgamma && dbeta && part && sums, "bn_bwd: null pointer");
+  YOGO_CHECK_ARG(B > 0 && C > 0 && HW > 0, "bn_bwd: bad shape");
+  const int nb = plane_blocks(HW, 8);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb, B * C), dim3(256), 0, stream, g, z, mean, invstd, part, C, HW);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, stream, part, B * nb, C, clip, dgamma, dbeta, sums, sums + C);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb, B * C), dim3(256), 0, stream, g, z, dz, mean, invstd, gamma, sums,
+                     sums + C, 1.0f / ((float)B * (float)HW), training, C, HW);
+  YOGO_CHECK_LAUNCH("bn_bwd");
+  return YOGO_OK;
+}
+
+extern "C" int yogo_partials_reduce(const float* part, int rows, int N, float clip, float* out, hipStream_t stream) {
+  YOGO_CHECK_ARG(part && out && rows > 0 && N > 0, "partials_reduce: bad arguments");
+  hipLaunchKernelGGL(partials_reduce_kernel, dim3(cdiv(N, 256)), dim3(256), 0, stream, part, rows, N, clip, out);
+  YOGO_CHECK_LAUNCH("partials_reduce");
+  return YOGO_OK;
+}
+
+extern "C" int yogo_channel_sum(const float* g, int B, int C, int HW, float clip, float* out, hipStream_t stream) {
+  YOGO_CHECK_ARG(g && out && B > 0 && C > 0 && HW > 0, "channel_sum: bad arguments");
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, stream, g, B, C, HW, clip, out);
+  YOGO_CHECK_LAUNCH("channel_sum");
+  return YOGO_OK;
+}

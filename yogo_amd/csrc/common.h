@@ -1,0 +1,66 @@
+// Shared helpers for the yogo_amd HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <cstring>
+
+#define YOGO_OK 0
+#define YOGO_ERR_ARG 1
+#define YOGO_ERR_HIP 2
+#define YOGO_ERR_WORKSPACE 3
+
+// defined in api_common.hip
+extern "C" const char* yogo_hip_last_error(void);
+void yogo_set_error(const char* fmt, ...);
+
+#define YOGO_CHECK_ARG(cond, ...)                 \
+  do {                                            \
+    if (!(cond)) {                                \
+      yogo_set_error(__VA_ARGS__);                \
+      return YOGO_ERR_ARG;                        \
+    }                                             \
+  } while (0)
+
+#define YOGO_CHECK_LAUNCH(name)                                               \
+  do {                                                                        \
+    hipError_t e__ = hipGetLastError();                                       \
+    if (e__ != hipSuccess) {                                                  \
+      yogo_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));  \
+      return YOGO_ERR_HIP;                                                    \
+    }                                                                         \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
+
+#define ACT_NONE 0
+#define ACT_LEAKY 1
+#define ACT_SILU 2
+#define LEAKY_SLOPE 0.01f
+
+__device__ __forceinline__ float act_fwd(float v, int act) {
+  if (act == ACT_LEAKY) return v > 0.f ? v : LEAKY_SLOPE * v;
+  if (act == ACT_SILU) return v / (1.f + __expf(-v));
+  return v;
+}
+// derivative of the activation; `ref` is the block OUTPUT for leaky (sign-preserving), the PRE-activation for silu
+__device__ __forceinline__ float act_bwd_factor(float ref, int act) {
+  if (act == ACT_LEAKY) return ref > 0.f ? 1.f : LEAKY_SLOPE;
+  if (act == ACT_SILU) {
+    float s = 1.f / (1.f + __expf(-ref));
+    return s * (1.f + ref * (1.f - s));
+  }
+  return 1.f;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

@@ -1,0 +1,209 @@
+// First convolution of the backbone: Cin = 1 (gray) or 3 (rgb), uint8 or fp32 input, 3x3 stride 1|2 pad 1.
+// Replaces nn.Conv2d(input_channels, C, 3, stride=2, padding=1, bias=False) + the uint8->float cast
+// (yogo/model_defns.py:34, yogo/model.py:272-273).
+//
+// K = 9*Cin is far too short for the matrix cores and the layer is HBM-bound (0.8 MB in, 12.75 MB out per
+// image at 772x1032): a direct VALU kernel, one output pixel per lane (coalesced NCHW stores per channel),
+// weights through the scalar cache, BatchNorm partial sums carried in registers across the thread's pixels.
+#include "common.h"
+
+#define CF_THREADS 256
+#define CF_PPT 4       // pixels per thread
+#define CF_COCHUNK 16  // output channels per register pass
+
+struct ConvFirstParams {
+  const void* in;
+  const float* w;          // OIHW [Cout][Cin][3][3]
+  const float* bias;       // optional
+  float* out;              // [B][Cout][OH][OW]
+  float* out_pre;          // optional pre-activation copy
+  const float* chan_scale; // optional [B][Cout]
+  float* stats_part;       // optional [B*gridDim.x][Cout][2]
+  int B, Cin, Cout, IH, IW, OH, OW, stride, act;
+};
+
+template <typename TIn, int CIN>
+__global__ __launch_bounds__(CF_THREADS) void conv_first_kernel(const ConvFirstParams p) {
+  __shared__ float red[4][2 * CF_COCHUNK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y;
+  const int npix = p.OH * p.OW;
+  const int pbase = blockIdx.x * (CF_THREADS * CF_PPT);
+  const TIn* inb = reinterpret_cast<const TIn*>(p.in) + (size_t)b * CIN * p.IH * p.IW;
+  const float* __restrict__ w = p.w;
+
+  for (int co0 = 0; co0 < p.Cout; co0 += CF_COCHUNK) {
+    float s[CF_COCHUNK], q[CF_COCHUNK];
+#pragma unroll
+    for (int c = 0; c < CF_COCHUNK; ++c) s[c] = q[c] = 0.f;
+#pragma unroll
+    for (int k = 0; k < CF_PPT; ++k) {
+      const int pix = pbase + k * CF_THREADS + tid;
+      const bool ok = pix < npix;
+      const int oy = ok ? pix / p.OW : 0;
+      const int ox = ok ? pix - oy * p.OW : 0;
+      float x[CIN * 9];
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int iy = oy * p.stride + kh - 1, ix = ox * p.stride + kw - 1;
+            float v = 0.f;
+            if (ok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) v = (float)inb[((size_t)ci * p.IH + iy) * p.IW + ix];
+            x[(ci * 3 + kh) * 3 + kw] = v;
+          }
+#pragma unroll
+      for (int c = 0; c < CF_COCHUNK; ++c) {
+        const int co = co0 + c;
+        if (co < p.Cout) {  // uniform
+          float acc = 0.f;
+#pragma unroll
+          for (int j = 0; j < CIN * 9; ++j) acc = fmaf(w[co * CIN * 9 + j], x[j], acc);
+          if (p.bias != nullptr) acc += p.bias[co];
+          if (ok) {
+            s[c] += acc;
+            q[c] += acc * acc;
+            const size_t idx = ((size_t)b * p.Cout + co) * npix + pix;
+            if (p.out_pre != nullptr) p.out_pre[idx] = acc;
+            float v = act_fwd(acc, p.act);
+            if (p.chan_scale != nullptr) v *= p.chan_scale[(size_t)b * p.Cout + co];
+            p.out[idx] = v;
+          }
+        }
+      }
+    }
+    if (p.stats_part != nullptr) {
+#pragma unroll
+      for (int c = 0; c < CF_COCHUNK; ++c) {
+        const float ss = wave_sum(s[c]), qq = wave_sum(q[c]);
+        if (lane == 0) {
+          red[wave][2 * c] = ss;
+          red[wave][2 * c + 1] = qq;
+        }
+      }
+      __syncthreads();
+      if (tid < 2 * CF_COCHUNK) {
+        const int c = tid >> 1;
+        if (co0 + c < p.Cout) {
+          const float v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+          p.stats_part[((size_t)(b * gridDim.x + blockIdx.x) * p.Cout + co0 + c) * 2 + (tid & 1)] = v;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// dW[co][ci][kh][kw] = sum_{b,pix} dy[b][co][pix] * x[b][ci][pix*stride + tap]; db likewise without x.
+// One workgroup per (pixel tile, image); partials [rows][Cout][CIN*9 + 1] are summed by channel_partials_reduce.
+struct ConvFirstWgradParams {
+  const void* in;
+  const float* dy;    // [B][Cout][OH][OW] (already multiplied by act'/mask)
+  float* part;        // [B*gridDim.x][Cout][CIN*9+1]
+  int B, Cin, Cout, IH, IW, OH, OW, stride;
+};
+
+template <typename TIn, int CIN>
+__global__ __launch_bounds__(CF_THREADS) void conv_first_wgrad_kernel(const ConvFirstWgradParams p) {
+  constexpr int NJ = CIN * 9 + 1;
+  __shared__ float red[4][NJ];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y;
+  const int npix = p.OH * p.OW;
+  const int pbase = blockIdx.x * (CF_THREADS * CF_PPT);
+  const TIn* inb = reinterpret_cast<const TIn*>(p.in) + (size_t)b * CIN * p.IH * p.IW;
+  float x[CF_PPT][CIN * 9];
+  bool okk[CF_PPT];
+#pragma unroll
+  for (int k = 0; k < CF_PPT; ++k) {
+    const int pix = pbase + k * CF_THREADS + tid;
+    const bool ok = pix < npix;
+    okk[k] = ok;
+    const int oy = ok ? pix / p.OW : 0;
+    const int ox = ok ? pix - oy * p.OW : 0;
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int iy = oy * p.stride + kh - 1, ix = ox * p.stride + kw - 1;
+          float v = 0.f;
+          if (ok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) v = (float)inb[((size_t)ci * p.IH + iy) * p.IW + ix];
+          x[k][(ci * 3 + kh) * 3 + kw] = v;
+        }
+  }
+  for (int co = 0; co < p.Cout; ++co) {
+    float acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < CF_PPT; ++k) {
+      const int pix = pbase + k * CF_THREADS + tid;
+      const float g = okk[k] ? p.dy[((size_t)b * p.Cout + co) * npix + pix] : 0.f;
+#pragma unroll
+      for (int j = 0; j < CIN * 9; ++j) acc[j] = fmaf(g, x[k][j], acc[j]);
+      acc[NJ - 1] += g;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const float v = wave_sum(acc[j]);
+      if (lane == 0) red[wave][j] = v;
+    }
+    __syncthreads();
+    if (tid < NJ)
+      p.part[((size_t)(b * gridDim.x + blockIdx.x) * p.Cout + co) * NJ + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    __syncthreads();
+  }
+}
+
+static int first_tiles(int OH, int OW) { return cdiv(OH * OW, CF_THREADS * CF_PPT); }
+
+extern "C" int yogo_conv_first_stats_rows(int B, int IH, int IW, int stride, int* rows) {
+  YOGO_CHECK_ARG(rows && (stride == 1 || stride == 2), "conv_first_stats_rows: bad arguments");
+  const int OH = (IH - 1) / stride + 1, OW = (IW - 1) / stride + 1;
+  *rows = B * first_tiles(OH, OW);
+  return YOGO_OK;
+}
+
+// in_dtype: 0 = uint8, 1 = float32
+extern "C" int yogo_conv_first_fwd(const void* in, int in_dtype, const float* w, const float* bias, float* out,
+                                   float* out_pre, const float* chan_scale, float* stats_part, int B, int Cin, int Cout,
+                                   int IH, int IW, int stride, int act, hipStream_t stream) {
+  YOGO_CHECK_ARG(in && w && out, "conv_first_fwd: null pointer");
+  YOGO_CHECK_ARG((Cin == 1 || Cin == 3) && Cout > 0 && IH > 0 && IW > 0 && (stride == 1 || stride == 2) && B >= 0,
+                 "conv_first_fwd: unsupported shape Cin=%d Cout=%d stride=%d", Cin, Cout, stride);
+  YOGO_CHECK_ARG(in_dtype == 0 || in_dtype == 1, "conv_first_fwd: in_dtype must be 0 (uint8) or 1 (float32)");
+  ConvFirstParams p{};
+  p.in = in; p.w = w; p.bias = bias; p.out = out; p.out_pre = out_pre; p.chan_scale = chan_scale; p.stats_part = stats_part;
+  p.B = B; p.Cin = Cin; p.Cout = Cout; p.IH = IH; p.IW = IW; p.stride = stride; p.act = act;
+  p.OH = (IH - 1) / stride + 1; p.OW = (IW - 1) / stride + 1;
+  if (B == 0) return YOGO_OK;
+  dim3 grid(first_tiles(p.OH, p.OW), B);
+  if (in_dtype == 0 && Cin == 1) hipLaunchKernelGGL((conv_first_kernel<uint8_t, 1>), grid, dim3(CF_THREADS), 0, stream, p);
+  else if (in_dtype == 0) hipLaunchKernelGGL((conv_first_kernel<uint8_t, 3>), grid, dim3(CF_THREADS), 0, stream, p);
+  else if (Cin == 1) hipLaunchKernelGGL((conv_first_kernel<float, 1>), grid, dim3(CF_THREADS), 0, stream, p);
+  else hipLaunchKernelGGL((conv_first_kernel<float, 3>), grid, dim3(CF_THREADS), 0, stream, p);
+  YOGO_CHECK_LAUNCH("conv_first_fwd");
+  return YOGO_OK;
+}
+
+// partial weight/bias gradients; part must hold rows*Cout*(Cin*9+1) floats with rows from yogo_conv_first_stats_rows
+extern "C" int yogo_conv_first_wgrad(const void* in, int in_dtype, const float* dy, float* part, int B, int Cin, int Cout,
+                                     int IH, int IW, int stride, hipStream_t stream) {
+  YOGO_CHECK_ARG(in && dy && part, "conv_first_wgrad: null pointer");
+  YOGO_CHECK_ARG((Cin == 1 || Cin == 3) && Cout > 0 && (stride == 1 || stride == 2), "conv_first_wgrad: unsupported shape");
+  ConvFirstWgradParams p{};
+  p.in = in; p.dy = dy; p.part = part; p.B = B; p.Cin = Cin; p.Cout = Cout; p.IH = IH; p.IW = IW; p.stride = stride;
+  p.OH = (IH - 1) / stride + 1; p.OW = (IW - 1) / stride + 1;
+  if (B == 0) return YOGO_OK;
+  dim3 grid(first_tiles(p.OH, p.OW), B);
+  if (in_dtype == 0 && Cin == 1) hipLaunchKernelGGL((conv_first_wgrad_kernel<uint8_t, 1>), grid, dim3(CF_THREADS), 0, stream, p);
+  else if (in_dtype == 0) hipLaunchKernelGGL((conv_first_wgrad_kernel<uint8_t, 3>), grid, dim3(CF_THREADS), 0, stream, p);
+  else if (Cin == 1) hipLaunchKernelGGL((conv_first_wgrad_kernel<float, 1>), grid, dim3(CF_THREADS), 0, stream, p);
+  else hipLaunchKernelGGL((conv_first_wgrad_kernel<float, 3>), grid, dim3(CF_THREADS), 0, stream, p);
+  YOGO_CHECK_LAUNCH("conv_first_wgrad");
+  return YOGO_OK;
+}

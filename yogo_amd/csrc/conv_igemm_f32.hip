@@ -1,0 +1,506 @@
+// Implicit-GEMM 3x3 / 1x1 convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), gfx950.
+//
+// Replaces the cuDNN conv2d forward + dgrad calls behind nn.Conv2d in the reference
+// (yogo/model_defns.py:30-77, called at yogo/model.py:275).
+//
+// GEMM view (per image):  out[m][pix] = sum_{tap t, k} Wp[t][k][m] * in[k][pix shifted by tap t]
+//   M axis  = output channel   (MFMA A operand, lane&31)
+//   N axis  = output pixel     (MFMA B operand, lane&31; 32 consecutive pixels of a flat tile)
+//   K axis  = (tap, input channel) -- two input channels per MFMA (lane>>5)
+// The input tile (NCHW rows incl. halo, zero padded) and the weight slice of CK channels are staged in
+// LDS; a lane's B address is base(pixel) + tap offset + channel stride, so one staged tile serves all taps.
+// The same kernel runs dgrad: stride-1 dgrad is a conv with flipped/transposed packed weights; stride-2
+// dgrad is four parity-class launches (1/2/2/4 taps) writing interleaved output lattices -- no zero
+// insertion, no wasted MFMAs.
+//
+// fp32 MFMA is an exact k-ordered fmaf chain (MI355X guide), so results differ from the CPU reference only
+// by summation order.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MAX_TAPS 9
+#define IGEMM_LDS_BUDGET (80 * 1024)
+
+struct IgemmParams {
+  const float* in;
+  const float* wp;          // packed [T][Kpad][Mpad]
+  const float* bias;        // [M] or null
+  float* out;               // [B][M][OH][OW]
+  float* out_pre;           // optional pre-activation copy (SiLU training)
+  const float* act_ref;     // dgrad epilogue: multiply by act'(ref) (same indexing as out)
+  const float* chan_scale;  // optional [B][M] (Dropout2d channel mask, already scaled)
+  float* stats_part;        // optional BN partial sums [B*gridDim.x][Mpad][2]
+  int B, K, Kpad, M, Mpad;
+  int IH, IW, OH, OW;
+  int OHt, OWt, oy0, ox0, osy, osx, a;
+  int T;
+  int toff[MAX_TAPS];       // LDS offset of tap t relative to tile origin
+  int dy_min, dx_min, span_y, span_x;
+  int ncb, TW, tiles_per_band;
+  int CK, nchunk, rows_max, LWp, chs, ldsw_off;
+  int act;                  // forward activation fused in epilogue
+  int ref_act;              // dgrad: activation whose derivative multiplies the result
+};
+
+template <int MW, int NW>
+__global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const IgemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int BM = 32 * MW;
+  constexpr int PT = 4 * NW * 32;
+  float* ldsI = smem;
+  float* ldsW = smem + p.ldsw_off;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31;
+  const int half = lane >> 5;
+  const int b = blockIdx.z;
+  const int m0 = blockIdx.y * BM;
+  const int cb = blockIdx.x / p.tiles_per_band;
+  const int tb = blockIdx.x - cb * p.tiles_per_band;
+  const int j0 = cb * p.TW;
+  const int bw = min(p.TW, p.OWt - j0);
+  const int NPb = p.OHt * bw;
+  const int p0 = tb * PT;
+  const size_t part_row = (size_t)(b * gridDim.x + blockIdx.x);
+
+  if (p0 >= NPb) {  // tile beyond a narrow last band: contributes nothing (uniform branch)
+    if (p.stats_part != nullptr && tid < BM) {
+      float* dst = p.stats_part + (part_row * p.Mpad + m0 + tid) * 2;
+      dst[0] = 0.f;
+      dst[1] = 0.f;
+    }
+    return;
+  }
+  const int p1 = min(p0 + PT, NPb);
+  const int i_lo = p0 / bw;
+  const int i_hi = (p1 - 1) / bw;
+  const int rows_in = (i_hi - i_lo) * p.a + p.span_y;
+  const int iy0 = i_lo * p.a + p.dy_min;
+  const int ix0 = j0 * p.a + p.dx_min;
+  const int lw = (bw - 1) * p.a + p.span_x;
+
+  int boff[NW];
+  int opix[NW];
+  bool pvalid[NW];
+#pragma unroll
+  for (int n = 0; n < NW; ++n) {
+    const int pp = p0 + (wave * NW + n) * 32 + l31;
+    pvalid[n] = pp < p1;
+    const int pc = pvalid[n] ? pp : (p1 - 1);
+    const int i = pc / bw;
+    const int j = pc - i * bw;
+    boff[n] = half * p.chs + ((i - i_lo) * p.a) * p.LWp + j * p.a;
+    opix[n] = (p.oy0 + p.osy * i) * p.OW + p.ox0 + p.osx * (j0 + j);
+  }
+
+  f32x16 acc[MW][NW];
+#pragma unroll
+  for (int mb = 0; mb < MW; ++mb)
+#pragma unroll
+    for (int n = 0; n < NW; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][n][r] = 0.f;
+
+  const float* inb = p.in + (size_t)b * p.K * p.IH * p.IW;
+  const int aoff = half * BM + l31;
+
+  for (int c = 0; c < p.nchunk; ++c) {
+    const int k0 = c * p.CK;
+    __syncthreads();
+    // ---- stage the input tile: CK channels x rows_in rows x lw columns, zero padded ------------------
+    const int ncr = p.CK * rows_in;
+    for (int cr = wave; cr < ncr; cr += 4) {
+      const int kc = cr / rows_in;
+      const int r = cr - kc * rows_in;
+      const int k = k0 + kc;
+      const int iy = iy0 + r;
+      const bool rowok = (k < p.K) && (iy >= 0) && (iy < p.IH);
+      const float* src = inb + ((size_t)(rowok ? k : 0) * p.IH + (rowok ? iy : 0)) * p.IW;
+      float* dst = ldsI + kc * p.chs + r * p.LWp;
+      for (int x = lane; x < lw; x += 64) {
+        const int ix = ix0 + x;
+        float v = 0.f;
+        if (rowok && ix >= 0 && ix < p.IW) v = src[ix];
+        dst[x] = v;
+      }
+    }
+    // ---- stage the weight slice [T][CK][BM] ------------------------------------------------------------
+    const int nW4 = p.T * p.CK * (BM / 4);
+    for (int e = tid; e < nW4; e += 256) {
+      const int tk = e / (BM / 4);
+      const int m4 = e - tk * (BM / 4);
+      const int t = tk / p.CK;
+      const int kk = tk - t * p.CK;
+      const float4* src = reinterpret_cast<const float4*>(p.wp + ((size_t)(t * p.Kpad + k0 + kk) * p.Mpad + m0)) + m4;
+      reinterpret_cast<float4*>(ldsW)[e] = *src;
+    }
+    __syncthreads();
+    // ---- MFMA over (tap, channel pair) -----------------------------------------------------------------
+    for (int t = 0; t < p.T; ++t) {
+      const float* wI = ldsI + p.toff[t];
+      const float* wW = ldsW + t * p.CK * BM + aoff;
+#pragma unroll 2
+      for (int kk = 0; kk < p.CK; kk += 2) {
+        float av[MW], bv[NW];
+#pragma unroll
+        for (int mb = 0; mb < MW; ++mb) av[mb] = wW[kk * BM + mb * 32];
+#pragma unroll
+        for (int n = 0; n < NW; ++n) bv[n] = wI[kk * p.chs + boff[n]];
+#pragma unroll
+        for (int mb = 0; mb < MW; ++mb)
+#pragma unroll
+          for (int n = 0; n < NW; ++n)
+            acc[mb][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mb], bv[n], acc[mb][n], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue -----------------------------------------------------------------------------------------
+  const size_t plane = (size_t)p.OH * p.OW;
+  const bool do_stats = p.stats_part != nullptr;
+  if (do_stats) __syncthreads();  // LDS is reused for the cross-wave reduction
+  float* red = smem;              // [4 waves][BM][2]
+#pragma unroll
+  for (int mb = 0; mb < MW; ++mb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ml = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int m = m0 + ml;
+      const bool mok = m < p.M;
+      const float bsv = (p.bias != nullptr && mok) ? p.bias[m] : 0.f;
+      const float cs = (p.chan_scale != nullptr && mok) ? p.chan_scale[(size_t)b * p.M + m] : 1.f;
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int n = 0; n < NW; ++n) {
+        float v = acc[mb][n][r] + bsv;
+        const bool ok = pvalid[n] && mok;
+        if (do_stats && ok) {
+          s += v;
+          q += v * v;
+        }
+        if (ok) {
+          const size_t idx = ((size_t)b * p.M + m) * plane + opix[n];
+          if (p.out_pre != nullptr) p.out_pre[idx] = v;
+          if (p.act_ref != nullptr) {
+            v *= act_bwd_factor(p.act_ref[idx], p.ref_act);
+          } else {
+            v = act_fwd(v, p.act);
+          }
+          p.out[idx] = v * cs;
+        }
+      }
+      if (do_stats) {
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+          s += __shfl_xor(s, o, 64);
+          q += __shfl_xor(q, o, 64);
+        }
+        if (l31 == 0) {
+          red[(wave * BM + ml) * 2 + 0] = s;
+          red[(wave * BM + ml) * 2 + 1] = q;
+        }
+      }
+    }
+  }
+  if (do_stats) {
+    __syncthreads();
+    if (tid < BM) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        s += red[(w * BM + tid) * 2 + 0];
+        q += red[(w * BM + tid) * 2 + 1];
+      }
+      float* dst = p.stats_part + (part_row * p.Mpad + m0 + tid) * 2;
+      dst[0] = s;
+      dst[1] = q;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// weight packing: OIHW -> [T][Kpad][Mpad] (zero padded).  transpose=0: k = ci, m = co (forward);
+// transpose=1: k = co, m = ci (dgrad).
+// ---------------------------------------------------------------------------------------------------------
+struct PackParams {
+  const float* w;
+  float* wp;
+  int Cin, Cout, ks, T, Kpad, Mpad, transpose;
+  int kh[MAX_TAPS], kw[MAX_TAPS];
+};
+
+__global__ void conv_pack_kernel(const PackParams p) {
+  const int total = p.T * p.Kpad * p.Mpad;
+  const int K = p.transpose ? p.Cout : p.Cin;
+  const int M = p.transpose ? p.Cin : p.Cout;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int m = e % p.Mpad;
+    const int k = (e / p.Mpad) % p.Kpad;
+    const int t = e / (p.Mpad * p.Kpad);
+    float v = 0.f;
+    if (k < K && m < M) {
+      const int co = p.transpose ? k : m;
+      const int ci = p.transpose ? m : k;
+      v = p.w[((co * p.Cin + ci) * p.ks + p.kh[t]) * p.ks + p.kw[t]];
+    }
+    p.wp[e] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Geom {
+  int B, K, M, IH, IW, OH, OW, OHt, OWt, oy0, ox0, osy, osx, a, T;
+  int dy[MAX_TAPS], dx[MAX_TAPS];
+};
+
+int pick_mw(int M) { return M <= 32 ? 1 : (M <= 64 ? 2 : 4); }
+int pick_nw(int mw) { return mw == 4 ? 2 : 4; }
+int kpad_of(int K) { return K >= 16 ? round_up(K, 16) : round_up(K, 2); }
+int mpad_of(int M) { return round_up(M, 32 * pick_mw(M)); }
+
+struct Tiling {
+  int ncb, TW, tiles_per_band, CK, rows_max, LWp, chs, ldsw_off, lds_bytes;
+};
+
+bool plan_tiling(const Geom& g, int Kpad, int MW, int NW, Tiling* out) {
+  const int BM = 32 * MW, PT = 128 * NW;
+  int dy_min = 1 << 30, dy_max = -(1 << 30), dx_min = 1 << 30, dx_max = -(1 << 30);
+  for (int t = 0; t < g.T; ++t) {
+    dy_min = min(dy_min, g.dy[t]);
+    dy_max = max(dy_max, g.dy[t]);
+    dx_min = min(dx_min, g.dx[t]);
+    dx_max = max(dx_max, g.dx[t]);
+  }
+  const int span_y = dy_max - dy_min + 1, span_x = dx_max - dx_min + 1;
+  const int want_ck = min(8, Kpad);
+  Tiling best{};
+  bool have = false;
+  for (int ncb = 1; ncb <= 16 && ncb <= g.OWt; ++ncb) {
+    const int TW = cdiv(g.OWt, ncb);
+    const int bw_min = g.OWt - (cdiv(g.OWt, TW) - 1) * TW;
+    if (cdiv(g.OWt, TW) != ncb || bw_min <= 0) continue;
+    const int LW = (TW - 1) * g.a + span_x;
+    const int LWp = LW;
+    const int nrow_lat = min(g.OHt, 1 + cdiv(PT - 1, bw_min));
+    const int rows_max = (nrow_lat - 1) * g.a + span_y;
+    const int chs = rows_max * LWp;
+    for (int CK : {16, 8, 4, 2}) {
+      if (Kpad % CK) continue;
+      const int ldsw_off = round_up(CK * chs, 4);
+      const int bytes = max((ldsw_off + g.T * CK * BM) * 4, 4 * BM * 2 * 4);
+      if (bytes > IGEMM_LDS_BUDGET) continue;
+      Tiling t{ncb, TW, cdiv(g.OHt * TW, PT), CK, rows_max, LWp, chs, ldsw_off, bytes};
+      if (!have || (best.CK < want_ck && CK > best.CK)) {
+        best = t;
+        have = true;
+      }
+      break;  // largest CK that fits for this ncb
+    }
+    if (have && best.CK >= want_ck) break;
+  }
+  if (!have) return false;
+  *out = best;
+  return true;
+}
+
+int launch_igemm(const Geom& g, const float* in, const float* wp, const float* bias, float* out, float* out_pre,
+                 const float* act_ref, int ref_act, const float* chan_scale, float* stats_part, int act,
+                 hipStream_t stream, int* stats_rows_out) {
+  const int MW = pick_mw(g.M), NW = pick_nw(MW);
+  const int Kpad = kpad_of(g.K), Mpad = mpad_of(g.M);
+  Tiling tl;
+  if (!plan_tiling(g, Kpad, MW, NW, &tl)) {
+    yogo_set_error("conv_igemm: no LDS tiling fits (K=%d M=%d OWt=%d a=%d)", g.K, g.M, g.OWt, g.a);
+    return YOGO_ERR_ARG;
+  }
+  IgemmParams p{};
+  p.in = in; p.wp = wp; p.bias = bias; p.out = out; p.out_pre = out_pre; p.act_ref = act_ref;
+  p.chan_scale = chan_scale; p.stats_part = stats_part;
+  p.B = g.B; p.K = g.K; p.Kpad = Kpad; p.M = g.M; p.Mpad = Mpad;
+  p.IH = g.IH; p.IW = g.IW; p.OH = g.OH; p.OW = g.OW;
+  p.OHt = g.OHt; p.OWt = g.OWt; p.oy0 = g.oy0; p.ox0 = g.ox0; p.osy = g.osy; p.osx = g.osx; p.a = g.a;
+  p.T = g.T;
+  int dy_min = 1 << 30, dy_max = -(1 << 30), dx_min = 1 << 30, dx_max = -(1 << 30);
+  for (int t = 0; t < g.T; ++t) {
+    dy_min = min(dy_min, g.dy[t]); dy_max = max(dy_max, g.dy[t]);
+    dx_min = min(dx_min, g.dx[t]); dx_max = max(dx_max, g.dx[t]);
+  }
+  p.dy_min = dy_min; p.dx_min = dx_min; p.span_y = dy_max - dy_min + 1; p.span_x = dx_max - dx_min + 1;
+  p.ncb = tl.ncb; p.TW = tl.TW; p.tiles_per_band = tl.tiles_per_band;
+  p.CK = tl.CK; p.nchunk = Kpad / tl.CK; p.rows_max = tl.rows_max; p.LWp = tl.LWp; p.chs = tl.chs;
+  p.ldsw_off = tl.ldsw_off;
+  for (int t = 0; t < g.T; ++t) p.toff[t] = (g.dy[t] - dy_min) * tl.LWp + (g.dx[t] - dx_min);
+  p.act = act; p.ref_act = ref_act;
+
+  dim3 grid(tl.ncb * tl.tiles_per_band, Mpad / (32 * MW), g.B);
+  if (stats_rows_out) *stats_rows_out = g.B * (int)grid.x;
+  if (g.B == 0 || g.OHt <= 0 || g.OWt <= 0) return YOGO_OK;
+#define LAUNCH(MW_, NW_)                                                                                    \
+  do {                                                                                                      \
+    static bool attr_set = false;                                                                           \
+    if (!attr_set) {                                                                                        \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32_kernel<MW_, NW_>),                  \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, IGEMM_LDS_BUDGET);                    \
+      attr_set = true;                                                                                      \
+    }                                                                                                       \
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<MW_, NW_>), grid, dim3(256), tl.lds_bytes, stream, p);        \
+  } while (0)
+  if (MW == 4) LAUNCH(4, 2);
+  else if (MW == 2) LAUNCH(2, 4);
+  else LAUNCH(1, 4);
+#undef LAUNCH
+  YOGO_CHECK_LAUNCH("conv_igemm_f32");
+  return YOGO_OK;
+}
+
+// taps of one stride-2 dgrad parity class (ph, pw): returns T and fills kh/kw/dy/dx
+int s2_class_taps(int ph, int pw, int* kh, int* kw, int* dy, int* dx) {
+  int T = 0;
+  for (int a = 0; a < 3; ++a) {
+    if (((ph + 1 - a) & 1) != 0) continue;
+    for (int c = 0; c < 3; ++c) {
+      if (((pw + 1 - c) & 1) != 0) continue;
+      kh[T] = a; kw[T] = c; dy[T] = (ph + 1 - a) / 2; dx[T] = (pw + 1 - c) / 2;
+      ++T;
+    }
+  }
+  return T;
+}
+
+size_t packed_floats(int K, int M, int T) { return (size_t)T * kpad_of(K) * mpad_of(M); }
+
+int check_conv_args(int ks, int stride) {
+  YOGO_CHECK_ARG((ks == 3 || ks == 1) && (stride == 1 || stride == 2) && !(ks == 1 && stride != 1),
+                 "conv: only 3x3 (stride 1|2, pad 1) and 1x1 (stride 1) are supported, got ks=%d stride=%d", ks, stride);
+  return YOGO_OK;
+}
+
+}  // namespace
+
+// =========================================================================================================
+// C ABI
+// =========================================================================================================
+// mode 0: forward packing; mode 1: dgrad packing (stride 2: four parity-class blocks back to back)
+extern "C" int yogo_conv_packed_bytes(int Cin, int Cout, int ks, int stride, int mode, size_t* bytes) {
+  if (int e = check_conv_args(ks, stride)) return e;
+  YOGO_CHECK_ARG(bytes != nullptr && Cin > 0 && Cout > 0, "conv_packed_bytes: bad arguments");
+  if (mode == 0) {
+    *bytes = packed_floats(Cin, Cout, ks * ks) * 4;
+  } else if (stride == 1) {
+    *bytes = packed_floats(Cout, Cin, ks * ks) * 4;
+  } else {
+    *bytes = packed_floats(Cout, Cin, 9) * 4;  // 1 + 2 + 2 + 4 taps over the four classes
+  }
+  return YOGO_OK;
+}
+
+extern "C" int yogo_conv_pack_f32(const float* w, float* packed, int Cin, int Cout, int ks, int stride, int mode,
+                                  hipStream_t stream) {
+  if (int e = check_conv_args(ks, stride)) return e;
+  YOGO_CHECK_ARG(w && packed && Cin > 0 && Cout > 0, "conv_pack: null pointer / bad shape");
+  auto launch = [&](PackParams& pp) {
+    const int total = pp.T * pp.Kpad * pp.Mpad;
+    hipLaunchKernelGGL(conv_pack_kernel, dim3(min(1024, cdiv(total, 256))), dim3(256), 0, stream, pp);
+  };
+  PackParams pp{};
+  pp.w = w; pp.Cin = Cin; pp.Cout = Cout; pp.ks = ks;
+  if (mode == 0) {
+    pp.wp = packed; pp.T = ks * ks; pp.Kpad = kpad_of(Cin); pp.Mpad = mpad_of(Cout); pp.transpose = 0;
+    for (int t = 0; t < pp.T; ++t) { pp.kh[t] = t / ks; pp.kw[t] = t % ks; }
+    launch(pp);
+  } else if (stride == 1) {
+    pp.wp = packed; pp.T = ks * ks; pp.Kpad = kpad_of(Cout); pp.Mpad = mpad_of(Cin); pp.transpose = 1;
+    for (int t = 0; t < pp.T; ++t) { pp.kh[t] = t / ks; pp.kw[t] = t % ks; }
+    launch(pp);
+  } else {
+    size_t off = 0;
+    for (int cls = 0; cls < 4; ++cls) {
+      int dy[MAX_TAPS], dx[MAX_TAPS];
+      pp.T = s2_class_taps(cls >> 1, cls & 1, pp.kh, pp.kw, dy, dx);
+      pp.wp = packed + off; pp.Kpad = kpad_of(Cout); pp.Mpad = mpad_of(Cin); pp.transpose = 1;
+      launch(pp);
+      off += packed_floats(Cout, Cin, pp.T);
+    }
+  }
+  YOGO_CHECK_LAUNCH("conv_pack");
+  return YOGO_OK;
+}
+
+// rows of the BN partial-sum buffer a forward launch writes (each row = Mpad x {sum, sumsq})
+extern "C" int yogo_conv2d_fwd_stats_shape(int B, int Cin, int Cout, int IH, int IW, int ks, int stride, int* rows,
+                                           int* mpad) {
+  if (int e = check_conv_args(ks, stride)) return e;
+  Geom g{};
+  const int pad = ks == 3 ? 1 : 0;
+  g.B = B; g.K = Cin; g.M = Cout; g.IH = IH; g.IW = IW;
+  g.OH = (IH + 2 * pad - ks) / stride + 1; g.OW = (IW + 2 * pad - ks) / stride + 1;
+  g.OHt = g.OH; g.OWt = g.OW; g.osy = g.osx = 1; g.a = stride; g.T = ks * ks;
+  for (int t = 0; t < g.T; ++t) { g.dy[t] = t / ks - pad; g.dx[t] = t % ks - pad; }
+  const int MW = pick_mw(Cout), NW = pick_nw(MW);
+  Tiling tl;
+  if (!plan_tiling(g, kpad_of(Cin), MW, NW, &tl)) {
+    yogo_set_error("conv2d_fwd_stats_shape: no tiling");
+    return YOGO_ERR_ARG;
+  }
+  *rows = B * tl.ncb * tl.tiles_per_band;
+  *mpad = mpad_of(Cout);
+  return YOGO_OK;
+}
+
+// out = chan_scale * act(conv(in, w) + bias); optional pre-activation copy and BN partial sums.
+extern "C" int yogo_conv2d_fwd_f32(const float* in, const float* packed, const float* bias, float* out, float* out_pre,
+                                   const float* chan_scale, float* stats_part, int B, int Cin, int Cout, int IH, int IW,
+                                   int ks, int stride, int act, hipStream_t stream) {
+  if (int e = check_conv_args(ks, stride)) return e;
+  YOGO_CHECK_ARG(in && packed && out, "conv2d_fwd: null pointer");
+  YOGO_CHECK_ARG(B >= 0 && Cin > 0 && Cout > 0 && IH > 0 && IW > 0, "conv2d_fwd: bad shape");
+  YOGO_CHECK_ARG(act >= 0 && act <= 2, "conv2d_fwd: bad activation %d", act);
+  Geom g{};
+  const int pad = ks == 3 ? 1 : 0;
+  g.B = B; g.K = Cin; g.M = Cout; g.IH = IH; g.IW = IW;
+  g.OH = (IH + 2 * pad - ks) / stride + 1; g.OW = (IW + 2 * pad - ks) / stride + 1;
+  g.OHt = g.OH; g.OWt = g.OW; g.oy0 = g.ox0 = 0; g.osy = g.osx = 1; g.a = stride; g.T = ks * ks;
+  for (int t = 0; t < g.T; ++t) { g.dy[t] = t / ks - pad; g.dx[t] = t % ks - pad; }
+  return launch_igemm(g, in, packed, bias, out, out_pre, nullptr, ACT_NONE, chan_scale, stats_part, act, stream, nullptr);
+}
+
+// dx = conv_transpose(dy, w) [* act'(act_ref)] [* chan_scale]; (IH, IW) are the forward conv's INPUT dims.
+extern "C" int yogo_conv2d_dgrad_f32(const float* dy, const float* packed_dgrad, float* dx, const float* act_ref,
+                                     int ref_act, const float* chan_scale, int B, int Cin, int Cout, int IH, int IW,
+                                     int ks, int stride, hipStream_t stream) {
+  if (int e = check_conv_args(ks, stride)) return e;
+  YOGO_CHECK_ARG(dy && packed_dgrad && dx, "conv2d_dgrad: null pointer");
+  YOGO_CHECK_ARG(B >= 0 && Cin > 0 && Cout > 0 && IH > 0 && IW > 0, "conv2d_dgrad: bad shape");
+  const int pad = ks == 3 ? 1 : 0;
+  const int OH = (IH + 2 * pad - ks) / stride + 1, OW = (IW + 2 * pad - ks) / stride + 1;
+  Geom g{};
+  g.B = B; g.K = Cout; g.M = Cin; g.IH = OH; g.IW = OW; g.OH = IH; g.OW = IW; g.a = 1;
+  if (stride == 1) {
+    g.OHt = IH; g.OWt = IW; g.osy = g.osx = 1; g.T = ks * ks;
+    for (int t = 0; t < g.T; ++t) { g.dy[t] = pad - t / ks; g.dx[t] = pad - t % ks; }
+    return launch_igemm(g, dy, packed_dgrad, nullptr, dx, nullptr, act_ref, ref_act, chan_scale, nullptr, ACT_NONE,
+                        stream, nullptr);
+  }
+  size_t off = 0;
+  for (int cls = 0; cls < 4; ++cls) {
+    const int ph = cls >> 1, pw = cls & 1;
+    int kh[MAX_TAPS], kw[MAX_TAPS];
+    g.T = s2_class_taps(ph, pw, kh, kw, g.dy, g.dx);
+    g.OHt = (IH - ph + 1) / 2; g.OWt = (IW - pw + 1) / 2;
+    g.oy0 = ph; g.ox0 = pw; g.osy = g.osx = 2;
+    if (g.OHt > 0 && g.OWt > 0) {
+      if (int e = launch_igemm(g, dy, packed_dgrad + off, nullptr, dx, nullptr, act_ref, ref_act, chan_scale, nullptr,
+                               ACT_NONE, stream, nullptr))
+        return e;
+    }
+    off += packed_floats(Cout, Cin, g.T);
+  }
+  return YOGO_OK;
+}

@@ -1,0 +1,328 @@
+"""Host-side executor of the backbone on the HIP kernels (libyogo_hip.so).
+
+Walks a :class:`~yogo_amd.model_defns.HipBackbone` (block grammar of yogo/model_defns.py: Conv2d, [BatchNorm2d],
+[LeakyReLU|SiLU], [Dropout2d]) into a layer table and runs forward / backward by calling the C ABI with raw device
+pointers on the current HIP stream.  PyTorch supplies device memory, the stream and the autograd edge only.
+
+Fusion plan (fp32):
+  block without BN :  conv + bias + activation + Dropout2d channel mask            -> 1 kernel
+  block with BN    :  conv (+bias) + per-workgroup BN partial sums | finalize | normalise + activation
+  backward         :  [BN backward] -> wgrad (+bias grad, +clamp) -> dgrad whose epilogue applies the previous block's
+                      activation derivative and dropout mask, so no separate element-wise backward passes exist.
+The per-parameter gradient clamp of yogo/model.py:76-77 is fused into the gradient-finishing kernels.
+"""
+from __future__ import annotations
+
+import weakref
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from yogo_amd import _hip
+
+ACT_NONE, ACT_LEAKY, ACT_SILU = 0, 1, 2
+
+
+@dataclass
+class Layer:
+    conv: nn.Conv2d
+    bn: Optional[nn.BatchNorm2d] = None
+    act: int = ACT_NONE
+    drop: Optional[nn.Dropout2d] = None
+
+    @property
+    def cin(self) -> int:
+        return self.conv.in_channels
+
+    @property
+    def cout(self) -> int:
+        return self.conv.out_channels
+
+    @property
+    def k(self) -> int:
+        return self.conv.kernel_size[0]
+
+    @property
+    def s(self) -> int:
+        return self.conv.stride[0]
+
+    def out_hw(self, h: int, w: int) -> Tuple[int, int]:
+        p = 1 if self.k == 3 else 0
+        return (h + 2 * p - self.k) // self.s + 1, (w + 2 * p - self.k) // self.s + 1
+
+
+@dataclass
+class Saved:
+    x_in: torch.Tensor
+    y: Optional[torch.Tensor] = None
+    z: Optional[torch.Tensor] = None       # conv output of a BN block
+    pre: Optional[torch.Tensor] = None     # pre-activation (SiLU blocks)
+    mask: Optional[torch.Tensor] = None    # Dropout2d channel mask, already scaled
+    mean: Optional[torch.Tensor] = None
+    invstd: Optional[torch.Tensor] = None
+    bn_train: bool = False
+
+
+def parse_backbone(backbone: nn.Sequential) -> List[Layer]:
+    layers: List[Layer] = []
+    for blk in backbone:
+        mods = [blk] if isinstance(blk, nn.Conv2d) else list(blk)
+        if not mods or not isinstance(mods[0], nn.Conv2d):
+            raise RuntimeError(f"yogo_amd: unsupported block {blk!r}: every block must start with nn.Conv2d")
+        conv = mods[0]
+        k, s, p = conv.kernel_size, conv.stride, conv.padding
+        ok = k[0] == k[1] and s[0] == s[1] and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == "zeros"
+        ok = ok and ((k[0] == 3 and p == (1, 1) and s[0] in (1, 2)) or (k[0] == 1 and p == (0, 0) and s[0] == 1))
+        if not ok:
+            raise RuntimeError(f"yogo_amd: unsupported convolution {conv!r} (3x3 pad 1 stride 1|2, or 1x1)")
+        L = Layer(conv=conv)
+        for m in mods[1:]:
+            if isinstance(m, nn.BatchNorm2d):
+                L.bn = m
+            elif isinstance(m, nn.LeakyReLU):
+                if abs(m.negative_slope - 0.01) > 1e-12:
+                    raise RuntimeError("yogo_amd: LeakyReLU slope must be 0.01")
+                L.act = ACT_LEAKY
+            elif isinstance(m, nn.SiLU):
+                L.act = ACT_SILU
+            elif isinstance(m, nn.Dropout2d):
+                L.drop = m
+            else:
+                raise RuntimeError(f"yogo_amd: unsupported module {m!r} in block")
+        if L.bn is not None and L.drop is not None:
+            raise RuntimeError("yogo_amd: BatchNorm + Dropout2d in one block is not part of the block grammar")
+        layers.append(L)
+    return layers
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.contiguous().float()
+
+
+class Engine:
+    def __init__(self, backbone: nn.Sequential):
+        self.backbone_ref = weakref.ref(backbone)
+        self.layers = parse_backbone(backbone)
+        self._pack: Dict[Tuple[int, int], Tuple[int, int, torch.Tensor]] = {}
+        self.clip: float = 0.0  # > 0: clamp parameter gradients to +-clip (set by YOGO from clip_value)
+
+    # ------------------------------------------------------------------------------------------------------
+    def invalidate_packed(self) -> None:
+        self._pack.clear()
+
+    def _packed(self, i: int, mode: int) -> torch.Tensor:
+        L = self.layers[i]
+        w = L.conv.weight
+        key = (i, mode)
+        hit = self._pack.get(key)
+        if hit is not None and hit[0] == w._version and hit[1] == w.data_ptr():
+            return hit[2]
+        nbytes = _hip.query_size("yogo_conv_packed_bytes", L.cin, L.cout, L.k, L.s, mode)
+        buf = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
+        _hip.call("yogo_conv_pack_f32", _f32(w.detach()), buf, L.cin, L.cout, L.k, L.s, mode, _hip.stream_ptr())
+        self._pack[key] = (w._version, w.data_ptr(), buf)
+        return buf
+
+    def _first_direct(self, i: int) -> bool:
+        L = self.layers[i]
+        return i == 0 and L.cin in (1, 3) and L.k == 3
+
+    # ------------------------------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, need_grad: bool) -> Tuple[torch.Tensor, List[Saved]]:
+        _hip.require_cuda(x, "the input batch")
+        if x.ndim != 4:
+            raise RuntimeError(f"yogo_amd: expected a [B,C,H,W] batch, got {tuple(x.shape)}")
+        dev = x.device
+        st = _hip.stream_ptr()
+        B = x.shape[0]
+        if x.dtype == torch.uint8:
+            cur = x.contiguous()
+        else:
+            cur = _f32(x)
+        saved: List[Saved] = []
+        for i, L in enumerate(self.layers):
+            if cur.shape[1] != L.cin:
+                raise RuntimeError(f"yogo_amd: layer {i} expects {L.cin} channels, got {cur.shape[1]}")
+            IH, IW = int(cur.shape[2]), int(cur.shape[3])
+            OH, OW = L.out_hw(IH, IW)
+            if OH <= 0 or OW <= 0:
+                raise RuntimeError(f"yogo_amd: image too small at layer {i}")
+            w = L.conv.weight
+            _hip.require_cuda(w, "the model parameters")
+            bias = _f32(L.conv.bias.detach()) if L.conv.bias is not None else None
+            S = Saved(x_in=cur)
+            mask = None
+            if L.drop is not None and L.drop.training and L.drop.p > 0:
+                p = float(L.drop.p)
+                mask = (torch.rand(B, L.cout, device=dev) >= p).to(torch.float32) / (1.0 - p)
+                S.mask = mask
+            has_bn = L.bn is not None
+            bn_train = has_bn and (L.bn.training or L.bn.running_mean is None)
+            out = torch.empty(B, L.cout, OH, OW, dtype=torch.float32, device=dev)
+            pre = None
+            if (not has_bn) and need_grad and L.act == ACT_SILU:
+                pre = torch.empty_like(out)
+            stats = None
+            rows = mpad = 0
+            direct = self._first_direct(i)
+            if bn_train:
+                if direct:
+                    rows = _hip.query_ints("yogo_conv_first_stats_rows", 1, B, IH, IW, L.s)[0]
+                    mpad = L.cout
+                else:
+                    rows, mpad = _hip.query_ints("yogo_conv2d_fwd_stats_shape", 2, B, L.cin, L.cout, IH, IW, L.k, L.s)
+                stats = torch.empty(rows * mpad * 2, dtype=torch.float32, device=dev)
+            fused_act = ACT_NONE if has_bn else L.act
+            if direct:
+                _hip.call("yogo_conv_first_fwd", cur, 0 if cur.dtype == torch.uint8 else 1, _f32(w.detach()), bias, out, pre,
+                          mask, stats, B, L.cin, L.cout, IH, IW, L.s, fused_act, st)
+            else:
+                if cur.dtype != torch.float32:
+                    cur = cur.float()
+                    S.x_in = cur
+                _hip.call("yogo_conv2d_fwd_f32", cur, self._packed(i, 0), bias, out, pre, mask, stats, B, L.cin, L.cout,
+                          IH, IW, L.k, L.s, fused_act, st)
+            if has_bn:
+                bn = L.bn
+                gamma = _f32(bn.weight.detach()) if bn.weight is not None else torch.ones(L.cout, device=dev)
+                beta = _f32(bn.bias.detach()) if bn.bias is not None else torch.zeros(L.cout, device=dev)
+                y = torch.empty_like(out) if need_grad else out
+                if bn_train:
+                    mean = torch.empty(L.cout, dtype=torch.float32, device=dev)
+                    invstd = torch.empty(L.cout, dtype=torch.float32, device=dev)
+                    track = bn.track_running_stats and bn.running_mean is not None
+                    if track and bn.momentum is None:
+                        raise RuntimeError("yogo_amd: BatchNorm2d(momentum=None) is not supported")
+                    _hip.call("yogo_bn_finalize", stats, rows, mpad, L.cout, B * OH * OW, float(bn.eps),
+                              float(bn.momentum if bn.momentum is not None else 0.0), mean, invstd,
+                              bn.running_mean if track else None, bn.running_var if track else None,
+                              bn.num_batches_tracked if track else None, st)
+                    _hip.call("yogo_bn_apply_act", out, y, mean, invstd, 0, float(bn.eps), gamma, beta, B, L.cout, OH * OW,
+                              L.act, st)
+                    S.mean, S.invstd = mean, invstd
+                else:
+                    _hip.call("yogo_bn_apply_act", out, y, bn.running_mean, bn.running_var, 1, float(bn.eps), gamma, beta, B,
+                              L.cout, OH * OW, L.act, st)
+                    if need_grad:
+                        invstd = torch.empty(L.cout, dtype=torch.float32, device=dev)
+                        _hip.call("yogo_bn_invstd", bn.running_var, float(bn.eps), invstd, L.cout, st)
+                        S.mean, S.invstd = bn.running_mean, invstd
+                S.bn_train = bn_train
+                S.z = out if need_grad else None
+                S.y = y
+                cur = y
+            else:
+                S.y = out
+                S.pre = pre
+                cur = out
+            saved.append(S if need_grad else Saved(x_in=cur))
+        return cur, saved
+
+    # ------------------------------------------------------------------------------------------------------
+    def backward(self, saved: List[Saved], graw: torch.Tensor) -> List[Optional[torch.Tensor]]:
+        """returns gradients in the order of ``backbone.parameters()``."""
+        st = _hip.stream_ptr()
+        dev = graw.device
+        clip = float(self.clip)
+        grads: Dict[int, torch.Tensor] = {}
+        g = _f32(graw)
+        n = len(self.layers)
+        for i in range(n - 1, -1, -1):
+            L, S = self.layers[i], saved[i]
+            B, _, OH, OW = g.shape
+            IH, IW = int(S.x_in.shape[2]), int(S.x_in.shape[3])
+            if L.bn is not None:
+                bn = L.bn
+                if L.act == ACT_SILU:
+                    raise RuntimeError("yogo_amd: backward through BatchNorm + SiLU blocks is not implemented yet")
+                gamma = _f32(bn.weight.detach()) if bn.weight is not None else torch.ones(L.cout, device=dev)
+                dgamma = torch.empty(L.cout, dtype=torch.float32, device=dev)
+                dbeta = torch.empty(L.cout, dtype=torch.float32, device=dev)
+                rows = _hip.query_ints("yogo_bn_bwd_rows", 1, B, OH * OW)[0]
+                part = torch.empty(rows * L.cout * 2, dtype=torch.float32, device=dev)
+                sums = torch.empty(2 * L.cout, dtype=torch.float32, device=dev)
+                _hip.call("yogo_bn_bwd", g, S.z, g, S.mean, S.invstd, gamma, dgamma, dbeta, part, sums, B, L.cout, OH * OW,
+                          1 if S.bn_train else 0, clip, st)
+                if bn.weight is not None:
+                    grads[id(bn.weight)] = dgamma
+                    grads[id(bn.bias)] = dbeta
+            # ---- weight / bias gradient -------------------------------------------------------------------------
+            dw = torch.empty_like(L.conv.weight, dtype=torch.float32, memory_format=torch.contiguous_format)
+            has_bias = L.conv.bias is not None
+            if self._first_direct(i):
+                rows = _hip.query_ints("yogo_conv_first_stats_rows", 1, B, IH, IW, L.s)[0]
+                nj = L.cin * 9 + 1
+                part = torch.empty(rows * L.cout * nj, dtype=torch.float32, device=dev)
+                x_in = S.x_in
+                _hip.call("yogo_conv_first_wgrad", x_in, 0 if x_in.dtype == torch.uint8 else 1, g, part, B, L.cin, L.cout, IH,
+                          IW, L.s, st)
+                red = torch.empty(L.cout, nj, dtype=torch.float32, device=dev)
+                _hip.call("yogo_partials_reduce", part, rows, L.cout * nj, clip, red, st)
+                dw.copy_(red[:, : nj - 1].reshape(dw.shape))
+                if has_bias:
+                    grads[id(L.conv.bias)] = red[:, nj - 1].contiguous()
+            else:
+                wsb = _hip.query_size("yogo_conv2d_wgrad_workspace_bytes", B, L.cin, L.cout, IH, IW, L.k, L.s)
+                ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
+                db = torch.empty(L.cout, dtype=torch.float32, device=dev) if has_bias else None
+                _hip.call("yogo_conv2d_wgrad_f32", S.x_in, g, dw, db, ws, B, L.cin, L.cout, IH, IW, L.k, L.s, clip, st)
+                if has_bias:
+                    grads[id(L.conv.bias)] = db
+            grads[id(L.conv.weight)] = dw
+            # ---- data gradient, with the previous block's activation derivative and dropout mask fused -------------
+            if i > 0:
+                Lp, Sp = self.layers[i - 1], saved[i - 1]
+                if Lp.act == ACT_SILU:
+                    act_ref = Sp.pre
+                    if act_ref is None:
+                        raise RuntimeError("yogo_amd: missing saved pre-activation for a SiLU block")
+                elif Lp.act == ACT_LEAKY:
+                    act_ref = Sp.y
+                else:
+                    act_ref = None
+                dx = torch.empty(B, L.cin, IH, IW, dtype=torch.float32, device=dev)
+                _hip.call("yogo_conv2d_dgrad_f32", g, self._packed(i, 1), dx, act_ref, Lp.act, Sp.mask, B, L.cin, L.cout, IH,
+                          IW, L.k, L.s, st)
+                g = dx
+        bb = self.backbone_ref()
+        return [grads.get(id(p)) for p in bb.parameters()]
+
+
+_ENGINES: "weakref.WeakKeyDictionary[nn.Module, Engine]" = weakref.WeakKeyDictionary()
+
+
+def get_engine(backbone: nn.Sequential) -> Engine:
+    eng = _ENGINES.get(backbone)
+    if eng is None:
+        eng = Engine(backbone)
+        _ENGINES[backbone] = eng
+    return eng
+
+
+class _BackboneFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, backbone, *params):  # type: ignore[override]
+        eng = get_engine(backbone)
+        raw, saved = eng.forward(x, need_grad=True)
+        ctx.eng = eng
+        ctx.saved = saved
+        return raw
+
+    @staticmethod
+    def backward(ctx, graw):  # type: ignore[override]
+        with torch.cuda.device(graw.device):
+            grads = ctx.eng.backward(ctx.saved, graw)
+        ctx.saved = None
+        return (None, None, *grads)
+
+
+def backbone_apply(backbone: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+    _hip.require_cuda(x, "the input batch")
+    params = list(backbone.parameters())
+    with torch.cuda.device(x.device):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            return _BackboneFn.apply(x, backbone, *params)
+        raw, _ = get_engine(backbone).forward(x, need_grad=False)
+        return raw

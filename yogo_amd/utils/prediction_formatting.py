@@ -1,0 +1,104 @@
+"""``format_preds`` and its batched form on the HIP decode/threshold/NMS kernel.
+
+Reference: yogo/utils/prediction_formatting.py:23-93 (``format_preds``), yogo/infer.py:60-124
+(``get_prediction_class_counts``, ``count_cells_for_formatted_preds``).  The reference runs ``format_preds`` once per
+image from a Python loop; here the whole batch is one kernel launch and the per-image results are slices of it.
+"""
+from __future__ import annotations
+
+from typing import List, Literal, Optional, Tuple, get_args
+
+import torch
+
+from yogo_amd import _hip
+
+BoxFormat = Literal["xyxy", "cxcywh"]
+
+
+def format_preds_batched(
+    pred: torch.Tensor,
+    obj_thresh: float = 0.5,
+    iou_thresh: float = 0.5,
+    box_format: BoxFormat = "cxcywh",
+    min_class_confidence_threshold: float = 0.0,
+) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """pred [B, 5+C, Sy, Sx] on the GPU -> (rows [B, cap, 5+C], cells int64 [B, cap], counts int32 [B]).
+
+    Image b's result is ``rows[b, :counts[b]]`` -- the same rows in the same order ``format_preds(pred[b])`` returns;
+    ``cells`` are the flat grid-cell indices (y*Sx + x) the rows came from.  No host synchronisation happens here.
+    """
+    if pred.ndim != 4:
+        raise ValueError(f"format_preds_batched expects (B, pred_shape, Sy, Sx), got {tuple(pred.shape)}")
+    if box_format not in get_args(BoxFormat):
+        raise ValueError(f"invalid box format {box_format}; valid box formats are {get_args(BoxFormat)}")
+    _hip.require_cuda(pred, "pred")
+    B, P, Sy, Sx = pred.shape
+    p = pred.detach().contiguous().float()
+    cap = Sy * Sx
+    dev = pred.device
+    rows = torch.empty(B, cap, P, dtype=torch.float32, device=dev)
+    cells = torch.empty(B, cap, dtype=torch.int64, device=dev)
+    counts = torch.empty(B, dtype=torch.int32, device=dev)
+    if B == 0:
+        return rows, cells, counts
+    with torch.cuda.device(dev):
+        ws = torch.empty(_hip.query_size("yogo_format_preds_workspace_bytes", B, Sy, Sx), dtype=torch.uint8, device=dev)
+        _hip.call("yogo_format_preds_batched", p, rows, cells, counts, ws, B, P, Sy, Sx, cap, float(obj_thresh), float(iou_thresh),
+                  0 if box_format == "cxcywh" else 1, float(min_class_confidence_threshold), _hip.stream_ptr())
+    return rows, cells, counts
+
+
+def format_preds(
+    pred: torch.Tensor,
+    obj_thresh: float = 0.5,
+    iou_thresh: float = 0.5,
+    box_format: BoxFormat = "cxcywh",
+    min_class_confidence_threshold: float = 0.0,
+) -> torch.Tensor:
+    """formats pred, prediction tensor straight from YOGO (unbatched, [5+C, Sy, Sx]), into [N, 5+C] after objectness
+    thresholding, NMS and the class-confidence filter.  For all thresholds, set to 0 to disable."""
+    if len(pred.shape) != 3:
+        raise ValueError(
+            "argument to format_pred should be unbatched result - " f"shape should be (pred_shape, Sy, Sx), got {pred.shape}"
+        )
+    elif box_format not in get_args(BoxFormat):
+        raise ValueError(f"invalid box format {box_format}; valid box formats are {get_args(BoxFormat)}")
+    rows, _, counts = format_preds_batched(pred[None], obj_thresh, iou_thresh, box_format, min_class_confidence_threshold)
+    n = int(counts[0].item())
+    return rows[0, :n]
+
+
+def split_batched(rows: torch.Tensor, counts: torch.Tensor) -> List[torch.Tensor]:
+    """one device->host copy of the counts, then views"""
+    c = counts.cpu().tolist()
+    return [rows[b, : c[b]] for b in range(len(c))]
+
+
+def count_cells_for_formatted_preds(formatted_class_predictions: torch.Tensor,
+                                    min_confidence_threshold: Optional[float] = None) -> torch.Tensor:
+    """class histogram by argmax over rows whose max confidence exceeds the threshold (yogo/infer.py:90-124)"""
+    if not len(formatted_class_predictions.shape) == 2:
+        raise ValueError(f"expected formatted_class_predictions to be shape (N, num_classes); got {formatted_class_predictions.shape}")
+    if min_confidence_threshold is not None:
+        if min_confidence_threshold < 0 or min_confidence_threshold > 1:
+            raise ValueError(f"min_confidence_threshold should be between 0 and 1; is {min_confidence_threshold}")
+    else:
+        min_confidence_threshold = 0
+    _, n_classes = formatted_class_predictions.shape
+    values, indices = formatted_class_predictions.max(dim=1)
+    mask = values > min_confidence_threshold
+    return torch.nn.functional.one_hot(indices[mask], num_classes=n_classes).sum(dim=0)
+
+
+def get_prediction_class_counts(batch_preds: torch.Tensor, obj_thresh=0.5, iou_thresh=0.5,
+                                min_class_confidence_threshold: float = 0) -> torch.Tensor:
+    """yogo/infer.py:60-87 over one batched launch"""
+    bs, pred_dim, Sy, Sx = batch_preds.shape
+    num_classes = pred_dim - 5
+    rows, _, counts = format_preds_batched(batch_preds, obj_thresh, iou_thresh, "cxcywh", min_class_confidence_threshold)
+    tot = torch.zeros(num_classes, dtype=torch.long)
+    for r in split_batched(rows, counts):
+        if r.numel() == 0:
+            continue
+        tot += count_cells_for_formatted_preds(r[:, 5:]).cpu()
+    return tot
