@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Benchmark of the YOGO hot path on MI355X: full training step (forward + loss + backward + AdamW) on synthetic
+772x1032 grayscale batches, base_model, 7 classes -- BASELINE.json's metric "training images/sec".
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One JSON line on rank 0.  A "step" is one optimisation step over one per-GPU batch resident in HBM (weak scaling:
+per-GPU batch fixed, the images are sharded over ranks, one RCCL all-reduce of the flat gradient per step).
+`roofline` is measured live with HIP events (torch.cuda.Event on the stream the kernels are launched on) around every
+launch of the dominant kernel, conv_igemm_f32_kernel<4,2> (forward + dgrad of the 128-channel 3x3 layers);
+`cpu_baseline` times the CPU oracle (oracle/yogo_oracle.py: the reference's algorithm on torch CPU ops) on a bounded
+sample of the same workload -- a reported baseline, never the target.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W, NUM_CLASSES = 772, 1032, 7
+ANCHOR_W, ANCHOR_H = 0.0425, 0.0555
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+TRAIN_GFLOP_PER_IMG = 66.48
+
+
+def cpu_baseline(batch: int = 8, steps: int = 2):
+    """oracle training step (fwd + loss + bwd + clamp + AdamW) on the host cores, bounded sample"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import yogo_oracle as O
+
+    cores = len(os.sched_getaffinity(0))
+    torch.set_num_threads(cores)
+    spec = O.arch("base_model", NUM_CLASSES)
+    sd = O.init_state(spec, seed=0)
+    x = O.synthetic_images(batch, H, W, seed=0)
+    Sx, Sy = O.grid_size(spec, H, W)
+    lab = O.synthetic_labels(batch, Sx, Sy, K=64, num_classes=NUM_CLASSES, seed=1)
+    names = [k for k, v in sd.items() if v.is_floating_point() and "running" not in k]
+    state = {k: (torch.zeros_like(sd[k]), torch.zeros_like(sd[k])) for k in names}
+
+    def one(step):
+        leaf = {k: sd[k].clone().requires_grad_(True) for k in names}
+        sdl = dict(sd)
+        sdl.update(leaf)
+        ns = {}
+        out = O.yogo_forward(x, sdl, spec, ANCHOR_W, ANCHOR_H, train=True, new_stats=ns)
+        loss, _ = O.yogo_loss(out, lab)
+        loss.backward()
+        g = O.clamp_grads({k: v.grad for k, v in leaf.items()})
+        lr = O.cosine_lr(step - 1, 3e-4, 1000, 3e-5)
+        for k in names:
+            p, m, v = O.adamw_step(sd[k], g[k], state[k][0], state[k][1], step, lr)
+            sd[k], state[k] = p.detach(), (m, v)
+        sd.update(ns)
+
+    one(1)  # warm-up
+    t0 = time.perf_counter()
+    for s in range(steps):
+        one(2 + s)
+    dt = time.perf_counter() - t0
+    return {"value": round(batch * steps / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} oracle train steps (fwd+loss+bwd+AdamW), fp32, batch {batch}, after 1 warm-up step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if args.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+
+    from yogo_amd.model import YOGO
+    from yogo_amd.synthetic import synthetic_images, synthetic_labels
+    from yogo_amd.train import HipTrainer
+    from yogo_amd.yogo_loss import YOGOLoss
+
+    torch.manual_seed(0)   # reference init under manual_seed(0); identical on every rank
+    model = YOGO((H, W), ANCHOR_W, ANCHOR_H, NUM_CLASSES).to(dev)
+    model.train()
+    B = args.batch
+    trainer = HipTrainer(model, YOGOLoss().to(dev), total_steps=args.steps + args.warmup + 1)
+    trainer.broadcast_parameters()
+    imgs = synthetic_images(B, H, W, device=dev, seed=100 + rank)
+    labels = synthetic_labels(B, model.Sx, model.Sy, K=64, num_classes=NUM_CLASSES, device=dev, seed=200 + rank)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        trainer.step(imgs, labels)
+    torch.cuda.synchronize()
+    barrier()
+    trainer.engine.prof = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.step(imgs, labels)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = trainer.engine.prof
+    trainer.engine.prof = None
+    loss_rec = trainer.loss_components()
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel, from the in-loop HIP events ---------------------------------------
+        sel = [e for e in prof if e[0] in ("fwd", "dgrad") and e[2] == 4]
+        ms = sum(e[4].elapsed_time(e[5]) for e in sel)
+        fl = sum(e[3] for e in sel)
+        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        by_kind = {}
+        for kind in ("fwd", "dgrad", "wgrad"):
+            es = [e for e in prof if e[0] == kind]
+            t_ms = sum(e[4].elapsed_time(e[5]) for e in es)
+            by_kind[kind] = {"ms_per_step": round(t_ms / args.steps, 3),
+                             "tflops": round(sum(e[3] for e in es) / max(t_ms, 1e-9) / 1e9, 2)}
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("conv_igemm_f32_kernel<4,2>", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {"bound": "mfma", "kernel": "conv_igemm_f32_kernel<4,2> (fwd+dgrad of the 128-channel 3x3 layers)",
+                "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "calls_timed": len(sel), "avg_call_ms": round(ms / max(1, len(sel)), 4)}
+        value = world * B * args.steps / dt
+        rec = {
+            "metric": "training images/sec (772x1032 gray)", "value": round(value, 2), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "full train step (fwd+loss+bwd+clamp+AdamW), base_model, 772x1032x1 uint8, 7 classes; "
+                                   "BASELINE configs[2]/[3] shape at fp32 storage+arithmetic",
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}"},
+            "roofline": roof,
+            "step_tflops": round(value * TRAIN_GFLOP_PER_IMG / 1e3, 2),
+            "conv_breakdown": by_kind,
+            "loss": round(loss_rec["loss"], 4),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(rec))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

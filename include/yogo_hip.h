@@ -102,8 +102,8 @@ int yogo_format_preds_batched(const float* pred, float* out_rows, long long* out
                               double min_class_confidence_threshold, yogo_stream_t stream);
 
 /* ---- optimiser: torch.optim.AdamW over one flat buffer, yogo/train.py:213-217,324 ---------------------------------------- */
-int yogo_adamw_step(float* p, const float* g, float* m, float* v, long long n, int step, float lr, float beta1, float beta2,
-                    float eps, float weight_decay, float grad_scale, yogo_stream_t stream);
+int yogo_adamw_step(float* p, const float* g, float* m, float* v, long long n, int step, double lr, double beta1,
+                    double beta2, double eps, double weight_decay, double grad_scale, yogo_stream_t stream);
 
 #ifdef __cplusplus
 }

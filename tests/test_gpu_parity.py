@@ -56,8 +56,11 @@ def test_train_forward_backward_matches_reference(fix):
     out.backward(outs["upstream"].cuda())
     got = {k: p.grad.cpu() for k, p in m.named_parameters()}
     assert set(got) == set(grads)
+    gmax = max(float(v.abs().max()) for v in grads.values())
     for k in grads:
-        assert rel_err(got[k], grads[k]) < 2e-3, k
+        # a conv bias in front of BatchNorm has a mathematically zero gradient (rounding noise only): absolute floor
+        err = float((got[k] - grads[k]).abs().max())
+        assert err < 2e-3 * float(grads[k].abs().max()) + 1e-6 * gmax, (k, err)
     sd_now = m.state_dict()
     for k, v in after.items():
         torch.testing.assert_close(sd_now[k].cpu(), v, rtol=2e-4, atol=1e-4)
@@ -96,8 +99,8 @@ def test_dropout_mask_statistics_and_scaling():
         if L.drop is not None:
             mask = saved[i].mask.cpu()
             p = L.drop.p
-            vals = set(np.round(mask.unique().numpy(), 5).tolist())
-            assert vals <= {0.0, round(1 / (1 - p), 5)}
+            for v in mask.unique().tolist():
+                assert v == 0.0 or abs(v - 1 / (1 - p)) < 1e-6
             y = saved[i].y.cpu()
             dead = (mask == 0)
             assert torch.all(y[dead] == 0)
@@ -219,3 +222,55 @@ def test_class_counts_match_oracle():
     got = get_prediction_class_counts(pred.cuda(), min_class_confidence_threshold=0.25)
     want = O.get_prediction_class_counts(pred, min_class_confidence_threshold=0.25)
     assert torch.equal(got, want)
+
+
+def test_trainer_steps_match_oracle():
+    """two full optimisation steps (fwd, loss, bwd, clamp, AdamW with cosine LR) against the CPU oracle"""
+    from yogo_amd.model import YOGO
+    from yogo_amd.train import HipTrainer
+    from yogo_amd.yogo_loss import YOGOLoss
+
+    torch.manual_seed(1)
+    Himg, Wimg, C, B = 96, 128, 7, 3
+    model = YOGO((Himg, Wimg), 0.0425, 0.0555, C).to("cuda")
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    spec = O.arch("base_model", C)
+    names = [k for k, v in sd.items() if k.startswith("model.") and v.is_floating_point() and "running" not in k]
+    mom = {k: (torch.zeros_like(sd[k]), torch.zeros_like(sd[k])) for k in names}
+    tr = HipTrainer(model, YOGOLoss().to("cuda"), total_steps=7)
+    for step in (1, 2):
+        x = O.synthetic_images(B, Himg, Wimg, seed=10 + step)
+        lab = O.synthetic_labels(B, model.Sx, model.Sy, K=5, num_classes=C, seed=20 + step)
+        tr.step(x.cuda(), lab.cuda())
+        leaf = {k: sd[k].clone().requires_grad_(True) for k in names}
+        sdl = dict(sd)
+        sdl.update(leaf)
+        ns = {}
+        pred = O.yogo_forward(x, sdl, spec, 0.0425, 0.0555, train=True, new_stats=ns)
+        loss, comps = O.yogo_loss(pred, lab)
+        loss.backward()
+        g = O.clamp_grads({k: v.grad for k, v in leaf.items()})
+        lr = O.cosine_lr(step - 1, 3e-4, 7, 3e-5)
+        for k in names:
+            p, m1, v1 = O.adamw_step(sd[k], g[k], mom[k][0], mom[k][1], step, lr)
+            sd[k], mom[k] = p.detach(), (m1, v1)
+        sd.update(ns)
+        got = tr.loss_components()
+        assert abs(got["loss"] - float(loss.detach())) < 2e-4 * abs(float(loss.detach()))
+        for k2 in ("iou_loss", "objectness_loss", "classification_loss"):
+            assert abs(got[k2] - comps[k2]) < 2e-4 * abs(comps[k2]) + 1e-6
+    now = model.state_dict()
+    for k in names:
+        # Adam normalises the step to ~lr, so a parameter moves by <= ~2*lr; compare the moves
+        assert float((now[k].cpu() - sd[k]).abs().max()) < 3e-5, k
+    for k, v in sd.items():
+        if "running" in k:
+            torch.testing.assert_close(now[k].cpu(), v, rtol=1e-4, atol=1e-4)
+        if "num_batches" in k:
+            assert int(now[k]) == 2
+    # the flat buffer really is the module's storage
+    assert all(p.data_ptr() >= tr.flat.flat.data_ptr() for p in model.parameters())

@@ -2,21 +2,31 @@
 // Replaces torch.optim.AdamW(foreach) of yogo/train.py:213-217, 324: weight decay 5e-2 on ALL
 // parameters (incl. BN and bias, as the reference does), betas (0.9, 0.999), eps 1e-8.
 // HBM-bound: 4 reads + 3 writes of 541 852 floats = 15.2 MB per step.
+// Scalars are formed in double on the host and rounded once to fp32, as torch does with its Python scalars.
 #include "common.h"
 
+struct AdamwScalars {
+  float decay;        // 1 - lr*wd
+  float w1;           // 1 - beta1
+  float beta2;
+  float w2;           // 1 - beta2
+  float step_size;    // lr / (1 - beta1^t)
+  float bc2_sqrt;     // sqrt(1 - beta2^t)
+  float eps;
+  float grad_scale;
+};
+
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                    float* __restrict__ v, long long n, float lr, float beta1, float beta2,
-                                                    float eps, float weight_decay, float bc1, float bc2_sqrt, float grad_scale) {
+                                                    float* __restrict__ v, long long n, const AdamwScalars s) {
   const long long stride = (long long)gridDim.x * 256;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-    const float gi = g[i] * grad_scale;
-    float pi = p[i];
-    pi = pi * (1.f - lr * weight_decay);
-    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
-    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    pi = pi - (lr / bc1) * (mi / denom);
-    p[i] = pi;
+    const float gi = g[i] * s.grad_scale;
+    const float pi = p[i] * s.decay;
+    const float m0 = m[i];
+    const float mi = m0 + s.w1 * (gi - m0);            // lerp
+    const float vi = v[i] * s.beta2 + (s.w2 * gi) * gi;  // mul + addcmul
+    const float denom = sqrtf(vi) / s.bc2_sqrt + s.eps;
+    p[i] = pi - s.step_size * (mi / denom);
     m[i] = mi;
     v[i] = vi;
   }
@@ -24,14 +34,20 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 
 // step is 1-based (the value AFTER incrementing, as in torch).  grad_scale multiplies the gradient first
 // (1/world_size after a sum all-reduce; 1 otherwise).
-extern "C" int yogo_adamw_step(float* p, const float* g, float* m, float* v, long long n, int step, float lr, float beta1,
-                               float beta2, float eps, float weight_decay, float grad_scale, hipStream_t stream) {
+extern "C" int yogo_adamw_step(float* p, const float* g, float* m, float* v, long long n, int step, double lr, double beta1,
+                               double beta2, double eps, double weight_decay, double grad_scale, hipStream_t stream) {
   YOGO_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "adamw_step: bad arguments");
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  AdamwScalars s;
+  s.decay = (float)(1.0 - lr * weight_decay);
+  s.w1 = (float)(1.0 - beta1);
+  s.beta2 = (float)beta2;
+  s.w2 = (float)(1.0 - beta2);
+  s.step_size = (float)(lr / (1.0 - pow(beta1, (double)step)));
+  s.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+  s.eps = (float)eps;
+  s.grad_scale = (float)grad_scale;
   const int blocks = (int)min((long long)2048, (n + 255) / 256);
-  hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
-                     (float)bc1, (float)sqrt(bc2), grad_scale);
+  hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, n, s);
   YOGO_CHECK_LAUNCH("adamw_step");
   return YOGO_OK;
 }

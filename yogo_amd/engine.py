@@ -107,6 +107,21 @@ class Engine:
         self.layers = parse_backbone(backbone)
         self._pack: Dict[Tuple[int, int], Tuple[int, int, torch.Tensor]] = {}
         self.clip: float = 0.0  # > 0: clamp parameter gradients to +-clip (set by YOGO from clip_value)
+        # optional per-launch HIP-event timing (bench.py): list of (kind, layer, mw, flops, start_event, end_event)
+        self.prof: Optional[list] = None
+        self._open = None
+
+    def _tick(self, kind: str, layer: int, flops: float, mw: int = 0) -> None:
+        if self.prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._open = (kind, layer, mw, flops, e0, e1)
+
+    def _tock(self) -> None:
+        if self._open is not None:
+            self._open[5].record()
+            self.prof.append(self._open)
+            self._open = None
 
     # ------------------------------------------------------------------------------------------------------
     def invalidate_packed(self) -> None:
@@ -182,8 +197,11 @@ class Engine:
                 if cur.dtype != torch.float32:
                     cur = cur.float()
                     S.x_in = cur
-                _hip.call("yogo_conv2d_fwd_f32", cur, self._packed(i, 0), bias, out, pre, mask, stats, B, L.cin, L.cout,
-                          IH, IW, L.k, L.s, fused_act, st)
+                pk = self._packed(i, 0)
+                self._tick("fwd", i, 2.0 * B * L.cout * L.cin * L.k * L.k * OH * OW, mw=4 if L.cout > 64 else (2 if L.cout > 32 else 1))
+                _hip.call("yogo_conv2d_fwd_f32", cur, pk, bias, out, pre, mask, stats, B, L.cin, L.cout, IH, IW, L.k, L.s,
+                          fused_act, st)
+                self._tock()
             if has_bn:
                 bn = L.bn
                 gamma = _f32(bn.weight.detach()) if bn.weight is not None else torch.ones(L.cout, device=dev)
@@ -221,12 +239,19 @@ class Engine:
         return cur, saved
 
     # ------------------------------------------------------------------------------------------------------
-    def backward(self, saved: List[Saved], graw: torch.Tensor) -> List[Optional[torch.Tensor]]:
-        """returns gradients in the order of ``backbone.parameters()``."""
+    def backward(self, saved: List[Saved], graw: torch.Tensor,
+                 grad_out: Optional[Dict[int, torch.Tensor]] = None) -> List[Optional[torch.Tensor]]:
+        """returns gradients in the order of ``backbone.parameters()``.  ``grad_out`` maps id(param) to a preallocated
+        contiguous destination (views of one flat gradient buffer in the trainer)."""
         st = _hip.stream_ptr()
         dev = graw.device
         clip = float(self.clip)
         grads: Dict[int, torch.Tensor] = {}
+
+        def dst(param: torch.Tensor) -> torch.Tensor:
+            if grad_out is not None and id(param) in grad_out:
+                return grad_out[id(param)]
+            return torch.empty(param.shape, dtype=torch.float32, device=dev)
         g = _f32(graw)
         n = len(self.layers)
         for i in range(n - 1, -1, -1):
@@ -238,8 +263,8 @@ class Engine:
                 if L.act == ACT_SILU:
                     raise RuntimeError("yogo_amd: backward through BatchNorm + SiLU blocks is not implemented yet")
                 gamma = _f32(bn.weight.detach()) if bn.weight is not None else torch.ones(L.cout, device=dev)
-                dgamma = torch.empty(L.cout, dtype=torch.float32, device=dev)
-                dbeta = torch.empty(L.cout, dtype=torch.float32, device=dev)
+                dgamma = dst(bn.weight) if bn.weight is not None else torch.empty(L.cout, dtype=torch.float32, device=dev)
+                dbeta = dst(bn.bias) if bn.bias is not None else torch.empty(L.cout, dtype=torch.float32, device=dev)
                 rows = _hip.query_ints("yogo_bn_bwd_rows", 1, B, OH * OW)[0]
                 part = torch.empty(rows * L.cout * 2, dtype=torch.float32, device=dev)
                 sums = torch.empty(2 * L.cout, dtype=torch.float32, device=dev)
@@ -249,7 +274,7 @@ class Engine:
                     grads[id(bn.weight)] = dgamma
                     grads[id(bn.bias)] = dbeta
             # ---- weight / bias gradient -------------------------------------------------------------------------
-            dw = torch.empty_like(L.conv.weight, dtype=torch.float32, memory_format=torch.contiguous_format)
+            dw = dst(L.conv.weight)
             has_bias = L.conv.bias is not None
             if self._first_direct(i):
                 rows = _hip.query_ints("yogo_conv_first_stats_rows", 1, B, IH, IW, L.s)[0]
@@ -262,12 +287,16 @@ class Engine:
                 _hip.call("yogo_partials_reduce", part, rows, L.cout * nj, clip, red, st)
                 dw.copy_(red[:, : nj - 1].reshape(dw.shape))
                 if has_bias:
-                    grads[id(L.conv.bias)] = red[:, nj - 1].contiguous()
+                    db = dst(L.conv.bias)
+                    db.copy_(red[:, nj - 1])
+                    grads[id(L.conv.bias)] = db
             else:
                 wsb = _hip.query_size("yogo_conv2d_wgrad_workspace_bytes", B, L.cin, L.cout, IH, IW, L.k, L.s)
                 ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
-                db = torch.empty(L.cout, dtype=torch.float32, device=dev) if has_bias else None
+                db = dst(L.conv.bias) if has_bias else None
+                self._tick("wgrad", i, 2.0 * B * L.cout * L.cin * L.k * L.k * OH * OW)
                 _hip.call("yogo_conv2d_wgrad_f32", S.x_in, g, dw, db, ws, B, L.cin, L.cout, IH, IW, L.k, L.s, clip, st)
+                self._tock()
                 if has_bias:
                     grads[id(L.conv.bias)] = db
             grads[id(L.conv.weight)] = dw
@@ -283,8 +312,10 @@ class Engine:
                 else:
                     act_ref = None
                 dx = torch.empty(B, L.cin, IH, IW, dtype=torch.float32, device=dev)
-                _hip.call("yogo_conv2d_dgrad_f32", g, self._packed(i, 1), dx, act_ref, Lp.act, Sp.mask, B, L.cin, L.cout, IH,
-                          IW, L.k, L.s, st)
+                pk = self._packed(i, 1)
+                self._tick("dgrad", i, 2.0 * B * L.cout * L.cin * L.k * L.k * OH * OW, mw=4 if L.cin > 64 else (2 if L.cin > 32 else 1))
+                _hip.call("yogo_conv2d_dgrad_f32", g, pk, dx, act_ref, Lp.act, Sp.mask, B, L.cin, L.cout, IH, IW, L.k, L.s, st)
+                self._tock()
                 g = dx
         bb = self.backbone_ref()
         return [grads.get(id(p)) for p in bb.parameters()]
