@@ -146,6 +146,16 @@ def main():
             t_ms = sum(e[4].elapsed_time(e[5]) for e in es)
             by_kind[kind] = {"ms_per_step": round(t_ms / args.steps, 3),
                              "tflops": round(sum(e[3] for e in es) / max(t_ms, 1e-9) / 1e9, 2)}
+        if os.environ.get("YOGO_BENCH_VERBOSE"):
+            agg = {}
+            for e in prof:
+                k = (e[0], e[1])
+                t_ms = e[4].elapsed_time(e[5])
+                a = agg.setdefault(k, [0.0, 0.0])
+                a[0] += t_ms
+                a[1] += e[3]
+            for (kind, layer), (t_ms, fl2) in sorted(agg.items(), key=lambda kv: (kv[0][1], kv[0][0])):
+                print(f"[bench] layer {layer} {kind:6s} {t_ms / args.steps:8.3f} ms/step  {fl2 / t_ms / 1e9:7.2f} TFLOP/s", file=sys.stderr)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):

@@ -75,7 +75,8 @@ int yogo_bn_bwd_rows(int B, int HW, int* rows);
 int yogo_bn_bwd(const float* g, const float* z, float* dz, const float* mean, const float* invstd, const float* gamma,
                 float* dgamma, float* dbeta, float* part, float* sums, int B, int C, int HW, int training, float clip,
                 yogo_stream_t stream);
-int yogo_partials_reduce(const float* part, int rows, int N, float clip, float* out, yogo_stream_t stream);
+/* `part` is folded in place (used as scratch) */
+int yogo_partials_reduce(float* part, int rows, int N, float clip, float* out, yogo_stream_t stream);
 int yogo_channel_sum(const float* g, int B, int C, int HW, float clip, float* out, yogo_stream_t stream);
 
 /* ---- box decode: YOGO.forward, yogo/model.py:277-313 ------------------------------------------------------------------ */

@@ -265,8 +265,10 @@ def test_trainer_steps_match_oracle():
             assert abs(got[k2] - comps[k2]) < 2e-4 * abs(comps[k2]) + 1e-6
     now = model.state_dict()
     for k in names:
-        # Adam normalises the step to ~lr, so a parameter moves by <= ~2*lr; compare the moves
-        assert float((now[k].cpu() - sd[k]).abs().max()) < 3e-5, k
+        # model.5.0.bias feeds straight into BatchNorm: its gradient is mathematically zero, what is computed is
+        # rounding noise, and Adam turns noise into +-lr steps (in the reference too) -- only bound its drift
+        tol = 2.5 * 2 * 3e-4 if k == "model.5.0.bias" else 3e-5
+        assert float((now[k].cpu() - sd[k]).abs().max()) < tol, k
     for k, v in sd.items():
         if "running" in k:
             torch.testing.assert_close(now[k].cpu(), v, rtol=1e-4, atol=1e-4)

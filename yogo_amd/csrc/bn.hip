@@ -270,8 +270,24 @@ extern "C" int yogo_bn_bwd(const float* g, const float* z, float* dz, const floa
   return YOGO_OK;
 }
 
-extern "C" int yogo_partials_reduce(const float* part, int rows, int N, float clip, float* out, hipStream_t stream) {
+// in-place fold: row s (s < S) <- sum of rows s, s+S, s+2S, ...; each element is read and written by one thread only
+__global__ __launch_bounds__(256) void partials_fold_kernel(float* __restrict__ part, int rows, int N, int S) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int s = blockIdx.y;
+  if (j >= N) return;
+  double acc = 0.0;
+  for (int r = s; r < rows; r += S) acc += (double)part[(size_t)r * N + j];
+  part[(size_t)s * N + j] = (float)acc;
+}
+
+// out[j] = clamp(sum_r part[r][j]).  NOTE: `part` is used as scratch (folded in place) when rows > 64.
+extern "C" int yogo_partials_reduce(float* part, int rows, int N, float clip, float* out, hipStream_t stream) {
   YOGO_CHECK_ARG(part && out && rows > 0 && N > 0, "partials_reduce: bad arguments");
+  if (rows > 64) {
+    const int S = 64;
+    hipLaunchKernelGGL(partials_fold_kernel, dim3(cdiv(N, 256), S), dim3(256), 0, stream, part, rows, N, S);
+    rows = S;
+  }
   hipLaunchKernelGGL(partials_reduce_kernel, dim3(cdiv(N, 256)), dim3(256), 0, stream, part, rows, N, clip, out);
   YOGO_CHECK_LAUNCH("partials_reduce");
   return YOGO_OK;

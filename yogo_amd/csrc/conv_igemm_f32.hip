@@ -38,7 +38,7 @@ struct IgemmParams {
   int toff[MAX_TAPS];       // LDS offset of tap t relative to tile origin
   int dy_min, dx_min, span_y, span_x;
   int ncb, TW, tiles_per_band;
-  int CK, nchunk, rows_max, LWp, chs, ldsw_off;
+  int CK, ck_shift, nchunk, rows_max, LWp, chs, ldsw_off, lds_dummy;
   int act;                  // forward activation fused in epilogue
   int ref_act;              // dgrad: activation whose derivative multiplies the result
 };
@@ -107,56 +107,113 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const IgemmParam
   const float* inb = p.in + (size_t)b * p.K * p.IH * p.IW;
   const int aoff = half * BM + l31;
 
+  // tap offsets live in one VGPR (lane t holds toff[t]); v_readlane turns them into scalars without touching lgkmcnt
+  const int toff_lane = p.toff[min(lane, MAX_TAPS - 1)];
+  const int hs_shift = p.ck_shift - 1;          // log2(k-steps per tap)
+  const int hs_mask = (p.CK >> 1) - 1;
+  const int nsteps = p.T * (p.CK >> 1);
+
+  // operands of k-step s: A = weights[tap][2 channels][BM], B = input tile shifted by the tap
+#define IGEMM_LOAD(AV, BV, S)                                                                     \
+  {                                                                                               \
+    const int s_ = min((S), nsteps - 1);                                                          \
+    const int t_ = s_ >> hs_shift;                                                                \
+    const int kk_ = (s_ & hs_mask) << 1;                                                          \
+    const float* wI_ = ldsI + __builtin_amdgcn_readlane(toff_lane, t_) + kk_ * p.chs;             \
+    const float* wW_ = ldsW + (t_ * p.CK + kk_) * BM + aoff;                                      \
+    _Pragma("unroll") for (int mb = 0; mb < MW; ++mb) AV[mb] = wW_[mb * 32];                      \
+    _Pragma("unroll") for (int n = 0; n < NW; ++n) BV[n] = wI_[boff[n]];                          \
+  }
+#define IGEMM_MFMA(AV, BV)                                                                        \
+  _Pragma("unroll") for (int mb = 0; mb < MW; ++mb)                                               \
+  _Pragma("unroll") for (int n = 0; n < NW; ++n)                                                  \
+    acc[mb][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[mb], BV[n], acc[mb][n], 0, 0, 0);
+
   for (int c = 0; c < p.nchunk; ++c) {
     const int k0 = c * p.CK;
     __syncthreads();
-    // ---- stage the input tile: CK channels x rows_in rows x lw columns, zero padded ------------------
+    // ---- stage the input tile: CK channels x rows_in rows x lw columns, zero padded.  Each wavefront takes four
+    //      (channel,row) lines per pass; loads are unconditional (clamped address + select) and issued together,
+    //      stores of out-of-range lines go to a dummy LDS word: no branches, four loads in flight per lane. ---------
     const int ncr = p.CK * rows_in;
-    for (int cr = wave; cr < ncr; cr += 4) {
-      const int kc = cr / rows_in;
-      const int r = cr - kc * rows_in;
-      const int k = k0 + kc;
-      const int iy = iy0 + r;
-      const bool rowok = (k < p.K) && (iy >= 0) && (iy < p.IH);
-      const float* src = inb + ((size_t)(rowok ? k : 0) * p.IH + (rowok ? iy : 0)) * p.IW;
-      float* dst = ldsI + kc * p.chs + r * p.LWp;
+    for (int cb0 = wave * 4; cb0 < ncr; cb0 += 16) {
+      int src[4], dst[4];
+      bool rok[4], wr[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int cr = cb0 + u;
+        const int crc = min(cr, ncr - 1);
+        const int kc = crc / rows_in;
+        const int r = crc - kc * rows_in;
+        const int k = k0 + kc;
+        const int iy = iy0 + r;
+        wr[u] = cr < ncr;
+        rok[u] = wr[u] && (k < p.K) && (iy >= 0) && (iy < p.IH);
+        src[u] = ((rok[u] ? k : 0) * p.IH + (rok[u] ? iy : 0)) * p.IW + ix0;
+        dst[u] = kc * p.chs + r * p.LWp;
+      }
       for (int x = lane; x < lw; x += 64) {
         const int ix = ix0 + x;
-        float v = 0.f;
-        if (rowok && ix >= 0 && ix < p.IW) v = src[ix];
-        dst[x] = v;
+        const bool xok = ix >= 0 && ix < p.IW;
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool ok = rok[u] && xok;
+          const float ld = inb[ok ? src[u] + x : 0];
+          v[u] = ok ? ld : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) smem[wr[u] ? dst[u] + x : p.lds_dummy] = v[u];
       }
     }
-    // ---- stage the weight slice [T][CK][BM] ------------------------------------------------------------
-    const int nW4 = p.T * p.CK * (BM / 4);
-    for (int e = tid; e < nW4; e += 256) {
-      const int tk = e / (BM / 4);
-      const int m4 = e - tk * (BM / 4);
-      const int t = tk / p.CK;
-      const int kk = tk - t * p.CK;
-      const float4* src = reinterpret_cast<const float4*>(p.wp + ((size_t)(t * p.Kpad + k0 + kk) * p.Mpad + m0)) + m4;
-      reinterpret_cast<float4*>(ldsW)[e] = *src;
+    // ---- stage the weight slice [T][CK][BM]: rows of BM floats, four float4 loads in flight per lane --------------
+    {
+      constexpr int Q = BM / 4;     // float4 per row
+      constexpr int RPP = 256 / Q;  // rows per pass
+      const int m4 = tid % Q, r0 = tid / Q;
+      const int nrows = p.T * p.CK;
+      const float* wbase = p.wp + (size_t)k0 * p.Mpad + m0 + m4 * 4;
+      const size_t tstride = (size_t)p.Kpad * p.Mpad;
+#define W_SRC(R) (wbase + (size_t)((R) >> p.ck_shift) * tstride + (size_t)((R) & (p.CK - 1)) * p.Mpad)
+#define W_DST(R) (smem + ((R) < nrows ? p.ldsw_off + ((R) * Q + m4) * 4 : p.lds_dummy))
+      for (int rb = r0; rb < nrows; rb += RPP * 4) {
+        const int ra = rb, rb1 = rb + RPP, rc = rb + 2 * RPP, rd = rb + 3 * RPP;
+        const float4 va = *reinterpret_cast<const float4*>(W_SRC(min(ra, nrows - 1)));
+        const float4 vb = *reinterpret_cast<const float4*>(W_SRC(min(rb1, nrows - 1)));
+        const float4 vc = *reinterpret_cast<const float4*>(W_SRC(min(rc, nrows - 1)));
+        const float4 vd = *reinterpret_cast<const float4*>(W_SRC(min(rd, nrows - 1)));
+        __builtin_amdgcn_sched_barrier(0);
+        *reinterpret_cast<float4*>(W_DST(ra)) = va;
+        *reinterpret_cast<float4*>(W_DST(rb1)) = vb;
+        *reinterpret_cast<float4*>(W_DST(rc)) = vc;
+        *reinterpret_cast<float4*>(W_DST(rd)) = vd;
+      }
+#undef W_SRC
+#undef W_DST
     }
     __syncthreads();
-    // ---- MFMA over (tap, channel pair) -----------------------------------------------------------------
-    for (int t = 0; t < p.T; ++t) {
-      const float* wI = ldsI + p.toff[t];
-      const float* wW = ldsW + t * p.CK * BM + aoff;
-#pragma unroll 2
-      for (int kk = 0; kk < p.CK; kk += 2) {
-        float av[MW], bv[NW];
-#pragma unroll
-        for (int mb = 0; mb < MW; ++mb) av[mb] = wW[kk * BM + mb * 32];
-#pragma unroll
-        for (int n = 0; n < NW; ++n) bv[n] = wI[kk * p.chs + boff[n]];
-#pragma unroll
-        for (int mb = 0; mb < MW; ++mb)
-#pragma unroll
-          for (int n = 0; n < NW; ++n)
-            acc[mb][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mb], bv[n], acc[mb][n], 0, 0, 0);
+    // ---- MFMA over k-steps (tap x channel pair), software pipelined with two operand sets: the LDS reads of step
+    //      s+1 are issued before the MW*NW MFMAs (>= 256 cycles) of step s, so LDS latency never stalls the pipe. ----
+    {
+      float a0[MW], b0[NW], a1[MW], b1[NW];
+      IGEMM_LOAD(a0, b0, 0);
+      int s = 0;
+      for (; s + 1 < nsteps; s += 2) {
+        IGEMM_LOAD(a1, b1, s + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        IGEMM_MFMA(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        IGEMM_LOAD(a0, b0, s + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        IGEMM_MFMA(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
       }
+      if (s < nsteps) IGEMM_MFMA(a0, b0);
     }
   }
+#undef IGEMM_LOAD
+#undef IGEMM_MFMA
 
   // ---- epilogue -----------------------------------------------------------------------------------------
   const size_t plane = (size_t)p.OH * p.OW;
@@ -291,10 +348,10 @@ bool plan_tiling(const Geom& g, int Kpad, int MW, int NW, Tiling* out) {
     const int nrow_lat = min(g.OHt, 1 + cdiv(PT - 1, bw_min));
     const int rows_max = (nrow_lat - 1) * g.a + span_y;
     const int chs = rows_max * LWp;
-    for (int CK : {16, 8, 4, 2}) {
+    for (int CK : {8, 4, 2}) {
       if (Kpad % CK) continue;
       const int ldsw_off = round_up(CK * chs, 4);
-      const int bytes = max((ldsw_off + g.T * CK * BM) * 4, 4 * BM * 2 * 4);
+      const int bytes = max((ldsw_off + g.T * CK * BM + 4) * 4, 4 * BM * 2 * 4);
       if (bytes > IGEMM_LDS_BUDGET) continue;
       Tiling t{ncb, TW, cdiv(g.OHt * TW, PT), CK, rows_max, LWp, chs, ldsw_off, bytes};
       if (!have || (best.CK < want_ck && CK > best.CK)) {
@@ -334,8 +391,9 @@ int launch_igemm(const Geom& g, const float* in, const float* wp, const float* b
   }
   p.dy_min = dy_min; p.dx_min = dx_min; p.span_y = dy_max - dy_min + 1; p.span_x = dx_max - dx_min + 1;
   p.ncb = tl.ncb; p.TW = tl.TW; p.tiles_per_band = tl.tiles_per_band;
-  p.CK = tl.CK; p.nchunk = Kpad / tl.CK; p.rows_max = tl.rows_max; p.LWp = tl.LWp; p.chs = tl.chs;
+  p.CK = tl.CK; p.ck_shift = tl.CK == 8 ? 3 : (tl.CK == 4 ? 2 : 1); p.nchunk = Kpad / tl.CK; p.rows_max = tl.rows_max; p.LWp = tl.LWp; p.chs = tl.chs;
   p.ldsw_off = tl.ldsw_off;
+  p.lds_dummy = tl.ldsw_off + g.T * tl.CK * 32 * MW;
   for (int t = 0; t < g.T; ++t) p.toff[t] = (g.dy[t] - dy_min) * tl.LWp + (g.dx[t] - dx_min);
   p.act = act; p.ref_act = ref_act;
 

@@ -57,6 +57,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradParams p) 
   const int u_end = min(p.units, u_begin + p.units_per_split);
   const size_t gplane = (size_t)p.OH * p.OW, xplane = (size_t)p.IH * p.IW;
   const int pad_y = -p.dy[0], pad_x = -p.dx[0];  // taps are ordered kh,kw ascending: dy[0] = -pad
+  int toff[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) toff[t] = (p.dy[t] + pad_y) * p.xp + (p.dx[t] + pad_x);
 
   for (int u = u_begin; u < u_end; ++u) {
     const int cw = u % p.nchunk_w;
@@ -73,31 +76,57 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradParams p) 
     const int iy0 = oy * p.stride - pad_y;
 
     __syncthreads();
-    // ---- stage g[MBW*32][wce] ------------------------------------------------------------------------------
+    // ---- stage g[MBW*32][wce]: one row segment (<= 64 floats) per wavefront instruction, 8 loads in flight ------
     {
       const float* gb = p.g + ((size_t)b * p.M) * gplane + (size_t)oy * p.OW + ox0;
-      const int total = MBW * 32 * wce;
-      for (int e = tid; e < total; e += 256) {
-        const int r = e / wce, c = e - r * wce;
-        const int m = m0 + r;
-        float v = 0.f;
-        if (m < p.M && c < wc) v = gb[(size_t)m * gplane + c];
-        ldsG[r * p.gp + c] = v;
+      const bool cok = lane < wc;       // real pixel (else zero padding up to wce)
+      const bool cwr = lane < wce;
+      for (int r8 = wave * 8; r8 < MBW * 32; r8 += 32) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int m = m0 + r8 + u;
+          const bool ok = cok && (m < p.M);
+          const float ld = gb[ok ? (size_t)m * gplane + lane : 0];
+          v[u] = ok ? ld : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (cwr) ldsG[(r8 + u) * p.gp + lane] = v[u];
       }
     }
-    // ---- stage x[NBW*32][xrows][xw] ------------------------------------------------------------------------
+    // ---- stage x[NBW*32][xrows][xw]: (channel,row) lines, 4 per wavefront pass ---------------------------------
     {
       const float* xb = p.x + ((size_t)b * p.N) * xplane;
-      const int per_ch = p.xrows * xw;
-      const int total = NBW * 32 * per_ch;
-      for (int e = tid; e < total; e += 256) {
-        const int ch = e / per_ch;
-        const int rem2 = e - ch * per_ch;
-        const int r = rem2 / xw, c = rem2 - r * xw;
-        const int n = n0 + ch, iy = iy0 + r, ix = ix0 + c;
-        float v = 0.f;
-        if (n < p.N && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) v = xb[(size_t)n * xplane + (size_t)iy * p.IW + ix];
-        ldsX[ch * xcs + r * p.xp + c] = v;
+      const int nlines = NBW * 32 * p.xrows;
+      for (int l4 = wave * 4; l4 < nlines; l4 += 16) {
+        int src[4], dst[4];
+        bool lok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int ln = l4 + u;                 // nlines is a multiple of 16: always in range
+          const int ch = ln / p.xrows;
+          const int r = ln - ch * p.xrows;
+          const int n = n0 + ch, iy = iy0 + r;
+          lok[u] = (n < p.N) && (iy >= 0) && (iy < p.IH);
+          src[u] = lok[u] ? (n * p.IH + iy) * p.IW + ix0 : 0;
+          dst[u] = ch * xcs + r * p.xp;
+        }
+        for (int c = lane; c < xw; c += 64) {
+          const int ix = ix0 + c;
+          const bool xok = ix >= 0 && ix < p.IW;
+          float v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const bool ok = lok[u] && xok;
+            const float ld = xb[ok ? src[u] + c : 0];
+            v[u] = ok ? ld : 0.f;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) ldsX[dst[u] + c] = v[u];
+        }
       }
     }
     __syncthreads();
@@ -107,17 +136,39 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradParams p) 
       for (int c = 0; c < wc; ++c) s += ldsG[tid * p.gp + c];
       bsum += s;
     }
-    // ---- MFMA over pixel pairs ---------------------------------------------------------------------------------
-    const int npair = wce >> 1;
-    const float* ga = ldsG + (mb * 32 + l31) * p.gp + half;
-    const float* xa = ldsX + (nb * 32 + l31) * xcs + half * p.stride;
-    for (int kp = ks; kp < npair; kp += KS) {
-      const float av = ga[2 * kp];
-      float bv[T];
-#pragma unroll
-      for (int t = 0; t < T; ++t) bv[t] = xa[(p.dy[t] + pad_y) * p.xp + (p.dx[t] + pad_x) + 2 * kp * p.stride];
-#pragma unroll
-      for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
+    // ---- MFMA over pixel pairs, two operand sets: the LDS reads of the next pair are issued before the T MFMAs
+    //      of the current one ---------------------------------------------------------------------------------------
+    {
+      const int npair = wce >> 1;
+      const int cnt = (npair - ks + KS - 1) / KS;  // pairs ks, ks+KS, ...
+      const float* ga = ldsG + (mb * 32 + l31) * p.gp + half;
+      const float* xa = ldsX + (nb * 32 + l31) * xcs + half * p.stride;
+#define WG_LOAD(AV, BV, I)                                                              \
+  {                                                                                     \
+    const int kp_ = ks + min((I), cnt - 1) * KS;                                        \
+    AV = ga[2 * kp_];                                                                   \
+    _Pragma("unroll") for (int t = 0; t < T; ++t) BV[t] = xa[toff[t] + 2 * kp_ * p.stride]; \
+  }
+#define WG_MFMA(AV, BV) \
+  _Pragma("unroll") for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV, BV[t], acc[t], 0, 0, 0);
+      if (cnt > 0) {
+        float a0, a1, b0[T], b1[T];
+        WG_LOAD(a0, b0, 0);
+        int i = 0;
+        for (; i + 1 < cnt; i += 2) {
+          WG_LOAD(a1, b1, i + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          WG_MFMA(a0, b0);
+          __builtin_amdgcn_sched_barrier(0);
+          WG_LOAD(a0, b0, i + 2);
+          __builtin_amdgcn_sched_barrier(0);
+          WG_MFMA(a1, b1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (i < cnt) WG_MFMA(a0, b0);
+      }
+#undef WG_LOAD
+#undef WG_MFMA
     }
   }
 
