@@ -16,6 +16,7 @@
 // fp32 MFMA is an exact k-ordered fmaf chain (MI355X guide), so results differ from the CPU reference only
 // by summation order.
 #include "common.h"
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -41,6 +42,8 @@ struct IgemmParams {
   int CK, ck_shift, nchunk, rows_max, LWp, chs, ldsw_off, lds_dummy;
   int act;                  // forward activation fused in epilogue
   int ref_act;              // dgrad: activation whose derivative multiplies the result
+  int pf;                   // 1: register-prefetch pipeline (shape fits its capacity), 0: direct staging
+  int dbg;                  // experiments only (YOGO_IGEMM_DBG): 1 = stage only chunk 0, 2 = skip MFMA
 };
 
 template <int MW, int NW>
@@ -129,13 +132,108 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const IgemmParam
   _Pragma("unroll") for (int n = 0; n < NW; ++n)                                                  \
     acc[mb][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[mb], BV[n], acc[mb][n], 0, 0, 0);
 
+  // ---- global -> register prefetch of one K-chunk (async-STAGE split): issued before the MFMA loop of the previous
+  //      chunk, committed to LDS after it, so the global-memory latency hides under ~9k cycles of matrix work.
+  //      Capacity per wavefront: PFL (channel,row) lines x NXI 64-wide column groups; per lane: NQ weight float4.
+  constexpr int PFL = 8, NXI = (MW == 4 ? 2 : 5), NQ = 5;  // the 128-accumulator config has the fewest spare VGPRs
+  constexpr int Q = BM / 4, RPP = 256 / Q;
+  const int m4 = tid % Q, r0 = tid / Q;
+  const int nrows = p.T * p.CK;
+  const size_t tstride = (size_t)p.Kpad * p.Mpad;
+  const int ncr = p.CK * rows_in;
+  const int nlw = (ncr - wave + 3) >> 2;  // lines owned by this wavefront: wave, wave+4, ...
+  const int nxi = (lw + 63) >> 6;
+  float pin[PFL][NXI];
+  float4 pw0, pw1, pw2, pw3, pw4;  // named (not an array): keeps them in registers
+  static_assert(NQ == 5, "PF_W_* macros are written for five weight registers");
+#define PF_W_LOAD(V, QI)                                                                              \
+  {                                                                                                   \
+    const int rw_ = min(r0 + (QI) * RPP, nrows - 1);                                                  \
+    V = *reinterpret_cast<const float4*>(wbase_ + (size_t)(rw_ >> p.ck_shift) * tstride +             \
+                                         (size_t)(rw_ & (p.CK - 1)) * p.Mpad);                        \
+  }
+#define PF_W_STORE(V, QI)                                                                             \
+  {                                                                                                   \
+    const int rw_ = r0 + (QI) * RPP;                                                                  \
+    *reinterpret_cast<float4*>(smem + (rw_ < nrows ? p.ldsw_off + (rw_ * Q + m4) * 4 : p.lds_dummy)) = V; \
+  }
+#define PF_ISSUE(K0)                                                                                              \
+  {                                                                                                               \
+    const float* wbase_ = p.wp + (size_t)(K0) * p.Mpad + m0 + m4 * 4;                                             \
+    PF_W_LOAD(pw0, 0) PF_W_LOAD(pw1, 1) PF_W_LOAD(pw2, 2) PF_W_LOAD(pw3, 3) PF_W_LOAD(pw4, 4)                     \
+    _Pragma("unroll") for (int l = 0; l < PFL; ++l) {                                                             \
+      const int line_ = min(wave + 4 * l, ncr - 1);                                                               \
+      const int kc_ = line_ / rows_in;                                                                            \
+      const int r_ = line_ - kc_ * rows_in;                                                                       \
+      const int k_ = (K0) + kc_, iy_ = iy0 + r_;                                                                  \
+      const bool rok_ = (l < nlw) && (k_ < p.K) && (iy_ >= 0) && (iy_ < p.IH);                                    \
+      const int src_ = ((rok_ ? k_ : 0) * p.IH + (rok_ ? iy_ : 0)) * p.IW + ix0;                                  \
+      _Pragma("unroll") for (int xi = 0; xi < NXI; ++xi) {                                                        \
+        const int x_ = lane + 64 * xi;                                                                            \
+        const int ix_ = ix0 + x_;                                                                                 \
+        const bool ok_ = rok_ && (x_ < lw) && (ix_ >= 0) && (ix_ < p.IW);                                         \
+        pin[l][xi] = inb[ok_ ? src_ + x_ : 0];  /* raw value; zero padding is applied at commit time */          \
+      }                                                                                                           \
+    }                                                                                                             \
+  }
+#define PF_COMMIT(K0)                                                                                             \
+  {                                                                                                               \
+    PF_W_STORE(pw0, 0) PF_W_STORE(pw1, 1) PF_W_STORE(pw2, 2) PF_W_STORE(pw3, 3) PF_W_STORE(pw4, 4)                \
+    _Pragma("unroll") for (int l = 0; l < PFL; ++l) {                                                             \
+      const int line_ = min(wave + 4 * l, ncr - 1);                                                               \
+      const int kc_ = line_ / rows_in;                                                                            \
+      const int r_ = line_ - kc_ * rows_in;                                                                       \
+      const int k_ = (K0) + kc_, iy_ = iy0 + r_;                                                                  \
+      const bool rok_ = (k_ < p.K) && (iy_ >= 0) && (iy_ < p.IH);                                                 \
+      const int dst_ = kc_ * p.chs + r_ * p.LWp;                                                                  \
+      _Pragma("unroll") for (int xi = 0; xi < NXI; ++xi) {                                                        \
+        const int x_ = lane + 64 * xi;                                                                            \
+        const int ix_ = ix0 + x_;                                                                                 \
+        const bool ok_ = rok_ && (ix_ >= 0) && (ix_ < p.IW);                                                      \
+        smem[(l < nlw && x_ < lw) ? dst_ + x_ : p.lds_dummy] = ok_ ? pin[l][xi] : 0.f;                            \
+      }                                                                                                           \
+    }                                                                                                             \
+  }
+#define IGEMM_COMPUTE()                                     \
+  {                                                         \
+    float a0[MW], b0[NW], a1[MW], b1[NW];                   \
+    IGEMM_LOAD(a0, b0, 0);                                  \
+    int s = 0;                                              \
+    for (; s + 1 < nsteps; s += 2) {                        \
+      IGEMM_LOAD(a1, b1, s + 1);                            \
+      __builtin_amdgcn_sched_barrier(0);                    \
+      IGEMM_MFMA(a0, b0);                                   \
+      __builtin_amdgcn_sched_barrier(0);                    \
+      IGEMM_LOAD(a0, b0, s + 2);                            \
+      __builtin_amdgcn_sched_barrier(0);                    \
+      IGEMM_MFMA(a1, b1);                                   \
+      __builtin_amdgcn_sched_barrier(0);                    \
+    }                                                       \
+    if (s < nsteps) IGEMM_MFMA(a0, b0);                     \
+  }
+
+  if (p.pf) {
+    PF_ISSUE(0);
+    PF_COMMIT(0);
+    __syncthreads();
+    for (int c = 0; c < p.nchunk; ++c) {
+      const bool more = c + 1 < p.nchunk;
+      if (more && !(p.dbg & 1)) PF_ISSUE((c + 1) * p.CK);
+      if (!(p.dbg & 2)) IGEMM_COMPUTE();
+      __syncthreads();
+      if (more && !(p.dbg & 1)) {
+        PF_COMMIT((c + 1) * p.CK);
+        __syncthreads();
+      }
+    }
+  } else
   for (int c = 0; c < p.nchunk; ++c) {
     const int k0 = c * p.CK;
     __syncthreads();
+    if (!((p.dbg & 1) && c > 0)) {
     // ---- stage the input tile: CK channels x rows_in rows x lw columns, zero padded.  Each wavefront takes four
     //      (channel,row) lines per pass; loads are unconditional (clamped address + select) and issued together,
     //      stores of out-of-range lines go to a dummy LDS word: no branches, four loads in flight per lane. ---------
-    const int ncr = p.CK * rows_in;
     for (int cb0 = wave * 4; cb0 < ncr; cb0 += 16) {
       int src[4], dst[4];
       bool rok[4], wr[4];
@@ -169,12 +267,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const IgemmParam
     }
     // ---- stage the weight slice [T][CK][BM]: rows of BM floats, four float4 loads in flight per lane --------------
     {
-      constexpr int Q = BM / 4;     // float4 per row
-      constexpr int RPP = 256 / Q;  // rows per pass
-      const int m4 = tid % Q, r0 = tid / Q;
-      const int nrows = p.T * p.CK;
       const float* wbase = p.wp + (size_t)k0 * p.Mpad + m0 + m4 * 4;
-      const size_t tstride = (size_t)p.Kpad * p.Mpad;
 #define W_SRC(R) (wbase + (size_t)((R) >> p.ck_shift) * tstride + (size_t)((R) & (p.CK - 1)) * p.Mpad)
 #define W_DST(R) (smem + ((R) < nrows ? p.ldsw_off + ((R) * Q + m4) * 4 : p.lds_dummy))
       for (int rb = r0; rb < nrows; rb += RPP * 4) {
@@ -192,26 +285,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const IgemmParam
 #undef W_SRC
 #undef W_DST
     }
+    }
     __syncthreads();
     // ---- MFMA over k-steps (tap x channel pair), software pipelined with two operand sets: the LDS reads of step
     //      s+1 are issued before the MW*NW MFMAs (>= 256 cycles) of step s, so LDS latency never stalls the pipe. ----
-    {
-      float a0[MW], b0[NW], a1[MW], b1[NW];
-      IGEMM_LOAD(a0, b0, 0);
-      int s = 0;
-      for (; s + 1 < nsteps; s += 2) {
-        IGEMM_LOAD(a1, b1, s + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        IGEMM_MFMA(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        IGEMM_LOAD(a0, b0, s + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        IGEMM_MFMA(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (s < nsteps) IGEMM_MFMA(a0, b0);
-    }
+    if (!(p.dbg & 2)) IGEMM_COMPUTE();
   }
+#undef PF_ISSUE
+#undef PF_W_LOAD
+#undef PF_W_STORE
+#undef PF_COMMIT
+#undef IGEMM_COMPUTE
 #undef IGEMM_LOAD
 #undef IGEMM_MFMA
 
@@ -317,13 +401,18 @@ struct Geom {
   int dy[MAX_TAPS], dx[MAX_TAPS];
 };
 
-int pick_mw(int M) { return M <= 32 ? 1 : (M <= 64 ? 2 : 4); }
-int pick_nw(int mw) { return mw == 4 ? 2 : 4; }
+int igemm_cfg() {  // experiments: YOGO_IGEMM_CFG=1 -> 64x(2x32)-pixel tiles for wide layers (3 workgroups per CU)
+  static int cfg = -1;
+  if (cfg < 0) { const char* e = getenv("YOGO_IGEMM_CFG"); cfg = e ? atoi(e) : 0; }
+  return cfg;
+}
+int pick_mw(int M) { return M <= 32 ? 1 : ((M <= 64 || igemm_cfg() == 1) ? 2 : 4); }
+int pick_nw(int mw, int M) { (void)M; return mw == 1 ? 4 : 2; }
 int kpad_of(int K) { return K >= 16 ? round_up(K, 16) : round_up(K, 2); }
 int mpad_of(int M) { return round_up(M, 32 * pick_mw(M)); }
 
 struct Tiling {
-  int ncb, TW, tiles_per_band, CK, rows_max, LWp, chs, ldsw_off, lds_bytes;
+  int ncb, TW, tiles_per_band, CK, rows_max, LWp, chs, ldsw_off, lds_bytes, pf;
 };
 
 bool plan_tiling(const Geom& g, int Kpad, int MW, int NW, Tiling* out) {
@@ -336,9 +425,10 @@ bool plan_tiling(const Geom& g, int Kpad, int MW, int NW, Tiling* out) {
     dx_max = max(dx_max, g.dx[t]);
   }
   const int span_y = dy_max - dy_min + 1, span_x = dx_max - dx_min + 1;
-  const int want_ck = min(8, Kpad);
+  // prefetch capacity of the kernel (PFL lines x NXI column groups per wavefront, NQ weight float4 per lane)
+  const int PFL = 8, NXI = (MW == 4 ? 2 : 5), NQ = 5, RPP = 256 / (BM / 4);
   Tiling best{};
-  bool have = false;
+  int best_score = -1;
   for (int ncb = 1; ncb <= 16 && ncb <= g.OWt; ++ncb) {
     const int TW = cdiv(g.OWt, ncb);
     const int bw_min = g.OWt - (cdiv(g.OWt, TW) - 1) * TW;
@@ -353,16 +443,16 @@ bool plan_tiling(const Geom& g, int Kpad, int MW, int NW, Tiling* out) {
       const int ldsw_off = round_up(CK * chs, 4);
       const int bytes = max((ldsw_off + g.T * CK * BM + 4) * 4, 4 * BM * 2 * 4);
       if (bytes > IGEMM_LDS_BUDGET) continue;
-      Tiling t{ncb, TW, cdiv(g.OHt * TW, PT), CK, rows_max, LWp, chs, ldsw_off, bytes};
-      if (!have || (best.CK < want_ck && CK > best.CK)) {
-        best = t;
-        have = true;
+      const bool pf = cdiv(CK * rows_max, 4) <= PFL && cdiv(LW, 64) <= NXI && cdiv(g.T * CK, RPP) <= NQ;
+      // score: prefetch-capable first, then deeper chunks, then fewer column bands (less halo)
+      const int score = (pf ? 1000 : 0) + CK * 10 - ncb;
+      if (score > best_score) {
+        best_score = score;
+        best = Tiling{ncb, TW, cdiv(g.OHt * TW, PT), CK, rows_max, LWp, chs, ldsw_off, bytes, pf ? 1 : 0};
       }
-      break;  // largest CK that fits for this ncb
     }
-    if (have && best.CK >= want_ck) break;
   }
-  if (!have) return false;
+  if (best_score < 0) return false;
   *out = best;
   return true;
 }
@@ -370,7 +460,7 @@ bool plan_tiling(const Geom& g, int Kpad, int MW, int NW, Tiling* out) {
 int launch_igemm(const Geom& g, const float* in, const float* wp, const float* bias, float* out, float* out_pre,
                  const float* act_ref, int ref_act, const float* chan_scale, float* stats_part, int act,
                  hipStream_t stream, int* stats_rows_out) {
-  const int MW = pick_mw(g.M), NW = pick_nw(MW);
+  const int MW = pick_mw(g.M), NW = pick_nw(MW, g.M);
   const int Kpad = kpad_of(g.K), Mpad = mpad_of(g.M);
   Tiling tl;
   if (!plan_tiling(g, Kpad, MW, NW, &tl)) {
@@ -395,9 +485,18 @@ int launch_igemm(const Geom& g, const float* in, const float* wp, const float* b
   p.ldsw_off = tl.ldsw_off;
   p.lds_dummy = tl.ldsw_off + g.T * tl.CK * 32 * MW;
   for (int t = 0; t < g.T; ++t) p.toff[t] = (g.dy[t] - dy_min) * tl.LWp + (g.dx[t] - dx_min);
-  p.act = act; p.ref_act = ref_act;
+  p.act = act; p.ref_act = ref_act; p.pf = tl.pf;
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("YOGO_IGEMM_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
 
   dim3 grid(tl.ncb * tl.tiles_per_band, Mpad / (32 * MW), g.B);
+  {
+    static int verbose = -1;
+    if (verbose < 0) verbose = getenv("YOGO_IGEMM_VERBOSE") ? 1 : 0;
+    if (verbose)
+      fprintf(stderr, "[igemm] K=%d M=%d in=%dx%d lat=%dx%d a=%d T=%d | MW=%d NW=%d ncb=%d TW=%d CK=%d rows=%d LW=%d lds=%d pf=%d grid=%ux%ux%u\n",
+              g.K, g.M, g.IH, g.IW, g.OHt, g.OWt, g.a, g.T, MW, NW, tl.ncb, tl.TW, tl.CK, tl.rows_max, tl.LWp, tl.lds_bytes,
+              tl.pf, grid.x, grid.y, grid.z);
+  }
   if (stats_rows_out) *stats_rows_out = g.B * (int)grid.x;
   if (g.B == 0 || g.OHt <= 0 || g.OWt <= 0) return YOGO_OK;
 #define LAUNCH(MW_, NW_)                                                                                    \
@@ -405,13 +504,13 @@ int launch_igemm(const Geom& g, const float* in, const float* wp, const float* b
     static bool attr_set = false;                                                                           \
     if (!attr_set) {                                                                                        \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32_kernel<MW_, NW_>),                  \
-                          hipFuncAttributeMaxDynamicSharedMemorySize, IGEMM_LDS_BUDGET);                    \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);                          \
       attr_set = true;                                                                                      \
     }                                                                                                       \
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<MW_, NW_>), grid, dim3(256), tl.lds_bytes, stream, p);        \
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<MW_, NW_>), grid, dim3(256), (p.dbg & 1024) ? 100 * 1024 : tl.lds_bytes, stream, p); \
   } while (0)
   if (MW == 4) LAUNCH(4, 2);
-  else if (MW == 2) LAUNCH(2, 4);
+  else if (MW == 2 && NW == 2) LAUNCH(2, 2);
   else LAUNCH(1, 4);
 #undef LAUNCH
   YOGO_CHECK_LAUNCH("conv_igemm_f32");
@@ -501,7 +600,7 @@ extern "C" int yogo_conv2d_fwd_stats_shape(int B, int Cin, int Cout, int IH, int
   g.OH = (IH + 2 * pad - ks) / stride + 1; g.OW = (IW + 2 * pad - ks) / stride + 1;
   g.OHt = g.OH; g.OWt = g.OW; g.osy = g.osx = 1; g.a = stride; g.T = ks * ks;
   for (int t = 0; t < g.T; ++t) { g.dy[t] = t / ks - pad; g.dx[t] = t % ks - pad; }
-  const int MW = pick_mw(Cout), NW = pick_nw(MW);
+  const int MW = pick_mw(Cout), NW = pick_nw(MW, Cout);
   Tiling tl;
   if (!plan_tiling(g, kpad_of(Cin), MW, NW, &tl)) {
     yogo_set_error("conv2d_fwd_stats_shape: no tiling");
