@@ -59,15 +59,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const IgemmParam
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31;
   const int half = lane >> 5;
-  const int b = blockIdx.z;
-  const int m0 = blockIdx.y * BM;
-  const int cb = blockIdx.x / p.tiles_per_band;
-  const int tb = blockIdx.x - cb * p.tiles_per_band;
+  // XCD-aware block remap (bijective): hardware deals consecutive block ids round-robin over the 8 XCDs; give each XCD a
+  // contiguous run of (image, tile) work so that vertically adjacent tiles -- which share halo rows -- hit the same L2.
+  const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
+  const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const unsigned xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
+  const unsigned widx = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+  const int bx = widx % gridDim.x;
+  const int by = (widx / gridDim.x) % gridDim.y;
+  const int b = widx / (gridDim.x * gridDim.y);
+  const int m0 = by * BM;
+  const int cb = bx / p.tiles_per_band;
+  const int tb = bx - cb * p.tiles_per_band;
   const int j0 = cb * p.TW;
   const int bw = min(p.TW, p.OWt - j0);
   const int NPb = p.OHt * bw;
   const int p0 = tb * PT;
-  const size_t part_row = (size_t)(b * gridDim.x + blockIdx.x);
+  const size_t part_row = (size_t)(b * gridDim.x + bx);
 
   if (p0 >= NPb) {  // tile beyond a narrow last band: contributes nothing (uniform branch)
     if (p.stats_part != nullptr && tid < BM) {
