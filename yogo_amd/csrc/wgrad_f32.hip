@@ -22,33 +22,50 @@ struct WgradParams {
   const float* g;   // [B][M][OH][OW]  grad w.r.t. conv output
   float* slab;      // [nsplit*KS][T][Mpad][Npad]
   float* bias_part; // optional [nsplit][Mpad]
-  int B, N, M, Npad, Mpad, IH, IW, OH, OW, stride, T;
-  int dy[WG_MAX_TAPS], dx[WG_MAX_TAPS];  // tap offsets relative to oy*stride, ox*stride (i.e. kh - pad)
-  int nchunk_w, Wc;       // column chunks per row, max chunk width (even)
+  int B, N, M, Npad, Mpad, IH, IW, OH, OW, pad;
+  int nchunk_w, base_w, rem_w, wce;   // column chunks per row (balanced), staged (even, zero padded) chunk width
+  int xw, per_ch;                     // staged input columns per line, elements per channel (xrows * xw)
+  unsigned inv_wce, inv_xw, inv_pc;   // ceil(2^32 / d) magic numbers for the flattened tile indexing
   int units, units_per_split;
-  int gp, xp, xrows;      // LDS pitches (odd) and staged input rows per unit (3 or 1)
-  int x_off;              // float offset of the x tile in LDS
+  int gp, xp;                         // LDS pitches (odd: conflict-free channel-strided reads)
+  int x_off;                          // float offset of the x tile in LDS
+  int lds_dummy;                      // float offset of a scratch word (stores of padding lanes)
 };
 
-// MBW co-blocks x NBW ci-blocks x KS pixel-splits = 4 waves
-template <int MBW, int NBW, int KS, int T>
-__global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradParams p) {
+// One unit = one output row segment (<= WC pixels) of one image.  Per unit the workgroup stages g[MBW*32][wce] and
+// x[NBW*32][3][xw] in LDS and every wavefront runs wce/2 k-steps of T MFMAs on its (co-block, ci-block) pair.
+// The global loads of unit u+1 are issued into registers BEFORE the MFMA loop of unit u and committed to LDS after it
+// (async-STAGE split), so HBM/L2 latency hides under ~10k cycles of matrix work.
+// Wavefront jobs: MBW co-blocks x NBW ci-blocks x KS pixel-splits x TG tap rows (TG = 3 for a 3x3 kernel: each wavefront
+// owns the three taps of one kernel row, i.e. 3 accumulator tiles = 48 VGPRs, which leaves room for the prefetch registers
+// and lets 3 wavefronts share each SIMD).  MBW*NBW*KS = 4, so a workgroup is 12 wavefronts (3x3) or 4 (1x1).
+template <int MBW, int NBW, int KS, int T, int S>
+__global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_f32_kernel(const WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int TG = (T == 1) ? 1 : 3;                         // tap groups (kernel rows)
+  constexpr int TT = T / TG;                                   // taps per wavefront
+  constexpr int NT = 64 * MBW * NBW * KS * TG;                 // threads per workgroup
+  constexpr int XR = (T == 1) ? 1 : 3;
+  constexpr int WC = (S == 1) ? 64 : 32;                       // max staged chunk width
+  constexpr int XWMAX = (WC - 1) * S + ((T == 1) ? 1 : 3);
+  constexpr int NGQ = (MBW * 32 * WC + NT - 1) / NT;           // g elements per lane
+  constexpr int NXQ = (NBW * 32 * XR * XWMAX + NT - 1) / NT;   // x elements per lane
   float* ldsG = smem;            // [MBW*32][gp]
-  float* ldsX = smem + p.x_off;  // [NBW*32][xrows][xp]
+  float* ldsX = smem + p.x_off;  // [NBW*32][XR][xp]
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ks = wave % KS;
-  const int nb = (wave / KS) % NBW;
-  const int mb = wave / (KS * NBW);
+  const int tg = wave % TG;
+  const int ks = (wave / TG) % KS;
+  const int nb = (wave / (TG * KS)) % NBW;
+  const int mb = wave / (TG * KS * NBW);
   const int split = blockIdx.x;
   const int n0 = blockIdx.y * (NBW * 32);
   const int m0 = blockIdx.z * (MBW * 32);
-  const int xcs = p.xrows * p.xp;  // channel stride in the x tile
+  const int xcs = XR * p.xp;  // channel stride in the x tile
 
-  f32x16 acc[T];
+  f32x16 acc[TT];
 #pragma unroll
-  for (int t = 0; t < T; ++t)
+  for (int t = 0; t < TT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float bsum = 0.f;  // bias partial of row (m0 + tid), tid < MBW*32
@@ -56,131 +73,137 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradParams p) 
   const int u_begin = split * p.units_per_split;
   const int u_end = min(p.units, u_begin + p.units_per_split);
   const size_t gplane = (size_t)p.OH * p.OW, xplane = (size_t)p.IH * p.IW;
-  const int pad_y = -p.dy[0], pad_x = -p.dx[0];  // taps are ordered kh,kw ascending: dy[0] = -pad
-  int toff[T];
-#pragma unroll
-  for (int t = 0; t < T; ++t) toff[t] = (p.dy[t] + pad_y) * p.xp + (p.dx[t] + pad_x);
+  const int trow = tg * p.xp;  // this wavefront's kernel row inside the staged x tile; its taps are columns 0..TT-1
 
-  for (int u = u_begin; u < u_end; ++u) {
-    const int cw = u % p.nchunk_w;
-    const int rowid = u / p.nchunk_w;
-    const int oy = rowid % p.OH;
-    const int b = rowid / p.OH;
-    // balanced column chunks
-    const int base_w = p.OW / p.nchunk_w, rem = p.OW - base_w * p.nchunk_w;
-    const int ox0 = cw * base_w + min(cw, rem);
-    const int wc = base_w + (cw < rem ? 1 : 0);
-    const int wce = (wc + 1) & ~1;  // even number of pixels (zero padded)
-    const int ix0 = ox0 * p.stride - pad_x;
-    const int xw = (wce - 1) * p.stride + (T == 1 ? 1 : 3);
-    const int iy0 = oy * p.stride - pad_y;
+  const int gtotal = MBW * 32 * p.wce;
+  const int xtotal = NBW * 32 * p.per_ch;
+  float gq[NGQ], xq[NXQ];
 
-    __syncthreads();
-    // ---- stage g[MBW*32][wce]: one row segment (<= 64 floats) per wavefront instruction, 8 loads in flight ------
-    {
-      const float* gb = p.g + ((size_t)b * p.M) * gplane + (size_t)oy * p.OW + ox0;
-      const bool cok = lane < wc;       // real pixel (else zero padding up to wce)
-      const bool cwr = lane < wce;
-      for (int r8 = wave * 8; r8 < MBW * 32; r8 += 32) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int m = m0 + r8 + u;
-          const bool ok = cok && (m < p.M);
-          const float ld = gb[ok ? (size_t)m * gplane + lane : 0];
-          v[u] = ok ? ld : 0.f;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (cwr) ldsG[(r8 + u) * p.gp + lane] = v[u];
-      }
-    }
-    // ---- stage x[NBW*32][xrows][xw]: (channel,row) lines, 4 per wavefront pass ---------------------------------
-    {
-      const float* xb = p.x + ((size_t)b * p.N) * xplane;
-      const int nlines = NBW * 32 * p.xrows;
-      for (int l4 = wave * 4; l4 < nlines; l4 += 16) {
-        int src[4], dst[4];
-        bool lok[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int ln = l4 + u;                 // nlines is a multiple of 16: always in range
-          const int ch = ln / p.xrows;
-          const int r = ln - ch * p.xrows;
-          const int n = n0 + ch, iy = iy0 + r;
-          lok[u] = (n < p.N) && (iy >= 0) && (iy < p.IH);
-          src[u] = lok[u] ? (n * p.IH + iy) * p.IW + ix0 : 0;
-          dst[u] = ch * xcs + r * p.xp;
-        }
-        for (int c = lane; c < xw; c += 64) {
-          const int ix = ix0 + c;
-          const bool xok = ix >= 0 && ix < p.IW;
-          float v[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const bool ok = lok[u] && xok;
-            const float ld = xb[ok ? src[u] + c : 0];
-            v[u] = ok ? ld : 0.f;
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int u = 0; u < 4; ++u) ldsX[dst[u] + c] = v[u];
-        }
-      }
-    }
-    __syncthreads();
-    // ---- bias partial: row sums of the staged g tile --------------------------------------------------------
-    if (p.bias_part != nullptr && blockIdx.y == 0 && tid < MBW * 32) {
-      float s = 0.f;
-      for (int c = 0; c < wc; ++c) s += ldsG[tid * p.gp + c];
-      bsum += s;
-    }
-    // ---- MFMA over pixel pairs, two operand sets: the LDS reads of the next pair are issued before the T MFMAs
-    //      of the current one ---------------------------------------------------------------------------------------
-    {
-      const int npair = wce >> 1;
-      const int cnt = (npair - ks + KS - 1) / KS;  // pairs ks, ks+KS, ...
-      const float* ga = ldsG + (mb * 32 + l31) * p.gp + half;
-      const float* xa = ldsX + (nb * 32 + l31) * xcs + half * p.stride;
-#define WG_LOAD(AV, BV, I)                                                              \
-  {                                                                                     \
-    const int kp_ = ks + min((I), cnt - 1) * KS;                                        \
-    AV = ga[2 * kp_];                                                                   \
-    _Pragma("unroll") for (int t = 0; t < T; ++t) BV[t] = xa[toff[t] + 2 * kp_ * p.stride]; \
+  // unit -> (image, output row, first column, real width)
+#define WG_UNIT(U, B_, OY_, OX0_, WCR_)                                   \
+  const int cwu_ = (U) % p.nchunk_w;                                      \
+  const int rowidu_ = (U) / p.nchunk_w;                                   \
+  const int OY_ = rowidu_ % p.OH;                                         \
+  const int B_ = rowidu_ / p.OH;                                          \
+  const int OX0_ = cwu_ * p.base_w + min(cwu_, p.rem_w);                  \
+  const int WCR_ = p.base_w + (cwu_ < p.rem_w ? 1 : 0);
+
+#define WG_ISSUE(U)                                                                                         \
+  {                                                                                                         \
+    WG_UNIT(U, b_, oy_, ox0_, wc_)                                                                          \
+    const float* gb_ = p.g + ((size_t)b_ * p.M) * gplane + (size_t)oy_ * p.OW + ox0_;                       \
+    _Pragma("unroll") for (int i = 0; i < NGQ; ++i) {                                                       \
+      const int e_ = min(tid + NT * i, gtotal - 1);                                                        \
+      const int r_ = __umulhi((unsigned)e_, p.inv_wce);                                                     \
+      const int c_ = e_ - r_ * p.wce;                                                                       \
+      const bool ok_ = (m0 + r_ < p.M) && (c_ < wc_);                                                       \
+      gq[i] = gb_[ok_ ? (m0 + r_) * (int)gplane + c_ : 0];                                               \
+    }                                                                                                       \
+    const float* xb_ = p.x + ((size_t)b_ * p.N) * xplane;                                                   \
+    const int iy0_ = oy_ * S - p.pad, ix0_ = ox0_ * S - p.pad;                                              \
+    _Pragma("unroll") for (int i = 0; i < NXQ; ++i) {                                                       \
+      const int e_ = min(tid + NT * i, xtotal - 1);                                                        \
+      const int ch_ = __umulhi((unsigned)e_, p.inv_pc);                                                     \
+      const int rm_ = e_ - ch_ * p.per_ch;                                                                  \
+      const int r_ = __umulhi((unsigned)rm_, p.inv_xw);                                                     \
+      const int c_ = rm_ - r_ * p.xw;                                                                       \
+      const int n_ = n0 + ch_, iy_ = iy0_ + r_, ix_ = ix0_ + c_;                                            \
+      const bool ok_ = (n_ < p.N) && (iy_ >= 0) && (iy_ < p.IH) && (ix_ >= 0) && (ix_ < p.IW);              \
+      xq[i] = xb_[ok_ ? (n_ * p.IH + iy_) * p.IW + ix_ : 0];                                \
+    }                                                                                                       \
+  }
+
+#define WG_COMMIT(U)                                                                                        \
+  {                                                                                                         \
+    WG_UNIT(U, b_, oy_, ox0_, wc_)                                                                          \
+    (void)b_;                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < NGQ; ++i) {                                                       \
+      const int e_ = tid + NT * i;                                                                         \
+      const int ec_ = min(e_, gtotal - 1);                                                                  \
+      const int r_ = __umulhi((unsigned)ec_, p.inv_wce);                                                    \
+      const int c_ = ec_ - r_ * p.wce;                                                                      \
+      const bool ok_ = (m0 + r_ < p.M) && (c_ < wc_);                                                       \
+      smem[e_ < gtotal ? r_ * p.gp + c_ : p.lds_dummy] = ok_ ? gq[i] : 0.f;                                 \
+    }                                                                                                       \
+    const int iy0_ = oy_ * S - p.pad, ix0_ = ox0_ * S - p.pad;                                              \
+    _Pragma("unroll") for (int i = 0; i < NXQ; ++i) {                                                       \
+      const int e_ = tid + NT * i;                                                                         \
+      const int ec_ = min(e_, xtotal - 1);                                                                  \
+      const int ch_ = __umulhi((unsigned)ec_, p.inv_pc);                                                    \
+      const int rm_ = ec_ - ch_ * p.per_ch;                                                                 \
+      const int r_ = __umulhi((unsigned)rm_, p.inv_xw);                                                     \
+      const int c_ = rm_ - r_ * p.xw;                                                                       \
+      const int n_ = n0 + ch_, iy_ = iy0_ + r_, ix_ = ix0_ + c_;                                            \
+      const bool ok_ = (n_ < p.N) && (iy_ >= 0) && (iy_ < p.IH) && (ix_ >= 0) && (ix_ < p.IW);              \
+      smem[e_ < xtotal ? p.x_off + ch_ * xcs + r_ * p.xp + c_ : p.lds_dummy] = ok_ ? xq[i] : 0.f;           \
+    }                                                                                                       \
+  }
+
+  const int npair = p.wce >> 1;
+  const int cnt = (npair - ks + KS - 1) / KS;  // pairs ks, ks+KS, ... of this wavefront
+  const float* ga = ldsG + (mb * 32 + l31) * p.gp + half;
+  const float* xa = ldsX + (nb * 32 + l31) * xcs + half * S;
+#define WG_LOAD(AV, BV, I)                                                        \
+  {                                                                               \
+    const int kp_ = ks + min((I), cnt - 1) * KS;                                  \
+    AV = ga[2 * kp_];                                                             \
+    _Pragma("unroll") for (int t = 0; t < TT; ++t) BV[t] = xa[trow + t + 2 * kp_ * S];  \
   }
 #define WG_MFMA(AV, BV) \
-  _Pragma("unroll") for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV, BV[t], acc[t], 0, 0, 0);
-      if (cnt > 0) {
-        float a0, a1, b0[T], b1[T];
-        WG_LOAD(a0, b0, 0);
-        int i = 0;
-        for (; i + 1 < cnt; i += 2) {
-          WG_LOAD(a1, b1, i + 1);
-          __builtin_amdgcn_sched_barrier(0);
-          WG_MFMA(a0, b0);
-          __builtin_amdgcn_sched_barrier(0);
-          WG_LOAD(a0, b0, i + 2);
-          __builtin_amdgcn_sched_barrier(0);
-          WG_MFMA(a1, b1);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if (i < cnt) WG_MFMA(a0, b0);
+  _Pragma("unroll") for (int t = 0; t < TT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV, BV[t], acc[t], 0, 0, 0);
+
+  if (u_begin < u_end) {
+    WG_ISSUE(u_begin);
+    WG_COMMIT(u_begin);
+  }
+  __syncthreads();
+  for (int u = u_begin; u < u_end; ++u) {
+    const bool more = u + 1 < u_end;
+    if (more) WG_ISSUE(u + 1);
+    // ---- bias partial: row sums of the staged g tile (padding columns hold zeros) ------------------------------
+    if (p.bias_part != nullptr && blockIdx.y == 0 && tid < MBW * 32) {
+      float s = 0.f;
+      for (int c = 0; c < p.wce; ++c) s += ldsG[tid * p.gp + c];
+      bsum += s;
+    }
+    // ---- MFMA over pixel pairs, two operand sets: the LDS reads of the next pair precede the T MFMAs of this one ----
+    if (cnt > 0) {
+      float a0, a1, b0[TT], b1[TT];
+      WG_LOAD(a0, b0, 0);
+      int i = 0;
+      for (; i + 1 < cnt; i += 2) {
+        WG_LOAD(a1, b1, i + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        WG_MFMA(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        WG_LOAD(a0, b0, i + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        WG_MFMA(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
       }
-#undef WG_LOAD
-#undef WG_MFMA
+      if (i < cnt) WG_MFMA(a0, b0);
+    }
+    __syncthreads();
+    if (more) {
+      WG_COMMIT(u + 1);
+      __syncthreads();
     }
   }
+#undef WG_UNIT
+#undef WG_ISSUE
+#undef WG_COMMIT
+#undef WG_LOAD
+#undef WG_MFMA
 
   // ---- write the slab: [split*KS + ks][t][m][n] ----------------------------------------------------------------
   float* sl = p.slab + (size_t)(split * KS + ks) * T * p.Mpad * p.Npad;
 #pragma unroll
-  for (int t = 0; t < T; ++t) {
+  for (int t = 0; t < TT; ++t) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       const int n = n0 + nb * 32 + l31;
-      sl[((size_t)t * p.Mpad + m) * p.Npad + n] = acc[t][r];
+      sl[((size_t)(tg * TT + t) * p.Mpad + m) * p.Npad + n] = acc[t][r];
     }
   }
   if (p.bias_part != nullptr && blockIdx.y == 0 && tid < MBW * 32) p.bias_part[(size_t)split * p.Mpad + m0 + tid] = bsum;
@@ -230,9 +253,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 namespace {
 
 struct WgradPlan {
-  int MBW, NBW, KS, Mpad, Npad, nchunk_w, Wc, units, nsplit, units_per_split, gp, xp, xrows, x_off, lds_bytes;
+  int MBW, NBW, KS, Mpad, Npad, nchunk_w, base_w, rem_w, wce, xw, per_ch, units, nsplit, units_per_split, gp, xp, x_off,
+      lds_dummy, lds_bytes;
   dim3 grid;
 };
+
+unsigned magic_u32(int d) { return (unsigned)(((1ull << 32) + (unsigned long long)d - 1ull) / (unsigned long long)d); }
 
 bool make_plan(int B, int N, int M, int IH, int IW, int ks, int stride, WgradPlan* pl) {
   const int pad = ks == 3 ? 1 : 0;
@@ -242,29 +268,28 @@ bool make_plan(int B, int N, int M, int IH, int IW, int ks, int stride, WgradPla
   if (MBW == 3) MBW = 2;
   int NBW = min(4 / MBW, nblocks);
   if (NBW == 3) NBW = 2;
-  int KS = 4 / (MBW * NBW);
+  const int KS = 4 / (MBW * NBW);
   pl->MBW = MBW; pl->NBW = NBW; pl->KS = KS;
   pl->Mpad = round_up(M, 32 * MBW);
   pl->Npad = round_up(N, 32 * NBW);
-  pl->xrows = ks == 3 ? 3 : 1;
-  int Wc = 0;
-  for (int cand : {64, 48, 32, 16, 8}) {
-    const int gp = (cand + 1) | 1;
-    const int xw = (cand - 1) * stride + (ks == 3 ? 3 : 1);
-    const int xp = xw | 1;
-    const int x_off = round_up(MBW * 32 * gp, 4);
-    const int bytes = (x_off + NBW * 32 * pl->xrows * xp) * 4;
-    if (bytes <= WGRAD_LDS_BUDGET) {
-      Wc = cand; pl->gp = gp; pl->xp = xp; pl->x_off = x_off; pl->lds_bytes = bytes;
-      break;
-    }
-  }
-  if (Wc == 0) return false;
-  pl->Wc = Wc;
-  pl->nchunk_w = cdiv(OW, Wc - 1);  // chunk widths are <= Wc - 1 before even padding
+  const int xrows = ks == 3 ? 3 : 1;
+  const int WC = stride == 1 ? 64 : 32;        // must match the kernel's compile-time WC
+  pl->nchunk_w = cdiv(OW, WC - 1);             // real chunk widths are <= WC - 1, so the even padded width fits WC
+  pl->base_w = OW / pl->nchunk_w;
+  pl->rem_w = OW - pl->base_w * pl->nchunk_w;
+  const int wmax = pl->base_w + (pl->rem_w > 0 ? 1 : 0);
+  pl->wce = (wmax + 1) & ~1;
+  pl->xw = (pl->wce - 1) * stride + (ks == 3 ? 3 : 1);
+  pl->per_ch = xrows * pl->xw;
+  pl->gp = (pl->wce + 1) | 1;
+  pl->xp = pl->xw | 1;
+  pl->x_off = round_up(MBW * 32 * pl->gp, 4);
+  pl->lds_dummy = pl->x_off + NBW * 32 * xrows * pl->xp;
+  pl->lds_bytes = (pl->lds_dummy + 4) * 4;
+  if (pl->lds_bytes > WGRAD_LDS_BUDGET || pl->wce > WC) return false;
   pl->units = B * OH * pl->nchunk_w;
   const int gy = pl->Npad / (32 * NBW), gz = pl->Mpad / (32 * MBW);
-  int nsplit = max(1, min(pl->units, (2 * 256) / max(1, gy * gz)));
+  int nsplit = max(1, min(pl->units, 256 / max(1, gy * gz)));  // one (12-wavefront) workgroup per CU
   pl->units_per_split = cdiv(pl->units, nsplit);
   nsplit = cdiv(pl->units, pl->units_per_split);
   pl->nsplit = nsplit;
@@ -272,17 +297,22 @@ bool make_plan(int B, int N, int M, int IH, int IW, int ks, int stride, WgradPla
   return true;
 }
 
-template <int MBW, int NBW, int KS>
-void launch_wgrad(const WgradParams& p, const WgradPlan& pl, int T, hipStream_t stream) {
-  if (T == 9) {
-    static bool s = false;
-    if (!s) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f32_kernel<MBW, NBW, KS, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_LDS_BUDGET); s = true; }
-    hipLaunchKernelGGL((wgrad_f32_kernel<MBW, NBW, KS, 9>), pl.grid, dim3(256), pl.lds_bytes, stream, p);
-  } else {
-    static bool s = false;
-    if (!s) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f32_kernel<MBW, NBW, KS, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_LDS_BUDGET); s = true; }
-    hipLaunchKernelGGL((wgrad_f32_kernel<MBW, NBW, KS, 1>), pl.grid, dim3(256), pl.lds_bytes, stream, p);
+template <int MBW, int NBW, int KS, int T, int S>
+void launch_one(const WgradParams& p, const WgradPlan& pl, hipStream_t stream) {
+  static bool s = false;
+  if (!s) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f32_kernel<MBW, NBW, KS, T, S>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_LDS_BUDGET);
+    s = true;
   }
+  hipLaunchKernelGGL((wgrad_f32_kernel<MBW, NBW, KS, T, S>), pl.grid, dim3(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)), pl.lds_bytes, stream, p);
+}
+
+template <int MBW, int NBW, int KS>
+void launch_wgrad(const WgradParams& p, const WgradPlan& pl, int T, int stride, hipStream_t stream) {
+  if (T == 1) launch_one<MBW, NBW, KS, 1, 1>(p, pl, stream);
+  else if (stride == 1) launch_one<MBW, NBW, KS, 9, 1>(p, pl, stream);
+  else launch_one<MBW, NBW, KS, 9, 2>(p, pl, stream);
 }
 
 }  // namespace
@@ -309,18 +339,19 @@ extern "C" int yogo_conv2d_wgrad_f32(const float* x, const float* g, float* dw, 
   p.x = x; p.g = g; p.slab = reinterpret_cast<float*>(workspace);
   p.bias_part = db ? p.slab + (size_t)pl.nsplit * pl.KS * T * pl.Mpad * pl.Npad : nullptr;
   p.B = B; p.N = Cin; p.M = Cout; p.Npad = pl.Npad; p.Mpad = pl.Mpad; p.IH = IH; p.IW = IW;
-  p.OH = (IH + 2 * pad - ks) / stride + 1; p.OW = (IW + 2 * pad - ks) / stride + 1; p.stride = stride; p.T = T;
-  for (int t = 0; t < T; ++t) { p.dy[t] = t / ks - pad; p.dx[t] = t % ks - pad; }
-  p.nchunk_w = pl.nchunk_w; p.Wc = pl.Wc; p.units = pl.units; p.units_per_split = pl.units_per_split;
-  p.gp = pl.gp; p.xp = pl.xp; p.xrows = pl.xrows; p.x_off = pl.x_off;
+  p.OH = (IH + 2 * pad - ks) / stride + 1; p.OW = (IW + 2 * pad - ks) / stride + 1; p.pad = pad;
+  p.nchunk_w = pl.nchunk_w; p.base_w = pl.base_w; p.rem_w = pl.rem_w; p.wce = pl.wce; p.xw = pl.xw; p.per_ch = pl.per_ch;
+  p.inv_wce = magic_u32(pl.wce); p.inv_xw = magic_u32(pl.xw); p.inv_pc = magic_u32(pl.per_ch);
+  p.units = pl.units; p.units_per_split = pl.units_per_split;
+  p.gp = pl.gp; p.xp = pl.xp; p.x_off = pl.x_off; p.lds_dummy = pl.lds_dummy;
   const int cfg = pl.MBW * 100 + pl.NBW * 10 + pl.KS;
   switch (cfg) {
-    case 411: launch_wgrad<4, 1, 1>(p, pl, T, stream); break;
-    case 221: launch_wgrad<2, 2, 1>(p, pl, T, stream); break;
-    case 212: launch_wgrad<2, 1, 2>(p, pl, T, stream); break;
-    case 141: launch_wgrad<1, 4, 1>(p, pl, T, stream); break;
-    case 122: launch_wgrad<1, 2, 2>(p, pl, T, stream); break;
-    case 114: launch_wgrad<1, 1, 4>(p, pl, T, stream); break;
+    case 411: launch_wgrad<4, 1, 1>(p, pl, T, stride, stream); break;
+    case 221: launch_wgrad<2, 2, 1>(p, pl, T, stride, stream); break;
+    case 212: launch_wgrad<2, 1, 2>(p, pl, T, stride, stream); break;
+    case 141: launch_wgrad<1, 4, 1>(p, pl, T, stride, stream); break;
+    case 122: launch_wgrad<1, 2, 2>(p, pl, T, stride, stream); break;
+    case 114: launch_wgrad<1, 1, 4>(p, pl, T, stride, stream); break;
     default:
       yogo_set_error("wgrad: unsupported wave layout %d", cfg);
       return YOGO_ERR_ARG;
