@@ -46,11 +46,17 @@ struct IgemmParams {
   int dbg;                  // experiments only (YOGO_IGEMM_DBG): 1 = stage only chunk 0, 2 = skip MFMA
 };
 
-template <int MW, int NW>
+// FUSED_S2: stride-2 dgrad with the four output parity classes computed from ONE staged dy tile.  The wavefront's
+// "pixel group" is 32 lattice positions (i, j); accumulator column n is the parity class (ph, pw) = (n>>1, n&1), i.e. the
+// output pixel (2i+ph, 2j+pw).  Each of the 9 taps feeds exactly one class, so the MFMA count equals a 3x3 conv over the
+// lattice: no zero insertion, no wasted matrix work, one launch instead of four.
+template <int MW, int NW, bool FUSED_S2 = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const IgemmParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  static_assert(!FUSED_S2 || NW == 4, "fused stride-2 dgrad: NW counts the four parity classes");
   constexpr int BM = 32 * MW;
-  constexpr int PT = 4 * NW * 32;
+  constexpr int NWP = FUSED_S2 ? 1 : NW;  // 32-pixel groups per wavefront
+  constexpr int PT = 4 * NWP * 32;
   float* ldsI = smem;
   float* ldsW = smem + p.ldsw_off;
 
@@ -93,18 +99,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const IgemmParam
   const int ix0 = j0 * p.a + p.dx_min;
   const int lw = (bw - 1) * p.a + p.span_x;
 
-  int boff[NW];
-  int opix[NW];
-  bool pvalid[NW];
+  int boff[NWP];
+  int opix[NWP];
+  bool pvalid[NWP];
+  int lat_i = 0, lat_j = 0;  // FUSED_S2: lattice position of this lane's pixel
 #pragma unroll
-  for (int n = 0; n < NW; ++n) {
-    const int pp = p0 + (wave * NW + n) * 32 + l31;
+  for (int n = 0; n < NWP; ++n) {
+    const int pp = p0 + (wave * NWP + n) * 32 + l31;
     pvalid[n] = pp < p1;
     const int pc = pvalid[n] ? pp : (p1 - 1);
     const int i = pc / bw;
     const int j = pc - i * bw;
     boff[n] = half * p.chs + ((i - i_lo) * p.a) * p.LWp + j * p.a;
     opix[n] = (p.oy0 + p.osy * i) * p.OW + p.ox0 + p.osx * (j0 + j);
+    lat_i = i;
+    lat_j = j0 + j;
   }
 
   f32x16 acc[MW][NW];
@@ -133,17 +142,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const IgemmParam
     const float* wI_ = ldsI + __builtin_amdgcn_readlane(toff_lane, t_) + kk_ * p.chs;             \
     const float* wW_ = ldsW + (t_ * p.CK + kk_) * BM + aoff;                                      \
     _Pragma("unroll") for (int mb = 0; mb < MW; ++mb) AV[mb] = wW_[mb * 32];                      \
-    _Pragma("unroll") for (int n = 0; n < NW; ++n) BV[n] = wI_[boff[n]];                          \
+    _Pragma("unroll") for (int n = 0; n < NWP; ++n) BV[n] = wI_[boff[n]];                         \
   }
 #define IGEMM_MFMA(AV, BV)                                                                        \
   _Pragma("unroll") for (int mb = 0; mb < MW; ++mb)                                               \
-  _Pragma("unroll") for (int n = 0; n < NW; ++n)                                                  \
+  _Pragma("unroll") for (int n = 0; n < NWP; ++n)                                                 \
     acc[mb][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[mb], BV[n], acc[mb][n], 0, 0, 0);
 
   // ---- global -> register prefetch of one K-chunk (async-STAGE split): issued before the MFMA loop of the previous
   //      chunk, committed to LDS after it, so the global-memory latency hides under ~9k cycles of matrix work.
   //      Capacity per wavefront: PFL (channel,row) lines x NXI 64-wide column groups; per lane: NQ weight float4.
-  constexpr int PFL = 8, NXI = (MW == 4 ? 2 : 5), NQ = 5;  // the 128-accumulator config has the fewest spare VGPRs
+  constexpr int PFL = 8, NXI = (MW == 4 ? 2 : (FUSED_S2 ? 3 : 5)), NQ = 5;  // fewer spare VGPRs -> smaller capacity
   constexpr int Q = BM / 4, RPP = 256 / Q;
   const int m4 = tid % Q, r0 = tid / Q;
   const int nrows = p.T * p.CK;
@@ -203,8 +212,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const IgemmParam
     }                                                                                                             \
   }
 #define IGEMM_COMPUTE()                                     \
-  {                                                         \
-    float a0[MW], b0[NW], a1[MW], b1[NW];                   \
+  if constexpr (FUSED_S2) {                                 \
+    IGEMM_COMPUTE_S2();                                     \
+  } else {                                                  \
+    float a0[MW], b0[NWP], a1[MW], b1[NWP];                 \
     IGEMM_LOAD(a0, b0, 0);                                  \
     int s = 0;                                              \
     for (; s + 1 < nsteps; s += 2) {                        \
@@ -218,6 +229,33 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const IgemmParam
       __builtin_amdgcn_sched_barrier(0);                    \
     }                                                       \
     if (s < nsteps) IGEMM_MFMA(a0, b0);                     \
+  }
+  // fused stride-2 dgrad: per channel pair, 4 shifted views of the dy tile (dy,dx in {0,1}) serve all 9 taps; tap u of the
+  // class-major packing (see s2_class_taps) feeds class S2_CLS[u] from view S2_VIEW[u] = 2*dy + dx
+#define S2_LOAD(AV, BV, KK)                                                                        \
+  {                                                                                                \
+    const int kk_ = min((KK), p.CK - 2);                                                           \
+    const float* wI_ = ldsI + kk_ * p.chs + boff[0];                                               \
+    BV[0] = wI_[0];                                                                                \
+    BV[1] = wI_[1];                                                                                \
+    BV[2] = wI_[p.LWp];                                                                            \
+    BV[3] = wI_[p.LWp + 1];                                                                        \
+    _Pragma("unroll") for (int u = 0; u < 9; ++u)                                                  \
+    _Pragma("unroll") for (int mb = 0; mb < MW; ++mb) AV[u][mb] = ldsW[(u * p.CK + kk_) * BM + aoff + mb * 32]; \
+  }
+#define S2_MFMA(AV, BV)                                                                            \
+  _Pragma("unroll") for (int u = 0; u < 9; ++u)                                                    \
+  _Pragma("unroll") for (int mb = 0; mb < MW; ++mb)                                                \
+    acc[mb][S2_CLS[u]] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[u][mb], BV[S2_VIEW[u]], acc[mb][S2_CLS[u]], 0, 0, 0);
+#define IGEMM_COMPUTE_S2()                                  \
+  {                                                         \
+    constexpr int S2_CLS[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};  \
+    constexpr int S2_VIEW[9] = {0, 1, 0, 2, 0, 3, 2, 1, 0}; \
+    for (int kk = 0; kk < p.CK; kk += 2) {                  \
+      float a0[9][MW], b0[4];                               \
+      S2_LOAD(a0, b0, kk);                                  \
+      S2_MFMA(a0, b0);                                      \
+    }                                                       \
   }
 
   if (p.pf) {
@@ -304,6 +342,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const IgemmParam
 #undef PF_W_STORE
 #undef PF_COMMIT
 #undef IGEMM_COMPUTE
+#undef IGEMM_COMPUTE_S2
+#undef S2_LOAD
+#undef S2_MFMA
 #undef IGEMM_LOAD
 #undef IGEMM_MFMA
 
@@ -325,13 +366,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const IgemmParam
 #pragma unroll
       for (int n = 0; n < NW; ++n) {
         float v = acc[mb][n][r] + bsv;
-        const bool ok = pvalid[n] && mok;
+        bool ok;
+        int op;
+        if constexpr (FUSED_S2) {
+          const int oy = 2 * lat_i + (n >> 1), ox = 2 * lat_j + (n & 1);
+          ok = pvalid[0] && mok && (oy < p.OH) && (ox < p.OW);
+          op = oy * p.OW + ox;
+        } else {
+          ok = pvalid[n] && mok;
+          op = opix[n];
+        }
         if (do_stats && ok) {
           s += v;
           q += v * v;
         }
         if (ok) {
-          const size_t idx = ((size_t)b * p.M + m) * plane + opix[n];
+          const size_t idx = ((size_t)b * p.M + m) * plane + op;
           if (p.out_pre != nullptr) p.out_pre[idx] = v;
           if (p.act_ref != nullptr) {
             v *= act_bwd_factor(p.act_ref[idx], p.ref_act);
@@ -423,7 +473,7 @@ struct Tiling {
   int ncb, TW, tiles_per_band, CK, rows_max, LWp, chs, ldsw_off, lds_bytes, pf;
 };
 
-bool plan_tiling(const Geom& g, int Kpad, int MW, int NW, Tiling* out) {
+bool plan_tiling(const Geom& g, int Kpad, int MW, int NW, Tiling* out, bool fused_s2 = false) {
   const int BM = 32 * MW, PT = 128 * NW;
   int dy_min = 1 << 30, dy_max = -(1 << 30), dx_min = 1 << 30, dx_max = -(1 << 30);
   for (int t = 0; t < g.T; ++t) {
@@ -434,7 +484,7 @@ bool plan_tiling(const Geom& g, int Kpad, int MW, int NW, Tiling* out) {
   }
   const int span_y = dy_max - dy_min + 1, span_x = dx_max - dx_min + 1;
   // prefetch capacity of the kernel (PFL lines x NXI column groups per wavefront, NQ weight float4 per lane)
-  const int PFL = 8, NXI = (MW == 4 ? 2 : 5), NQ = 5, RPP = 256 / (BM / 4);
+  const int PFL = 8, NXI = (MW == 4 ? 2 : (fused_s2 ? 3 : 5)), NQ = 5, RPP = 256 / (BM / 4);
   Tiling best{};
   int best_score = -1;
   for (int ncb = 1; ncb <= 16 && ncb <= g.OWt; ++ncb) {
@@ -467,11 +517,13 @@ bool plan_tiling(const Geom& g, int Kpad, int MW, int NW, Tiling* out) {
 
 int launch_igemm(const Geom& g, const float* in, const float* wp, const float* bias, float* out, float* out_pre,
                  const float* act_ref, int ref_act, const float* chan_scale, float* stats_part, int act,
-                 hipStream_t stream, int* stats_rows_out) {
-  const int MW = pick_mw(g.M), NW = pick_nw(MW, g.M);
+                 hipStream_t stream, int* stats_rows_out, bool fused_s2 = false) {
+  // fused stride-2 dgrad: 64 (or 32) output channels x 32 lattice positions x 4 parity classes per wavefront
+  const int MW = fused_s2 ? (g.M > 32 ? 2 : 1) : pick_mw(g.M);
+  const int NW = fused_s2 ? 1 : pick_nw(MW, g.M);
   const int Kpad = kpad_of(g.K), Mpad = mpad_of(g.M);
   Tiling tl;
-  if (!plan_tiling(g, Kpad, MW, NW, &tl)) {
+  if (!plan_tiling(g, Kpad, MW, NW, &tl, fused_s2)) {
     yogo_set_error("conv_igemm: no LDS tiling fits (K=%d M=%d OWt=%d a=%d)", g.K, g.M, g.OWt, g.a);
     return YOGO_ERR_ARG;
   }
@@ -507,19 +559,22 @@ int launch_igemm(const Geom& g, const float* in, const float* wp, const float* b
   }
   if (stats_rows_out) *stats_rows_out = g.B * (int)grid.x;
   if (g.B == 0 || g.OHt <= 0 || g.OWt <= 0) return YOGO_OK;
-#define LAUNCH(MW_, NW_)                                                                                    \
+#define LAUNCH(MW_, NW_, FU_)                                                                               \
   do {                                                                                                      \
     static bool attr_set = false;                                                                           \
     if (!attr_set) {                                                                                        \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32_kernel<MW_, NW_>),                  \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32_kernel<MW_, NW_, FU_>),       \
                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);                          \
       attr_set = true;                                                                                      \
     }                                                                                                       \
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<MW_, NW_>), grid, dim3(256), (p.dbg & 1024) ? 100 * 1024 : tl.lds_bytes, stream, p); \
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<MW_, NW_, FU_>), grid, dim3(256), (p.dbg & 1024) ? 100 * 1024 : tl.lds_bytes, stream, p); \
   } while (0)
-  if (MW == 4) LAUNCH(4, 2);
-  else if (MW == 2 && NW == 2) LAUNCH(2, 2);
-  else LAUNCH(1, 4);
+  if (fused_s2) {
+    if (MW == 2) LAUNCH(2, 4, true);
+    else LAUNCH(1, 4, true);
+  } else if (MW == 4) LAUNCH(4, 2, false);
+  else if (MW == 2) LAUNCH(2, 2, false);
+  else LAUNCH(1, 4, false);
 #undef LAUNCH
   YOGO_CHECK_LAUNCH("conv_igemm_f32");
   return YOGO_OK;
@@ -653,19 +708,20 @@ extern "C" int yogo_conv2d_dgrad_f32(const float* dy, const float* packed_dgrad,
     return launch_igemm(g, dy, packed_dgrad, nullptr, dx, nullptr, act_ref, ref_act, chan_scale, nullptr, ACT_NONE,
                         stream, nullptr);
   }
-  size_t off = 0;
+  // stride 2: one fused launch over the lattice (i, j) = (oy>>1, ox>>1); taps in the class-major order of the packing
+  g.T = 0;
   for (int cls = 0; cls < 4; ++cls) {
-    const int ph = cls >> 1, pw = cls & 1;
-    int kh[MAX_TAPS], kw[MAX_TAPS];
-    g.T = s2_class_taps(ph, pw, kh, kw, g.dy, g.dx);
-    g.OHt = (IH - ph + 1) / 2; g.OWt = (IW - pw + 1) / 2;
-    g.oy0 = ph; g.ox0 = pw; g.osy = g.osx = 2;
-    if (g.OHt > 0 && g.OWt > 0) {
-      if (int e = launch_igemm(g, dy, packed_dgrad + off, nullptr, dx, nullptr, act_ref, ref_act, chan_scale, nullptr,
-                               ACT_NONE, stream, nullptr))
-        return e;
+    int kh[MAX_TAPS], kw[MAX_TAPS], dyc[MAX_TAPS], dxc[MAX_TAPS];
+    const int tc = s2_class_taps(cls >> 1, cls & 1, kh, kw, dyc, dxc);
+    for (int t = 0; t < tc; ++t) {
+      g.dy[g.T] = dyc[t];
+      g.dx[g.T] = dxc[t];
+      ++g.T;
     }
-    off += packed_floats(Cout, Cin, g.T);
   }
-  return YOGO_OK;
+  g.OHt = (IH + 1) / 2; g.OWt = (IW + 1) / 2;
+  g.oy0 = g.ox0 = 0; g.osy = g.osx = 2;
+  return launch_igemm(g, dy, packed_dgrad, nullptr, dx, nullptr, act_ref, ref_act, chan_scale, nullptr, ACT_NONE, stream,
+                      nullptr, /*fused_s2=*/true);
 }
+
