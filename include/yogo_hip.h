@@ -72,9 +72,11 @@ int yogo_bn_apply_act(const float* z, float* y, const float* mean, const float* 
                       const float* gamma, const float* beta, int B, int C, int HW, int act, yogo_stream_t stream);
 int yogo_bn_invstd(const float* var, float eps, float* invstd, int C, yogo_stream_t stream);
 int yogo_bn_bwd_rows(int B, int HW, int* rows);
+/* g: gradient w.r.t. the block OUTPUT; the activation derivative (act) is applied inside from the recomputed
+ * pre-activation, then dz, dgamma, dbeta (clamped to +-clip when clip > 0) */
 int yogo_bn_bwd(const float* g, const float* z, float* dz, const float* mean, const float* invstd, const float* gamma,
-                float* dgamma, float* dbeta, float* part, float* sums, int B, int C, int HW, int training, float clip,
-                yogo_stream_t stream);
+                const float* beta, int act, float* dgamma, float* dbeta, float* part, float* sums, int B, int C, int HW,
+                int training, float clip, yogo_stream_t stream);
 /* `part` is folded in place (used as scratch) */
 int yogo_partials_reduce(float* part, int rows, int N, float clip, float* out, yogo_stream_t stream);
 int yogo_channel_sum(const float* g, int B, int C, int HW, float clip, float* out, yogo_stream_t stream);

@@ -193,14 +193,15 @@ def test_batchnorm_train_and_backward(shape):
     torch.testing.assert_close(rmd.cpu(), rm_ref, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(rvd.cpu(), rv_ref, rtol=1e-3, atol=1e-3)
     assert int(nbt.item()) == 1
-    # backward: producer applies act' -> g
-    gbn = dev(gy * torch.where(y_ref.detach() > 0, 1.0, 0.01))
+    # backward: g is the gradient w.r.t. the block output; the kernels apply LeakyReLU' from the recomputed pre-activation
+    gbn = dev(gy)
     rows = H.query_ints("yogo_bn_bwd_rows", 1, B, HW)[0]
     partb = torch.empty(rows * C * 2, device="cuda")
     sums = torch.empty(2 * C, device="cuda")
     dgamma, dbeta = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
     dz = torch.empty_like(zd)
-    H.call("yogo_bn_bwd", gbn, zd, dz, mean, invstd, dev(gamma.detach()), dgamma, dbeta, partb, sums, B, C, HW, 1, 0.0, st)
+    H.call("yogo_bn_bwd", gbn, zd, dz, mean, invstd, dev(gamma.detach()), dev(beta.detach()), 1, dgamma, dbeta, partb, sums, B, C, HW,
+           1, 0.0, st)
     assert rel_err(dz.cpu(), z.grad) < 1e-3
     assert rel_err(dgamma.cpu(), gamma.grad) < 1e-3
     assert rel_err(dbeta.cpu(), beta.grad) < 1e-4

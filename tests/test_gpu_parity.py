@@ -43,7 +43,7 @@ def test_forward_eval_matches_reference(fix):
             assert torch.equal(v.cpu(), sd[k])
 
 
-@pytest.mark.parametrize("fix", NETS[:3])
+@pytest.mark.parametrize("fix", NETS)
 def test_train_forward_backward_matches_reference(fix):
     meta, x, sd, grads, after, outs = load_net_fixture(fix)
     m = build_model(meta, sd)

@@ -78,22 +78,25 @@ __global__ __launch_bounds__(256) void bn_apply_act_kernel(const float* __restri
 }
 
 // ---- backward reduce: per (plane chunk) partial sums of g and g * xhat -------------------------------------------
-// g is the gradient w.r.t. the BN output (activation derivative already applied by the producer).
+// g is the gradient w.r.t. the block output; when act != none the activation derivative is applied here, from the
+// recomputed pre-activation xhat*gamma + beta (so no pre-activation tensor has to be saved, LeakyReLU and SiLU alike).
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ z,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                            float* __restrict__ part, int C, int HW) {
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            int act, float* __restrict__ part, int C, int HW) {
   __shared__ float sh[2][4];
   const int plane = blockIdx.y;  // b*C + c
   const int c = plane % C;
   const int b = plane / C;
-  const float mu = mean[c], is = invstd[c];
+  const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
   const float* gp = g + (size_t)plane * HW;
   const float* zp = z + (size_t)plane * HW;
   float s = 0.f, q = 0.f;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
-    const float gv = gp[i];
+    const float xh = (zp[i] - mu) * is;
+    const float gv = gp[i] * act_bwd_factor(fmaf(xh, ga, be), act);
     s += gv;
-    q += gv * ((zp[i] - mu) * is);
+    q += gv * xh;
   }
   s = wave_sum(s);
   q = wave_sum(q);
@@ -149,11 +152,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ z,
                                                            float* __restrict__ dz, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int act,
                                                            const float* __restrict__ sum_g, const float* __restrict__ sum_gx,
                                                            float inv_count, int training, int C, int HW) {
   const int plane = blockIdx.y;
   const int c = plane % C;
-  const float mu = mean[c], is = invstd[c], gi = gamma[c] * is;
+  const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c], gi = ga * is;
   const float mg = training ? sum_g[c] * inv_count : 0.f;
   const float mgx = training ? sum_gx[c] * inv_count : 0.f;
   const float* gp = g + (size_t)plane * HW;
@@ -161,7 +165,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   float* dp = dz + (size_t)plane * HW;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
     const float xh = (zp[i] - mu) * is;
-    dp[i] = gi * (gp[i] - mg - xh * mgx);
+    const float gv = gp[i] * act_bwd_factor(fmaf(xh, ga, be), act);
+    dp[i] = gi * (gv - mg - xh * mgx);
   }
 }
 
@@ -257,14 +262,14 @@ extern "C" int yogo_bn_bwd_rows(int B, int HW, int* rows) {
 // g: grad w.r.t. BN output; z: saved conv output; part: workspace rows*C*2 floats (rows from yogo_bn_bwd_rows).
 // Writes dz (may alias g), dgamma, dbeta (clamped to +-clip when clip > 0).  sums: workspace 2*C floats.
 extern "C" int yogo_bn_bwd(const float* g, const float* z, float* dz, const float* mean, const float* invstd,
-                           const float* gamma, float* dgamma, float* dbeta, float* part, float* sums, int B, int C, int HW,
-                           int training, float clip, hipStream_t stream) {
-  YOGO_CHECK_ARG(g && z && dz && mean && invstd && gamma && dgamma && dbeta && part && sums, "bn_bwd: null pointer");
+                           const float* gamma, const float* beta, int act, float* dgamma, float* dbeta, float* part,
+                           float* sums, int B, int C, int HW, int training, float clip, hipStream_t stream) {
+  YOGO_CHECK_ARG(g && z && dz && mean && invstd && gamma && beta && dgamma && dbeta && part && sums, "bn_bwd: null pointer");
   YOGO_CHECK_ARG(B > 0 && C > 0 && HW > 0, "bn_bwd: bad shape");
   const int nb = plane_blocks(HW, 8);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb, B * C), dim3(256), 0, stream, g, z, mean, invstd, part, C, HW);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb, B * C), dim3(256), 0, stream, g, z, mean, invstd, gamma, beta, act, part, C, HW);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, stream, part, B * nb, C, clip, dgamma, dbeta, sums, sums + C);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb, B * C), dim3(256), 0, stream, g, z, dz, mean, invstd, gamma, sums,
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb, B * C), dim3(256), 0, stream, g, z, dz, mean, invstd, gamma, beta, act, sums,
                      sums + C, 1.0f / ((float)B * (float)HW), training, C, HW);
   YOGO_CHECK_LAUNCH("bn_bwd");
   return YOGO_OK;

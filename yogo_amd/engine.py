@@ -260,16 +260,16 @@ class Engine:
             IH, IW = int(S.x_in.shape[2]), int(S.x_in.shape[3])
             if L.bn is not None:
                 bn = L.bn
-                if L.act == ACT_SILU:
-                    raise RuntimeError("yogo_amd: backward through BatchNorm + SiLU blocks is not implemented yet")
                 gamma = _f32(bn.weight.detach()) if bn.weight is not None else torch.ones(L.cout, device=dev)
+                beta = _f32(bn.bias.detach()) if bn.bias is not None else torch.zeros(L.cout, device=dev)
                 dgamma = dst(bn.weight) if bn.weight is not None else torch.empty(L.cout, dtype=torch.float32, device=dev)
                 dbeta = dst(bn.bias) if bn.bias is not None else torch.empty(L.cout, dtype=torch.float32, device=dev)
                 rows = _hip.query_ints("yogo_bn_bwd_rows", 1, B, OH * OW)[0]
                 part = torch.empty(rows * L.cout * 2, dtype=torch.float32, device=dev)
                 sums = torch.empty(2 * L.cout, dtype=torch.float32, device=dev)
-                _hip.call("yogo_bn_bwd", g, S.z, g, S.mean, S.invstd, gamma, dgamma, dbeta, part, sums, B, L.cout, OH * OW,
-                          1 if S.bn_train else 0, clip, st)
+                # g arrives as dL/d(block output): the BN-backward kernels apply the activation derivative themselves
+                _hip.call("yogo_bn_bwd", g, S.z, g, S.mean, S.invstd, gamma, beta, L.act, dgamma, dbeta, part, sums, B, L.cout,
+                          OH * OW, 1 if S.bn_train else 0, clip, st)
                 if bn.weight is not None:
                     grads[id(bn.weight)] = dgamma
                     grads[id(bn.bias)] = dbeta
@@ -303,7 +303,10 @@ class Engine:
             # ---- data gradient, with the previous block's activation derivative and dropout mask fused -------------
             if i > 0:
                 Lp, Sp = self.layers[i - 1], saved[i - 1]
-                if Lp.act == ACT_SILU:
+                ref_act = Lp.act
+                if Lp.bn is not None:
+                    act_ref, ref_act = None, ACT_NONE   # BatchNorm backward applies the activation derivative
+                elif Lp.act == ACT_SILU:
                     act_ref = Sp.pre
                     if act_ref is None:
                         raise RuntimeError("yogo_amd: missing saved pre-activation for a SiLU block")
@@ -314,7 +317,7 @@ class Engine:
                 dx = torch.empty(B, L.cin, IH, IW, dtype=torch.float32, device=dev)
                 pk = self._packed(i, 1)
                 self._tick("dgrad", i, 2.0 * B * L.cout * L.cin * L.k * L.k * OH * OW, mw=4 if L.cin > 64 else (2 if L.cin > 32 else 1))
-                _hip.call("yogo_conv2d_dgrad_f32", g, pk, dx, act_ref, Lp.act, Sp.mask, B, L.cin, L.cout, IH, IW, L.k, L.s, st)
+                _hip.call("yogo_conv2d_dgrad_f32", g, pk, dx, act_ref, ref_act, Sp.mask, B, L.cin, L.cout, IH, IW, L.k, L.s, st)
                 self._tock()
                 g = dx
         bb = self.backbone_ref()
