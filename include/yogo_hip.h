@@ -104,6 +104,19 @@ int yogo_format_preds_batched(const float* pred, float* out_rows, long long* out
                               int B, int P, int Sy, int Sx, int cap, double obj_thresh, double iou_thresh, int box_format,
                               double min_class_confidence_threshold, yogo_stream_t stream);
 
+/* ---- bf16 inference convolutions: the bf16-autocast forward of `yogo infer`, yogo/infer.py:313-317 ------------------------
+ * activations in "NCHW8c" = [B][C/8][H][W][8] bf16 (C padded to a multiple of 16), eval-mode BatchNorm folded by the caller
+ * into `scale` (weights) and `bias`.                                                                                          */
+int yogo_conv_bf16_packed_bytes(int Cin, int Cout, int ksize, size_t* bytes);
+int yogo_conv_bf16_pack(const float* w_oihw, const float* scale, void* packed, int Cin, int Cout, int ksize,
+                        yogo_stream_t stream);
+int yogo_bf16_channel_blocks(int C);
+/* y = act(conv(x) + bias); out: bf16 NCHW8c, or fp32 NCHW when out_f32 != NULL (the head) */
+int yogo_conv2d_fwd_bf16(const void* in, const void* packed, const float* bias, void* out, float* out_f32, int B, int Cin,
+                         int Cout, int IH, int IW, int ksize, int stride, int act, yogo_stream_t stream);
+int yogo_conv_first_fwd_bf16(const void* in, int in_dtype, const float* w, const float* bias, void* out, int B, int Cin,
+                             int Cout, int IH, int IW, int stride, int act, yogo_stream_t stream);
+
 /* ---- optimiser: torch.optim.AdamW over one flat buffer, yogo/train.py:213-217,324 ---------------------------------------- */
 int yogo_adamw_step(float* p, const float* g, float* m, float* v, long long n, int step, double lr, double beta1,
                     double beta2, double eps, double weight_decay, double grad_scale, yogo_stream_t stream);

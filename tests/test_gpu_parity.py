@@ -280,3 +280,51 @@ def test_trainer_steps_match_oracle():
             assert int(now[k]) == 2
     # the flat buffer really is the module's storage
     assert all(p.data_ptr() >= tr.flat.flat.data_ptr() for p in model.parameters())
+
+
+@pytest.mark.parametrize("fix", ["net_base_64x96.npz", "net_quarter_rgb_50x70.npz", "net_depth0_40x56.npz", "net_silu_64x96.npz"])
+def test_bf16_inference_forward(fix):
+    """`yogo infer` runs the model under bf16 autocast (yogo/infer.py:313-317).  bf16 storage + bf16 MFMA with fp32
+    accumulation against the fp32 reference output: tolerance = bf16 rounding through 8 layers (stated: 3e-2 of the range)."""
+    meta, x, sd, grads, after, outs = load_net_fixture(fix)
+    m = build_model(meta, sd, inference=True)
+    m.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        raw = m.model(x.cuda())
+        out = m(x.cuda())
+    assert raw.dtype == torch.float32 and out.dtype == torch.float32
+    ref = outs["raw_eval"]
+    err = float((raw.cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 3e-2, err
+    # decoded: boxes / objectness / class probabilities are all O(1) quantities
+    d = (out.cpu() - outs["out_inf"]).abs()
+    assert float(d[:, [0, 1, 4]].max()) < 2e-2 and float(d[:, 5:].max()) < 6e-2
+    rel_wh = d[:, 2:4] / outs["out_inf"][:, 2:4].abs().clamp_min(1e-6)
+    assert float(rel_wh.max()) < 0.15
+    # and the fp32 path is untouched outside autocast
+    with torch.no_grad():
+        raw32 = m.model(x.cuda().float())
+    assert rel_err(raw32.cpu(), ref) < 1e-4
+
+
+def test_bf16_inference_full_size():
+    z = load_npz("net_base_full_eval.npz")
+    meta = json.loads(str(z["meta"]))
+    _, _, sd, *_ = load_net_fixture("net_base_64x96.npz")
+    for k, v in z.items():
+        if k.startswith("sd/"):
+            sd[k[3:]] = as_t(v)
+    sd["_Cxs"], sd["_Cys"] = O.make_grids(129, 97)
+    sd["img_size"] = torch.tensor([772, 1032])
+    m = build_model(dict(model="base_model", H=772, W=1032, num_classes=7, anchor_w=0.0425, anchor_h=0.0555), sd, inference=True)
+    m.eval()
+    g = torch.Generator().manual_seed(meta["x_seed"])
+    x = torch.randint(0, 256, (1, 1, 772, 1032), dtype=torch.uint8, generator=g)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        out = m(x.cuda()).cpu()
+    want = as_t(z["out_inf"])
+    d = (out - want).abs()
+    # bf16 keeps 8 significand bits: logits of magnitude ~10 carry ~4e-2 absolute error after 8 layers, which the sigmoid /
+    # softmax map to at most a few 1e-2 of probability
+    assert float(d[:, [0, 1, 4]].max()) < 4e-2 and float(d[:, 5:].max()) < 8e-2
+    assert float(d[:, [0, 1, 4]].mean()) < 2e-3

@@ -355,8 +355,129 @@ class _BackboneFn(torch.autograd.Function):
 def backbone_apply(backbone: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
     _hip.require_cuda(x, "the input batch")
     params = list(backbone.parameters())
+    if not backbone.training and not torch.is_grad_enabled() and (
+            bf16_inference_requested() or getattr(backbone, "bf16_inference", False)):
+        raw = backbone_infer_bf16(backbone, x)
+        if raw is not None:
+            return raw
     with torch.cuda.device(x.device):
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             return _BackboneFn.apply(x, backbone, *params)
         raw, _ = get_engine(backbone).forward(x, need_grad=False)
         return raw
+
+class InferEngineBF16:
+    """Eval-mode forward on the bf16 matrix cores (the reference runs `yogo infer` under bf16 autocast, yogo/infer.py:313-317).
+
+    Activations live in NCHW8c bf16 ([B][C/8][H][W][8]); eval-mode BatchNorm is folded into the packed weights (per-output-
+    channel scale) and the bias; bias + activation are fused into the conv epilogue; the last layer writes fp32 NCHW for the
+    decode / NMS kernels.  Folded tensors and packed weights are cached and rebuilt when any parameter or buffer changes.
+    """
+
+    def __init__(self, engine: Engine):
+        self.engine = engine
+        self._key = None
+        self._prep: List[Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]] = []
+
+    def _state_key(self):
+        k = []
+        for L in self.engine.layers:
+            ts = [L.conv.weight, L.conv.bias]
+            if L.bn is not None:
+                ts += [L.bn.weight, L.bn.bias, L.bn.running_mean, L.bn.running_var]
+            for t in ts:
+                k.append(None if t is None else (t.data_ptr(), t._version))
+        return tuple(k)
+
+    def supported(self) -> bool:
+        L0 = self.engine.layers[0]
+        if not (L0.cin in (1, 3) and L0.k == 3):
+            return False
+        return all(L.bn is None or (not L.bn.training and L.bn.running_mean is not None) for L in self.engine.layers)
+
+    @torch.no_grad()
+    def _prepare(self) -> None:
+        key = self._state_key()
+        if key == self._key:
+            return
+        st = _hip.stream_ptr()
+        prep = []
+        for i, L in enumerate(self.engine.layers):
+            w = _f32(L.conv.weight.detach())
+            bias = L.conv.bias.detach().float() if L.conv.bias is not None else None
+            scale = None
+            if L.bn is not None:
+                bn = L.bn
+                gamma = bn.weight.detach().float() if bn.weight is not None else torch.ones_like(bn.running_var)
+                beta = bn.bias.detach().float() if bn.bias is not None else torch.zeros_like(bn.running_var)
+                scale = gamma / torch.sqrt(bn.running_var.float() + bn.eps)
+                base = bias if bias is not None else torch.zeros_like(scale)
+                bias = beta + (base - bn.running_mean.float()) * scale
+            if i == 0:
+                wf = w * scale[:, None, None, None] if scale is not None else w
+                prep.append((wf.contiguous(), bias.contiguous() if bias is not None else None))
+            else:
+                nbytes = _hip.query_size("yogo_conv_bf16_packed_bytes", L.cin, L.cout, L.k)
+                packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+                _hip.call("yogo_conv_bf16_pack", w, scale.contiguous() if scale is not None else None, packed, L.cin, L.cout, L.k, st)
+                prep.append((packed, bias.contiguous() if bias is not None else None))
+        self._prep = prep
+        self._key = key
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        _hip.require_cuda(x, "the input batch")
+        if x.ndim != 4:
+            raise RuntimeError(f"yogo_amd: expected a [B,C,H,W] batch, got {tuple(x.shape)}")
+        self._prepare()
+        st = _hip.stream_ptr()
+        dev = x.device
+        B = x.shape[0]
+        cur = x.contiguous() if x.dtype == torch.uint8 else _f32(x)
+        H, W = int(cur.shape[2]), int(cur.shape[3])
+        n = len(self.engine.layers)
+        for i, L in enumerate(self.engine.layers):
+            OH, OW = L.out_hw(H, W)
+            if OH <= 0 or OW <= 0:
+                raise RuntimeError(f"yogo_amd: image too small at layer {i}")
+            wq, bias = self._prep[i]
+            last = i == n - 1
+            if i == 0:
+                if cur.shape[1] != L.cin:
+                    raise RuntimeError(f"yogo_amd: layer 0 expects {L.cin} channels, got {cur.shape[1]}")
+                mb = _hip.lib().yogo_bf16_channel_blocks(L.cout)
+                out = torch.empty(B, mb, OH, OW, 8, dtype=torch.bfloat16, device=dev)
+                _hip.call("yogo_conv_first_fwd_bf16", cur, 0 if cur.dtype == torch.uint8 else 1, wq, bias, out, B, L.cin, L.cout, H, W,
+                          L.s, L.act, st)
+                if last:
+                    raise RuntimeError("yogo_amd: a one-layer network is not supported by the bf16 inference path")
+            elif last:
+                out = torch.empty(B, L.cout, OH, OW, dtype=torch.float32, device=dev)
+                _hip.call("yogo_conv2d_fwd_bf16", cur, wq, bias, None, out, B, L.cin, L.cout, H, W, L.k, L.s, L.act, st)
+            else:
+                mb = _hip.lib().yogo_bf16_channel_blocks(L.cout)
+                out = torch.empty(B, mb, OH, OW, 8, dtype=torch.bfloat16, device=dev)
+                _hip.call("yogo_conv2d_fwd_bf16", cur, wq, bias, out, None, B, L.cin, L.cout, H, W, L.k, L.s, L.act, st)
+            cur, H, W = out, OH, OW
+        return cur
+
+
+def bf16_inference_requested() -> bool:
+    """True inside `torch.autocast("cuda", dtype=torch.bfloat16)` -- how the reference's predict() asks for half inference"""
+    try:
+        return bool(torch.is_autocast_enabled()) and torch.get_autocast_gpu_dtype() == torch.bfloat16
+    except Exception:
+        return False
+
+
+def backbone_infer_bf16(backbone: nn.Sequential, x: torch.Tensor) -> Optional[torch.Tensor]:
+    """raw head output via the bf16 path, or None when the model state does not allow it (train-mode BatchNorm, ...)"""
+    eng = get_engine(backbone)
+    inf = getattr(eng, "_infer_bf16", None)
+    if inf is None:
+        inf = InferEngineBF16(eng)
+        eng._infer_bf16 = inf
+    if not inf.supported():
+        return None
+    with torch.cuda.device(x.device):
+        return inf.forward(x)
