@@ -71,6 +71,43 @@ def cpu_baseline(batch: int = 8, steps: int = 2):
             "sample": f"{steps} oracle train steps (fwd+loss+bwd+AdamW), fp32, batch {batch}, after 1 warm-up step"}
 
 
+def inference_extras(model, dev, B: int = 64):
+    """secondary numbers (not the headline metric): eval forward + decode at fp32 and under bf16 autocast (how `yogo infer`
+    runs the model), and the batched threshold+NMS kernel on the 'realistic' synthetic prediction tensor"""
+    from yogo_amd.synthetic import synthetic_images, synthetic_predictions
+    from yogo_amd.utils import format_preds_batched
+
+    model.eval()
+    model.inference = True
+    x = synthetic_images(B, H, W, device=dev, seed=7)
+    out = {}
+
+    def timed(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    with torch.no_grad():
+        ms32 = timed(lambda: model(x))
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            ms16 = timed(lambda: model(x))
+        preds = synthetic_predictions(256, model.Sx, model.Sy, NUM_CLASSES, K=100, device=dev)
+        msn = timed(lambda: format_preds_batched(preds))
+    out["forward_decode_fp32_images_per_s"] = round(B / ms32 * 1e3, 1)
+    out["forward_decode_bf16_images_per_s"] = round(B / ms16 * 1e3, 1)
+    out["threshold_nms_realistic_images_per_s"] = round(256 / msn * 1e3, 1)
+    out["note"] = "eval-mode base_model, batch 64 (forward) / 256 (NMS, 100 objects per image); secondary to the training metric"
+    model.train()
+    model.inference = False
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,6 +222,8 @@ def main():
             "conv_breakdown": by_kind,
             "loss": round(loss_rec["loss"], 4),
         }
+        if world == 1:
+            rec["inference"] = inference_extras(model, dev)
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline()
         print(json.dumps(rec))

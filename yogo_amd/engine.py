@@ -316,7 +316,9 @@ class Engine:
                     act_ref = None
                 dx = torch.empty(B, L.cin, IH, IW, dtype=torch.float32, device=dev)
                 pk = self._packed(i, 1)
-                self._tick("dgrad", i, 2.0 * B * L.cout * L.cin * L.k * L.k * OH * OW, mw=4 if L.cin > 64 else (2 if L.cin > 32 else 1))
+                # mw tags the kernel instantiation for bench.py's roofline: stride-2 dgrad runs the fused <.,4,true> kernel
+                mw_tag = 20 if L.s == 2 else (4 if L.cin > 64 else (2 if L.cin > 32 else 1))
+                self._tick("dgrad", i, 2.0 * B * L.cout * L.cin * L.k * L.k * OH * OW, mw=mw_tag)
                 _hip.call("yogo_conv2d_dgrad_f32", g, pk, dx, act_ref, ref_act, Sp.mask, B, L.cin, L.cout, IH, IW, L.k, L.s, st)
                 self._tock()
                 g = dx

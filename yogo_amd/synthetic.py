@@ -28,3 +28,40 @@ def synthetic_labels(B: int, Sx: int, Sy: int, K: int = 64, num_classes: int = 7
     for k in range(K):
         out.scatter_(2, cell[:, None, k : k + 1].expand(B, 6, 1), vals[:, :, k : k + 1])
     return out.view(B, 6, Sy, Sx)
+
+
+def synthetic_predictions(B: int, Sx: int, Sy: int, num_classes: int = 7, K: int = 100, device="cuda", seed: int = 2) -> torch.Tensor:
+    """'realistic' post-process input: K objects per image, each predicted by 1-4 neighbouring cells
+    with 5 %-jittered boxes, objectness U(0.5, 1), soft-maxed class logits; every other cell has objectness U(0, 0.4)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    P = 5 + num_classes
+    out = torch.zeros(B, P, Sy, Sx, device=device)
+    out[:, 4] = torch.rand(B, Sy, Sx, device=device, generator=g) * 0.4
+    out[:, 0] = (torch.arange(Sx, device=device).float()[None, None, :] + 0.5) / Sx
+    out[:, 1] = (torch.arange(Sy, device=device).float()[None, :, None] + 0.5) / Sy
+    out[:, 2] = 0.0425
+    out[:, 3] = 0.0555
+    out[:, 5:] = torch.softmax(torch.randn(B, num_classes, Sy, Sx, device=device, generator=g), dim=1)
+    cx = torch.rand(B, K, device=device, generator=g) * 0.9 + 0.05
+    cy = torch.rand(B, K, device=device, generator=g) * 0.9 + 0.05
+    w = 0.0425 * torch.exp(torch.randn(B, K, device=device, generator=g) * 0.2)
+    h = 0.0555 * torch.exp(torch.randn(B, K, device=device, generator=g) * 0.2)
+    ncell = torch.randint(1, 5, (B, K), device=device, generator=g)
+    logits = torch.randn(B, K, num_classes, device=device, generator=g) * 2
+    flat = out.view(B, P, Sy * Sx)
+    i0 = (cx * Sx).long().clamp(0, Sx - 1)
+    j0 = (cy * Sy).long().clamp(0, Sy - 1)
+    for n, (di, dj) in enumerate([(0, 0), (1, 0), (0, 1), (1, 1)]):
+        use = (ncell > n)
+        i = (i0 + di).clamp(max=Sx - 1)
+        j = (j0 + dj).clamp(max=Sy - 1)
+        cell = j * Sx + i
+        jit = 0.05 * torch.randn(B, K, 4, device=device, generator=g)
+        vals = torch.stack((cx + w * jit[..., 0], cy + h * jit[..., 1], w * (1 + jit[..., 2]), h * (1 + jit[..., 3]),
+                            0.5 + 0.5 * torch.rand(B, K, device=device, generator=g)), dim=1)
+        cls = torch.softmax(logits + 0.3 * torch.randn(B, K, num_classes, device=device, generator=g), dim=2).permute(0, 2, 1)
+        vals = torch.cat((vals, cls), dim=1)                       # [B, P, K]
+        cur = torch.gather(flat, 2, cell[:, None, :].expand(B, P, K))
+        vals = torch.where(use[:, None, :], vals, cur)
+        flat.scatter_(2, cell[:, None, :].expand(B, P, K), vals)
+    return out
