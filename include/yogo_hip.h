@@ -104,18 +104,44 @@ int yogo_format_preds_batched(const float* pred, float* out_rows, long long* out
                               int B, int P, int Sy, int Sx, int cap, double obj_thresh, double iou_thresh, int box_format,
                               double min_class_confidence_threshold, yogo_stream_t stream);
 
-/* ---- bf16 inference convolutions: the bf16-autocast forward of `yogo infer`, yogo/infer.py:313-317 ------------------------
- * activations in "NCHW8c" = [B][C/8][H][W][8] bf16 (C padded to a multiple of 16), eval-mode BatchNorm folded by the caller
- * into `scale` (weights) and `bias`.                                                                                          */
-int yogo_conv_bf16_packed_bytes(int Cin, int Cout, int ksize, size_t* bytes);
-int yogo_conv_bf16_pack(const float* w_oihw, const float* scale, void* packed, int Cin, int Cout, int ksize,
-                        yogo_stream_t stream);
+/* ---- bf16 path: the bf16-autocast forward of `yogo infer` (yogo/infer.py:313-317) and half-precision training
+ * (yogo/train.py:315-318, --half) -------------------------------------------------------------------------------------------
+ * Activations and activation gradients in "NCHW8c" = [B][C/8][H][W][8] bf16 (C padded to a multiple of 16; padding
+ * channels hold zeros); weights, BatchNorm statistics, parameter gradients, optimiser state stay fp32.
+ * Inference folds eval-mode BatchNorm into `scale` (weights) and `bias` on the caller's side.                               */
 int yogo_bf16_channel_blocks(int C);
-/* y = act(conv(x) + bias); out: bf16 NCHW8c, or fp32 NCHW when out_f32 != NULL (the head) */
-int yogo_conv2d_fwd_bf16(const void* in, const void* packed, const float* bias, void* out, float* out_f32, int B, int Cin,
-                         int Cout, int IH, int IW, int ksize, int stride, int act, yogo_stream_t stream);
+/* mode 0: forward packing (optional per-output-channel scale); mode 1: dgrad packing (roles swapped, taps flipped) */
+int yogo_conv_bf16_packed_bytes(int Cin, int Cout, int ksize, int mode, size_t* bytes);
+int yogo_conv_bf16_pack(const float* w_oihw, const float* scale, void* packed, int Cin, int Cout, int ksize, int mode,
+                        yogo_stream_t stream);
+int yogo_conv2d_fwd_bf16_stats_shape(int B, int Cin, int Cout, int IH, int IW, int ksize, int stride, int* rows, int* mpad);
+/* y = chan_scale * act(conv(x) + bias); out: bf16 NCHW8c, or fp32 NCHW when out_f32 != NULL (the head);
+ * stats_part (optional): BatchNorm partial (sum, sumsq) of the fp32 pre-activation */
+int yogo_conv2d_fwd_bf16(const void* in, const void* packed, const float* bias, void* out, float* out_f32,
+                         const float* chan_scale, float* stats_part, int B, int Cin, int Cout, int IH, int IW, int ksize,
+                         int stride, int act, yogo_stream_t stream);
+/* dx = conv_transpose(dy) * act'(act_ref) * chan_scale, everything bf16 NCHW8c; (IH, IW) = forward INPUT dims */
+int yogo_conv2d_dgrad_bf16(const void* dy, const void* packed_dgrad, void* dx, const void* act_ref, int ref_act,
+                           const float* chan_scale, int B, int Cin, int Cout, int IH, int IW, int ksize, int stride,
+                           yogo_stream_t stream);
+/* fp32 dw/db from bf16 NCHW8c x and g (exact fp32 MFMA on the widened values); workspace as yogo_conv2d_wgrad_f32 */
+int yogo_conv2d_wgrad_bf16in(const void* x, const void* g, float* dw, float* db, void* workspace, int B, int Cin, int Cout,
+                             int IH, int IW, int ksize, int stride, float clip, yogo_stream_t stream);
 int yogo_conv_first_fwd_bf16(const void* in, int in_dtype, const float* w, const float* bias, void* out, int B, int Cin,
                              int Cout, int IH, int IW, int stride, int act, yogo_stream_t stream);
+int yogo_conv_first_fwd_train_bf16(const void* in, int in_dtype, const float* w, const float* bias, void* out_bf16,
+                                   const float* chan_scale, float* stats_part, int B, int Cin, int Cout, int IH, int IW,
+                                   int stride, int act, yogo_stream_t stream);
+int yogo_conv_first_wgrad_bf16g(const void* in, int in_dtype, const void* dy_bf16, float* part, int B, int Cin, int Cout,
+                                int IH, int IW, int stride, yogo_stream_t stream);
+int yogo_bn_apply_act_bf16(const void* z, void* y, const float* mean, const float* invstd_or_var, int stat_is_var, float eps,
+                           const float* gamma, const float* beta, int B, int C, int HW, int act, yogo_stream_t stream);
+int yogo_bn_bwd_bf16_rows(int B, int HW, int* rows);
+int yogo_bn_bwd_bf16(const void* g, const void* z, void* dz, const float* mean, const float* invstd, const float* gamma,
+                     const float* beta, int act, float* dgamma, float* dbeta, float* part, float* sums, int B, int C, int HW,
+                     int training, float clip, yogo_stream_t stream);
+int yogo_nchw_f32_to_bf16_8c(const float* in, void* out, int B, int C, int HW, yogo_stream_t stream);
+int yogo_bf16_8c_to_nchw_f32(const void* in, float* out, int B, int C, int HW, yogo_stream_t stream);
 
 /* ---- optimiser: torch.optim.AdamW over one flat buffer, yogo/train.py:213-217,324 ---------------------------------------- */
 int yogo_adamw_step(float* p, const float* g, float* m, float* v, long long n, int step, double lr, double beta1,

@@ -1,0 +1,182 @@
+"""bf16 path (NCHW8c activations, bf16 MFMA, fp32 accumulation / statistics / parameter gradients) against fp32 references.
+Tolerances are bf16's: 8 significand bits -> ~4e-3 relative rounding per stored value; stated per check."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import yogo_oracle as O
+from _util import load_net_fixture, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def H():
+    from yogo_amd import _hip
+
+    return _hip
+
+
+def to8c(t):
+    h = H()
+    B, C, Hh, W = t.shape
+    cb = h.lib().yogo_bf16_channel_blocks(C)
+    out = torch.empty(B, cb, Hh, W, 8, dtype=torch.bfloat16, device="cuda")
+    h.call("yogo_nchw_f32_to_bf16_8c", t.cuda().contiguous().float(), out, B, C, Hh * W, h.stream_ptr())
+    return out
+
+
+def from8c(t, C):
+    h = H()
+    B, cb, Hh, W, _ = t.shape
+    out = torch.empty(B, C, Hh, W, device="cuda")
+    h.call("yogo_bf16_8c_to_nchw_f32", t, out, B, C, Hh * W, h.stream_ptr())
+    return out.cpu()
+
+
+def bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+def test_layout_round_trip():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 12, 7, 9, generator=g)
+    y = to8c(x)
+    assert y.shape == (2, 2, 7, 9, 8)
+    assert torch.equal(from8c(y, 12), bf(x))
+    # the layout itself: unit (b, cb, h, w) holds channels cb*8 .. cb*8+7, padding channels are zero
+    ref = torch.zeros(2, 16, 7, 9)
+    ref[:, :12] = bf(x)
+    assert torch.equal(y.cpu().float(), ref.view(2, 2, 8, 7, 9).permute(0, 1, 3, 4, 2))
+
+
+CASES = [(2, 16, 32, 20, 37, 3, 1), (1, 32, 64, 21, 40, 3, 2), (2, 64, 128, 13, 19, 3, 1), (1, 128, 128, 25, 33, 3, 2),
+         (2, 128, 128, 9, 129, 3, 1), (1, 128, 12, 7, 11, 1, 1), (1, 24, 40, 11, 9, 3, 1), (1, 16, 32, 3, 600, 3, 1)]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_bf16_fwd_dgrad_wgrad(case):
+    h = H()
+    B, Cin, Cout, IH, IW, k, s = case
+    g = torch.Generator().manual_seed(hash(case) % 997)
+    x = bf(torch.randn(B, Cin, IH, IW, generator=g)).requires_grad_(True)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)).requires_grad_(True)
+    b = torch.randn(Cout, generator=g, requires_grad=True)
+    wb = bf(w.detach())
+    pad = 1 if k == 3 else 0
+    ref_pre = F.conv2d(x, wb.requires_grad_(True), b, stride=s, padding=pad)
+    OH, OW = ref_pre.shape[2:]
+    st = h.stream_ptr()
+    mask = (torch.rand(B, Cout, generator=g) > 0.3).float() * 1.5
+    # ---- forward: bias + leaky + channel mask + BatchNorm partial sums ----------------------------------------------
+    packed = torch.empty(h.query_size("yogo_conv_bf16_packed_bytes", Cin, Cout, k, 0), dtype=torch.uint8, device="cuda")
+    h.call("yogo_conv_bf16_pack", w.detach().cuda(), None, packed, Cin, Cout, k, 0, st)
+    rows, mpad = h.query_ints("yogo_conv2d_fwd_bf16_stats_shape", 2, B, Cin, Cout, IH, IW, k, s)
+    stats = torch.full((rows, mpad, 2), float("nan"), device="cuda")
+    out = torch.full((B, h.lib().yogo_bf16_channel_blocks(Cout), OH, OW, 8), float("nan"), dtype=torch.bfloat16, device="cuda")
+    x8 = to8c(x.detach())
+    h.call("yogo_conv2d_fwd_bf16", x8, packed, b.detach().cuda(), out, None, mask.cuda(), stats, B, Cin, Cout, IH, IW, k, s, 1, st)
+    want = F.leaky_relu(ref_pre.detach(), 0.01) * mask[:, :, None, None]
+    got = from8c(out, Cout)
+    assert rel_err(got, want) < 8e-3, case           # one bf16 rounding of the output
+    ssum = stats.cpu().double().sum(0)[:Cout]
+    torch.testing.assert_close(ssum[:, 0], ref_pre.detach().double().sum((0, 2, 3)), rtol=1e-3, atol=2e-2)
+    torch.testing.assert_close(ssum[:, 1], (ref_pre.detach().double() ** 2).sum((0, 2, 3)), rtol=1e-3, atol=2e-2)
+    # padding channels of the output tensor are zero
+    padc = out.cpu().float().view(B, -1, OH, OW, 8).permute(0, 1, 4, 2, 3).reshape(B, -1, OH, OW)[:, Cout:]
+    assert padc.numel() == 0 or float(padc.abs().max()) == 0.0
+    # fp32 NCHW output mode (the head)
+    o32 = torch.full((B, Cout, OH, OW), float("nan"), device="cuda")
+    h.call("yogo_conv2d_fwd_bf16", x8, packed, b.detach().cuda(), None, o32, None, None, B, Cin, Cout, IH, IW, k, s, 0, st)
+    assert rel_err(o32.cpu(), ref_pre.detach()) < 2e-5 * max(1.0, np.sqrt(Cin * k * k) / 8), case
+    # ---- backward ---------------------------------------------------------------------------------------------------------
+    gy = bf(torch.randn(ref_pre.shape, generator=g))
+    ref_pre.backward(gy)
+    gy8 = to8c(gy)
+    pd = torch.empty(h.query_size("yogo_conv_bf16_packed_bytes", Cin, Cout, k, 1), dtype=torch.uint8, device="cuda")
+    h.call("yogo_conv_bf16_pack", w.detach().cuda(), None, pd, Cin, Cout, k, 1, st)
+    dx = torch.full((B, h.lib().yogo_bf16_channel_blocks(Cin), IH, IW, 8), float("nan"), dtype=torch.bfloat16, device="cuda")
+    refy = bf(torch.randn(B, Cin, IH, IW, generator=g))
+    cmask = (torch.rand(B, Cin, generator=g) > 0.3).float() * 1.25
+    h.call("yogo_conv2d_dgrad_bf16", gy8, pd, dx, None, 0, None, B, Cin, Cout, IH, IW, k, s, st)
+    assert rel_err(from8c(dx, Cin), x.grad) < 8e-3, case
+    h.call("yogo_conv2d_dgrad_bf16", gy8, pd, dx, to8c(refy), 1, cmask.cuda(), B, Cin, Cout, IH, IW, k, s, st)
+    want = x.grad * torch.where(refy > 0, 1.0, 0.01) * cmask[:, :, None, None]
+    assert rel_err(from8c(dx, Cin), want) < 8e-3, case
+    # wgrad from bf16 inputs is exact fp32 MFMA on the widened values
+    ws = torch.empty(h.query_size("yogo_conv2d_wgrad_workspace_bytes", B, Cin, Cout, IH, IW, k, s) // 4, device="cuda")
+    dw = torch.full((Cout, Cin, k, k), float("nan"), device="cuda")
+    db = torch.full((Cout,), float("nan"), device="cuda")
+    h.call("yogo_conv2d_wgrad_bf16in", x8, gy8, dw, db, ws, B, Cin, Cout, IH, IW, k, s, 0.0, st)
+    assert rel_err(dw.cpu(), wb.grad) < 3e-5, case
+    assert rel_err(db.cpu(), b.grad) < 3e-5, case
+
+
+def test_batchnorm_bf16():
+    h = H()
+    B, C, Hh, W = 3, 20, 11, 13
+    g = torch.Generator().manual_seed(4)
+    z = bf(torch.randn(B, C, Hh, W, generator=g) * 3 + 2).requires_grad_(True)
+    gamma = (1 + 0.1 * torch.randn(C, generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn(C, generator=g)).requires_grad_(True)
+    y_ref = F.leaky_relu(F.batch_norm(z, None, None, gamma, beta, training=True, eps=1e-5), 0.01)
+    gy = bf(torch.randn(z.shape, generator=g))
+    y_ref.backward(gy)
+    st = h.stream_ptr()
+    zz = z.detach()
+    mean = zz.mean((0, 2, 3)).cuda()
+    invstd = (1 / torch.sqrt(zz.var((0, 2, 3), unbiased=False) + 1e-5)).cuda()
+    z8 = to8c(zz)
+    y8 = torch.empty_like(z8)
+    h.call("yogo_bn_apply_act_bf16", z8, y8, mean, invstd, 0, 1e-5, gamma.detach().cuda(), beta.detach().cuda(), B, C, Hh * W, 1, st)
+    assert rel_err(from8c(y8, C), y_ref.detach()) < 8e-3
+    rows = h.query_ints("yogo_bn_bwd_bf16_rows", 1, B, Hh * W)[0]
+    part = torch.empty(rows * C * 2, device="cuda")
+    sums = torch.empty(2 * C, device="cuda")
+    dgamma, dbeta = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    g8 = to8c(gy)
+    dz8 = torch.empty_like(g8)
+    h.call("yogo_bn_bwd_bf16", g8, z8, dz8, mean, invstd, gamma.detach().cuda(), beta.detach().cuda(), 1, dgamma, dbeta, part, sums, B,
+           C, Hh * W, 1, 0.0, st)
+    assert rel_err(from8c(dz8, C), z.grad) < 1e-2
+    assert rel_err(dgamma.cpu(), gamma.grad) < 1e-3 and rel_err(dbeta.cpu(), beta.grad) < 1e-3
+
+
+def test_bf16_training_step_tracks_fp32():
+    """one optimisation step with bf16 activations vs the same step in fp32 (HipTrainer half=True / False)"""
+    from yogo_amd.model import YOGO
+    from yogo_amd.train import HipTrainer
+    from yogo_amd.yogo_loss import YOGOLoss
+
+    Himg, Wimg, C, B = 96, 128, 7, 4
+    x = O.synthetic_images(B, Himg, Wimg, seed=31).cuda()
+    res = {}
+    for half in (False, True):
+        torch.manual_seed(3)
+        model = YOGO((Himg, Wimg), 0.0425, 0.0555, C, clip_value=1e9).cuda()   # unclamped: compare the raw gradients
+        model.train()
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout2d):
+                m.p = 0.0
+        lab = O.synthetic_labels(B, model.Sx, model.Sy, K=6, num_classes=C, seed=32).cuda()
+        tr = HipTrainer(model, YOGOLoss().cuda(), total_steps=5, half=half)
+        tr.step(x, lab)
+        res[half] = (tr.loss_components(), tr.flat.grad.clone().cpu(), [n for n, _ in model.named_parameters()],
+                     [p.numel() for p in model.parameters()], {k: v.cpu().clone() for k, v in model.state_dict().items() if "running" in k})
+    l32, g32, names, sizes, rs32 = res[False]
+    l16, g16, _, _, rs16 = res[True]
+    assert abs(l16["loss"] - l32["loss"]) < 2e-2 * abs(l32["loss"]), (l16, l32)
+    off = 0
+    for n, sz in zip(names, sizes):
+        a, b_ = g16[off:off + sz], g32[off:off + sz]
+        off += sz
+        if float(b_.abs().max()) < 1e-6:
+            continue   # e.g. a conv bias in front of BatchNorm: mathematically zero
+        cos = float((a * b_).sum() / (a.norm() * b_.norm() + 1e-30))
+        ratio = float(a.norm() / (b_.norm() + 1e-30))
+        print(f"{n:24s} cos {cos:.4f} norm ratio {ratio:.4f}")
+        # bf16 activations and activation gradients (8 significand bits) through 8 layers: direction and scale are kept,
+        # element-wise agreement is not expected
+        assert cos > 0.95 and 0.9 < ratio < 1.1, (n, cos, ratio)
+    for k in rs32:
+        torch.testing.assert_close(rs16[k], rs32[k], rtol=2e-2, atol=2e-2)

@@ -304,3 +304,219 @@ extern "C" int yogo_channel_sum(const float* g, int B, int C, int HW, float clip
   YOGO_CHECK_LAUNCH("channel_sum");
   return YOGO_OK;
 }
+
+// =========================================================================================================
+// bf16 NCHW8c variants (training in bf16 storage): one 16-byte unit = 8 consecutive channels of one pixel.
+// A "plane" is (image, channel block); statistics stay fp32 / fp64.
+// =========================================================================================================
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+struct Bn8cParams {
+  float mu[8], sc[8], sh[8], ga[8], is[8];
+};
+
+__device__ __forceinline__ void bn8c_load(Bn8cParams& q, int cb, int C, const float* mean, const float* invstd_or_var,
+                                          int stat_is_var, float eps, const float* gamma, const float* beta) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = min(cb * 8 + j, C - 1);
+    const float is = stat_is_var ? 1.0f / sqrtf(invstd_or_var[c] + eps) : invstd_or_var[c];
+    q.mu[j] = mean[c];
+    q.is[j] = is;
+    q.ga[j] = gamma[c];
+    q.sc[j] = is * gamma[c];
+    q.sh[j] = beta[c];
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_act_8c_kernel(const u32x4_t* __restrict__ z, u32x4_t* __restrict__ y,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd_or_var, int stat_is_var, float eps,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              int C, int Cb, int HW, int act) {
+  const int plane = blockIdx.y;  // b*Cb + cb
+  const int cb = plane % Cb;
+  Bn8cParams q;
+  bn8c_load(q, cb, C, mean, invstd_or_var, stat_is_var, eps, gamma, beta);
+  const u32x4_t* zp = z + (size_t)plane * HW;
+  u32x4_t* yp = y + (size_t)plane * HW;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+    const bf16x8_t v = __builtin_bit_cast(bf16x8_t, zp[i]);
+    bf16x8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float r = act_fwd(fmaf((float)v[j] - q.mu[j], q.sc[j], q.sh[j]), act);
+      o[j] = (cb * 8 + j < C) ? (__bf16)r : (__bf16)0.f;
+    }
+    yp[i] = __builtin_bit_cast(u32x4_t, o);
+  }
+}
+
+// partial sums of g' and g' * xhat per channel, g' = g * act'(xhat*gamma + beta)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_8c_kernel(const u32x4_t* __restrict__ g, const u32x4_t* __restrict__ z,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               int act, float* __restrict__ part, int C, int Cb, int HW) {
+  __shared__ float sh[4][16];
+  const int plane = blockIdx.y;
+  const int cb = plane % Cb, b = plane / Cb;
+  Bn8cParams q;
+  bn8c_load(q, cb, C, mean, invstd, 0, 0.f, gamma, beta);
+  const u32x4_t* gp = g + (size_t)plane * HW;
+  const u32x4_t* zp = z + (size_t)plane * HW;
+  float s[8], t[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = t[j] = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+    const bf16x8_t gv = __builtin_bit_cast(bf16x8_t, gp[i]);
+    const bf16x8_t zv = __builtin_bit_cast(bf16x8_t, zp[i]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = ((float)zv[j] - q.mu[j]) * q.is[j];
+      const float ge = (float)gv[j] * act_bwd_factor(fmaf(xh, q.ga[j], q.sh[j]), act);
+      s[j] += ge;
+      t[j] += ge * xh;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float a = wave_sum(s[j]), c = wave_sum(t[j]);
+    if (lane == 0) {
+      sh[wave][2 * j] = a;
+      sh[wave][2 * j + 1] = c;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    const int j = threadIdx.x >> 1;
+    if (cb * 8 + j < C)
+      part[((size_t)(b * gridDim.x + blockIdx.x) * C + cb * 8 + j) * 2 + (threadIdx.x & 1)] =
+          sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_8c_kernel(const u32x4_t* __restrict__ g, const u32x4_t* __restrict__ z,
+                                                              u32x4_t* __restrict__ dz, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, int act,
+                                                              const float* __restrict__ sum_g, const float* __restrict__ sum_gx,
+                                                              float inv_count, int training, int C, int Cb, int HW) {
+  const int plane = blockIdx.y;
+  const int cb = plane % Cb;
+  Bn8cParams q;
+  bn8c_load(q, cb, C, mean, invstd, 0, 0.f, gamma, beta);
+  float mg[8], mgx[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = min(cb * 8 + j, C - 1);
+    mg[j] = training ? sum_g[c] * inv_count : 0.f;
+    mgx[j] = training ? sum_gx[c] * inv_count : 0.f;
+  }
+  const u32x4_t* gp = g + (size_t)plane * HW;
+  const u32x4_t* zp = z + (size_t)plane * HW;
+  u32x4_t* dp = dz + (size_t)plane * HW;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+    const bf16x8_t gv = __builtin_bit_cast(bf16x8_t, gp[i]);
+    const bf16x8_t zv = __builtin_bit_cast(bf16x8_t, zp[i]);
+    bf16x8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = ((float)zv[j] - q.mu[j]) * q.is[j];
+      const float ge = (float)gv[j] * act_bwd_factor(fmaf(xh, q.ga[j], q.sh[j]), act);
+      const float r = q.sc[j] * (ge - mg[j] - xh * mgx[j]);
+      o[j] = (cb * 8 + j < C) ? (__bf16)r : (__bf16)0.f;
+    }
+    dp[i] = __builtin_bit_cast(u32x4_t, o);
+  }
+}
+
+// fp32 NCHW -> bf16 NCHW8c (Cb channel blocks, padding channels zero) and back
+__global__ __launch_bounds__(256) void nchw_f32_to_8c_kernel(const float* __restrict__ in, u32x4_t* __restrict__ out, int C, int Cb,
+                                                             int HW) {
+  const int plane = blockIdx.y;  // b*Cb + cb
+  const int cb = plane % Cb, b = plane / Cb;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+    bf16x8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cb * 8 + j;
+      o[j] = (c < C) ? (__bf16)in[((size_t)b * C + c) * HW + i] : (__bf16)0.f;
+    }
+    out[(size_t)plane * HW + i] = __builtin_bit_cast(u32x4_t, o);
+  }
+}
+
+__global__ __launch_bounds__(256) void nchw8c_to_f32_kernel(const u32x4_t* __restrict__ in, float* __restrict__ out, int C, int Cb,
+                                                            int HW) {
+  const int plane = blockIdx.y;
+  const int cb = plane % Cb, b = plane / Cb;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+    const bf16x8_t v = __builtin_bit_cast(bf16x8_t, in[(size_t)plane * HW + i]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cb * 8 + j;
+      if (c < C) out[((size_t)b * C + c) * HW + i] = (float)v[j];
+    }
+  }
+}
+
+static inline int cb_of(int C) { return ((C + 15) / 16) * 2; }  // channel blocks: C padded to a multiple of 16
+
+extern "C" int yogo_bn_apply_act_bf16(const void* z, void* y, const float* mean, const float* invstd_or_var, int stat_is_var,
+                                      float eps, const float* gamma, const float* beta, int B, int C, int HW, int act,
+                                      hipStream_t stream) {
+  YOGO_CHECK_ARG(z && y && mean && invstd_or_var && gamma && beta && C > 0 && HW > 0 && B >= 0, "bn_apply_act_bf16: bad arguments");
+  if (B == 0) return YOGO_OK;
+  const int Cb = cb_of(C);
+  YOGO_CHECK_ARG(B * Cb <= 65535, "bn_apply_act_bf16: batch * channel blocks exceeds 65535");
+  hipLaunchKernelGGL(bn_apply_act_8c_kernel, dim3(plane_blocks(HW, 4), B * Cb), dim3(256), 0, stream,
+                     reinterpret_cast<const u32x4_t*>(z), reinterpret_cast<u32x4_t*>(y), mean, invstd_or_var, stat_is_var, eps,
+                     gamma, beta, C, Cb, HW, act);
+  YOGO_CHECK_LAUNCH("bn_apply_act_bf16");
+  return YOGO_OK;
+}
+
+extern "C" int yogo_bn_bwd_bf16_rows(int B, int HW, int* rows) {
+  YOGO_CHECK_ARG(rows != nullptr, "bn_bwd_bf16_rows: null");
+  *rows = B * plane_blocks(HW, 4);
+  return YOGO_OK;
+}
+
+// bf16 NCHW8c g (gradient w.r.t. the block output), z (saved conv output) -> dz (may alias g), dgamma, dbeta
+extern "C" int yogo_bn_bwd_bf16(const void* g, const void* z, void* dz, const float* mean, const float* invstd,
+                                const float* gamma, const float* beta, int act, float* dgamma, float* dbeta, float* part,
+                                float* sums, int B, int C, int HW, int training, float clip, hipStream_t stream) {
+  YOGO_CHECK_ARG(g && z && dz && mean && invstd && gamma && beta && dgamma && dbeta && part && sums, "bn_bwd_bf16: null pointer");
+  YOGO_CHECK_ARG(B > 0 && C > 0 && HW > 0, "bn_bwd_bf16: bad shape");
+  const int Cb = cb_of(C), nb = plane_blocks(HW, 4);
+  YOGO_CHECK_ARG(B * Cb <= 65535, "bn_bwd_bf16: batch * channel blocks exceeds 65535");
+  const u32x4_t* g4 = reinterpret_cast<const u32x4_t*>(g);
+  const u32x4_t* z4 = reinterpret_cast<const u32x4_t*>(z);
+  hipLaunchKernelGGL(bn_bwd_reduce_8c_kernel, dim3(nb, B * Cb), dim3(256), 0, stream, g4, z4, mean, invstd, gamma, beta, act, part, C,
+                     Cb, HW);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, stream, part, B * nb, C, clip, dgamma, dbeta, sums, sums + C);
+  hipLaunchKernelGGL(bn_bwd_apply_8c_kernel, dim3(nb, B * Cb), dim3(256), 0, stream, g4, z4, reinterpret_cast<u32x4_t*>(dz), mean,
+                     invstd, gamma, beta, act, sums, sums + C, 1.0f / ((float)B * (float)HW), training, C, Cb, HW);
+  YOGO_CHECK_LAUNCH("bn_bwd_bf16");
+  return YOGO_OK;
+}
+
+extern "C" int yogo_nchw_f32_to_bf16_8c(const float* in, void* out, int B, int C, int HW, hipStream_t stream) {
+  YOGO_CHECK_ARG(in && out && B > 0 && C > 0 && HW > 0, "nchw_f32_to_bf16_8c: bad arguments");
+  const int Cb = cb_of(C);
+  hipLaunchKernelGGL(nchw_f32_to_8c_kernel, dim3(plane_blocks(HW, 2), B * Cb), dim3(256), 0, stream, in,
+                     reinterpret_cast<u32x4_t*>(out), C, Cb, HW);
+  YOGO_CHECK_LAUNCH("nchw_f32_to_bf16_8c");
+  return YOGO_OK;
+}
+
+extern "C" int yogo_bf16_8c_to_nchw_f32(const void* in, float* out, int B, int C, int HW, hipStream_t stream) {
+  YOGO_CHECK_ARG(in && out && B > 0 && C > 0 && HW > 0, "bf16_8c_to_nchw_f32: bad arguments");
+  const int Cb = cb_of(C);
+  hipLaunchKernelGGL(nchw8c_to_f32_kernel, dim3(plane_blocks(HW, 2), B * Cb), dim3(256), 0, stream,
+                     reinterpret_cast<const u32x4_t*>(in), out, C, Cb, HW);
+  YOGO_CHECK_LAUNCH("bf16_8c_to_nchw_f32");
+  return YOGO_OK;
+}

@@ -33,6 +33,10 @@ struct ConvBf16Params {
   const float* bias;  // [M] fp32 or null
   u32x2* out;         // bf16 8c viewed as 8-byte halves: [B][Mb][OH][OW][2]
   float* out_f32;     // OUT_F32: fp32 NCHW [B][M][OH][OW]
+  const u32x2* act_ref;     // training dgrad: multiply by act'(ref); ref = bf16 tensor shaped like `out` (8-byte halves)
+  const float* chan_scale;  // optional [B][M] Dropout2d channel mask (already scaled)
+  float* stats_part;        // optional BatchNorm partial sums [B*gridDim.x][Mpad][2] of the fp32 pre-activation
+  int ref_act, ups;         // ups = 1: the input is read as if zero-upsampled by 2 (stride-2 dgrad; no HBM cost)
   int B, Kb, M, Mpad, Mb;
   int IH, IW, OH, OW, a, T;
   int toff[BF_MAX_TAPS];
@@ -67,7 +71,14 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvBf16Params 
   const int bw = min(p.TW, p.OW - j0);
   const int NPb = p.OH * bw;
   const int p0 = tb * PT;
-  if (p0 >= NPb) return;
+  if (p0 >= NPb) {
+    if (p.stats_part != nullptr && tid < BM) {
+      float* dst = p.stats_part + (((size_t)b * gridDim.x + bx) * p.Mpad + m0 + tid) * 2;
+      dst[0] = 0.f;
+      dst[1] = 0.f;
+    }
+    return;
+  }
   const int p1 = min(p0 + PT, NPb);
   const int i_lo = p0 / bw, i_hi = (p1 - 1) / bw;
   const int rows_in = (i_hi - i_lo) * p.a + p.span_y;
@@ -133,19 +144,21 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvBf16Params 
         const int r = crc - kc * rows_in;
         const int kb = kb0 + kc, iy = iy0 + r;
         wr[u] = cr < ncr;
-        rok[u] = wr[u] && (kb < p.Kb) && (iy >= 0) && (iy < p.IH);
-        src[u] = ((rok[u] ? kb : 0) * p.IH + (rok[u] ? iy : 0)) * p.IW + ix0;
+        const int ry = p.ups ? (iy >> 1) : iy;
+        rok[u] = wr[u] && (kb < p.Kb) && (iy >= 0) && (ry < p.IH) && !(p.ups && (iy & 1));
+        src[u] = ((rok[u] ? kb : 0) * p.IH + (rok[u] ? ry : 0)) * p.IW;
         dst[u] = kc * p.chs + r * p.LWp;
       }
       for (int x = lane; x < lw; x += 64) {
         const int ix = ix0 + x;
-        const bool xok = ix >= 0 && ix < p.IW;
+        const int rx = p.ups ? (ix >> 1) : ix;
+        const bool xok = ix >= 0 && rx < p.IW && !(p.ups && (ix & 1));
         // named registers (an array of u32x4 is not promoted out of scratch by hipcc); loads unconditional + select
         const bool k0 = rok[0] && xok, k1 = rok[1] && xok, k2 = rok[2] && xok, k3 = rok[3] && xok;
-        const u32x4 l0 = inb[k0 ? src[0] + x : 0];
-        const u32x4 l1 = inb[k1 ? src[1] + x : 0];
-        const u32x4 l2 = inb[k2 ? src[2] + x : 0];
-        const u32x4 l3 = inb[k3 ? src[3] + x : 0];
+        const u32x4 l0 = inb[k0 ? src[0] + rx : 0];
+        const u32x4 l1 = inb[k1 ? src[1] + rx : 0];
+        const u32x4 l2 = inb[k2 ? src[2] + rx : 0];
+        const u32x4 l3 = inb[k3 ? src[3] + rx : 0];
         __builtin_amdgcn_sched_barrier(0);
         smem4[wr[0] ? dst[0] + x : p.lds_dummy] = k0 ? l0 : zero4;
         smem4[wr[1] ? dst[1] + x : p.lds_dummy] = k1 ? l1 : zero4;
@@ -199,56 +212,116 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvBf16Params 
 #undef BF_LOAD
 #undef BF_MFMA
 
-  // ---- epilogue: bias + activation, then bf16 NCHW8c (8 bytes per lane) or fp32 NCHW -------------------------------------
+  // ---- epilogue: bias (+ BatchNorm partial sums of the fp32 pre-activation) + activation [or act'(ref)] + channel mask,
+  //      then bf16 NCHW8c (8 bytes per lane) or fp32 NCHW ---------------------------------------------------------------
   const size_t plane = (size_t)p.OH * p.OW;
+  const bool do_stats = p.stats_part != nullptr;
+  if (do_stats) __syncthreads();  // LDS is reused for the cross-wave reduction
+  float* red = reinterpret_cast<float*>(smem4);  // [4 waves][BM][2]
 #pragma unroll
   for (int mb = 0; mb < MW; ++mb) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int cbase = m0 + mb * 32 + 8 * g + 4 * half;  // this lane's 4 consecutive output channels
-      float bs[4];
+      const int cl = mb * 32 + 8 * g + 4 * half;  // local channel of this lane's 4 consecutive output channels
+      const int cbase = m0 + cl;
+      float bs[4], cs[4], s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) bs[i] = (p.bias != nullptr && cbase + i < p.M) ? p.bias[cbase + i] : 0.f;
+      for (int i = 0; i < 4; ++i) {
+        bs[i] = (p.bias != nullptr && cbase + i < p.M) ? p.bias[cbase + i] : 0.f;
+        cs[i] = (p.chan_scale != nullptr && cbase + i < p.M) ? p.chan_scale[(size_t)b * p.M + cbase + i] : 1.f;
+      }
 #pragma unroll
       for (int n = 0; n < NW; ++n) {
         float v[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = act_fwd(acc[mb][n][4 * g + i] + bs[i], p.act);
-        if (!pvalid[n]) continue;
-        if constexpr (OUT_F32) {
+        for (int i = 0; i < 4; ++i) v[i] = acc[mb][n][4 * g + i] + bs[i];
+        if (do_stats && pvalid[n]) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (cbase + i < p.M) p.out_f32[((size_t)b * p.M + cbase + i) * plane + opix[n]] = v[i];
-        } else {
-          const int cblk = cbase >> 3;
-          if (cblk < p.Mb) {
-            bf16x4 o;
+          for (int i = 0; i < 4; ++i) {
+            s4[i] += v[i];
+            q4[i] += v[i] * v[i];
+          }
+        }
+        if (pvalid[n]) {
+          if constexpr (OUT_F32) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = (cbase + i < p.M) ? (__bf16)v[i] : (__bf16)0.f;
-            p.out[(((size_t)b * p.Mb + cblk) * plane + opix[n]) * 2 + half] = __builtin_bit_cast(u32x2, o);
+            for (int i = 0; i < 4; ++i)
+              if (cbase + i < p.M) p.out_f32[((size_t)b * p.M + cbase + i) * plane + opix[n]] = act_fwd(v[i], p.act) * cs[i];
+          } else {
+            const int cblk = cbase >> 3;
+            if (cblk < p.Mb) {
+              const size_t hidx = (((size_t)b * p.Mb + cblk) * plane + opix[n]) * 2 + half;
+              if (p.act_ref != nullptr) {
+                const bf16x4 rf = __builtin_bit_cast(bf16x4, p.act_ref[hidx]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] *= act_bwd_factor((float)rf[i], p.ref_act);
+              } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = act_fwd(v[i], p.act);
+              }
+              bf16x4 o;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) o[i] = (cbase + i < p.M) ? (__bf16)(v[i] * cs[i]) : (__bf16)0.f;
+              p.out[hidx] = __builtin_bit_cast(u32x2, o);
+            }
+          }
+        }
+      }
+      if (do_stats) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float s = s4[i], q = q4[i];
+#pragma unroll
+          for (int o = 16; o > 0; o >>= 1) {
+            s += __shfl_xor(s, o, 64);
+            q += __shfl_xor(q, o, 64);
+          }
+          if (l31 == 0) {
+            red[(wave * BM + cl + i) * 2 + 0] = s;
+            red[(wave * BM + cl + i) * 2 + 1] = q;
           }
         }
       }
     }
   }
+  if (do_stats) {
+    __syncthreads();
+    if (tid < BM) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        s += red[(w * BM + tid) * 2 + 0];
+        q += red[(w * BM + tid) * 2 + 1];
+      }
+      float* dst = p.stats_part + (((size_t)b * gridDim.x + bx) * p.Mpad + m0 + tid) * 2;
+      dst[0] = s;
+      dst[1] = q;
+    }
+  }
 }
 
 // ---- weight packing: OIHW fp32 (x optional per-output-channel scale = folded BatchNorm) -> [T][Kb][Mpad] units ----------
+// dgrad = 1: GEMM roles swapped (k = co, m = ci) and the kernel flipped, so the data gradient is a plain stride-1 conv
 __global__ void conv_bf16_pack_kernel(const float* __restrict__ w, const float* __restrict__ scale, u32x4* __restrict__ wp,
-                                      int Cin, int Cout, int ks, int Kb, int Mpad) {
+                                      int Cin, int Cout, int ks, int Kb, int Mpad, int dgrad) {
   const int T = ks * ks;
   const int total = T * Kb * Mpad;
+  const int Kc = dgrad ? Cout : Cin, Mc = dgrad ? Cin : Cout;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
     const int m = e % Mpad;
     const int kb = (e / Mpad) % Kb;
     const int t = e / (Mpad * Kb);
+    const int tt = dgrad ? (T - 1 - t) : t;  // flipped tap
     bf16x8 o;
-    const float sc = (m < Cout && scale != nullptr) ? scale[m] : 1.f;
+    const float sc = (!dgrad && m < Cout && scale != nullptr) ? scale[m] : 1.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int ci = kb * 8 + j;
+      const int k = kb * 8 + j;
       float v = 0.f;
-      if (m < Cout && ci < Cin) v = w[((size_t)(m * Cin + ci) * ks + t / ks) * ks + t % ks] * sc;
+      if (m < Mc && k < Kc) {
+        const int co = dgrad ? k : m, ci = dgrad ? m : k;
+        v = w[((size_t)(co * Cin + ci) * ks + tt / ks) * ks + tt % ks] * sc;
+      }
       o[j] = (__bf16)v;
     }
     wp[e] = __builtin_bit_cast(u32x4, o);
@@ -351,20 +424,23 @@ bool bf_plan(int OH, int OW, int a, int T, int span, int Kb, int MW, int NW, BfT
 // =========================================================================================================
 // C ABI
 // =========================================================================================================
-extern "C" int yogo_conv_bf16_packed_bytes(int Cin, int Cout, int ks, size_t* bytes) {
+// mode 0: forward (k = ci, m = co); mode 1: dgrad (k = co, m = ci, flipped taps)
+extern "C" int yogo_conv_bf16_packed_bytes(int Cin, int Cout, int ks, int mode, size_t* bytes) {
   YOGO_CHECK_ARG(bytes && Cin > 0 && Cout > 0 && (ks == 1 || ks == 3), "conv_bf16_packed_bytes: bad arguments");
-  *bytes = (size_t)ks * ks * bf_kb_of(Cin) * bf_mpad_of(Cout) * 16;
+  const int K = mode ? Cout : Cin, M = mode ? Cin : Cout;
+  *bytes = (size_t)ks * ks * bf_kb_of(K) * bf_mpad_of(M) * 16;
   return YOGO_OK;
 }
 
 // scale (optional, [Cout]): per-output-channel factor folded into the weights (eval-mode BatchNorm: gamma / sqrt(var + eps))
-extern "C" int yogo_conv_bf16_pack(const float* w_oihw, const float* scale, void* packed, int Cin, int Cout, int ks,
+extern "C" int yogo_conv_bf16_pack(const float* w_oihw, const float* scale, void* packed, int Cin, int Cout, int ks, int mode,
                                    hipStream_t stream) {
   YOGO_CHECK_ARG(w_oihw && packed && Cin > 0 && Cout > 0 && (ks == 1 || ks == 3), "conv_bf16_pack: bad arguments");
-  const int Kb = bf_kb_of(Cin), Mpad = bf_mpad_of(Cout);
+  const int K = mode ? Cout : Cin, M = mode ? Cin : Cout;
+  const int Kb = bf_kb_of(K), Mpad = bf_mpad_of(M);
   const int total = ks * ks * Kb * Mpad;
   hipLaunchKernelGGL(conv_bf16_pack_kernel, dim3(min(1024, cdiv(total, 256))), dim3(256), 0, stream, w_oihw, scale,
-                     reinterpret_cast<u32x4*>(packed), Cin, Cout, ks, Kb, Mpad);
+                     reinterpret_cast<u32x4*>(packed), Cin, Cout, ks, Kb, Mpad, mode);
   YOGO_CHECK_LAUNCH("conv_bf16_pack");
   return YOGO_OK;
 }
@@ -372,47 +448,56 @@ extern "C" int yogo_conv_bf16_pack(const float* w_oihw, const float* scale, void
 // channel blocks of a bf16 NCHW8c tensor with C channels AS THE NEXT LAYER READS IT (padded to 16 channels = 2 blocks)
 extern "C" int yogo_bf16_channel_blocks(int C) { return bf_kb_of(C); }
 
-// in: bf16 NCHW8c [B][kb(Cin)][IH][IW][8]; out: bf16 NCHW8c [B][kb(Cout)][OH][OW][8], or fp32 NCHW when out_f32 != NULL.
-// y = act(conv(x, packed) + bias)
-extern "C" int yogo_conv2d_fwd_bf16(const void* in, const void* packed, const float* bias, void* out, float* out_f32, int B,
-                                    int Cin, int Cout, int IH, int IW, int ks, int stride, int act, hipStream_t stream) {
-  YOGO_CHECK_ARG(in && packed && (out || out_f32), "conv2d_fwd_bf16: null pointer");
-  YOGO_CHECK_ARG((ks == 3 || ks == 1) && (stride == 1 || stride == 2) && !(ks == 1 && stride != 1) && B >= 0 && Cin > 0 &&
-                     Cout > 0 && IH > 0 && IW > 0, "conv2d_fwd_bf16: unsupported shape");
-  const int pad = ks == 3 ? 1 : 0, T = ks * ks;
-  const int OH = (IH + 2 * pad - ks) / stride + 1, OW = (IW + 2 * pad - ks) / stride + 1;
-  const int MW = bf_pick_mw(Cout), NW = bf_pick_nw(MW);
-  const int Kb = bf_kb_of(Cin), Mpad = bf_mpad_of(Cout);
+namespace {
+
+// One launcher for forward and data-gradient.  (K, M) are the GEMM contraction / output channel counts, (IH, IW) the
+// physical input dims, (OH, OW) the output dims, `a` the input step per output pixel, ups = 1 reads the input as if
+// zero-upsampled by 2.
+int launch_conv_bf16(const void* in, const void* packed, const float* bias, void* out, float* out_f32, const void* act_ref,
+                     int ref_act, const float* chan_scale, float* stats_part, int B, int K, int M, int IH, int IW, int OH,
+                     int OW, int ks, int a, int ups, int act, hipStream_t stream, int* stats_rows, int* stats_mpad) {
+  const int T = ks * ks, pad = ks == 3 ? 1 : 0;
+  const int MW = bf_pick_mw(M), NW = bf_pick_nw(MW);
+  const int Kb = bf_kb_of(K), Mpad = bf_mpad_of(M);
   BfTiling tl;
-  YOGO_CHECK_ARG(bf_plan(OH, OW, stride, T, ks, Kb, MW, NW, &tl), "conv2d_fwd_bf16: no LDS tiling fits");
+  if (!bf_plan(OH, OW, a, T, ks, Kb, MW, NW, &tl)) {
+    yogo_set_error("conv_bf16: no LDS tiling fits (K=%d M=%d OW=%d a=%d)", K, M, OW, a);
+    return YOGO_ERR_ARG;
+  }
+  dim3 grid(tl.ncb * tl.tiles_per_band, Mpad / (32 * MW), B);
+  if (stats_rows) *stats_rows = B * (int)grid.x;
+  if (stats_mpad) *stats_mpad = Mpad;
+  if (in == nullptr) return YOGO_OK;  // shape query only
   ConvBf16Params p{};
   p.in = reinterpret_cast<const u32x4*>(in); p.wp = reinterpret_cast<const u32x4*>(packed); p.bias = bias;
   p.out = reinterpret_cast<u32x2*>(out); p.out_f32 = out_f32;
-  p.B = B; p.Kb = Kb; p.M = Cout; p.Mpad = Mpad; p.Mb = bf_kb_of(Cout);
-  p.IH = IH; p.IW = IW; p.OH = OH; p.OW = OW; p.a = stride; p.T = T;
+  p.act_ref = reinterpret_cast<const u32x2*>(act_ref); p.ref_act = ref_act; p.chan_scale = chan_scale; p.stats_part = stats_part;
+  p.ups = ups;
+  p.B = B; p.Kb = Kb; p.M = M; p.Mpad = Mpad; p.Mb = bf_kb_of(M);
+  p.IH = IH; p.IW = IW; p.OH = OH; p.OW = OW; p.a = a; p.T = T;
   p.dy_min = -pad; p.dx_min = -pad; p.span_y = ks; p.span_x = ks;
   for (int t = 0; t < T; ++t) p.toff[t] = (t / ks) * tl.LWp + (t % ks);
   p.ncb = tl.ncb; p.TW = tl.TW; p.tiles_per_band = tl.tiles_per_band;
   p.CKb = tl.CKb; p.nchunk = Kb / tl.CKb; p.rows_max = tl.rows_max; p.LWp = tl.LWp; p.chs = tl.chs;
   p.ldsw_off = tl.ldsw_off; p.lds_dummy = tl.lds_dummy; p.act = act;
   if (B == 0) return YOGO_OK;
-  dim3 grid(tl.ncb * tl.tiles_per_band, Mpad / (32 * MW), B);
+  const int lds_bytes = max(tl.lds_bytes, 4 * 32 * MW * 2 * 4);
   {
     static int verbose = -1;
     if (verbose < 0) verbose = getenv("YOGO_IGEMM_VERBOSE") ? 1 : 0;
     if (verbose)
-      fprintf(stderr, "[bf16] K=%d M=%d in=%dx%d s=%d T=%d | MW=%d NW=%d ncb=%d TW=%d CKb=%d rows=%d LW=%d lds=%d grid=%ux%ux%u\n", Cin,
-              Cout, IH, IW, stride, T, MW, NW, tl.ncb, tl.TW, tl.CKb, tl.rows_max, tl.LWp, tl.lds_bytes, grid.x, grid.y, grid.z);
+      fprintf(stderr, "[bf16] K=%d M=%d in=%dx%d a=%d ups=%d T=%d | MW=%d NW=%d ncb=%d TW=%d CKb=%d rows=%d LW=%d lds=%d grid=%ux%ux%u\n",
+              K, M, IH, IW, a, ups, T, MW, NW, tl.ncb, tl.TW, tl.CKb, tl.rows_max, tl.LWp, lds_bytes, grid.x, grid.y, grid.z);
   }
 #define BFLAUNCH(MW_, NW_, F32_)                                                                                       \
   do {                                                                                                                 \
     static bool attr_set = false;                                                                                      \
     if (!attr_set) {                                                                                                   \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<MW_, NW_, F32_>),                      \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, BF_LDS_MAX);                            \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, BF_LDS_MAX);                               \
       attr_set = true;                                                                                                 \
     }                                                                                                                  \
-    hipLaunchKernelGGL((conv_bf16_kernel<MW_, NW_, F32_>), grid, dim3(256), tl.lds_bytes, stream, p);                  \
+    hipLaunchKernelGGL((conv_bf16_kernel<MW_, NW_, F32_>), grid, dim3(256), lds_bytes, stream, p);                     \
   } while (0)
   if (out_f32 != nullptr) {
     if (MW == 4) BFLAUNCH(4, 2, true);
@@ -424,8 +509,50 @@ extern "C" int yogo_conv2d_fwd_bf16(const void* in, const void* packed, const fl
     else BFLAUNCH(1, 4, false);
   }
 #undef BFLAUNCH
-  YOGO_CHECK_LAUNCH("conv2d_fwd_bf16");
+  YOGO_CHECK_LAUNCH("conv_bf16");
   return YOGO_OK;
+}
+
+int check_bf16_conv(int B, int Cin, int Cout, int IH, int IW, int ks, int stride) {
+  YOGO_CHECK_ARG((ks == 3 || ks == 1) && (stride == 1 || stride == 2) && !(ks == 1 && stride != 1) && B >= 0 && Cin > 0 &&
+                     Cout > 0 && IH > 0 && IW > 0, "conv_bf16: unsupported shape");
+  return YOGO_OK;
+}
+
+}  // namespace
+
+// rows / row stride of the BatchNorm partial-sum buffer a forward launch fills when stats_part != NULL
+extern "C" int yogo_conv2d_fwd_bf16_stats_shape(int B, int Cin, int Cout, int IH, int IW, int ks, int stride, int* rows, int* mpad) {
+  if (int e = check_bf16_conv(B, Cin, Cout, IH, IW, ks, stride)) return e;
+  const int pad = ks == 3 ? 1 : 0;
+  return launch_conv_bf16(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, B, Cin, Cout, IH, IW,
+                          (IH + 2 * pad - ks) / stride + 1, (IW + 2 * pad - ks) / stride + 1, ks, stride, 0, 0, nullptr, rows, mpad);
+}
+
+// in: bf16 NCHW8c [B][kb(Cin)][IH][IW][8]; out: bf16 NCHW8c [B][kb(Cout)][OH][OW][8], or fp32 NCHW when out_f32 != NULL.
+// y = chan_scale * act(conv(x, packed) + bias); stats_part (optional) receives (sum, sumsq) of conv + bias per channel.
+extern "C" int yogo_conv2d_fwd_bf16(const void* in, const void* packed, const float* bias, void* out, float* out_f32,
+                                    const float* chan_scale, float* stats_part, int B, int Cin, int Cout, int IH, int IW,
+                                    int ks, int stride, int act, hipStream_t stream) {
+  YOGO_CHECK_ARG(in && packed && (out || out_f32), "conv2d_fwd_bf16: null pointer");
+  if (int e = check_bf16_conv(B, Cin, Cout, IH, IW, ks, stride)) return e;
+  const int pad = ks == 3 ? 1 : 0;
+  return launch_conv_bf16(in, packed, bias, out, out_f32, nullptr, 0, chan_scale, stats_part, B, Cin, Cout, IH, IW,
+                          (IH + 2 * pad - ks) / stride + 1, (IW + 2 * pad - ks) / stride + 1, ks, stride, 0, act, stream,
+                          nullptr, nullptr);
+}
+
+// dx = conv_transpose(dy) * act'(act_ref) * chan_scale, all bf16 NCHW8c; (IH, IW) = the forward conv's INPUT dims.
+// Stride 2 reads dy as if zero-upsampled (the zeros are produced while staging into LDS, they cost MFMA slots only).
+extern "C" int yogo_conv2d_dgrad_bf16(const void* dy, const void* packed_dgrad, void* dx, const void* act_ref, int ref_act,
+                                      const float* chan_scale, int B, int Cin, int Cout, int IH, int IW, int ks, int stride,
+                                      hipStream_t stream) {
+  YOGO_CHECK_ARG(dy && packed_dgrad && dx, "conv2d_dgrad_bf16: null pointer");
+  if (int e = check_bf16_conv(B, Cin, Cout, IH, IW, ks, stride)) return e;
+  const int pad = ks == 3 ? 1 : 0;
+  const int OHf = (IH + 2 * pad - ks) / stride + 1, OWf = (IW + 2 * pad - ks) / stride + 1;
+  return launch_conv_bf16(dy, packed_dgrad, nullptr, dx, nullptr, act_ref, ref_act, chan_scale, nullptr, B, Cout, Cin, OHf, OWf,
+                          IH, IW, ks, 1, stride == 2 ? 1 : 0, ACT_NONE, stream, nullptr, nullptr);
 }
 
 // first conv (Cin 1|3; in_dtype 0 = uint8, 1 = float32), fp32 weights [Cout][Cin][3][3] with BatchNorm already folded;

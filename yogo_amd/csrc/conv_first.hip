@@ -11,7 +11,12 @@
 #define CF_PPT 4       // pixels per thread
 #define CF_COCHUNK 16  // output channels per register pass
 
+typedef __bf16 cf_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int cf_u32x4 __attribute__((ext_vector_type(4)));
+
 struct ConvFirstParams {
+  cf_u32x4* out_bf16;      // when set: output goes to bf16 NCHW8c [B][Mb][OH][OW] units instead of `out`
+  int Mb;
   const void* in;
   const float* w;          // OIHW [Cout][Cin][3][3]
   const float* bias;       // optional
@@ -54,22 +59,39 @@ __global__ __launch_bounds__(CF_THREADS) void conv_first_kernel(const ConvFirstP
             if (ok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) v = (float)inb[((size_t)ci * p.IH + iy) * p.IW + ix];
             x[(ci * 3 + kh) * 3 + kw] = v;
           }
+      float vout[CF_COCHUNK];
 #pragma unroll
       for (int c = 0; c < CF_COCHUNK; ++c) {
         const int co = co0 + c;
+        vout[c] = 0.f;
         if (co < p.Cout) {  // uniform
           float acc = 0.f;
 #pragma unroll
           for (int j = 0; j < CIN * 9; ++j) acc = fmaf(w[co * CIN * 9 + j], x[j], acc);
           if (p.bias != nullptr) acc += p.bias[co];
+          float v = act_fwd(acc, p.act);
+          if (p.chan_scale != nullptr) v *= p.chan_scale[(size_t)b * p.Cout + co];
+          vout[c] = v;
           if (ok) {
             s[c] += acc;
             q[c] += acc * acc;
-            const size_t idx = ((size_t)b * p.Cout + co) * npix + pix;
-            if (p.out_pre != nullptr) p.out_pre[idx] = acc;
-            float v = act_fwd(acc, p.act);
-            if (p.chan_scale != nullptr) v *= p.chan_scale[(size_t)b * p.Cout + co];
-            p.out[idx] = v;
+            if (p.out_bf16 == nullptr) {
+              const size_t idx = ((size_t)b * p.Cout + co) * npix + pix;
+              if (p.out_pre != nullptr) p.out_pre[idx] = acc;
+              p.out[idx] = v;
+            }
+          }
+        }
+      }
+      if (p.out_bf16 != nullptr && ok) {  // two 16-byte units (8 channels each) per pixel and 16-channel pass
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+          const int cb = (co0 >> 3) + hb;
+          if (cb < p.Mb) {
+            cf_bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (__bf16)vout[hb * 8 + j];
+            p.out_bf16[((size_t)b * p.Mb + cb) * npix + pix] = __builtin_bit_cast(cf_u32x4, o);
           }
         }
       }
@@ -99,6 +121,8 @@ __global__ __launch_bounds__(CF_THREADS) void conv_first_kernel(const ConvFirstP
 // dW[co][ci][kh][kw] = sum_{b,pix} dy[b][co][pix] * x[b][ci][pix*stride + tap]; db likewise without x.
 // One workgroup per (pixel tile, image); partials [rows][Cout][CIN*9 + 1] are summed by channel_partials_reduce.
 struct ConvFirstWgradParams {
+  const cf_u32x4* dy_bf16;  // when set: gradient in bf16 NCHW8c [B][Mb][OH][OW] units
+  int Mb;
   const void* in;
   const float* dy;    // [B][Cout][OH][OW] (already multiplied by act'/mask)
   float* part;        // [B*gridDim.x][Cout][CIN*9+1]
@@ -142,7 +166,15 @@ __global__ __launch_bounds__(CF_THREADS) void conv_first_wgrad_kernel(const Conv
 #pragma unroll
     for (int k = 0; k < CF_PPT; ++k) {
       const int pix = pbase + k * CF_THREADS + tid;
-      const float g = okk[k] ? p.dy[((size_t)b * p.Cout + co) * npix + pix] : 0.f;
+      float g = 0.f;
+      if (okk[k]) {
+        if (p.dy_bf16 != nullptr) {
+          const cf_bf16x8 u = __builtin_bit_cast(cf_bf16x8, p.dy_bf16[((size_t)b * p.Mb + (co >> 3)) * npix + pix]);
+          g = (float)u[co & 7];
+        } else {
+          g = p.dy[((size_t)b * p.Cout + co) * npix + pix];
+        }
+      }
 #pragma unroll
       for (int j = 0; j < CIN * 9; ++j) acc[j] = fmaf(g, x[k][j], acc[j]);
       acc[NJ - 1] += g;
@@ -168,15 +200,37 @@ extern "C" int yogo_conv_first_stats_rows(int B, int IH, int IW, int stride, int
   return YOGO_OK;
 }
 
+static int conv_first_fwd_impl(const void* in, int in_dtype, const float* w, const float* bias, float* out, void* out_bf16,
+                               float* out_pre, const float* chan_scale, float* stats_part, int B, int Cin, int Cout, int IH,
+                               int IW, int stride, int act, hipStream_t stream);
+
 // in_dtype: 0 = uint8, 1 = float32
 extern "C" int yogo_conv_first_fwd(const void* in, int in_dtype, const float* w, const float* bias, float* out,
                                    float* out_pre, const float* chan_scale, float* stats_part, int B, int Cin, int Cout,
                                    int IH, int IW, int stride, int act, hipStream_t stream) {
-  YOGO_CHECK_ARG(in && w && out, "conv_first_fwd: null pointer");
+  YOGO_CHECK_ARG(out != nullptr, "conv_first_fwd: null pointer");
+  return conv_first_fwd_impl(in, in_dtype, w, bias, out, nullptr, out_pre, chan_scale, stats_part, B, Cin, Cout, IH, IW, stride, act,
+                             stream);
+}
+
+// training variant with bf16 NCHW8c output (+ fp32 BatchNorm partial sums): out = chan_scale * act(conv + bias)
+extern "C" int yogo_conv_first_fwd_train_bf16(const void* in, int in_dtype, const float* w, const float* bias, void* out_bf16,
+                                              const float* chan_scale, float* stats_part, int B, int Cin, int Cout, int IH,
+                                              int IW, int stride, int act, hipStream_t stream) {
+  YOGO_CHECK_ARG(out_bf16 != nullptr, "conv_first_fwd_train_bf16: null pointer");
+  return conv_first_fwd_impl(in, in_dtype, w, bias, nullptr, out_bf16, nullptr, chan_scale, stats_part, B, Cin, Cout, IH, IW, stride,
+                             act, stream);
+}
+
+static int conv_first_fwd_impl(const void* in, int in_dtype, const float* w, const float* bias, float* out, void* out_bf16,
+                               float* out_pre, const float* chan_scale, float* stats_part, int B, int Cin, int Cout, int IH,
+                               int IW, int stride, int act, hipStream_t stream) {
+  YOGO_CHECK_ARG(in && w, "conv_first_fwd: null pointer");
   YOGO_CHECK_ARG((Cin == 1 || Cin == 3) && Cout > 0 && IH > 0 && IW > 0 && (stride == 1 || stride == 2) && B >= 0,
                  "conv_first_fwd: unsupported shape Cin=%d Cout=%d stride=%d", Cin, Cout, stride);
   YOGO_CHECK_ARG(in_dtype == 0 || in_dtype == 1, "conv_first_fwd: in_dtype must be 0 (uint8) or 1 (float32)");
   ConvFirstParams p{};
+  p.out_bf16 = reinterpret_cast<cf_u32x4*>(out_bf16); p.Mb = ((Cout + 15) / 16) * 2;
   p.in = in; p.w = w; p.bias = bias; p.out = out; p.out_pre = out_pre; p.chan_scale = chan_scale; p.stats_part = stats_part;
   p.B = B; p.Cin = Cin; p.Cout = Cout; p.IH = IH; p.IW = IW; p.stride = stride; p.act = act;
   p.OH = (IH - 1) / stride + 1; p.OW = (IW - 1) / stride + 1;
@@ -190,12 +244,29 @@ extern "C" int yogo_conv_first_fwd(const void* in, int in_dtype, const float* w,
   return YOGO_OK;
 }
 
+static int conv_first_wgrad_impl(const void* in, int in_dtype, const float* dy, const void* dy_bf16, float* part, int B, int Cin,
+                                 int Cout, int IH, int IW, int stride, hipStream_t stream);
+
 // partial weight/bias gradients; part must hold rows*Cout*(Cin*9+1) floats with rows from yogo_conv_first_stats_rows
 extern "C" int yogo_conv_first_wgrad(const void* in, int in_dtype, const float* dy, float* part, int B, int Cin, int Cout,
                                      int IH, int IW, int stride, hipStream_t stream) {
-  YOGO_CHECK_ARG(in && dy && part, "conv_first_wgrad: null pointer");
+  YOGO_CHECK_ARG(dy != nullptr, "conv_first_wgrad: null pointer");
+  return conv_first_wgrad_impl(in, in_dtype, dy, nullptr, part, B, Cin, Cout, IH, IW, stride, stream);
+}
+
+// same with the gradient in bf16 NCHW8c
+extern "C" int yogo_conv_first_wgrad_bf16g(const void* in, int in_dtype, const void* dy_bf16, float* part, int B, int Cin,
+                                           int Cout, int IH, int IW, int stride, hipStream_t stream) {
+  YOGO_CHECK_ARG(dy_bf16 != nullptr, "conv_first_wgrad_bf16g: null pointer");
+  return conv_first_wgrad_impl(in, in_dtype, nullptr, dy_bf16, part, B, Cin, Cout, IH, IW, stride, stream);
+}
+
+static int conv_first_wgrad_impl(const void* in, int in_dtype, const float* dy, const void* dy_bf16, float* part, int B, int Cin,
+                                 int Cout, int IH, int IW, int stride, hipStream_t stream) {
+  YOGO_CHECK_ARG(in && part, "conv_first_wgrad: null pointer");
   YOGO_CHECK_ARG((Cin == 1 || Cin == 3) && Cout > 0 && (stride == 1 || stride == 2), "conv_first_wgrad: unsupported shape");
   ConvFirstWgradParams p{};
+  p.dy_bf16 = reinterpret_cast<const cf_u32x4*>(dy_bf16); p.Mb = ((Cout + 15) / 16) * 2;
   p.in = in; p.dy = dy; p.part = part; p.B = B; p.Cin = Cin; p.Cout = Cout; p.IH = IH; p.IW = IW; p.stride = stride;
   p.OH = (IH - 1) / stride + 1; p.OW = (IW - 1) / stride + 1;
   if (B == 0) return YOGO_OK;

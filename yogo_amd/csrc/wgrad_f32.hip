@@ -13,6 +13,8 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int wg_u32x4 __attribute__((ext_vector_type(4)));
 
 #define WG_MAX_TAPS 9
 #define WGRAD_LDS_BUDGET (80 * 1024)
@@ -30,6 +32,7 @@ struct WgradParams {
   int gp, xp;                         // LDS pitches (odd: conflict-free channel-strided reads)
   int x_off;                          // float offset of the x tile in LDS
   int lds_dummy;                      // float offset of a scratch word (stores of padding lanes)
+  int Nb, Mbk;                        // BF: channel blocks of the bf16 NCHW8c x / g tensors
 };
 
 // One unit = one output row segment (<= WC pixels) of one image.  Per unit the workgroup stages g[MBW*32][wce] and
@@ -39,7 +42,9 @@ struct WgradParams {
 // Wavefront jobs: MBW co-blocks x NBW ci-blocks x KS pixel-splits x TG tap rows (TG = 3 for a 3x3 kernel: each wavefront
 // owns the three taps of one kernel row, i.e. 3 accumulator tiles = 48 VGPRs, which leaves room for the prefetch registers
 // and lets 3 wavefronts share each SIMD).  MBW*NBW*KS = 4, so a workgroup is 12 wavefronts (3x3) or 4 (1x1).
-template <int MBW, int NBW, int KS, int T, int S>
+// BF: x and g are bf16 NCHW8c tensors (16-byte units of 8 channels); they are widened to fp32 while being committed to LDS,
+// the matrix work stays exact fp32 MFMA.
+template <int MBW, int NBW, int KS, int T, int S, bool BF = false>
 __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_f32_kernel(const WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int TG = (T == 1) ? 1 : 3;                         // tap groups (kernel rows)
@@ -77,7 +82,13 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
 
   const int gtotal = MBW * 32 * p.wce;
   const int xtotal = NBW * 32 * p.per_ch;
-  float gq[NGQ], xq[NXQ];
+  float gq[BF ? 1 : NGQ], xq[BF ? 1 : NXQ];
+  // BF mode: units of 8 channels
+  constexpr int NGU = (MBW * 4 * WC + NT - 1) / NT;
+  constexpr int NXU = (NBW * 4 * XR * XWMAX + NT - 1) / NT;
+  wg_u32x4 gu[BF ? NGU : 1], xu[BF ? NXU : 1];
+  const int gtotal_u = MBW * 4 * p.wce;
+  const int xtotal_u = NBW * 4 * p.per_ch;
 
   // unit -> (image, output row, first column, real width)
 #define WG_UNIT(U, B_, OY_, OX0_, WCR_)                                   \
@@ -139,6 +150,72 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
     }                                                                                                       \
   }
 
+#define WG_ISSUE_BF(U)                                                                                      \
+  {                                                                                                         \
+    WG_UNIT(U, b_, oy_, ox0_, wc_)                                                                          \
+    const wg_u32x4* gb_ = reinterpret_cast<const wg_u32x4*>(p.g) + ((size_t)b_ * p.Mbk) * gplane + (size_t)oy_ * p.OW + ox0_; \
+    _Pragma("unroll") for (int i = 0; i < NGU; ++i) {                                                       \
+      const int e_ = min(tid + NT * i, gtotal_u - 1);                                                       \
+      const int cb_ = __umulhi((unsigned)e_, p.inv_wce);                                                    \
+      const int c_ = e_ - cb_ * p.wce;                                                                      \
+      const bool ok_ = ((m0 >> 3) + cb_ < p.Mbk) && (c_ < wc_);                                             \
+      gu[i] = gb_[ok_ ? ((m0 >> 3) + cb_) * (int)gplane + c_ : 0];                                          \
+    }                                                                                                       \
+    const wg_u32x4* xb_ = reinterpret_cast<const wg_u32x4*>(p.x) + ((size_t)b_ * p.Nb) * xplane;            \
+    const int iy0_ = oy_ * S - p.pad, ix0_ = ox0_ * S - p.pad;                                              \
+    _Pragma("unroll") for (int i = 0; i < NXU; ++i) {                                                       \
+      const int e_ = min(tid + NT * i, xtotal_u - 1);                                                       \
+      const int cb_ = __umulhi((unsigned)e_, p.inv_pc);                                                     \
+      const int rm_ = e_ - cb_ * p.per_ch;                                                                  \
+      const int r_ = __umulhi((unsigned)rm_, p.inv_xw);                                                     \
+      const int c_ = rm_ - r_ * p.xw;                                                                       \
+      const int nb_ = (n0 >> 3) + cb_, iy_ = iy0_ + r_, ix_ = ix0_ + c_;                                    \
+      const bool ok_ = (nb_ < p.Nb) && (iy_ >= 0) && (iy_ < p.IH) && (ix_ >= 0) && (ix_ < p.IW);            \
+      xu[i] = xb_[ok_ ? (nb_ * p.IH + iy_) * p.IW + ix_ : 0];                                               \
+    }                                                                                                       \
+  }
+#define WG_COMMIT_BF(U)                                                                                     \
+  {                                                                                                         \
+    WG_UNIT(U, b_, oy_, ox0_, wc_)                                                                          \
+    (void)b_;                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < NGU; ++i) {                                                       \
+      const int e_ = tid + NT * i;                                                                          \
+      const int ec_ = min(e_, gtotal_u - 1);                                                                \
+      const int cb_ = __umulhi((unsigned)ec_, p.inv_wce);                                                   \
+      const int c_ = ec_ - cb_ * p.wce;                                                                     \
+      const bool ok_ = ((m0 >> 3) + cb_ < p.Mbk) && (c_ < wc_);                                             \
+      const wg_bf16x8 v_ = __builtin_bit_cast(wg_bf16x8, gu[i]);                                            \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                         \
+        smem[e_ < gtotal_u ? (cb_ * 8 + j) * p.gp + c_ : p.lds_dummy] = ok_ ? (float)v_[j] : 0.f;           \
+    }                                                                                                       \
+    const int iy0_ = oy_ * S - p.pad, ix0_ = ox0_ * S - p.pad;                                              \
+    _Pragma("unroll") for (int i = 0; i < NXU; ++i) {                                                       \
+      const int e_ = tid + NT * i;                                                                          \
+      const int ec_ = min(e_, xtotal_u - 1);                                                                \
+      const int cb_ = __umulhi((unsigned)ec_, p.inv_pc);                                                    \
+      const int rm_ = ec_ - cb_ * p.per_ch;                                                                 \
+      const int r_ = __umulhi((unsigned)rm_, p.inv_xw);                                                     \
+      const int c_ = rm_ - r_ * p.xw;                                                                       \
+      const int nb_ = (n0 >> 3) + cb_, iy_ = iy0_ + r_, ix_ = ix0_ + c_;                                    \
+      const bool ok_ = (nb_ < p.Nb) && (iy_ >= 0) && (iy_ < p.IH) && (ix_ >= 0) && (ix_ < p.IW);            \
+      const wg_bf16x8 v_ = __builtin_bit_cast(wg_bf16x8, xu[i]);                                            \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                         \
+        smem[e_ < xtotal_u ? p.x_off + (cb_ * 8 + j) * xcs + r_ * p.xp + c_ : p.lds_dummy] = ok_ ? (float)v_[j] : 0.f; \
+    }                                                                                                       \
+  }
+#define WG_ISSUE_ANY(U)   \
+  if constexpr (BF) {     \
+    WG_ISSUE_BF(U)        \
+  } else {                \
+    WG_ISSUE(U)           \
+  }
+#define WG_COMMIT_ANY(U)  \
+  if constexpr (BF) {     \
+    WG_COMMIT_BF(U)       \
+  } else {                \
+    WG_COMMIT(U)          \
+  }
+
   const int npair = p.wce >> 1;
   const int cnt = (npair - ks + KS - 1) / KS;  // pairs ks, ks+KS, ... of this wavefront
   const float* ga = ldsG + (mb * 32 + l31) * p.gp + half;
@@ -153,13 +230,13 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
   _Pragma("unroll") for (int t = 0; t < TT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV, BV[t], acc[t], 0, 0, 0);
 
   if (u_begin < u_end) {
-    WG_ISSUE(u_begin);
-    WG_COMMIT(u_begin);
+    WG_ISSUE_ANY(u_begin);
+    WG_COMMIT_ANY(u_begin);
   }
   __syncthreads();
   for (int u = u_begin; u < u_end; ++u) {
     const bool more = u + 1 < u_end;
-    if (more) WG_ISSUE(u + 1);
+    if (more) WG_ISSUE_ANY(u + 1);
     // ---- bias partial: row sums of the staged g tile (padding columns hold zeros) ------------------------------
     if (p.bias_part != nullptr && blockIdx.y == 0 && tid < MBW * 32) {
       float s = 0.f;
@@ -185,12 +262,16 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
     }
     __syncthreads();
     if (more) {
-      WG_COMMIT(u + 1);
+      WG_COMMIT_ANY(u + 1);
       __syncthreads();
     }
   }
 #undef WG_UNIT
 #undef WG_ISSUE
+#undef WG_ISSUE_BF
+#undef WG_COMMIT_BF
+#undef WG_ISSUE_ANY
+#undef WG_COMMIT_ANY
 #undef WG_COMMIT
 #undef WG_LOAD
 #undef WG_MFMA
@@ -297,22 +378,29 @@ bool make_plan(int B, int N, int M, int IH, int IW, int ks, int stride, WgradPla
   return true;
 }
 
-template <int MBW, int NBW, int KS, int T, int S>
+template <int MBW, int NBW, int KS, int T, int S, bool BF>
 void launch_one(const WgradParams& p, const WgradPlan& pl, hipStream_t stream) {
   static bool s = false;
   if (!s) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f32_kernel<MBW, NBW, KS, T, S>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f32_kernel<MBW, NBW, KS, T, S, BF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_LDS_BUDGET);
     s = true;
   }
-  hipLaunchKernelGGL((wgrad_f32_kernel<MBW, NBW, KS, T, S>), pl.grid, dim3(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)), pl.lds_bytes, stream, p);
+  hipLaunchKernelGGL((wgrad_f32_kernel<MBW, NBW, KS, T, S, BF>), pl.grid, dim3(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)), pl.lds_bytes,
+                     stream, p);
 }
 
 template <int MBW, int NBW, int KS>
-void launch_wgrad(const WgradParams& p, const WgradPlan& pl, int T, int stride, hipStream_t stream) {
-  if (T == 1) launch_one<MBW, NBW, KS, 1, 1>(p, pl, stream);
-  else if (stride == 1) launch_one<MBW, NBW, KS, 9, 1>(p, pl, stream);
-  else launch_one<MBW, NBW, KS, 9, 2>(p, pl, stream);
+void launch_wgrad(const WgradParams& p, const WgradPlan& pl, int T, int stride, bool bf, hipStream_t stream) {
+  if (bf) {
+    if (T == 1) launch_one<MBW, NBW, KS, 1, 1, true>(p, pl, stream);
+    else if (stride == 1) launch_one<MBW, NBW, KS, 9, 1, true>(p, pl, stream);
+    else launch_one<MBW, NBW, KS, 9, 2, true>(p, pl, stream);
+  } else {
+    if (T == 1) launch_one<MBW, NBW, KS, 1, 1, false>(p, pl, stream);
+    else if (stride == 1) launch_one<MBW, NBW, KS, 9, 1, false>(p, pl, stream);
+    else launch_one<MBW, NBW, KS, 9, 2, false>(p, pl, stream);
+  }
 }
 
 }  // namespace
@@ -327,8 +415,24 @@ extern "C" int yogo_conv2d_wgrad_workspace_bytes(int B, int Cin, int Cout, int I
 }
 
 // dw (OIHW) and optional db, both clamped to +-clip when clip > 0.  x: layer input, g: grad w.r.t. conv output.
+static int wgrad_impl(const void* x, const void* g, bool bf, float* dw, float* db, void* workspace, int B, int Cin, int Cout, int IH,
+                      int IW, int ks, int stride, float clip, hipStream_t stream);
+
 extern "C" int yogo_conv2d_wgrad_f32(const float* x, const float* g, float* dw, float* db, void* workspace, int B, int Cin,
                                      int Cout, int IH, int IW, int ks, int stride, float clip, hipStream_t stream) {
+  return wgrad_impl(x, g, false, dw, db, workspace, B, Cin, Cout, IH, IW, ks, stride, clip, stream);
+}
+
+// x and g in bf16 NCHW8c (channels padded to 16); fp32 gradients out.  Same workspace size as the fp32 entry point.
+extern "C" int yogo_conv2d_wgrad_bf16in(const void* x, const void* g, float* dw, float* db, void* workspace, int B, int Cin,
+                                        int Cout, int IH, int IW, int ks, int stride, float clip, hipStream_t stream) {
+  return wgrad_impl(x, g, true, dw, db, workspace, B, Cin, Cout, IH, IW, ks, stride, clip, stream);
+}
+
+static int wgrad_impl(const void* x_, const void* g_, bool bf, float* dw, float* db, void* workspace, int B, int Cin, int Cout, int IH,
+                      int IW, int ks, int stride, float clip, hipStream_t stream) {
+  const float* x = reinterpret_cast<const float*>(x_);
+  const float* g = reinterpret_cast<const float*>(g_);
   YOGO_CHECK_ARG(x && g && dw && workspace, "conv2d_wgrad: null pointer");
   YOGO_CHECK_ARG(B > 0 && Cin > 0 && Cout > 0 && IH > 0 && IW > 0 && (ks == 1 || ks == 3) && (stride == 1 || stride == 2) &&
                      !(ks == 1 && stride != 1), "conv2d_wgrad: bad shape");
@@ -344,14 +448,15 @@ extern "C" int yogo_conv2d_wgrad_f32(const float* x, const float* g, float* dw, 
   p.inv_wce = magic_u32(pl.wce); p.inv_xw = magic_u32(pl.xw); p.inv_pc = magic_u32(pl.per_ch);
   p.units = pl.units; p.units_per_split = pl.units_per_split;
   p.gp = pl.gp; p.xp = pl.xp; p.x_off = pl.x_off; p.lds_dummy = pl.lds_dummy;
+  p.Nb = ((Cin + 15) / 16) * 2; p.Mbk = ((Cout + 15) / 16) * 2;
   const int cfg = pl.MBW * 100 + pl.NBW * 10 + pl.KS;
   switch (cfg) {
-    case 411: launch_wgrad<4, 1, 1>(p, pl, T, stride, stream); break;
-    case 221: launch_wgrad<2, 2, 1>(p, pl, T, stride, stream); break;
-    case 212: launch_wgrad<2, 1, 2>(p, pl, T, stride, stream); break;
-    case 141: launch_wgrad<1, 4, 1>(p, pl, T, stride, stream); break;
-    case 122: launch_wgrad<1, 2, 2>(p, pl, T, stride, stream); break;
-    case 114: launch_wgrad<1, 1, 4>(p, pl, T, stride, stream); break;
+    case 411: launch_wgrad<4, 1, 1>(p, pl, T, stride, bf, stream); break;
+    case 221: launch_wgrad<2, 2, 1>(p, pl, T, stride, bf, stream); break;
+    case 212: launch_wgrad<2, 1, 2>(p, pl, T, stride, bf, stream); break;
+    case 141: launch_wgrad<1, 4, 1>(p, pl, T, stride, bf, stream); break;
+    case 122: launch_wgrad<1, 2, 2>(p, pl, T, stride, bf, stream); break;
+    case 114: launch_wgrad<1, 1, 4>(p, pl, T, stride, bf, stream); break;
     default:
       yogo_set_error("wgrad: unsupported wave layout %d", cfg);
       return YOGO_ERR_ARG;

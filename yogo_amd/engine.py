@@ -326,6 +326,182 @@ class Engine:
         return [grads.get(id(p)) for p in bb.parameters()]
 
 
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bf16 training: activations / activation gradients in NCHW8c bf16, fp32 weights, statistics and parameter gradients
+# (the reference's `--half` training is fp16 autocast, yogo/train.py:315-318; bf16 needs no loss scaling)
+# ---------------------------------------------------------------------------------------------------------------------
+def _blocks(c: int) -> int:
+    return ((c + 15) // 16) * 2
+
+
+def _packed_bf16(eng: Engine, i: int, mode: int) -> torch.Tensor:
+    L = eng.layers[i]
+    w = L.conv.weight
+    key = (i, 10 + mode)
+    hit = eng._pack.get(key)
+    if hit is not None and hit[0] == w._version and hit[1] == w.data_ptr():
+        return hit[2]
+    nbytes = _hip.query_size("yogo_conv_bf16_packed_bytes", L.cin, L.cout, L.k, mode)
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    _hip.call("yogo_conv_bf16_pack", _f32(w.detach()), None, buf, L.cin, L.cout, L.k, mode, _hip.stream_ptr())
+    eng._pack[key] = (w._version, w.data_ptr(), buf)
+    return buf
+
+
+def forward_bf16_train(eng: Engine, x: torch.Tensor) -> Tuple[torch.Tensor, List[Saved]]:
+    _hip.require_cuda(x, "the input batch")
+    dev, st, B = x.device, _hip.stream_ptr(), x.shape[0]
+    if not eng._first_direct(0):
+        raise RuntimeError("yogo_amd: bf16 training needs a 1- or 3-channel 3x3 first convolution")
+    cur = x.contiguous() if x.dtype == torch.uint8 else _f32(x)
+    H, W = int(cur.shape[2]), int(cur.shape[3])
+    saved: List[Saved] = []
+    n = len(eng.layers)
+    for i, L in enumerate(eng.layers):
+        OH, OW = L.out_hw(H, W)
+        if OH <= 0 or OW <= 0:
+            raise RuntimeError(f"yogo_amd: image too small at layer {i}")
+        last = i == n - 1
+        has_bn = L.bn is not None
+        if L.act == ACT_SILU and not has_bn:
+            raise RuntimeError("yogo_amd: bf16 training of SiLU blocks without BatchNorm is not implemented (use fp32)")
+        bias = _f32(L.conv.bias.detach()) if L.conv.bias is not None else None
+        S = Saved(x_in=cur)
+        mask = None
+        if L.drop is not None and L.drop.training and L.drop.p > 0:
+            pdrop = float(L.drop.p)
+            mask = (torch.rand(B, L.cout, device=dev) >= pdrop).to(torch.float32) / (1.0 - pdrop)
+            S.mask = mask
+        bn_train = has_bn and (L.bn.training or L.bn.running_mean is None)
+        fused_act = ACT_NONE if has_bn else L.act
+        stats = None
+        rows = mpad = 0
+        if bn_train:
+            if i == 0:
+                rows, mpad = _hip.query_ints("yogo_conv_first_stats_rows", 1, B, H, W, L.s)[0], L.cout
+            else:
+                rows, mpad = _hip.query_ints("yogo_conv2d_fwd_bf16_stats_shape", 2, B, L.cin, L.cout, H, W, L.k, L.s)
+            stats = torch.empty(rows * mpad * 2, dtype=torch.float32, device=dev)
+        out8 = None if last else torch.empty(B, _blocks(L.cout), OH, OW, 8, dtype=torch.bfloat16, device=dev)
+        out32 = torch.empty(B, L.cout, OH, OW, dtype=torch.float32, device=dev) if last else None
+        if last and (has_bn or mask is not None):
+            raise RuntimeError("yogo_amd: BatchNorm / Dropout on the last layer is not supported by the bf16 path")
+        if i == 0:
+            _hip.call("yogo_conv_first_fwd_train_bf16", cur, 0 if cur.dtype == torch.uint8 else 1, _f32(L.conv.weight.detach()), bias,
+                      out8, mask, stats, B, L.cin, L.cout, H, W, L.s, fused_act, st)
+        else:
+            _hip.call("yogo_conv2d_fwd_bf16", cur, _packed_bf16(eng, i, 0), bias, out8, out32, mask, stats, B, L.cin, L.cout, H, W,
+                      L.k, L.s, fused_act, st)
+        if has_bn:
+            bn = L.bn
+            gamma = _f32(bn.weight.detach()) if bn.weight is not None else torch.ones(L.cout, device=dev)
+            beta = _f32(bn.bias.detach()) if bn.bias is not None else torch.zeros(L.cout, device=dev)
+            y = torch.empty_like(out8)
+            if bn_train:
+                mean = torch.empty(L.cout, dtype=torch.float32, device=dev)
+                invstd = torch.empty(L.cout, dtype=torch.float32, device=dev)
+                track = bn.track_running_stats and bn.running_mean is not None
+                _hip.call("yogo_bn_finalize", stats, rows, mpad, L.cout, B * OH * OW, float(bn.eps),
+                          float(bn.momentum if bn.momentum is not None else 0.0), mean, invstd,
+                          bn.running_mean if track else None, bn.running_var if track else None,
+                          bn.num_batches_tracked if track else None, st)
+                _hip.call("yogo_bn_apply_act_bf16", out8, y, mean, invstd, 0, float(bn.eps), gamma, beta, B, L.cout, OH * OW, L.act, st)
+            else:
+                invstd = torch.empty(L.cout, dtype=torch.float32, device=dev)
+                _hip.call("yogo_bn_invstd", bn.running_var, float(bn.eps), invstd, L.cout, st)
+                mean = bn.running_mean
+                _hip.call("yogo_bn_apply_act_bf16", out8, y, mean, invstd, 0, float(bn.eps), gamma, beta, B, L.cout, OH * OW, L.act, st)
+            S.mean, S.invstd, S.bn_train, S.z, S.y = mean, invstd, bn_train, out8, y
+            cur = y
+        else:
+            S.y = out32 if last else out8
+            cur = S.y
+        saved.append(S)
+        H, W = OH, OW
+    return cur, saved
+
+
+def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
+                        grad_out: Optional[Dict[int, torch.Tensor]] = None) -> List[Optional[torch.Tensor]]:
+    st, dev, clip = _hip.stream_ptr(), graw.device, float(eng.clip)
+    grads: Dict[int, torch.Tensor] = {}
+
+    def dst(param: torch.Tensor) -> torch.Tensor:
+        if grad_out is not None and id(param) in grad_out:
+            return grad_out[id(param)]
+        return torch.empty(param.shape, dtype=torch.float32, device=dev)
+
+    graw = _f32(graw)
+    B, P, Sy, Sx = graw.shape
+    g = torch.empty(B, _blocks(P), Sy, Sx, 8, dtype=torch.bfloat16, device=dev)
+    _hip.call("yogo_nchw_f32_to_bf16_8c", graw, g, B, P, Sy * Sx, st)
+    n = len(eng.layers)
+    for i in range(n - 1, -1, -1):
+        L, S = eng.layers[i], saved[i]
+        OH, OW = int(g.shape[2]), int(g.shape[3])
+        if i == 0:
+            IH, IW = int(S.x_in.shape[2]), int(S.x_in.shape[3])
+        else:
+            IH, IW = int(S.x_in.shape[2]), int(S.x_in.shape[3])   # NCHW8c: [B, Cb, H, W, 8]
+        if L.bn is not None:
+            bn = L.bn
+            gamma = _f32(bn.weight.detach()) if bn.weight is not None else torch.ones(L.cout, device=dev)
+            beta = _f32(bn.bias.detach()) if bn.bias is not None else torch.zeros(L.cout, device=dev)
+            dgamma = dst(bn.weight) if bn.weight is not None else torch.empty(L.cout, dtype=torch.float32, device=dev)
+            dbeta = dst(bn.bias) if bn.bias is not None else torch.empty(L.cout, dtype=torch.float32, device=dev)
+            rows = _hip.query_ints("yogo_bn_bwd_bf16_rows", 1, B, OH * OW)[0]
+            part = torch.empty(rows * L.cout * 2, dtype=torch.float32, device=dev)
+            sums = torch.empty(2 * L.cout, dtype=torch.float32, device=dev)
+            _hip.call("yogo_bn_bwd_bf16", g, S.z, g, S.mean, S.invstd, gamma, beta, L.act, dgamma, dbeta, part, sums, B, L.cout, OH * OW,
+                      1 if S.bn_train else 0, clip, st)
+            if bn.weight is not None:
+                grads[id(bn.weight)] = dgamma
+                grads[id(bn.bias)] = dbeta
+        dw = dst(L.conv.weight)
+        has_bias = L.conv.bias is not None
+        if i == 0:
+            rows = _hip.query_ints("yogo_conv_first_stats_rows", 1, B, IH, IW, L.s)[0]
+            nj = L.cin * 9 + 1
+            part = torch.empty(rows * L.cout * nj, dtype=torch.float32, device=dev)
+            _hip.call("yogo_conv_first_wgrad_bf16g", S.x_in, 0 if S.x_in.dtype == torch.uint8 else 1, g, part, B, L.cin, L.cout, IH, IW,
+                      L.s, st)
+            red = torch.empty(L.cout, nj, dtype=torch.float32, device=dev)
+            _hip.call("yogo_partials_reduce", part, rows, L.cout * nj, clip, red, st)
+            dw.copy_(red[:, : nj - 1].reshape(dw.shape))
+            if has_bias:
+                db = dst(L.conv.bias)
+                db.copy_(red[:, nj - 1])
+                grads[id(L.conv.bias)] = db
+        else:
+            wsb = _hip.query_size("yogo_conv2d_wgrad_workspace_bytes", B, L.cin, L.cout, IH, IW, L.k, L.s)
+            ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
+            db = dst(L.conv.bias) if has_bias else None
+            eng._tick("wgrad", i, 2.0 * B * L.cout * L.cin * L.k * L.k * OH * OW)
+            _hip.call("yogo_conv2d_wgrad_bf16in", S.x_in, g, dw, db, ws, B, L.cin, L.cout, IH, IW, L.k, L.s, clip, st)
+            eng._tock()
+            if has_bias:
+                grads[id(L.conv.bias)] = db
+        grads[id(L.conv.weight)] = dw
+        if i > 0:
+            Lp, Sp = eng.layers[i - 1], saved[i - 1]
+            ref_act = Lp.act
+            if Lp.bn is not None or Lp.act == ACT_NONE:
+                act_ref, ref_act = None, ACT_NONE
+            elif Lp.act == ACT_LEAKY:
+                act_ref = Sp.y
+            else:
+                raise RuntimeError("yogo_amd: bf16 training of SiLU blocks without BatchNorm is not implemented (use fp32)")
+            dx = torch.empty(B, _blocks(L.cin), IH, IW, 8, dtype=torch.bfloat16, device=dev)
+            eng._tick("dgrad", i, 2.0 * B * L.cout * L.cin * L.k * L.k * OH * OW, mw=30)
+            _hip.call("yogo_conv2d_dgrad_bf16", g, _packed_bf16(eng, i, 1), dx, act_ref, ref_act, Sp.mask, B, L.cin, L.cout, IH, IW,
+                      L.k, L.s, st)
+            eng._tock()
+            g = dx
+    bb = eng.backbone_ref()
+    return [grads.get(id(p)) for p in bb.parameters()]
+
+
 _ENGINES: "weakref.WeakKeyDictionary[nn.Module, Engine]" = weakref.WeakKeyDictionary()
 
 
@@ -419,9 +595,9 @@ class InferEngineBF16:
                 wf = w * scale[:, None, None, None] if scale is not None else w
                 prep.append((wf.contiguous(), bias.contiguous() if bias is not None else None))
             else:
-                nbytes = _hip.query_size("yogo_conv_bf16_packed_bytes", L.cin, L.cout, L.k)
+                nbytes = _hip.query_size("yogo_conv_bf16_packed_bytes", L.cin, L.cout, L.k, 0)
                 packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-                _hip.call("yogo_conv_bf16_pack", w, scale.contiguous() if scale is not None else None, packed, L.cin, L.cout, L.k, st)
+                _hip.call("yogo_conv_bf16_pack", w, scale.contiguous() if scale is not None else None, packed, L.cin, L.cout, L.k, 0, st)
                 prep.append((packed, bias.contiguous() if bias is not None else None))
         self._prep = prep
         self._key = key
@@ -455,11 +631,11 @@ class InferEngineBF16:
                     raise RuntimeError("yogo_amd: a one-layer network is not supported by the bf16 inference path")
             elif last:
                 out = torch.empty(B, L.cout, OH, OW, dtype=torch.float32, device=dev)
-                _hip.call("yogo_conv2d_fwd_bf16", cur, wq, bias, None, out, B, L.cin, L.cout, H, W, L.k, L.s, L.act, st)
+                _hip.call("yogo_conv2d_fwd_bf16", cur, wq, bias, None, out, None, None, B, L.cin, L.cout, H, W, L.k, L.s, L.act, st)
             else:
                 mb = _hip.lib().yogo_bf16_channel_blocks(L.cout)
                 out = torch.empty(B, mb, OH, OW, 8, dtype=torch.bfloat16, device=dev)
-                _hip.call("yogo_conv2d_fwd_bf16", cur, wq, bias, out, None, B, L.cin, L.cout, H, W, L.k, L.s, L.act, st)
+                _hip.call("yogo_conv2d_fwd_bf16", cur, wq, bias, out, None, None, None, B, L.cin, L.cout, H, W, L.k, L.s, L.act, st)
             cur, H, W = out, OH, OW
         return cur
 

@@ -70,6 +70,7 @@ class HipTrainer:
         total_steps: int = 1000,
         decay_factor: float = 10.0,
         process_group=None,
+        half: bool = False,
     ):
         self.model = model
         self.loss = loss if loss is not None else YOGOLoss()
@@ -80,6 +81,7 @@ class HipTrainer:
         self.t_max = max(1, int(total_steps))
         self.eta_min = learning_rate / decay_factor
         self.global_step = 0
+        self.half = bool(half)   # bf16 activations / activation gradients (the reference's --half is fp16 autocast)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.flat = FlatParams(model)
@@ -113,7 +115,12 @@ class HipTrainer:
             if not imgs.is_floating_point() and imgs.dtype != torch.uint8:
                 imgs = imgs.float()
             # ---- forward: backbone + decode ------------------------------------------------------------------
-            raw, saved = eng.forward(imgs, need_grad=True)
+            if self.half:
+                from yogo_amd.engine import backward_bf16_train, forward_bf16_train
+
+                raw, saved = forward_bf16_train(eng, imgs)
+            else:
+                raw, saved = eng.forward(imgs, need_grad=True)
             B, P, Sy, Sx = raw.shape
             aw, ah, wm, hm = m._decode_scalars()
             pred = torch.empty_like(raw)
@@ -129,7 +136,10 @@ class HipTrainer:
             # ---- backward: decode, then the backbone (clamp fused into the gradient kernels) -------------------------
             graw = torch.empty_like(raw)
             _hip.call("yogo_decode_bwd", raw, pred, gpred, graw, B, P, Sy, Sx, int(bool(m.inference)), st)
-            eng.backward(saved, graw, grad_out=self.flat.grad_views)
+            if self.half:
+                backward_bf16_train(eng, saved, graw, grad_out=self.flat.grad_views)
+            else:
+                eng.backward(saved, graw, grad_out=self.flat.grad_views)
             # ---- data-parallel exchange: one RCCL all-reduce of the flat gradient --------------------------------------
             scale = 1.0
             if self.world > 1:
