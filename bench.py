@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32: fp32 storage + exact fp32 MFMA (default); bf16: bf16 activations/gradients + bf16 MFMA, fp32 master weights")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; default) or gloo (rehearsal of the N>1 path on one GPU)")
     args = ap.parse_args()
 
@@ -146,7 +148,7 @@ def main():
     model = YOGO((H, W), ANCHOR_W, ANCHOR_H, NUM_CLASSES).to(dev)
     model.train()
     B = args.batch
-    trainer = HipTrainer(model, YOGOLoss().to(dev), total_steps=args.steps + args.warmup + 1)
+    trainer = HipTrainer(model, YOGOLoss().to(dev), total_steps=args.steps + args.warmup + 1, half=(args.dtype == "bf16"))
     trainer.broadcast_parameters()
     imgs = synthetic_images(B, H, W, device=dev, seed=100 + rank)
     labels = synthetic_labels(B, model.Sx, model.Sy, K=64, num_classes=NUM_CLASSES, device=dev, seed=200 + rank)
@@ -213,7 +215,7 @@ def main():
         rec = {
             "metric": "training images/sec (772x1032 gray)", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "full train step (fwd+loss+bwd+clamp+AdamW), base_model, 772x1032x1 uint8, 7 classes; "
                                    "BASELINE configs[2]/[3] shape at fp32 storage+arithmetic",
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}"},

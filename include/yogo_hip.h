@@ -127,6 +127,10 @@ int yogo_conv2d_dgrad_bf16(const void* dy, const void* packed_dgrad, void* dx, c
 /* fp32 dw/db from bf16 NCHW8c x and g (exact fp32 MFMA on the widened values); workspace as yogo_conv2d_wgrad_f32 */
 int yogo_conv2d_wgrad_bf16in(const void* x, const void* g, float* dw, float* db, void* workspace, int B, int Cin, int Cout,
                              int IH, int IW, int ksize, int stride, float clip, yogo_stream_t stream);
+/* the same on the bf16 matrix cores (contraction over pixels through transposed LDS reads), fp32 accumulation */
+int yogo_conv2d_wgrad_bf16_workspace_bytes(int B, int Cin, int Cout, int IH, int IW, int ksize, int stride, size_t* bytes);
+int yogo_conv2d_wgrad_bf16(const void* x, const void* g, float* dw, float* db, void* workspace, int B, int Cin, int Cout,
+                           int IH, int IW, int ksize, int stride, float clip, yogo_stream_t stream);
 int yogo_conv_first_fwd_bf16(const void* in, int in_dtype, const float* w, const float* bias, void* out, int B, int Cin,
                              int Cout, int IH, int IW, int stride, int act, yogo_stream_t stream);
 int yogo_conv_first_fwd_train_bf16(const void* in, int in_dtype, const float* w, const float* bias, void* out_bf16,

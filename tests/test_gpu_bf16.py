@@ -110,6 +110,18 @@ def test_conv_bf16_fwd_dgrad_wgrad(case):
     h.call("yogo_conv2d_wgrad_bf16in", x8, gy8, dw, db, ws, B, Cin, Cout, IH, IW, k, s, 0.0, st)
     assert rel_err(dw.cpu(), wb.grad) < 3e-5, case
     assert rel_err(db.cpu(), b.grad) < 3e-5, case
+    # ... and on the bf16 matrix cores (contraction over pixels via transposed LDS reads): products of bf16 values are exact in
+    # fp32, only the accumulation order differs
+    ws2 = torch.empty(h.query_size("yogo_conv2d_wgrad_bf16_workspace_bytes", B, Cin, Cout, IH, IW, k, s) // 4, device="cuda")
+    for clip in (0.0, 0.05):
+        dw2 = torch.full((Cout, Cin, k, k), float("nan"), device="cuda")
+        db2 = torch.full((Cout,), float("nan"), device="cuda")
+        h.call("yogo_conv2d_wgrad_bf16", x8, gy8, dw2, db2, ws2, B, Cin, Cout, IH, IW, k, s, clip, st)
+        wg, bg = wb.grad, b.grad
+        if clip > 0:
+            wg, bg = wg.clamp(-clip, clip), bg.clamp(-clip, clip)
+        assert float((dw2.cpu() - wg).abs().max()) < 1e-4 * float(wb.grad.abs().max()), (case, clip)
+        assert float((db2.cpu() - bg).abs().max()) < 1e-4 * float(b.grad.abs().max()), (case, clip)
 
 
 def test_batchnorm_bf16():

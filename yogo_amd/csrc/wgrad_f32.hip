@@ -331,6 +331,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// slab reduction shared with wgrad_bf16.hip (kernels cannot be launched across translation units without RDC)
+extern "C" int yogo_internal_wgrad_reduce(const float* slab, int nslab, int T, int M, int N, int Mpad, int Npad, float clip, float* dw,
+                                          const float* bias_part, int nbias, float* db, hipStream_t stream) {
+  const int nw = (int)(((size_t)T * Mpad * Npad) / 64);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nw + (db ? cdiv(M, 256) : 0)), dim3(256), 0, stream, slab, nslab, T, M, N, Mpad, Npad,
+                     clip, dw, bias_part, nbias, db);
+  YOGO_CHECK_LAUNCH("wgrad_reduce");
+  return YOGO_OK;
+}
+
 namespace {
 
 struct WgradPlan {

@@ -335,6 +335,11 @@ def _blocks(c: int) -> int:
     return ((c + 15) // 16) * 2
 
 
+import os as _os
+
+_WGRAD_BF16_MFMA = _os.environ.get("YOGO_WGRAD_BF16", "1") != "0"   # 0: fp32-MFMA weight gradients on the widened inputs
+
+
 def _packed_bf16(eng: Engine, i: int, mode: int) -> torch.Tensor:
     L = eng.layers[i]
     w = L.conv.weight
@@ -474,11 +479,16 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
                 db.copy_(red[:, nj - 1])
                 grads[id(L.conv.bias)] = db
         else:
-            wsb = _hip.query_size("yogo_conv2d_wgrad_workspace_bytes", B, L.cin, L.cout, IH, IW, L.k, L.s)
-            ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
             db = dst(L.conv.bias) if has_bias else None
             eng._tick("wgrad", i, 2.0 * B * L.cout * L.cin * L.k * L.k * OH * OW)
-            _hip.call("yogo_conv2d_wgrad_bf16in", S.x_in, g, dw, db, ws, B, L.cin, L.cout, IH, IW, L.k, L.s, clip, st)
+            if _WGRAD_BF16_MFMA:
+                wsb = _hip.query_size("yogo_conv2d_wgrad_bf16_workspace_bytes", B, L.cin, L.cout, IH, IW, L.k, L.s)
+                ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
+                _hip.call("yogo_conv2d_wgrad_bf16", S.x_in, g, dw, db, ws, B, L.cin, L.cout, IH, IW, L.k, L.s, clip, st)
+            else:   # exact fp32 MFMA on the widened bf16 inputs
+                wsb = _hip.query_size("yogo_conv2d_wgrad_workspace_bytes", B, L.cin, L.cout, IH, IW, L.k, L.s)
+                ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
+                _hip.call("yogo_conv2d_wgrad_bf16in", S.x_in, g, dw, db, ws, B, L.cin, L.cout, IH, IW, L.k, L.s, clip, st)
             eng._tock()
             if has_bias:
                 grads[id(L.conv.bias)] = db
