@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 H, W, NUM_CLASSES = 772, 1032, 7
 ANCHOR_W, ANCHOR_H = 0.0425, 0.0555
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+HBM_PEAK_GBS = 8000.0           # same table, "HBM3E peak BW" (6.29 TB/s measured copy)
 TRAIN_GFLOP_PER_IMG = 66.48
 
 
@@ -113,10 +114,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (BASELINE configs[2]/[3]: 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
-                    help="f32: fp32 storage + exact fp32 MFMA (default); bf16: bf16 activations/gradients + bf16 MFMA, fp32 master weights")
+    ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"],
+                    help="bf16 (default, BASELINE configs[2]): bf16 activations/gradients + bf16 MFMA, fp32 master weights and "
+                         "statistics; f32: fp32 storage + exact fp32 MFMA")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; default) or gloo (rehearsal of the N>1 path on one GPU)")
     args = ap.parse_args()
 
@@ -180,44 +182,62 @@ def main():
 
     if rank == 0:
         # ---- roofline of the dominant kernel, from the in-loop HIP events ---------------------------------------
-        sel = [e for e in prof if e[0] in ("fwd", "dgrad") and e[2] == 4]
-        ms = sum(e[4].elapsed_time(e[5]) for e in sel)
-        fl = sum(e[3] for e in sel)
-        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        def ms_of(es):
+            return sum(e[4].elapsed_time(e[5]) for e in es)
+
         by_kind = {}
         for kind in ("fwd", "dgrad", "wgrad"):
             es = [e for e in prof if e[0] == kind]
-            t_ms = sum(e[4].elapsed_time(e[5]) for e in es)
+            t_ms = ms_of(es)
             by_kind[kind] = {"ms_per_step": round(t_ms / args.steps, 3),
                              "tflops": round(sum(e[3] for e in es) / max(t_ms, 1e-9) / 1e9, 2)}
         if os.environ.get("YOGO_BENCH_VERBOSE"):
             agg = {}
             for e in prof:
                 k = (e[0], e[1])
-                t_ms = e[4].elapsed_time(e[5])
-                a = agg.setdefault(k, [0.0, 0.0])
-                a[0] += t_ms
+                a = agg.setdefault(k, [0.0, 0.0, 0.0])
+                a[0] += e[4].elapsed_time(e[5])
                 a[1] += e[3]
-            for (kind, layer), (t_ms, fl2) in sorted(agg.items(), key=lambda kv: (kv[0][1], kv[0][0])):
-                print(f"[bench] layer {layer} {kind:6s} {t_ms / args.steps:8.3f} ms/step  {fl2 / t_ms / 1e9:7.2f} TFLOP/s", file=sys.stderr)
+                a[2] += e[6]
+            for (kind, layer), (t_ms, fl2, by2) in sorted(agg.items(), key=lambda kv: (kv[0][1], kv[0][0])):
+                print(f"[bench] layer {layer} {kind:6s} {t_ms / args.steps:8.3f} ms/step  {fl2 / t_ms / 1e9:7.2f} TFLOP/s  "
+                      f"{by2 / t_ms / 1e6:8.1f} GB/s", file=sys.stderr)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        tj = {}
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("conv_igemm_f32_kernel<4,2>", {}).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
             except Exception:
-                traffic = None
-        roof = {"bound": "mfma", "kernel": "conv_igemm_f32_kernel<4,2> (fwd+dgrad of the 128-channel 3x3 layers)",
-                "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                "calls_timed": len(sel), "avg_call_ms": round(ms / max(1, len(sel)), 4)}
+                tj = {}
+        if args.dtype == "bf16":
+            # every bf16 layer sits under the HBM roof (ridge ~312 FLOP/B, the widest layer offers ~230): the dominant kernel
+            # is conv_bf16_kernel (forward + data gradient), priced in algorithmic bytes (input + output once, bf16)
+            sel = [e for e in prof if e[0] in ("fwd", "dgrad") and e[2] == 30]
+            ms = ms_of(sel)
+            gbs = sum(e[6] for e in sel) / max(ms, 1e-9) / 1e6
+            traffic = tj.get("conv_bf16_kernel<4,2,false>", {}).get("hbm_bytes_per_launch")
+            roof = {"bound": "hbm", "kernel": "conv_bf16_kernel<*> (bf16 forward + data-gradient convolutions)",
+                    "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                    "traffic": traffic, "calls_timed": len(sel), "avg_call_ms": round(ms / max(1, len(sel)), 4),
+                    "mfma_tflops": round(sum(e[3] for e in sel) / max(ms, 1e-9) / 1e9, 1)}
+        else:
+            sel = [e for e in prof if e[0] in ("fwd", "dgrad") and e[2] == 4]
+            ms = ms_of(sel)
+            fl = sum(e[3] for e in sel)
+            achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            traffic = tj.get("conv_igemm_f32_kernel<4,2,false>", {}).get("hbm_bytes_per_launch")
+            roof = {"bound": "mfma", "kernel": "conv_igemm_f32_kernel<4,2> (fwd+dgrad of the 128-channel 3x3 layers)",
+                    "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "calls_timed": len(sel), "avg_call_ms": round(ms / max(1, len(sel)), 4)}
         value = world * B * args.steps / dt
         rec = {
             "metric": "training images/sec (772x1032 gray)", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "full train step (fwd+loss+bwd+clamp+AdamW), base_model, 772x1032x1 uint8, 7 classes; "
-                                   "BASELINE configs[2]/[3] shape at fp32 storage+arithmetic",
+            "config": {"workload": "BASELINE configs[2]: full train step (fwd+loss+bwd+clamp+AdamW), base_model, 772x1032x1 uint8, "
+                                   "7 classes" + ("" if args.dtype == "bf16" else " -- run at fp32 storage+arithmetic"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}"},
             "roofline": roof,
             "step_tflops": round(value * TRAIN_GFLOP_PER_IMG / 1e3, 2),

@@ -46,11 +46,14 @@ struct ConvBf16Params {
   int act;
 };
 
-template <int MW, int NW, bool OUT_F32>
-__global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvBf16Params p) {
+// NWV wavefronts per workgroup, each owning NW 32-pixel groups x all MW channel blocks: NWV = 8 shares one staged weight
+// slice between 512 output pixels (the weight slice is the larger part of the LDS traffic at 128 channels).
+template <int MW, int NW, bool OUT_F32, int NWV>
+__global__ __launch_bounds__(64 * NWV, (NWV == 8 ? 2 : 2)) void conv_bf16_kernel(const ConvBf16Params p) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem4[];
   constexpr int BM = 32 * MW;
-  constexpr int PT = 4 * NW * 32;
+  constexpr int NT = 64 * NWV;
+  constexpr int PT = NWV * NW * 32;
   u32x4* ldsI = smem4;
   u32x4* ldsW = smem4 + p.ldsw_off;
 
@@ -109,6 +112,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvBf16Params 
   const u32x4* inb = p.in + (size_t)b * p.Kb * p.IH * p.IW;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
   const int toff_lane = p.toff[min(lane, BF_MAX_TAPS - 1)];
+  // ceil(2^32 / d) magic numbers for the flattened tile indexing (d = 1 is special-cased where they are used)
+  const unsigned inv_lw = (unsigned)(((1ull << 32) + (unsigned)lw - 1ull) / (unsigned)lw);
+  const unsigned inv_perkb = (unsigned)(((1ull << 32) + (unsigned)(rows_in * lw) - 1ull) / (unsigned)(rows_in * lw));
   const int hk = p.CKb >> 1;  // k-steps (16 channels) per tap and chunk
   const int nsteps = p.T * hk;
 
@@ -131,44 +137,46 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvBf16Params 
   for (int c = 0; c < p.nchunk; ++c) {
     const int kb0 = c * p.CKb;
     __syncthreads();
-    // ---- stage the input tile: CKb channel blocks x rows_in rows x lw units, zero padded; 4 lines per wavefront pass ----
-    const int ncr = p.CKb * rows_in;
-    for (int cb0 = wave * 4; cb0 < ncr; cb0 += 16) {
-      int src[4], dst[4];
-      bool rok[4], wr[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int cr = cb0 + u;
-        const int crc = min(cr, ncr - 1);
-        const int kc = crc / rows_in;
-        const int r = crc - kc * rows_in;
-        const int kb = kb0 + kc, iy = iy0 + r;
-        wr[u] = cr < ncr;
-        const int ry = p.ups ? (iy >> 1) : iy;
-        rok[u] = wr[u] && (kb < p.Kb) && (iy >= 0) && (ry < p.IH) && !(p.ups && (iy & 1));
-        src[u] = ((rok[u] ? kb : 0) * p.IH + (rok[u] ? ry : 0)) * p.IW;
-        dst[u] = kc * p.chs + r * p.LWp;
+    // ---- stage the input tile: CKb channel blocks x rows_in rows x lw units, zero padded.  Flattened over all lanes
+    //      (magic-number division by the tile's row length), four independent 16-byte loads in flight per lane. -----------
+    {
+      const int per_kb = rows_in * lw;
+      const int itotal = p.CKb * per_kb;
+#define BI_LOAD(V, OK, E)                                                                          \
+      {                                                                                            \
+        const int e_ = min((E), itotal - 1);                                                       \
+        const int kc_ = per_kb == 1 ? e_ : (int)__umulhi((unsigned)e_, inv_perkb);                 \
+        const int rm_ = e_ - kc_ * per_kb;                                                         \
+        const int r_ = lw == 1 ? rm_ : (int)__umulhi((unsigned)rm_, inv_lw);                       \
+        const int x_ = rm_ - r_ * lw;                                                              \
+        const int kb_ = kb0 + kc_, iy_ = iy0 + r_, ix_ = ix0 + x_;                                 \
+        const int ry_ = p.ups ? (iy_ >> 1) : iy_, rx_ = p.ups ? (ix_ >> 1) : ix_;                  \
+        OK = (kb_ < p.Kb) && (iy_ >= 0) && (ry_ < p.IH) && (ix_ >= 0) && (rx_ < p.IW) &&           \
+             !(p.ups && ((iy_ | ix_) & 1));                                                        \
+        V = inb[OK ? (kb_ * p.IH + ry_) * p.IW + rx_ : 0];                                         \
       }
-      for (int x = lane; x < lw; x += 64) {
-        const int ix = ix0 + x;
-        const int rx = p.ups ? (ix >> 1) : ix;
-        const bool xok = ix >= 0 && rx < p.IW && !(p.ups && (ix & 1));
-        // named registers (an array of u32x4 is not promoted out of scratch by hipcc); loads unconditional + select
-        const bool k0 = rok[0] && xok, k1 = rok[1] && xok, k2 = rok[2] && xok, k3 = rok[3] && xok;
-        const u32x4 l0 = inb[k0 ? src[0] + rx : 0];
-        const u32x4 l1 = inb[k1 ? src[1] + rx : 0];
-        const u32x4 l2 = inb[k2 ? src[2] + rx : 0];
-        const u32x4 l3 = inb[k3 ? src[3] + rx : 0];
+#define BI_STORE(V, OK, E)                                                                         \
+      {                                                                                            \
+        const int e_ = min((E), itotal - 1);                                                       \
+        const int kc_ = per_kb == 1 ? e_ : (int)__umulhi((unsigned)e_, inv_perkb);                 \
+        const int rm_ = e_ - kc_ * per_kb;                                                         \
+        const int r_ = lw == 1 ? rm_ : (int)__umulhi((unsigned)rm_, inv_lw);                       \
+        const int x_ = rm_ - r_ * lw;                                                              \
+        smem4[(E) < itotal ? kc_ * p.chs + r_ * p.LWp + x_ : p.lds_dummy] = OK ? V : zero4;        \
+      }
+      for (int e0 = tid; e0 < itotal; e0 += NT * 4) {
+        u32x4 l0, l1, l2, l3;
+        bool k0, k1, k2, k3;
+        BI_LOAD(l0, k0, e0) BI_LOAD(l1, k1, e0 + NT) BI_LOAD(l2, k2, e0 + 2 * NT) BI_LOAD(l3, k3, e0 + 3 * NT)
         __builtin_amdgcn_sched_barrier(0);
-        smem4[wr[0] ? dst[0] + x : p.lds_dummy] = k0 ? l0 : zero4;
-        smem4[wr[1] ? dst[1] + x : p.lds_dummy] = k1 ? l1 : zero4;
-        smem4[wr[2] ? dst[2] + x : p.lds_dummy] = k2 ? l2 : zero4;
-        smem4[wr[3] ? dst[3] + x : p.lds_dummy] = k3 ? l3 : zero4;
+        BI_STORE(l0, k0, e0) BI_STORE(l1, k1, e0 + NT) BI_STORE(l2, k2, e0 + 2 * NT) BI_STORE(l3, k3, e0 + 3 * NT)
       }
+#undef BI_LOAD
+#undef BI_STORE
     }
     // ---- stage the weight slice [T][CKb][BM] units: rows of BM units ------------------------------------------------------
     {
-      constexpr int RPP = 256 / BM;  // rows per pass (2 for BM = 128)
+      constexpr int RPP = NT / BM;  // rows per pass
       const int m_ = tid % BM, r0 = tid / BM;
       const int nrows = p.T * p.CKb;
       const u32x4* wbase = p.wp + (size_t)kb0 * p.Mpad + m0 + m_;
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvBf16Params 
   const size_t plane = (size_t)p.OH * p.OW;
   const bool do_stats = p.stats_part != nullptr;
   if (do_stats) __syncthreads();  // LDS is reused for the cross-wave reduction
-  float* red = reinterpret_cast<float*>(smem4);  // [4 waves][BM][2]
+  float* red = reinterpret_cast<float*>(smem4);  // [NWV waves][BM][2]
 #pragma unroll
   for (int mb = 0; mb < MW; ++mb) {
 #pragma unroll
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvBf16Params 
     if (tid < BM) {
       float s = 0.f, q = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) {
+      for (int w = 0; w < NWV; ++w) {
         s += red[(w * BM + tid) * 2 + 0];
         q += red[(w * BM + tid) * 2 + 1];
       }
@@ -387,10 +395,10 @@ struct BfTiling {
   int ncb, TW, tiles_per_band, CKb, rows_max, LWp, chs, ldsw_off, lds_dummy, lds_bytes;
 };
 
-bool bf_plan(int OH, int OW, int a, int T, int span, int Kb, int MW, int NW, BfTiling* out, int budget = BF_LDS_BUDGET) {
-  const int BM = 32 * MW, PT = 128 * NW;
+bool bf_plan(int OH, int OW, int a, int T, int span, int Kb, int MW, int NW, int NWV, BfTiling* out, int budget = BF_LDS_BUDGET) {
+  const int BM = 32 * MW, PT = 32 * NWV * NW;
   BfTiling best{};
-  int best_score = -1;
+  long long best_score = -1;
   for (int ncb = 1; ncb <= 16 && ncb <= OW; ++ncb) {
     const int TW = cdiv(OW, ncb);
     const int bw_min = OW - (cdiv(OW, TW) - 1) * TW;
@@ -405,16 +413,16 @@ bool bf_plan(int OH, int OW, int a, int T, int span, int Kb, int MW, int NW, BfT
       const int dummy = ldsw_off + T * CKb * BM;
       const int bytes = (dummy + 1) * 16;
       if (bytes > budget) continue;
-      // halo-efficient (few staged units per output pixel) and deep chunks preferred
-      const int staged = rows_max * LW;  // per channel block per tile
-      const int score = CKb * 1000000 - staged * 10 - ncb;
+      // deep chunks first, then the least staged input over the whole image (halo overhead), then fewer bands
+      const long long staged = (long long)ncb * cdiv(OH * TW, PT) * rows_max * LW;  // units per channel block and image
+      const long long score = (long long)CKb * 100000000000LL - staged * 100 - ncb;
       if (best_score < 0 || score > best_score) {
         best_score = score;
         best = BfTiling{ncb, TW, cdiv(OH * TW, PT), CKb, rows_max, LW, chs, ldsw_off, dummy, bytes};
       }
     }
   }
-  if (best_score < 0) return budget < BF_LDS_MAX ? bf_plan(OH, OW, a, T, span, Kb, MW, NW, out, BF_LDS_MAX) : false;
+  if (best_score < 0) return budget < BF_LDS_MAX ? bf_plan(OH, OW, a, T, span, Kb, MW, NW, NWV, out, BF_LDS_MAX) : false;
   *out = best;
   return true;
 }
@@ -458,9 +466,10 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
                      int OW, int ks, int a, int ups, int act, hipStream_t stream, int* stats_rows, int* stats_mpad) {
   const int T = ks * ks, pad = ks == 3 ? 1 : 0;
   const int MW = bf_pick_mw(M), NW = bf_pick_nw(MW);
+  const int NWV = (MW == 4) ? 8 : 4;  // 128-channel tiles: 8 wavefronts share the staged weight slice
   const int Kb = bf_kb_of(K), Mpad = bf_mpad_of(M);
   BfTiling tl;
-  if (!bf_plan(OH, OW, a, T, ks, Kb, MW, NW, &tl)) {
+  if (!bf_plan(OH, OW, a, T, ks, Kb, MW, NW, NWV, &tl, NWV == 8 ? BF_LDS_MAX : BF_LDS_BUDGET)) {
     yogo_set_error("conv_bf16: no LDS tiling fits (K=%d M=%d OW=%d a=%d)", K, M, OW, a);
     return YOGO_ERR_ARG;
   }
@@ -481,7 +490,7 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
   p.CKb = tl.CKb; p.nchunk = Kb / tl.CKb; p.rows_max = tl.rows_max; p.LWp = tl.LWp; p.chs = tl.chs;
   p.ldsw_off = tl.ldsw_off; p.lds_dummy = tl.lds_dummy; p.act = act;
   if (B == 0) return YOGO_OK;
-  const int lds_bytes = max(tl.lds_bytes, 4 * 32 * MW * 2 * 4);
+  const int lds_bytes = max(tl.lds_bytes, NWV * 32 * MW * 2 * 4);
   {
     static int verbose = -1;
     if (verbose < 0) verbose = getenv("YOGO_IGEMM_VERBOSE") ? 1 : 0;
@@ -489,24 +498,24 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
       fprintf(stderr, "[bf16] K=%d M=%d in=%dx%d a=%d ups=%d T=%d | MW=%d NW=%d ncb=%d TW=%d CKb=%d rows=%d LW=%d lds=%d grid=%ux%ux%u\n",
               K, M, IH, IW, a, ups, T, MW, NW, tl.ncb, tl.TW, tl.CKb, tl.rows_max, tl.LWp, lds_bytes, grid.x, grid.y, grid.z);
   }
-#define BFLAUNCH(MW_, NW_, F32_)                                                                                       \
+#define BFLAUNCH(MW_, NW_, F32_, NWV_)                                                                                 \
   do {                                                                                                                 \
     static bool attr_set = false;                                                                                      \
     if (!attr_set) {                                                                                                   \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<MW_, NW_, F32_>),                      \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<MW_, NW_, F32_, NWV_>),                \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, BF_LDS_MAX);                               \
       attr_set = true;                                                                                                 \
     }                                                                                                                  \
-    hipLaunchKernelGGL((conv_bf16_kernel<MW_, NW_, F32_>), grid, dim3(256), lds_bytes, stream, p);                     \
+    hipLaunchKernelGGL((conv_bf16_kernel<MW_, NW_, F32_, NWV_>), grid, dim3(64 * NWV_), lds_bytes, stream, p);         \
   } while (0)
   if (out_f32 != nullptr) {
-    if (MW == 4) BFLAUNCH(4, 2, true);
-    else if (MW == 2) BFLAUNCH(2, 2, true);
-    else BFLAUNCH(1, 4, true);
+    if (MW == 4) BFLAUNCH(4, 2, true, 8);
+    else if (MW == 2) BFLAUNCH(2, 2, true, 4);
+    else BFLAUNCH(1, 4, true, 4);
   } else {
-    if (MW == 4) BFLAUNCH(4, 2, false);
-    else if (MW == 2) BFLAUNCH(2, 2, false);
-    else BFLAUNCH(1, 4, false);
+    if (MW == 4) BFLAUNCH(4, 2, false, 8);
+    else if (MW == 2) BFLAUNCH(2, 2, false, 4);
+    else BFLAUNCH(1, 4, false, 4);
   }
 #undef BFLAUNCH
   YOGO_CHECK_LAUNCH("conv_bf16");

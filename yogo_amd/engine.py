@@ -111,11 +111,12 @@ class Engine:
         self.prof: Optional[list] = None
         self._open = None
 
-    def _tick(self, kind: str, layer: int, flops: float, mw: int = 0) -> None:
+    def _tick(self, kind: str, layer: int, flops: float, mw: int = 0, nbytes: float = 0.0) -> None:
+        """open a HIP-event bracket around one kernel call (bench.py): algorithmic FLOPs and bytes of that call"""
         if self.prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            self._open = (kind, layer, mw, flops, e0, e1)
+            self._open = (kind, layer, mw, flops, e0, e1, nbytes)
 
     def _tock(self) -> None:
         if self._open is not None:
@@ -396,8 +397,12 @@ def forward_bf16_train(eng: Engine, x: torch.Tensor) -> Tuple[torch.Tensor, List
             _hip.call("yogo_conv_first_fwd_train_bf16", cur, 0 if cur.dtype == torch.uint8 else 1, _f32(L.conv.weight.detach()), bias,
                       out8, mask, stats, B, L.cin, L.cout, H, W, L.s, fused_act, st)
         else:
-            _hip.call("yogo_conv2d_fwd_bf16", cur, _packed_bf16(eng, i, 0), bias, out8, out32, mask, stats, B, L.cin, L.cout, H, W,
-                      L.k, L.s, fused_act, st)
+            pk = _packed_bf16(eng, i, 0)
+            # algorithmic bytes: input + output once at storage precision (bf16 NCHW8c, channels padded to 16; fp32 head)
+            nbytes = B * (_blocks(L.cin) * 8 * H * W * 2 + (L.cout * OH * OW * 4 if last else _blocks(L.cout) * 8 * OH * OW * 2))
+            eng._tick("fwd", i, 2.0 * B * L.cout * L.cin * L.k * L.k * OH * OW, mw=30, nbytes=nbytes)
+            _hip.call("yogo_conv2d_fwd_bf16", cur, pk, bias, out8, out32, mask, stats, B, L.cin, L.cout, H, W, L.k, L.s, fused_act, st)
+            eng._tock()
         if has_bn:
             bn = L.bn
             gamma = _f32(bn.weight.detach()) if bn.weight is not None else torch.ones(L.cout, device=dev)
@@ -480,7 +485,8 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
                 grads[id(L.conv.bias)] = db
         else:
             db = dst(L.conv.bias) if has_bias else None
-            eng._tick("wgrad", i, 2.0 * B * L.cout * L.cin * L.k * L.k * OH * OW)
+            eng._tick("wgrad", i, 2.0 * B * L.cout * L.cin * L.k * L.k * OH * OW, mw=30,
+                      nbytes=B * 2 * 8 * (_blocks(L.cout) * OH * OW + _blocks(L.cin) * IH * IW))
             if _WGRAD_BF16_MFMA:
                 wsb = _hip.query_size("yogo_conv2d_wgrad_bf16_workspace_bytes", B, L.cin, L.cout, IH, IW, L.k, L.s)
                 ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
@@ -503,9 +509,10 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
             else:
                 raise RuntimeError("yogo_amd: bf16 training of SiLU blocks without BatchNorm is not implemented (use fp32)")
             dx = torch.empty(B, _blocks(L.cin), IH, IW, 8, dtype=torch.bfloat16, device=dev)
-            eng._tick("dgrad", i, 2.0 * B * L.cout * L.cin * L.k * L.k * OH * OW, mw=30)
-            _hip.call("yogo_conv2d_dgrad_bf16", g, _packed_bf16(eng, i, 1), dx, act_ref, ref_act, Sp.mask, B, L.cin, L.cout, IH, IW,
-                      L.k, L.s, st)
+            pk = _packed_bf16(eng, i, 1)
+            nbytes = B * 2 * 8 * (_blocks(L.cout) * OH * OW + _blocks(L.cin) * IH * IW * (2 if act_ref is not None else 1))
+            eng._tick("dgrad", i, 2.0 * B * L.cout * L.cin * L.k * L.k * OH * OW, mw=30, nbytes=nbytes)
+            _hip.call("yogo_conv2d_dgrad_bf16", g, pk, dx, act_ref, ref_act, Sp.mask, B, L.cin, L.cout, IH, IW, L.k, L.s, st)
             eng._tock()
             g = dx
     bb = eng.backbone_ref()
