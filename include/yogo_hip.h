@@ -110,7 +110,8 @@ int yogo_format_preds_batched(const float* pred, float* out_rows, long long* out
  * channels hold zeros); weights, BatchNorm statistics, parameter gradients, optimiser state stay fp32.
  * Inference folds eval-mode BatchNorm into `scale` (weights) and `bias` on the caller's side.                               */
 int yogo_bf16_channel_blocks(int C);
-/* mode 0: forward packing (optional per-output-channel scale); mode 1: dgrad packing (roles swapped, taps flipped) */
+/* mode 0: forward packing (optional per-output-channel scale); mode 1: dgrad packing (roles swapped, taps flipped);
+ * mode 2: dgrad packing for a stride-2 3x3 convolution (as 1, tap slices in output-parity-class order) */
 int yogo_conv_bf16_packed_bytes(int Cin, int Cout, int ksize, int mode, size_t* bytes);
 int yogo_conv_bf16_pack(const float* w_oihw, const float* scale, void* packed, int Cin, int Cout, int ksize, int mode,
                         yogo_stream_t stream);

@@ -15,6 +15,7 @@
 // kernel is built around few, wide memory operations rather than around MFMA issue.
 #include "common.h"
 #include <cstdlib>
+#include <vector>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -24,41 +25,68 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 #define BF_MAX_TAPS 9
-#define BF_LDS_BUDGET (80 * 1024)      // two workgroups per CU
-#define BF_LDS_MAX (150 * 1024)        // fallback: one workgroup per CU
+#define BF_LDS_BUDGET (80 * 1024)      // two 4-wavefront workgroups per CU
+#define BF_LDS_MAX (160 * 1024)        // one workgroup per CU (all of the LDS)
 
 struct ConvBf16Params {
   const u32x4* in;    // [B][Kb][IH][IW] units
   const u32x4* wp;    // [T][Kb][Mpad] units (8 input channels of one output channel each)
   const float* bias;  // [M] fp32 or null
   u32x2* out;         // bf16 8c viewed as 8-byte halves: [B][Mb][OH][OW][2]
-  float* out_f32;     // OUT_F32: fp32 NCHW [B][M][OH][OW]
+  float* out_f32;     // when set: fp32 NCHW [B][M][OH][OW] instead of `out`
   const u32x2* act_ref;     // training dgrad: multiply by act'(ref); ref = bf16 tensor shaped like `out` (8-byte halves)
   const float* chan_scale;  // optional [B][M] Dropout2d channel mask (already scaled)
   float* stats_part;        // optional BatchNorm partial sums [B*gridDim.x][Mpad][2] of the fp32 pre-activation
-  int ref_act, ups;         // ups = 1: the input is read as if zero-upsampled by 2 (stride-2 dgrad; no HBM cost)
+  int ref_act;
   int B, Kb, M, Mpad, Mb;
   int IH, IW, OH, OW, a, T;
-  int toff[BF_MAX_TAPS];
   int dy_min, dx_min, span_y, span_x;
   int ncb, TW, tiles_per_band;
-  int CKb, nchunk, rows_max, LWp, chs, ldsw_off, lds_dummy;
+  int CKb, ckb_shift, nchunk, ldsw_off, lds_dummy;
   int act;
+  // dma = 1: a chunk fits the kernel's PF slots and two LDS buffers -> chunk c+1 streams into the other buffer by LDS-DMA
+  // while the matrix cores work on chunk c.  ni_slots / n_slots: input / all slots of a chunk; bufu: units per buffer.
+  int dma, ni_slots, n_slots, bufu;
+  int dbg;  // experiments (YOGO_BF16_DBG): 1 = no output stores, 2 = no MFMA loop, 4 = no DMA
+  unsigned long long* stamps;  // experiments (YOGO_BF16_STAMPS): [workgroup][4] s_memtime at start / loop / epilogue / end
 };
+
+// sum over the 32 lanes of each half-wave with DPP adds (no LDS traffic); the result is valid in lanes 16-31 / 48-63
+__device__ __forceinline__ float half_wave_sum(float v) {
+#define DPP_ADD(CTRL, ROWMASK)                                                                                         \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, false));
+  DPP_ADD(0xB1, 0xf)   // quad_perm [1,0,3,2]
+  DPP_ADD(0x4E, 0xf)   // quad_perm [2,3,0,1]
+  DPP_ADD(0x141, 0xf)  // row_half_mirror
+  DPP_ADD(0x140, 0xf)  // row_mirror: every lane holds its row's (16 lanes) total
+  DPP_ADD(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
+#undef DPP_ADD
+  return v;
+}
 
 // NWV wavefronts per workgroup, each owning NW 32-pixel groups x all MW channel blocks: NWV = 8 shares one staged weight
 // slice between 512 output pixels (the weight slice is the larger part of the LDS traffic at 128 channels).
-template <int MW, int NW, bool OUT_F32, int NWV>
-__global__ __launch_bounds__(64 * NWV, (NWV == 8 ? 2 : 2)) void conv_bf16_kernel(const ConvBf16Params p) {
+//
+// S2D: data gradient of a stride-2 3x3 convolution, decomposed by output parity.  dx[2a+py][2b+px] only receives the taps
+// with ky = py+1 (mod 2), kx = px+1 (mod 2): 1 + 2 + 2 + 4 = 9 tap-GEMMs per 2x2 output quad instead of the 36 a
+// zero-upsampled formulation spends.  A workgroup owns one row parity py (blockIdx.y & 1) and computes both column parities
+// (two accumulator sets) from ONE staged, un-upsampled dy tile with a one-unit halo; the weight slices arrive in class order
+// (pack mode 2) so a workgroup stages only the 3 (py = 0) or 6 (py = 1) taps it needs.
+//
+// PF: slots (16-byte elements per lane and chunk) of the LDS-DMA pipeline.  When a chunk fits (p.dma) the kernel runs
+//   barrier -> issue DMA(c+1 -> buffer (c+1)&1) -> MFMA(c from buffer c&1): one barrier per chunk, no staging registers, no
+//   ds_write, no vector-ALU address work inside the loop (every lane's source offsets are decoded once per workgroup).
+template <int MW, int NW, int NWV, bool S2D, int PF, bool OUT_F32>
+__global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Params p) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem4[];
   constexpr int BM = 32 * MW;
+  constexpr int BM_SHIFT = MW == 4 ? 7 : (MW == 2 ? 6 : 5);
   constexpr int NT = 64 * NWV;
   constexpr int PT = NWV * NW * 32;
-  u32x4* ldsI = smem4;
-  u32x4* ldsW = smem4 + p.ldsw_off;
-
+  constexpr int NC = S2D ? 2 : 1;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned long long t_start = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
   // XCD-aware bijective remap: contiguous runs of (image, tile) per XCD so halo rows hit the same L2
   const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
   const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
@@ -67,226 +95,365 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 ? 2 : 2)) void conv_bf16_kernel
   const int bx = widx % gridDim.x;
   const int by = (widx / gridDim.x) % gridDim.y;
   const int b = widx / (gridDim.x * gridDim.y);
-  const int m0 = by * BM;
+  const int py = S2D ? (by & 1) : 0;
+  const int m0 = (S2D ? (by >> 1) : by) * BM;
+  // S2D tiles the quad grid of this row parity; everything else tiles the output
+  const int OHt = S2D ? ((p.OH - py + 1) >> 1) : p.OH;
+  const int OWt = S2D ? ((p.OW + 1) >> 1) : p.OW;
+  const int span_y = S2D ? 1 + py : p.span_y;
+  const int tbase = S2D ? 3 * py : 0;       // first weight slice
+  const int ntap = S2D ? 3 + 3 * py : p.T;  // weight slices this workgroup uses
+  const int n0tap = S2D ? 1 + py : ntap;    // ... of which belong to column parity 0
   const int cb = bx / p.tiles_per_band;
   const int tb = bx - cb * p.tiles_per_band;
   const int j0 = cb * p.TW;
-  const int bw = min(p.TW, p.OW - j0);
-  const int NPb = p.OH * bw;
+  const int bw = min(p.TW, OWt - j0);
+  const int NPb = OHt * bw;
   const int p0 = tb * PT;
   if (p0 >= NPb) {
-    if (p.stats_part != nullptr && tid < BM) {
+    if (!S2D && p.stats_part != nullptr && tid < BM) {
       float* dst = p.stats_part + (((size_t)b * gridDim.x + bx) * p.Mpad + m0 + tid) * 2;
       dst[0] = 0.f;
       dst[1] = 0.f;
     }
     return;
   }
+  // bias / channel scale of this workgroup's channels: fetched now, parked in LDS for the epilogue
+  float bias_reg = 0.f, scale_reg = 0.f;
+  if (tid < BM && m0 + tid < p.M) {
+    bias_reg = p.bias != nullptr ? p.bias[m0 + tid] : 0.f;
+    scale_reg = p.chan_scale != nullptr ? p.chan_scale[(size_t)b * p.M + m0 + tid] : 1.f;
+  }
   const int p1 = min(p0 + PT, NPb);
   const int i_lo = p0 / bw, i_hi = (p1 - 1) / bw;
-  const int rows_in = (i_hi - i_lo) * p.a + p.span_y;
+  const int rows_in = (i_hi - i_lo) * p.a + span_y;
   const int iy0 = i_lo * p.a + p.dy_min;
   const int ix0 = j0 * p.a + p.dx_min;
   const int lw = (bw - 1) * p.a + p.span_x;
 
   int boff[NW], opix[NW];
-  bool pvalid[NW];
+  bool pvalid[NW], pvalid1[NW];
 #pragma unroll
   for (int n = 0; n < NW; ++n) {
     const int pp = p0 + (wave * NW + n) * 32 + l31;
     pvalid[n] = pp < p1;
     const int pc = pvalid[n] ? pp : (p1 - 1);
     const int i = pc / bw, j = pc - i * bw;
-    boff[n] = ((i - i_lo) * p.a) * p.LWp + j * p.a;
-    opix[n] = i * p.OW + j0 + j;
+    boff[n] = ((i - i_lo) * p.a) * lw + j * p.a;
+    if constexpr (S2D) {
+      opix[n] = (2 * i + py) * p.OW + 2 * (j0 + j);
+      pvalid1[n] = pvalid[n] && (2 * (j0 + j) + 1 < p.OW);
+    } else {
+      opix[n] = i * p.OW + j0 + j;
+      pvalid1[n] = false;
+    }
   }
 
-  f32x16 acc[MW][NW];
+  f32x16 acc[NC][MW][NW];
 #pragma unroll
-  for (int mb = 0; mb < MW; ++mb)
+  for (int c = 0; c < NC; ++c)
 #pragma unroll
-    for (int n = 0; n < NW; ++n)
+    for (int mb = 0; mb < MW; ++mb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mb][n][r] = 0.f;
+      for (int n = 0; n < NW; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][mb][n][r] = 0.f;
 
   const u32x4* inb = p.in + (size_t)b * p.Kb * p.IH * p.IW;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  const int toff_lane = p.toff[min(lane, BF_MAX_TAPS - 1)];
-  // ceil(2^32 / d) magic numbers for the flattened tile indexing (d = 1 is special-cased where they are used)
-  const unsigned inv_lw = (unsigned)(((1ull << 32) + (unsigned)lw - 1ull) / (unsigned)lw);
-  const unsigned inv_perkb = (unsigned)(((1ull << 32) + (unsigned)(rows_in * lw) - 1ull) / (unsigned)(rows_in * lw));
-  const int hk = p.CKb >> 1;  // k-steps (16 channels) per tap and chunk
-  const int nsteps = p.T * hk;
+  // LDS image of a chunk: the input tile [CKb][rows_in][lw] units at its natural pitch (element e of the flattened staging
+  // order sits at unit e -- the image LDS-DMA writes), the weight slices [ntap][CKb][BM] from unit p.ldsw_off on.
+  // Tap offsets inside the tile, one per lane (read back with v_readlane):
+  int toff_lane;
+  {
+    const int ti = min(tbase + lane, BF_MAX_TAPS - 1);
+    if constexpr (S2D) toff_lane = ((0x190 >> ti) & 1) * lw + ((0x144 >> ti) & 1);  // dy (row, col) of the class-ordered slices
+    else toff_lane = p.span_x == 3 ? (ti / 3) * lw + (ti % 3) : 0;
+  }
+  // ceil(2^32 / d) magic numbers for the flattened tile indexing; d = 1 uses 2^32 - 1 (umulhi gives e - 1 for e > 0) plus
+  // a branch-free correction
+  const int per_kb = rows_in * lw;
+  const int one_lw = lw == 1, one_perkb = per_kb == 1;
+  const unsigned inv_lw = one_lw ? 0xFFFFFFFFu : (unsigned)(((1ull << 32) + (unsigned)lw - 1ull) / (unsigned)lw);
+  const unsigned inv_perkb = one_perkb ? 0xFFFFFFFFu : (unsigned)(((1ull << 32) + (unsigned)per_kb - 1ull) / (unsigned)per_kb);
+  const int hk_shift = p.ckb_shift - 1;  // k-steps (16 channels) per tap and chunk = CKb / 2
+  const int hk = 1 << hk_shift;
+  // one chunk = CKb channel blocks of the input tile (rows_in x lw units, zero padded) followed by the weight slices
+  // [ntap][CKb][BM]; both are staged through ONE flattened element index so every lane carries the same number of loads
+  const int itotal = p.CKb * per_kb;
+  const int total = itotal + ntap * p.CKb * BM;
 
-#define BF_LOAD(AV, BV, S)                                                                        \
+#define ST_DECODE(E)                                                                               \
+  const int e_ = min((E), total - 1);                                                              \
+  const bool isw_ = e_ >= itotal;                                                                  \
+  const int ei_ = isw_ ? 0 : e_;                                                                   \
+  const int kc_ = (int)__umulhi((unsigned)ei_, inv_perkb) + (one_perkb & (ei_ != 0));              \
+  const int rm_ = ei_ - kc_ * per_kb;                                                              \
+  const int r_ = (int)__umulhi((unsigned)rm_, inv_lw) + (one_lw & (rm_ != 0));                     \
+  const int x_ = rm_ - r_ * lw;                                                                    \
+  const int w_ = e_ - itotal;
+#define ST_LOAD(V, E, KB0)                                                                         \
+  {                                                                                                \
+    ST_DECODE(E)                                                                                   \
+    const int iy_ = iy0 + r_, ix_ = ix0 + x_;                                                      \
+    const bool ok_ = isw_ || ((iy_ >= 0) && (iy_ < p.IH) && (ix_ >= 0) && (ix_ < p.IW));           \
+    const int R_ = w_ >> BM_SHIFT;                                                                 \
+    const int wi_ = ((tbase + (R_ >> p.ckb_shift)) * p.Kb + (KB0) + (R_ & (p.CKb - 1))) * p.Mpad + \
+                    m0 + (w_ & (BM - 1));                                                          \
+    const int ii_ = ok_ ? (((KB0) + kc_) * p.IH + iy_) * p.IW + ix_ : 0;                           \
+    const u32x4* src_ = isw_ ? p.wp + wi_ : inb + ii_;                                             \
+    V = *src_;                                                                                     \
+  }
+// the decode is redone at commit time (from a laundered thread index) so nothing but the data stays live across the MFMAs
+#define ST_STORE(V, E)                                                                             \
+  {                                                                                                \
+    ST_DECODE(E)                                                                                   \
+    const int iy_ = iy0 + r_, ix_ = ix0 + x_;                                                      \
+    const bool ok_ = isw_ || ((iy_ >= 0) && (iy_ < p.IH) && (ix_ >= 0) && (ix_ < p.IW));           \
+    const int dst_ = (E) < total ? (isw_ ? p.ldsw_off + w_ : ei_) : p.lds_dummy;                   \
+    smem4[dst_] = ok_ ? V : zero4;                                                                 \
+  }
+#define LAUNDER_TID(T) int T = tid; asm volatile("" : "+v"(T));
+
+#define BF_LOAD(AV, BV, S, SEND)                                                                  \
   {                                                                                               \
-    const int s_ = min((S), nsteps - 1);                                                          \
-    const int t_ = s_ / hk;                                                                       \
-    const int kb_ = 2 * (s_ - t_ * hk) + half;                                                    \
-    const u32x4* wI_ = ldsI + kb_ * p.chs + __builtin_amdgcn_readlane(toff_lane, t_);             \
-    const u32x4* wW_ = ldsW + (t_ * p.CKb + kb_) * BM + l31;                                      \
+    const int s_ = min((S), (SEND)-1);                                                            \
+    const int t_ = s_ >> hk_shift;                                                                \
+    const int kb_ = 2 * (s_ & (hk - 1)) + half;                                                   \
+    const u32x4* wI_ = ldsI + kb_ * per_kb + __builtin_amdgcn_readlane(toff_lane, t_);            \
+    const u32x4* wW_ = ldsW + ((t_ << p.ckb_shift) + kb_) * BM + l31;                             \
     _Pragma("unroll") for (int mb = 0; mb < MW; ++mb) AV[mb] = wW_[mb * 32];                      \
     _Pragma("unroll") for (int n = 0; n < NW; ++n) BV[n] = wI_[boff[n]];                          \
   }
-#define BF_MFMA(AV, BV)                                                                           \
+#define BF_MFMA(CI, AV, BV)                                                                       \
   _Pragma("unroll") for (int mb = 0; mb < MW; ++mb)                                               \
   _Pragma("unroll") for (int n = 0; n < NW; ++n)                                                  \
-    acc[mb][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, AV[mb]),      \
-                                                         __builtin_bit_cast(bf16x8, BV[n]), acc[mb][n], 0, 0, 0);
+    acc[CI][mb][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, AV[mb]),  \
+                                                             __builtin_bit_cast(bf16x8, BV[n]), acc[CI][mb][n], 0, 0, 0);
+// MFMA over steps [SBEG, SEND) = (tap, 16-channel step); operands of step s+1 are read before the MFMAs of step s
+#define BF_RUN(CI, SBEG, SEND)                                                                    \
+  {                                                                                               \
+    u32x4 a0[MW], b0[NW], a1[MW], b1[NW];                                                         \
+    int s = (SBEG);                                                                               \
+    BF_LOAD(a0, b0, s, SEND);                                                                     \
+    for (; s + 1 < (SEND); s += 2) {                                                              \
+      BF_LOAD(a1, b1, s + 1, SEND);                                                               \
+      __builtin_amdgcn_sched_barrier(0);                                                          \
+      BF_MFMA(CI, a0, b0);                                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                          \
+      BF_LOAD(a0, b0, s + 2, SEND);                                                               \
+      __builtin_amdgcn_sched_barrier(0);                                                          \
+      BF_MFMA(CI, a1, b1);                                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                          \
+    }                                                                                             \
+    if (s < (SEND)) BF_MFMA(CI, a0, b0);                                                          \
+  }
+#define BF_COMPUTE()                                                                              \
+  {                                                                                               \
+    BF_RUN(0, 0, n0tap * hk)                                                                      \
+    if constexpr (S2D) BF_RUN(NC - 1, n0tap * hk, ntap * hk)                                      \
+  }
 
-  for (int c = 0; c < p.nchunk; ++c) {
-    const int kb0 = c * p.CKb;
-    __syncthreads();
-    // ---- stage the input tile: CKb channel blocks x rows_in rows x lw units, zero padded.  Flattened over all lanes
-    //      (magic-number division by the tile's row length), four independent 16-byte loads in flight per lane. -----------
-    {
-      const int per_kb = rows_in * lw;
-      const int itotal = p.CKb * per_kb;
-#define BI_LOAD(V, OK, E)                                                                          \
-      {                                                                                            \
-        const int e_ = min((E), itotal - 1);                                                       \
-        const int kc_ = per_kb == 1 ? e_ : (int)__umulhi((unsigned)e_, inv_perkb);                 \
-        const int rm_ = e_ - kc_ * per_kb;                                                         \
-        const int r_ = lw == 1 ? rm_ : (int)__umulhi((unsigned)rm_, inv_lw);                       \
-        const int x_ = rm_ - r_ * lw;                                                              \
-        const int kb_ = kb0 + kc_, iy_ = iy0 + r_, ix_ = ix0 + x_;                                 \
-        const int ry_ = p.ups ? (iy_ >> 1) : iy_, rx_ = p.ups ? (ix_ >> 1) : ix_;                  \
-        OK = (kb_ < p.Kb) && (iy_ >= 0) && (ry_ < p.IH) && (ix_ >= 0) && (rx_ < p.IW) &&           \
-             !(p.ups && ((iy_ | ix_) & 1));                                                        \
-        V = inb[OK ? (kb_ * p.IH + ry_) * p.IW + rx_ : 0];                                         \
-      }
-#define BI_STORE(V, OK, E)                                                                         \
-      {                                                                                            \
-        const int e_ = min((E), itotal - 1);                                                       \
-        const int kc_ = per_kb == 1 ? e_ : (int)__umulhi((unsigned)e_, inv_perkb);                 \
-        const int rm_ = e_ - kc_ * per_kb;                                                         \
-        const int r_ = lw == 1 ? rm_ : (int)__umulhi((unsigned)rm_, inv_lw);                       \
-        const int x_ = rm_ - r_ * lw;                                                              \
-        smem4[(E) < itotal ? kc_ * p.chs + r_ * p.LWp + x_ : p.lds_dummy] = OK ? V : zero4;        \
-      }
-      for (int e0 = tid; e0 < itotal; e0 += NT * 4) {
+  const unsigned long long t_loop = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+  if (p.dma) {
+    // Every lane owns PF fixed elements of a chunk: slots [0, ni) cover the input tile, [ni, ns) the weight slices.  The
+    // source byte offset of each is decoded ONCE; image borders, tile tails and unused slices become out-of-range offsets,
+    // which the buffer unit turns into zeros written to LDS.  A chunk then costs one `buffer_load_dwordx4 ... lds` per slot
+    // with the chunk's base in the scalar offset.
+    constexpr unsigned OOB = 0x80000000u;
+    const int ni = p.ni_slots, ns = p.n_slots;
+    const int wtotal = total - itotal;
+    int voff[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int e = tid + i * NT;
+      const int ei_ = min(e, itotal - 1);
+      const int kc_ = (int)__umulhi((unsigned)ei_, inv_perkb) + (one_perkb & (ei_ != 0));
+      const int rm_ = ei_ - kc_ * per_kb;
+      const int r_ = (int)__umulhi((unsigned)rm_, inv_lw) + (one_lw & (rm_ != 0));
+      const int x_ = rm_ - r_ * lw;
+      const int iy_ = iy0 + r_, ix_ = ix0 + x_;
+      const bool iok = (e < itotal) && (iy_ >= 0) && (iy_ < p.IH) && (ix_ >= 0) && (ix_ < p.IW);
+      const int w_ = e - ni * NT;
+      const bool wok = (w_ >= 0) && (w_ < wtotal);
+      const int R_ = w_ >> BM_SHIFT;
+      const int wi_ = ((tbase + (R_ >> p.ckb_shift)) * p.Kb + (R_ & (p.CKb - 1))) * p.Mpad + m0 + (w_ & (BM - 1));
+      const int ii_ = (kc_ * p.IH + iy_) * p.IW + ix_;
+      voff[i] = (i >= ni) ? (wok ? wi_ * 16 : (int)OOB) : (iok ? ii_ * 16 : (int)OOB);
+    }
+    const int ibytes = p.Kb * p.IH * p.IW * 16, wbytes = p.T * p.Kb * p.Mpad * 16;
+    const int so_i = p.CKb * p.IH * p.IW * 16, so_w = p.CKb * p.Mpad * 16;
+    const auto rs_i = __builtin_amdgcn_make_buffer_rsrc((void*)inb, (short)0, ibytes, 0x00020000);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, (short)0, wbytes, 0x00020000);
+#if defined(__HIP_DEVICE_COMPILE__)  // LDS address space and the DMA builtin exist in the device pass only
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#define DMA_ISSUE(C)                                                                                                   \
+  {                                                                                                                    \
+    u32x4* lb_ = smem4 + ((C) & 1) * p.bufu + wave * 64;                                                               \
+    _Pragma("unroll") for (int i = 0; i < PF; ++i) {                                                                   \
+      if (i < ni) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_i, (lds_ptr_t)(lb_ + i * NT), 16, voff[i], (C) * so_i, 0, 0); \
+      else if (i < ns) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(lb_ + i * NT), 16, voff[i], (C) * so_w, 0, 0); \
+    }                                                                                                                  \
+  }
+#else
+#define DMA_ISSUE(C) (void)ns, (void)so_i, (void)so_w, (void)rs_i, (void)rs_w, (void)voff;
+#endif
+    DMA_ISSUE(0)
+    for (int c = 0; c < p.nchunk; ++c) {
+      __syncthreads();  // chunk c has landed (every wave drained its DMA) and nobody reads the other buffer any more
+      if (c + 1 < p.nchunk && !(p.dbg & 4)) { DMA_ISSUE(c + 1) }
+      const u32x4* ldsI = smem4 + (c & 1) * p.bufu;
+      const u32x4* ldsW = ldsI + p.ldsw_off;
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(p.dbg & 2)) BF_COMPUTE()
+    }
+#undef DMA_ISSUE
+  } else {
+    for (int c = 0; c < p.nchunk; ++c) {
+      const int kb0 = c * p.CKb;
+      const u32x4* ldsI = smem4;
+      const u32x4* ldsW = smem4 + p.ldsw_off;
+      __syncthreads();
+      for (int e0 = tid; e0 < total; e0 += NT * 4) {
         u32x4 l0, l1, l2, l3;
-        bool k0, k1, k2, k3;
-        BI_LOAD(l0, k0, e0) BI_LOAD(l1, k1, e0 + NT) BI_LOAD(l2, k2, e0 + 2 * NT) BI_LOAD(l3, k3, e0 + 3 * NT)
+        ST_LOAD(l0, e0, kb0) ST_LOAD(l1, e0 + NT, kb0) ST_LOAD(l2, e0 + 2 * NT, kb0) ST_LOAD(l3, e0 + 3 * NT, kb0)
         __builtin_amdgcn_sched_barrier(0);
-        BI_STORE(l0, k0, e0) BI_STORE(l1, k1, e0 + NT) BI_STORE(l2, k2, e0 + 2 * NT) BI_STORE(l3, k3, e0 + 3 * NT)
+        ST_STORE(l0, e0) ST_STORE(l1, e0 + NT) ST_STORE(l2, e0 + 2 * NT) ST_STORE(l3, e0 + 3 * NT)
       }
-#undef BI_LOAD
-#undef BI_STORE
-    }
-    // ---- stage the weight slice [T][CKb][BM] units: rows of BM units ------------------------------------------------------
-    {
-      constexpr int RPP = NT / BM;  // rows per pass
-      const int m_ = tid % BM, r0 = tid / BM;
-      const int nrows = p.T * p.CKb;
-      const u32x4* wbase = p.wp + (size_t)kb0 * p.Mpad + m0 + m_;
-      const size_t tstride = (size_t)p.Kb * p.Mpad;
-#define BW_SRC(R) (wbase + (size_t)((R) / p.CKb) * tstride + (size_t)((R) % p.CKb) * p.Mpad)
-#define BW_DST(R) (smem4 + ((R) < nrows ? p.ldsw_off + (R) * BM + m_ : p.lds_dummy))
-      for (int rb = r0; rb < nrows; rb += RPP * 4) {
-        const int ra = rb, rb1 = rb + RPP, rc = rb + 2 * RPP, rd = rb + 3 * RPP;
-        const u32x4 va = *BW_SRC(min(ra, nrows - 1));
-        const u32x4 vb = *BW_SRC(min(rb1, nrows - 1));
-        const u32x4 vc = *BW_SRC(min(rc, nrows - 1));
-        const u32x4 vd = *BW_SRC(min(rd, nrows - 1));
-        __builtin_amdgcn_sched_barrier(0);
-        *BW_DST(ra) = va;
-        *BW_DST(rb1) = vb;
-        *BW_DST(rc) = vc;
-        *BW_DST(rd) = vd;
-      }
-#undef BW_SRC
-#undef BW_DST
-    }
-    __syncthreads();
-    // ---- MFMA over (tap, 16-channel step), operands of step s+1 read before the MFMAs of step s --------------------------
-    {
-      u32x4 a0[MW], b0[NW], a1[MW], b1[NW];
-      BF_LOAD(a0, b0, 0);
-      int s = 0;
-      for (; s + 1 < nsteps; s += 2) {
-        BF_LOAD(a1, b1, s + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        BF_MFMA(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        BF_LOAD(a0, b0, s + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        BF_MFMA(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (s < nsteps) BF_MFMA(a0, b0);
+      __syncthreads();
+      BF_COMPUTE()
     }
   }
+#undef ST_DECODE
+#undef ST_LOAD
+#undef ST_STORE
+#undef LAUNDER_TID
 #undef BF_LOAD
 #undef BF_MFMA
+#undef BF_RUN
+#undef BF_COMPUTE
 
+  const unsigned long long t_epi = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
   // ---- epilogue: bias (+ BatchNorm partial sums of the fp32 pre-activation) + activation [or act'(ref)] + channel mask,
-  //      then bf16 NCHW8c (8 bytes per lane) or fp32 NCHW ---------------------------------------------------------------
+  //      then bf16 NCHW8c or fp32 NCHW.  The per-channel bias / scale of the BM channels go through LDS (fetched before the
+  //      main loop); bf16 output: the two half-waves exchange one 8-byte group (v_permlane32_swap) so that every lane stores
+  //      a whole 16-byte unit -- lanes 0-31 channel block cb, lanes 32-63 block cb + 1 -- through a buffer descriptor whose
+  //      range check drops the tail pixels (no per-store address arithmetic, no branches).
   const size_t plane = (size_t)p.OH * p.OW;
-  const bool do_stats = p.stats_part != nullptr;
-  if (do_stats) __syncthreads();  // LDS is reused for the cross-wave reduction
-  float* red = reinterpret_cast<float*>(smem4);  // [NWV waves][BM][2]
+  const bool do_stats = !S2D && p.stats_part != nullptr;
+  float* eb = reinterpret_cast<float*>(smem4);  // [BM] bias
+  float* es = eb + BM;                          // [BM] channel scale (0 for padding channels)
+  float* red = es + BM;                         // [NWV waves][BM][2]
+  __syncthreads();  // the staged tiles are dead
+  if (tid < BM) {
+    eb[tid] = bias_reg;
+    es[tid] = scale_reg;
+  }
+  __syncthreads();
+  if constexpr (OUT_F32) {
 #pragma unroll
-  for (int mb = 0; mb < MW; ++mb) {
+    for (int mb = 0; mb < MW; ++mb) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int cl = mb * 32 + 8 * g + 4 * half;  // local channel of this lane's 4 consecutive output channels
-      const int cbase = m0 + cl;
-      float bs[4], cs[4], s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int g = 0; g < 4; ++g) {
+        const int cl = mb * 32 + 8 * g + 4 * half;
+        const int cbase = m0 + cl;
+        const float4 bs = *reinterpret_cast<const float4*>(eb + cl), cs = *reinterpret_cast<const float4*>(es + cl);
+        const float bsa[4] = {bs.x, bs.y, bs.z, bs.w}, csa[4] = {cs.x, cs.y, cs.z, cs.w};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        bs[i] = (p.bias != nullptr && cbase + i < p.M) ? p.bias[cbase + i] : 0.f;
-        cs[i] = (p.chan_scale != nullptr && cbase + i < p.M) ? p.chan_scale[(size_t)b * p.M + cbase + i] : 1.f;
-      }
+        for (int c = 0; c < NC; ++c)
 #pragma unroll
-      for (int n = 0; n < NW; ++n) {
-        float v[4];
+          for (int n = 0; n < NW; ++n) {
+            const bool valid = (c == 0 ? pvalid[n] : pvalid1[n]) && !(p.dbg & 1);
+            if (valid) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = acc[mb][n][4 * g + i] + bs[i];
-        if (do_stats && pvalid[n]) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            s4[i] += v[i];
-            q4[i] += v[i] * v[i];
-          }
-        }
-        if (pvalid[n]) {
-          if constexpr (OUT_F32) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              if (cbase + i < p.M) p.out_f32[((size_t)b * p.M + cbase + i) * plane + opix[n]] = act_fwd(v[i], p.act) * cs[i];
-          } else {
-            const int cblk = cbase >> 3;
-            if (cblk < p.Mb) {
-              const size_t hidx = (((size_t)b * p.Mb + cblk) * plane + opix[n]) * 2 + half;
-              if (p.act_ref != nullptr) {
-                const bf16x4 rf = __builtin_bit_cast(bf16x4, p.act_ref[hidx]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] *= act_bwd_factor((float)rf[i], p.ref_act);
-              } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = act_fwd(v[i], p.act);
-              }
-              bf16x4 o;
-#pragma unroll
-              for (int i = 0; i < 4; ++i) o[i] = (cbase + i < p.M) ? (__bf16)(v[i] * cs[i]) : (__bf16)0.f;
-              p.out[hidx] = __builtin_bit_cast(u32x2, o);
+              for (int i = 0; i < 4; ++i)
+                if (cbase + i < p.M)
+                  p.out_f32[((size_t)b * p.M + cbase + i) * plane + opix[n] + c] = act_fwd(acc[c][mb][n][4 * g + i] + bsa[i], p.act) * csa[i];
             }
           }
-        }
       }
-      if (do_stats) {
+    }
+  } else {
+    const bool plain = p.act == ACT_NONE && p.act_ref == nullptr;
+    const int plane16 = (int)plane * 16;
+    const auto rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (size_t)b * p.Mb * plane * 2), (short)0, p.Mb * plane16, 0x00020000);
+    int vo[NC][NW];  // byte offset of this lane's unit inside its image: lanes 32-63 write the next channel block
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float s = s4[i], q = q4[i];
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
-          for (int o = 16; o > 0; o >>= 1) {
-            s += __shfl_xor(s, o, 64);
-            q += __shfl_xor(q, o, 64);
+      for (int n = 0; n < NW; ++n) {
+        const bool valid = (c == 0 ? pvalid[n] : pvalid1[n]) && !(p.dbg & 1);
+        vo[c][n] = valid ? (opix[n] + c) * 16 + half * plane16 : (int)0x80000000u;
+      }
+#pragma unroll
+    for (int mb = 0; mb < MW; ++mb) {
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        const int cb = (m0 >> 3) + mb * 4 + 2 * gp;  // channel block the lower half-wave stores (uniform); Mb is even
+        if (cb >= p.Mb) continue;
+        const int cl = mb * 32 + 16 * gp + 4 * half;  // local channel of group A; group B = cl + 8
+        const float4 bA = *reinterpret_cast<const float4*>(eb + cl), bB = *reinterpret_cast<const float4*>(eb + cl + 8);
+        const float4 sA = *reinterpret_cast<const float4*>(es + cl), sB = *reinterpret_cast<const float4*>(es + cl + 8);
+        const float ba[8] = {bA.x, bA.y, bA.z, bA.w, bB.x, bB.y, bB.z, bB.w};
+        const float sa[8] = {sA.x, sA.y, sA.z, sA.w, sB.x, sB.y, sB.z, sB.w};
+        float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, q8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+#pragma unroll
+          for (int n = 0; n < NW; ++n) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = acc[c][mb][n][8 * gp + i] + ba[i];
+            if (do_stats) {
+              const float m = pvalid[n] ? 1.f : 0.f;
+#pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                const float vm = v[i] * m;
+                s8[i] += vm;
+                q8[i] += vm * v[i];
+              }
+            }
+            if (!plain) {
+              if (p.act_ref != nullptr) {
+                const bool valid = c == 0 ? pvalid[n] : pvalid1[n];
+                if (valid) {
+                  const size_t h0 = (((size_t)b * p.Mb + cb) * plane + opix[n] + c) * 2 + half;
+                  const bf16x4 r0 = __builtin_bit_cast(bf16x4, p.act_ref[h0]);
+                  const bf16x4 r1 = __builtin_bit_cast(bf16x4, p.act_ref[h0 + plane * 2]);
+#pragma unroll
+                  for (int i = 0; i < 4; ++i) {
+                    v[i] *= act_bwd_factor((float)r0[i], p.ref_act);
+                    v[4 + i] *= act_bwd_factor((float)r1[i], p.ref_act);
+                  }
+                }
+              } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = act_fwd(v[i], p.act);
+              }
+            }
+            bf16x8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (__bf16)(v[i] * sa[i]);
+            u32x4 w = __builtin_bit_cast(u32x4, o);  // (x, y) = group A, (z, w) = group B of this lane's pixel
+            // lanes 32-63 hand their group A down, lanes 0-31 hand their group B up
+            const auto r0 = __builtin_amdgcn_permlane32_swap(w.x, w.z, false, false);
+            const auto r1 = __builtin_amdgcn_permlane32_swap(w.y, w.w, false, false);
+            const u32x4 st = {r0[0], r1[0], r0[1], r1[1]};
+            // the channel-block offset goes into the vector offset: with a scalar offset register hipcc (ROCm 7.2) leaves
+            // out the wait state between a 16-byte buffer store and a VALU write of its data registers, and gfx950 then
+            // stores the overwritten values
+            __builtin_amdgcn_raw_buffer_store_b128(st, rs_o, vo[c][n] + cb * plane16, 0, 0);
           }
-          if (l31 == 0) {
-            red[(wave * BM + cl + i) * 2 + 0] = s;
-            red[(wave * BM + cl + i) * 2 + 1] = q;
+        }
+        if (do_stats) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float s = half_wave_sum(s8[i]), q = half_wave_sum(q8[i]);
+            if (l31 == 31) {
+              const int ch = cl + (i < 4 ? i : 4 + i);  // group B starts 8 channels above group A
+              red[(wave * BM + ch) * 2 + 0] = s;
+              red[(wave * BM + ch) * 2 + 1] = q;
+            }
           }
         }
       }
@@ -306,10 +473,16 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 ? 2 : 2)) void conv_bf16_kernel
       dst[1] = q;
     }
   }
+  if (p.stamps && tid == 0) {
+    unsigned long long* d = p.stamps + (size_t)widx * 4;
+    d[0] = t_start; d[1] = t_loop; d[2] = t_epi; d[3] = __builtin_amdgcn_s_memtime();
+  }
 }
 
 // ---- weight packing: OIHW fp32 (x optional per-output-channel scale = folded BatchNorm) -> [T][Kb][Mpad] units ----------
 // dgrad = 1: GEMM roles swapped (k = co, m = ci) and the kernel flipped, so the data gradient is a plain stride-1 conv
+// dgrad = 2: as 1, slices stored in the parity-class order of the stride-2 data gradient (see conv_bf16_kernel, S2D):
+//            row parity 0 -> taps (1,1) | (1,0) (1,2); row parity 1 -> taps (0,1) (2,1) | (0,0) (0,2) (2,0) (2,2)
 __global__ void conv_bf16_pack_kernel(const float* __restrict__ w, const float* __restrict__ scale, u32x4* __restrict__ wp,
                                       int Cin, int Cout, int ks, int Kb, int Mpad, int dgrad) {
   const int T = ks * ks;
@@ -319,7 +492,8 @@ __global__ void conv_bf16_pack_kernel(const float* __restrict__ w, const float* 
     const int m = e % Mpad;
     const int kb = (e / Mpad) % Kb;
     const int t = e / (Mpad * Kb);
-    const int tt = dgrad ? (T - 1 - t) : t;  // flipped tap
+    const int ts = dgrad == 2 ? (int)((0x862071534ull >> (4 * t)) & 15ull) : t;
+    const int tt = dgrad ? (T - 1 - ts) : ts;  // flipped tap
     bf16x8 o;
     const float sc = (!dgrad && m < Cout && scale != nullptr) ? scale[m] : 1.f;
 #pragma unroll
@@ -392,14 +566,16 @@ int bf_kb_of(int K) { return round_up(K, 16) / 8; }
 int bf_mpad_of(int M) { return round_up(M, 32 * bf_pick_mw(M)); }
 
 struct BfTiling {
-  int ncb, TW, tiles_per_band, CKb, rows_max, LWp, chs, ldsw_off, lds_dummy, lds_bytes;
+  int ncb, TW, tiles_per_band, CKb, rows_max, LW, ldsw_off, lds_dummy, lds_bytes, dma, ni_slots, n_slots, bufu;
 };
 
-bool bf_plan(int OH, int OW, int a, int T, int span, int Kb, int MW, int NW, int NWV, BfTiling* out, int budget = BF_LDS_BUDGET) {
-  const int BM = 32 * MW, PT = 32 * NWV * NW;
+// (OH, OW): the grid the workgroups tile (output pixels; quads for the stride-2 data gradient), T: weight slices staged at
+// most, PF: DMA slots of the kernel variant.  LDS image of a chunk: input tile from unit 0, weight slices from ldsw_off.
+bool bf_plan(int OH, int OW, int a, int T, int span, int Kb, int MW, int NW, int NWV, int PF, int budget, BfTiling* out) {
+  const int BM = 32 * MW, PT = 32 * NWV * NW, NT = 64 * NWV;
   BfTiling best{};
   long long best_score = -1;
-  for (int ncb = 1; ncb <= 16 && ncb <= OW; ++ncb) {
+  for (int ncb = 1; ncb <= 24 && ncb <= OW; ++ncb) {
     const int TW = cdiv(OW, ncb);
     const int bw_min = OW - (cdiv(OW, TW) - 1) * TW;
     if (cdiv(OW, TW) != ncb || bw_min <= 0) continue;
@@ -409,20 +585,23 @@ bool bf_plan(int OH, int OW, int a, int T, int span, int Kb, int MW, int NW, int
     const int chs = rows_max * LW;
     for (int CKb : {8, 4, 2}) {
       if (Kb % CKb) continue;
-      const int ldsw_off = CKb * chs;
+      const int ni = cdiv(CKb * chs, NT), nw = cdiv(T * CKb * BM, NT);
+      const int ldsw_off = ni * NT;  // slot-aligned, so a DMA slot is all input or all weights
+      const int bufu = (ni + nw) * NT;
+      const int dma = (ni + nw <= PF && 2 * bufu * 16 <= budget) ? 1 : 0;
       const int dummy = ldsw_off + T * CKb * BM;
-      const int bytes = (dummy + 1) * 16;
+      const int bytes = dma ? 2 * bufu * 16 : (dummy + 1) * 16;
       if (bytes > budget) continue;
-      // deep chunks first, then the least staged input over the whole image (halo overhead), then fewer bands
+      // pipelined chunks first, then deep chunks, then the least staged input over the whole image (halo overhead)
       const long long staged = (long long)ncb * cdiv(OH * TW, PT) * rows_max * LW;  // units per channel block and image
-      const long long score = (long long)CKb * 100000000000LL - staged * 100 - ncb;
+      const long long score = dma * 100000000000000LL + (long long)CKb * 100000000000LL - staged * 100 - ncb;
       if (best_score < 0 || score > best_score) {
         best_score = score;
-        best = BfTiling{ncb, TW, cdiv(OH * TW, PT), CKb, rows_max, LW, chs, ldsw_off, dummy, bytes};
+        best = BfTiling{ncb, TW, cdiv(OH * TW, PT), CKb, rows_max, LW, ldsw_off, dummy, bytes, dma, ni, ni + nw, bufu};
       }
     }
   }
-  if (best_score < 0) return budget < BF_LDS_MAX ? bf_plan(OH, OW, a, T, span, Kb, MW, NW, NWV, out, BF_LDS_MAX) : false;
+  if (best_score < 0) return false;
   *out = best;
   return true;
 }
@@ -432,7 +611,8 @@ bool bf_plan(int OH, int OW, int a, int T, int span, int Kb, int MW, int NW, int
 // =========================================================================================================
 // C ABI
 // =========================================================================================================
-// mode 0: forward (k = ci, m = co); mode 1: dgrad (k = co, m = ci, flipped taps)
+// mode 0: forward (k = ci, m = co); mode 1: dgrad (k = co, m = ci, flipped taps); mode 2: dgrad of a stride-2 3x3 conv
+// (as 1, slices in parity-class order)
 extern "C" int yogo_conv_bf16_packed_bytes(int Cin, int Cout, int ks, int mode, size_t* bytes) {
   YOGO_CHECK_ARG(bytes && Cin > 0 && Cout > 0 && (ks == 1 || ks == 3), "conv_bf16_packed_bytes: bad arguments");
   const int K = mode ? Cout : Cin, M = mode ? Cin : Cout;
@@ -443,7 +623,8 @@ extern "C" int yogo_conv_bf16_packed_bytes(int Cin, int Cout, int ks, int mode, 
 // scale (optional, [Cout]): per-output-channel factor folded into the weights (eval-mode BatchNorm: gamma / sqrt(var + eps))
 extern "C" int yogo_conv_bf16_pack(const float* w_oihw, const float* scale, void* packed, int Cin, int Cout, int ks, int mode,
                                    hipStream_t stream) {
-  YOGO_CHECK_ARG(w_oihw && packed && Cin > 0 && Cout > 0 && (ks == 1 || ks == 3), "conv_bf16_pack: bad arguments");
+  YOGO_CHECK_ARG(w_oihw && packed && Cin > 0 && Cout > 0 && (ks == 1 || ks == 3) && mode >= 0 && mode <= 2 && !(mode == 2 && ks != 3),
+                 "conv_bf16_pack: bad arguments");
   const int K = mode ? Cout : Cin, M = mode ? Cin : Cout;
   const int Kb = bf_kb_of(K), Mpad = bf_mpad_of(M);
   const int total = ks * ks * Kb * Mpad;
@@ -459,21 +640,30 @@ extern "C" int yogo_bf16_channel_blocks(int C) { return bf_kb_of(C); }
 namespace {
 
 // One launcher for forward and data-gradient.  (K, M) are the GEMM contraction / output channel counts, (IH, IW) the
-// physical input dims, (OH, OW) the output dims, `a` the input step per output pixel, ups = 1 reads the input as if
-// zero-upsampled by 2.
+// physical input dims, (OH, OW) the output dims, `a` the input step per output pixel; s2d = 1: parity-decomposed data
+// gradient of a stride-2 3x3 convolution (input = dy, output = dx, weights packed with mode 2).
 int launch_conv_bf16(const void* in, const void* packed, const float* bias, void* out, float* out_f32, const void* act_ref,
                      int ref_act, const float* chan_scale, float* stats_part, int B, int K, int M, int IH, int IW, int OH,
-                     int OW, int ks, int a, int ups, int act, hipStream_t stream, int* stats_rows, int* stats_mpad) {
+                     int OW, int ks, int a, int s2d, int act, hipStream_t stream, int* stats_rows, int* stats_mpad) {
   const int T = ks * ks, pad = ks == 3 ? 1 : 0;
-  const int MW = bf_pick_mw(M), NW = bf_pick_nw(MW);
+  const int MW = bf_pick_mw(M);
+  const bool small_n = s2d || a == 2;  // two accumulator sets / four-fold input tile: half the pixel groups per wavefront
+  const int NW = MW == 1 ? (small_n ? 2 : 4) : (small_n ? 1 : 2);
   const int NWV = (MW == 4) ? 8 : 4;  // 128-channel tiles: 8 wavefronts share the staged weight slice
+  const int PF = NWV == 8 ? 10 : 16;  // = 160 KB / 128 KB of LDS for the two buffers at most
   const int Kb = bf_kb_of(K), Mpad = bf_mpad_of(M);
+  // the grid the workgroups tile: output pixels, or 2x2 output quads of one row parity
+  const int OHt = s2d ? (OH + 1) / 2 : OH, OWt = s2d ? (OW + 1) / 2 : OW;
   BfTiling tl;
-  if (!bf_plan(OH, OW, a, T, ks, Kb, MW, NW, NWV, &tl, NWV == 8 ? BF_LDS_MAX : BF_LDS_BUDGET)) {
+  // 4-wavefront workgroups: two per CU when the pipelined tiling fits half the LDS
+  bool planned = false;
+  if (NWV == 4) planned = bf_plan(OHt, OWt, s2d ? 1 : a, s2d ? 6 : T, s2d ? 2 : ks, Kb, MW, NW, NWV, PF, BF_LDS_BUDGET, &tl) && tl.dma;
+  if (!planned) planned = bf_plan(OHt, OWt, s2d ? 1 : a, s2d ? 6 : T, s2d ? 2 : ks, Kb, MW, NW, NWV, PF, BF_LDS_MAX, &tl);
+  if (!planned) {
     yogo_set_error("conv_bf16: no LDS tiling fits (K=%d M=%d OW=%d a=%d)", K, M, OW, a);
     return YOGO_ERR_ARG;
   }
-  dim3 grid(tl.ncb * tl.tiles_per_band, Mpad / (32 * MW), B);
+  dim3 grid(tl.ncb * tl.tiles_per_band, (Mpad / (32 * MW)) * (s2d ? 2 : 1), B);
   if (stats_rows) *stats_rows = B * (int)grid.x;
   if (stats_mpad) *stats_mpad = Mpad;
   if (in == nullptr) return YOGO_OK;  // shape query only
@@ -481,44 +671,88 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
   p.in = reinterpret_cast<const u32x4*>(in); p.wp = reinterpret_cast<const u32x4*>(packed); p.bias = bias;
   p.out = reinterpret_cast<u32x2*>(out); p.out_f32 = out_f32;
   p.act_ref = reinterpret_cast<const u32x2*>(act_ref); p.ref_act = ref_act; p.chan_scale = chan_scale; p.stats_part = stats_part;
-  p.ups = ups;
   p.B = B; p.Kb = Kb; p.M = M; p.Mpad = Mpad; p.Mb = bf_kb_of(M);
-  p.IH = IH; p.IW = IW; p.OH = OH; p.OW = OW; p.a = a; p.T = T;
-  p.dy_min = -pad; p.dx_min = -pad; p.span_y = ks; p.span_x = ks;
-  for (int t = 0; t < T; ++t) p.toff[t] = (t / ks) * tl.LWp + (t % ks);
+  p.IH = IH; p.IW = IW; p.OH = OH; p.OW = OW; p.T = T;
+  if (s2d) {
+    p.a = 1; p.dy_min = 0; p.dx_min = 0; p.span_y = 2; p.span_x = 2;
+  } else {
+    p.a = a; p.dy_min = -pad; p.dx_min = -pad; p.span_y = ks; p.span_x = ks;
+  }
   p.ncb = tl.ncb; p.TW = tl.TW; p.tiles_per_band = tl.tiles_per_band;
-  p.CKb = tl.CKb; p.nchunk = Kb / tl.CKb; p.rows_max = tl.rows_max; p.LWp = tl.LWp; p.chs = tl.chs;
+  p.CKb = tl.CKb; p.ckb_shift = tl.CKb == 8 ? 3 : (tl.CKb == 4 ? 2 : 1); p.nchunk = Kb / tl.CKb;
   p.ldsw_off = tl.ldsw_off; p.lds_dummy = tl.lds_dummy; p.act = act;
+  p.dma = tl.dma; p.ni_slots = tl.ni_slots; p.n_slots = tl.n_slots; p.bufu = tl.bufu;
+  {
+    static int nopf = -1;
+    if (nopf < 0) nopf = getenv("YOGO_BF16_NO_DMA") ? 1 : 0;  // experiments: synchronous staging through registers
+    if (nopf && (tl.lds_dummy + 1) * 16 <= BF_LDS_MAX) p.dma = 0;
+    static int dbg = -1;
+    if (dbg < 0) dbg = getenv("YOGO_BF16_DBG") ? atoi(getenv("YOGO_BF16_DBG")) : 0;
+    p.dbg = dbg;
+    static unsigned long long* stamps = nullptr;
+    static int want_stamps = -1;
+    if (want_stamps < 0) want_stamps = getenv("YOGO_BF16_STAMPS") ? 1 : 0;
+    if (want_stamps) {
+      if (!stamps) (void)hipMalloc(&stamps, (size_t)1 << 24);
+      const size_t nwg = (size_t)grid.x * grid.y * grid.z;
+      if (nwg * 32 <= ((size_t)1 << 24)) { (void)hipMemsetAsync(stamps, 0, nwg * 32, stream); p.stamps = stamps; }
+    }
+  }
   if (B == 0) return YOGO_OK;
-  const int lds_bytes = max(tl.lds_bytes, NWV * 32 * MW * 2 * 4);
+  const int lds_bytes = max(p.dma ? tl.lds_bytes : (tl.lds_dummy + 1) * 16, (2 + 2 * NWV) * 32 * MW * 4);
   {
     static int verbose = -1;
     if (verbose < 0) verbose = getenv("YOGO_IGEMM_VERBOSE") ? 1 : 0;
     if (verbose)
-      fprintf(stderr, "[bf16] K=%d M=%d in=%dx%d a=%d ups=%d T=%d | MW=%d NW=%d ncb=%d TW=%d CKb=%d rows=%d LW=%d lds=%d grid=%ux%ux%u\n",
-              K, M, IH, IW, a, ups, T, MW, NW, tl.ncb, tl.TW, tl.CKb, tl.rows_max, tl.LWp, lds_bytes, grid.x, grid.y, grid.z);
+      fprintf(stderr, "[bf16] K=%d M=%d in=%dx%d a=%d s2d=%d T=%d | MW=%d NW=%d NWV=%d ncb=%d TW=%d CKb=%d rows=%d LW=%d lds=%d dma=%d slots=%d+%d grid=%ux%ux%u\n",
+              K, M, IH, IW, a, s2d, T, MW, NW, NWV, tl.ncb, tl.TW, tl.CKb, tl.rows_max, tl.LW, lds_bytes, p.dma, tl.ni_slots,
+              tl.n_slots - tl.ni_slots, grid.x, grid.y, grid.z);
   }
-#define BFLAUNCH(MW_, NW_, F32_, NWV_)                                                                                 \
+#define BFLAUNCH_(MW_, NW_, NWV_, S2D_, PF_, F32_)                                                                          \
   do {                                                                                                                 \
     static bool attr_set = false;                                                                                      \
     if (!attr_set) {                                                                                                   \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<MW_, NW_, F32_, NWV_>),                \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<MW_, NW_, NWV_, S2D_, PF_, F32_>),     \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, BF_LDS_MAX);                               \
       attr_set = true;                                                                                                 \
     }                                                                                                                  \
-    hipLaunchKernelGGL((conv_bf16_kernel<MW_, NW_, F32_, NWV_>), grid, dim3(64 * NWV_), lds_bytes, stream, p);         \
+    hipLaunchKernelGGL((conv_bf16_kernel<MW_, NW_, NWV_, S2D_, PF_, F32_>), grid, dim3(64 * NWV_), lds_bytes, stream, p); \
   } while (0)
-  if (out_f32 != nullptr) {
-    if (MW == 4) BFLAUNCH(4, 2, true, 8);
-    else if (MW == 2) BFLAUNCH(2, 2, true, 4);
-    else BFLAUNCH(1, 4, true, 4);
+#define BFLAUNCH(MW_, NW_, NWV_, S2D_, PF_)                                    \
+  do {                                                                         \
+    if (out_f32 != nullptr) BFLAUNCH_(MW_, NW_, NWV_, S2D_, PF_, true);        \
+    else BFLAUNCH_(MW_, NW_, NWV_, S2D_, PF_, false);                          \
+  } while (0)
+  if (s2d) {
+    if (MW == 4) BFLAUNCH_(4, 1, 8, true, 10, false);
+    else if (MW == 2) BFLAUNCH_(2, 1, 4, true, 16, false);
+    else BFLAUNCH_(1, 2, 4, true, 16, false);
+  } else if (a == 2) {
+    if (MW == 4) BFLAUNCH(4, 1, 8, false, 10);
+    else if (MW == 2) BFLAUNCH(2, 1, 4, false, 16);
+    else BFLAUNCH(1, 2, 4, false, 16);
   } else {
-    if (MW == 4) BFLAUNCH(4, 2, false, 8);
-    else if (MW == 2) BFLAUNCH(2, 2, false, 4);
-    else BFLAUNCH(1, 4, false, 4);
+    if (MW == 4) BFLAUNCH(4, 2, 8, false, 10);
+    else if (MW == 2) BFLAUNCH(2, 2, 4, false, 16);
+    else BFLAUNCH(1, 4, 4, false, 16);
   }
 #undef BFLAUNCH
+#undef BFLAUNCH_
   YOGO_CHECK_LAUNCH("conv_bf16");
+  if (p.stamps) {  // experiments: mean cycles per phase over the workgroups
+    const size_t nwg = (size_t)grid.x * grid.y * grid.z;
+    std::vector<unsigned long long> h(nwg * 4);
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpy(h.data(), p.stamps, nwg * 32, hipMemcpyDeviceToHost);
+    double a = 0, b = 0, c = 0; size_t n = 0;
+    for (size_t i = 0; i < nwg; ++i) {
+      if (h[i * 4 + 3] == 0) continue;
+      a += (double)(h[i * 4 + 1] - h[i * 4]); b += (double)(h[i * 4 + 2] - h[i * 4 + 1]); c += (double)(h[i * 4 + 3] - h[i * 4 + 2]); ++n;
+    }
+    unsigned long long lo = ~0ull, hi = 0;
+    for (size_t i = 0; i < nwg; ++i) if (h[i * 4 + 3]) { lo = h[i * 4] < lo ? h[i * 4] : lo; hi = h[i * 4 + 3] > hi ? h[i * 4 + 3] : hi; }
+    fprintf(stderr, "[bf16 stamps] wgs=%zu prologue=%.0f loop=%.0f epilogue=%.0f shader cycles per workgroup, kernel span=%llu cycles\n", n, a / n, b / n, c / n, hi - lo);
+  }
   return YOGO_OK;
 }
 
@@ -552,7 +786,8 @@ extern "C" int yogo_conv2d_fwd_bf16(const void* in, const void* packed, const fl
 }
 
 // dx = conv_transpose(dy) * act'(act_ref) * chan_scale, all bf16 NCHW8c; (IH, IW) = the forward conv's INPUT dims.
-// Stride 2 reads dy as if zero-upsampled (the zeros are produced while staging into LDS, they cost MFMA slots only).
+// Stride 1: weights packed with mode 1.  Stride 2 (3x3): weights packed with mode 2; the gradient is computed per output
+// parity class from the un-upsampled dy tile (9 tap-GEMMs per 2x2 output quad).
 extern "C" int yogo_conv2d_dgrad_bf16(const void* dy, const void* packed_dgrad, void* dx, const void* act_ref, int ref_act,
                                       const float* chan_scale, int B, int Cin, int Cout, int IH, int IW, int ks, int stride,
                                       hipStream_t stream) {
@@ -561,7 +796,7 @@ extern "C" int yogo_conv2d_dgrad_bf16(const void* dy, const void* packed_dgrad, 
   const int pad = ks == 3 ? 1 : 0;
   const int OHf = (IH + 2 * pad - ks) / stride + 1, OWf = (IW + 2 * pad - ks) / stride + 1;
   return launch_conv_bf16(dy, packed_dgrad, nullptr, dx, nullptr, act_ref, ref_act, chan_scale, nullptr, B, Cout, Cin, OHf, OWf,
-                          IH, IW, ks, 1, stride == 2 ? 1 : 0, ACT_NONE, stream, nullptr, nullptr);
+                          IH, IW, ks, 1, (stride == 2 && ks == 3) ? 1 : 0, ACT_NONE, stream, nullptr, nullptr);
 }
 
 // first conv (Cin 1|3; in_dtype 0 = uint8, 1 = float32), fp32 weights [Cout][Cin][3][3] with BatchNorm already folded;

@@ -509,7 +509,7 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
             else:
                 raise RuntimeError("yogo_amd: bf16 training of SiLU blocks without BatchNorm is not implemented (use fp32)")
             dx = torch.empty(B, _blocks(L.cin), IH, IW, 8, dtype=torch.bfloat16, device=dev)
-            pk = _packed_bf16(eng, i, 1)
+            pk = _packed_bf16(eng, i, 2 if (L.s == 2 and L.k == 3) else 1)
             nbytes = B * 2 * 8 * (_blocks(L.cout) * OH * OW + _blocks(L.cin) * IH * IW * (2 if act_ref is not None else 1))
             eng._tick("dgrad", i, 2.0 * B * L.cout * L.cin * L.k * L.k * OH * OW, mw=30, nbytes=nbytes)
             _hip.call("yogo_conv2d_dgrad_bf16", g, pk, dx, act_ref, ref_act, Sp.mask, B, L.cin, L.cout, IH, IW, L.k, L.s, st)
