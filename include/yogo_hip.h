@@ -60,7 +60,9 @@ int yogo_conv_first_stats_rows(int B, int IH, int IW, int stride, int* rows);
 int yogo_conv_first_fwd(const void* in, int in_dtype, const float* w_oihw, const float* bias, float* out, float* out_pre,
                         const float* chan_scale, float* stats_part, int B, int Cin, int Cout, int IH, int IW, int stride,
                         int act, yogo_stream_t stream);
-/* partial gradients [rows][Cout][Cin*9 + 1] (last column = bias); finish with yogo_partials_reduce */
+/* partial gradients [rows][Cout][Cin*9 + 1] (last column = bias), rows from yogo_conv_first_wgrad_rows; finish with
+ * yogo_partials_reduce */
+int yogo_conv_first_wgrad_rows(int B, int IH, int IW, int stride, int* rows);
 int yogo_conv_first_wgrad(const void* in, int in_dtype, const float* dy, float* part, int B, int Cin, int Cout, int IH,
                           int IW, int stride, yogo_stream_t stream);
 

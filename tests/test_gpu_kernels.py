@@ -153,6 +153,7 @@ def test_conv_first(cin, cout, stride, u8):
     gy = torch.randn(ref.shape, generator=g)
     ref.backward(gy)
     nj = cin * 9 + 1
+    rows = H.query_ints("yogo_conv_first_wgrad_rows", 1, B, IH, IW, stride)[0]
     part = torch.empty(rows * cout * nj, device="cuda")
     H.call("yogo_conv_first_wgrad", dev(x), 0 if u8 else 1, dev(gy), part, B, cin, cout, IH, IW, stride, st)
     red = torch.empty(cout, nj, device="cuda")

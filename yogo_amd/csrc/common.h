@@ -54,10 +54,19 @@ __device__ __forceinline__ float act_bwd_factor(float ref, int act) {
   return 1.f;
 }
 
+// Sum over the 64 lanes with DPP adds (no LDS traffic): quads, half rows, rows, rows 0->1 / 2->3, rows 0..1 -> 3; lane 63
+// then holds the total, which is broadcast through a scalar register.  Call it from wave-uniform control flow only.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+#define YOGO_DPP_ADD(CTRL, ROWMASK) \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, false));
+  YOGO_DPP_ADD(0xB1, 0xf)   // quad_perm [1,0,3,2]
+  YOGO_DPP_ADD(0x4E, 0xf)   // quad_perm [2,3,0,1]
+  YOGO_DPP_ADD(0x141, 0xf)  // row_half_mirror
+  YOGO_DPP_ADD(0x140, 0xf)  // row_mirror
+  YOGO_DPP_ADD(0x142, 0xa)  // row_bcast:15 -> rows 1, 3
+  YOGO_DPP_ADD(0x143, 0xc)  // row_bcast:31 -> rows 2, 3
+#undef YOGO_DPP_ADD
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll

@@ -129,69 +129,105 @@ struct ConvFirstWgradParams {
   int B, Cin, Cout, IH, IW, OH, OW, stride;
 };
 
-template <typename TIn, int CIN>
+#define CFW_PPT 16  // pixels per thread of the weight-gradient kernel (accumulators live in registers across them)
+
+// Per pass of COC output channels every lane keeps COC x (9*CIN + 1) accumulators over its CFW_PPT pixels, so the cross-lane
+// reduction (DPP adds) is paid once per 4096 pixels and pass instead of once per pixel group.
+template <typename TIn, int CIN, bool BF16G>
 __global__ __launch_bounds__(CF_THREADS) void conv_first_wgrad_kernel(const ConvFirstWgradParams p) {
   constexpr int NJ = CIN * 9 + 1;
-  __shared__ float red[4][NJ];
+  constexpr int COC = CIN == 1 ? 16 : 4;
+  __shared__ float red[4][COC * NJ];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y;
   const int npix = p.OH * p.OW;
-  const int pbase = blockIdx.x * (CF_THREADS * CF_PPT);
+  const int pbase = blockIdx.x * (CF_THREADS * CFW_PPT);
   const TIn* inb = reinterpret_cast<const TIn*>(p.in) + (size_t)b * CIN * p.IH * p.IW;
-  float x[CF_PPT][CIN * 9];
-  bool okk[CF_PPT];
+  for (int co0 = 0; co0 < p.Cout; co0 += COC) {
+    float acc[COC][NJ];
 #pragma unroll
-  for (int k = 0; k < CF_PPT; ++k) {
-    const int pix = pbase + k * CF_THREADS + tid;
-    const bool ok = pix < npix;
-    okk[k] = ok;
-    const int oy = ok ? pix / p.OW : 0;
-    const int ox = ok ? pix - oy * p.OW : 0;
+    for (int c = 0; c < COC; ++c)
 #pragma unroll
-    for (int ci = 0; ci < CIN; ++ci)
-#pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int iy = oy * p.stride + kh - 1, ix = ox * p.stride + kw - 1;
-          float v = 0.f;
-          if (ok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) v = (float)inb[((size_t)ci * p.IH + iy) * p.IW + ix];
-          x[k][(ci * 3 + kh) * 3 + kw] = v;
-        }
-  }
-  for (int co = 0; co < p.Cout; ++co) {
-    float acc[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) acc[j] = 0.f;
-#pragma unroll
-    for (int k = 0; k < CF_PPT; ++k) {
+      for (int j = 0; j < NJ; ++j) acc[c][j] = 0.f;
+    for (int k = 0; k < CFW_PPT; ++k) {
       const int pix = pbase + k * CF_THREADS + tid;
-      float g = 0.f;
-      if (okk[k]) {
-        if (p.dy_bf16 != nullptr) {
-          const cf_bf16x8 u = __builtin_bit_cast(cf_bf16x8, p.dy_bf16[((size_t)b * p.Mb + (co >> 3)) * npix + pix]);
-          g = (float)u[co & 7];
+      const bool ok = pix < npix;
+      const int pc = ok ? pix : 0;
+      const int oy = pc / p.OW, ox = pc - oy * p.OW;
+      float x[CIN * 9];
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int iy = oy * p.stride + kh - 1, ix = ox * p.stride + kw - 1;
+            const bool in = ok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+            const float v = (float)inb[in ? ((size_t)ci * p.IH + iy) * p.IW + ix : 0];
+            x[(ci * 3 + kh) * 3 + kw] = in ? v : 0.f;
+          }
+      float g[COC];
+      if constexpr (BF16G) {
+        if constexpr (COC == 16) {
+#pragma unroll
+          for (int hb = 0; hb < 2; ++hb) {
+            const int cb = min((co0 >> 3) + hb, p.Mb - 1);
+            const cf_bf16x8 u = __builtin_bit_cast(cf_bf16x8, p.dy_bf16[((size_t)b * p.Mb + cb) * npix + pc]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[hb * 8 + j] = (ok && co0 + hb * 8 + j < p.Cout) ? (float)u[j] : 0.f;
+          }
         } else {
-          g = p.dy[((size_t)b * p.Cout + co) * npix + pix];
+          const cf_bf16x8 u = __builtin_bit_cast(cf_bf16x8, p.dy_bf16[((size_t)b * p.Mb + (co0 >> 3)) * npix + pc]);
+#pragma unroll
+          for (int c = 0; c < COC; ++c) {
+            float sel = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sel = ((co0 & 7) + c == j) ? (float)u[j] : sel;
+            g[c] = (ok && co0 + c < p.Cout) ? sel : 0.f;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < COC; ++c) {
+          const bool cok = ok && co0 + c < p.Cout;
+          const float v = p.dy[cok ? ((size_t)b * p.Cout + co0 + c) * npix + pc : 0];
+          g[c] = cok ? v : 0.f;
         }
       }
 #pragma unroll
-      for (int j = 0; j < CIN * 9; ++j) acc[j] = fmaf(g, x[k][j], acc[j]);
-      acc[NJ - 1] += g;
+      for (int c = 0; c < COC; ++c) {
+#pragma unroll
+        for (int j = 0; j < CIN * 9; ++j) acc[c][j] = fmaf(g[c], x[j], acc[c][j]);
+        acc[c][NJ - 1] += g[c];
+      }
     }
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const float v = wave_sum(acc[j]);
-      if (lane == 0) red[wave][j] = v;
-    }
+    for (int c = 0; c < COC; ++c)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const float v = wave_sum(acc[c][j]);
+        if (lane == 0) red[wave][c * NJ + j] = v;
+      }
     __syncthreads();
-    if (tid < NJ)
-      p.part[((size_t)(b * gridDim.x + blockIdx.x) * p.Cout + co) * NJ + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    if (tid < COC * NJ) {
+      const int c = tid / NJ, j = tid - c * NJ;
+      if (co0 + c < p.Cout)
+        p.part[((size_t)(b * gridDim.x + blockIdx.x) * p.Cout + co0 + c) * NJ + j] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    }
     __syncthreads();
   }
 }
 
 static int first_tiles(int OH, int OW) { return cdiv(OH * OW, CF_THREADS * CF_PPT); }
+static int first_wgrad_tiles(int OH, int OW) { return cdiv(OH * OW, CF_THREADS * CFW_PPT); }
+
+// rows of the partial buffer the weight-gradient kernels fill
+extern "C" int yogo_conv_first_wgrad_rows(int B, int IH, int IW, int stride, int* rows) {
+  YOGO_CHECK_ARG(rows && (stride == 1 || stride == 2), "conv_first_wgrad_rows: bad arguments");
+  const int OH = (IH - 1) / stride + 1, OW = (IW - 1) / stride + 1;
+  *rows = B * first_wgrad_tiles(OH, OW);
+  return YOGO_OK;
+}
 
 extern "C" int yogo_conv_first_stats_rows(int B, int IH, int IW, int stride, int* rows) {
   YOGO_CHECK_ARG(rows && (stride == 1 || stride == 2), "conv_first_stats_rows: bad arguments");
@@ -247,7 +283,7 @@ static int conv_first_fwd_impl(const void* in, int in_dtype, const float* w, con
 static int conv_first_wgrad_impl(const void* in, int in_dtype, const float* dy, const void* dy_bf16, float* part, int B, int Cin,
                                  int Cout, int IH, int IW, int stride, hipStream_t stream);
 
-// partial weight/bias gradients; part must hold rows*Cout*(Cin*9+1) floats with rows from yogo_conv_first_stats_rows
+// partial weight/bias gradients; part must hold rows*Cout*(Cin*9+1) floats with rows from yogo_conv_first_wgrad_rows
 extern "C" int yogo_conv_first_wgrad(const void* in, int in_dtype, const float* dy, float* part, int B, int Cin, int Cout,
                                      int IH, int IW, int stride, hipStream_t stream) {
   YOGO_CHECK_ARG(dy != nullptr, "conv_first_wgrad: null pointer");
@@ -270,11 +306,17 @@ static int conv_first_wgrad_impl(const void* in, int in_dtype, const float* dy, 
   p.in = in; p.dy = dy; p.part = part; p.B = B; p.Cin = Cin; p.Cout = Cout; p.IH = IH; p.IW = IW; p.stride = stride;
   p.OH = (IH - 1) / stride + 1; p.OW = (IW - 1) / stride + 1;
   if (B == 0) return YOGO_OK;
-  dim3 grid(first_tiles(p.OH, p.OW), B);
-  if (in_dtype == 0 && Cin == 1) hipLaunchKernelGGL((conv_first_wgrad_kernel<uint8_t, 1>), grid, dim3(CF_THREADS), 0, stream, p);
-  else if (in_dtype == 0) hipLaunchKernelGGL((conv_first_wgrad_kernel<uint8_t, 3>), grid, dim3(CF_THREADS), 0, stream, p);
-  else if (Cin == 1) hipLaunchKernelGGL((conv_first_wgrad_kernel<float, 1>), grid, dim3(CF_THREADS), 0, stream, p);
-  else hipLaunchKernelGGL((conv_first_wgrad_kernel<float, 3>), grid, dim3(CF_THREADS), 0, stream, p);
+  dim3 grid(first_wgrad_tiles(p.OH, p.OW), B);
+#define CFW_LAUNCH(TIN, CIN_)                                                                                          \
+  do {                                                                                                                 \
+    if (dy_bf16 != nullptr) hipLaunchKernelGGL((conv_first_wgrad_kernel<TIN, CIN_, true>), grid, dim3(CF_THREADS), 0, stream, p); \
+    else hipLaunchKernelGGL((conv_first_wgrad_kernel<TIN, CIN_, false>), grid, dim3(CF_THREADS), 0, stream, p);        \
+  } while (0)
+  if (in_dtype == 0 && Cin == 1) CFW_LAUNCH(uint8_t, 1);
+  else if (in_dtype == 0) CFW_LAUNCH(uint8_t, 3);
+  else if (Cin == 1) CFW_LAUNCH(float, 1);
+  else CFW_LAUNCH(float, 3);
+#undef CFW_LAUNCH
   YOGO_CHECK_LAUNCH("conv_first_wgrad");
   return YOGO_OK;
 }

@@ -278,7 +278,7 @@ class Engine:
             dw = dst(L.conv.weight)
             has_bias = L.conv.bias is not None
             if self._first_direct(i):
-                rows = _hip.query_ints("yogo_conv_first_stats_rows", 1, B, IH, IW, L.s)[0]
+                rows = _hip.query_ints("yogo_conv_first_wgrad_rows", 1, B, IH, IW, L.s)[0]
                 nj = L.cin * 9 + 1
                 part = torch.empty(rows * L.cout * nj, dtype=torch.float32, device=dev)
                 x_in = S.x_in
@@ -471,7 +471,7 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
         dw = dst(L.conv.weight)
         has_bias = L.conv.bias is not None
         if i == 0:
-            rows = _hip.query_ints("yogo_conv_first_stats_rows", 1, B, IH, IW, L.s)[0]
+            rows = _hip.query_ints("yogo_conv_first_wgrad_rows", 1, B, IH, IW, L.s)[0]
             nj = L.cin * 9 + 1
             part = torch.empty(rows * L.cout * nj, dtype=torch.float32, device=dev)
             _hip.call("yogo_conv_first_wgrad_bf16g", S.x_in, 0 if S.x_in.dtype == torch.uint8 else 1, g, part, B, L.cin, L.cout, IH, IW,
