@@ -1,5 +1,6 @@
 """micro-benchmark of single bf16 conv launches (experiments; not part of the product).
-usage: bench_conv_bf16.py [B] [which]   which = comma list of layer names (l1..l7) x kind (f = fwd, d = dgrad), e.g. l5f,l4d"""
+usage: bench_conv_bf16.py [B] [which]   which = comma list of layer names (l1..l7) x kind (f = fwd with BatchNorm sums, a = fwd with bias + leaky + channel mask,
+d = dgrad, r = dgrad with act'(ref) and channel mask), e.g. l5f,l4r"""
 import os
 import sys
 
@@ -24,17 +25,22 @@ def bench(name, B, Cin, Cout, IH, IW, k, s, kind, reps=10):
     w = torch.randn(Cout, Cin, k, k, device="cuda") * 0.05
     x8 = torch.randn(B, blocks(Cin), IH, IW, 8, device="cuda").to(torch.bfloat16)
     y8 = torch.randn(B, blocks(Cout), OH, OW, 8, device="cuda").to(torch.bfloat16)
-    mode = 0 if kind == "f" else (2 if (s == 2 and k == 3) else 1)
+    mode = 0 if kind in "fa" else (2 if (s == 2 and k == 3) else 1)
     packed = torch.empty(H.query_size("yogo_conv_bf16_packed_bytes", Cin, Cout, k, mode), dtype=torch.uint8, device="cuda")
     H.call("yogo_conv_bf16_pack", w, None, packed, Cin, Cout, k, mode, st)
-    if kind == "f":
+    if kind in "fa":
         rows, mpad = H.query_ints("yogo_conv2d_fwd_bf16_stats_shape", 2, B, Cin, Cout, IH, IW, k, s)
         stats = torch.empty(rows * mpad * 2, device="cuda")
-        f = lambda: H.call("yogo_conv2d_fwd_bf16", x8, packed, None, y8, None, None, stats, B, Cin, Cout, IH, IW, k, s, 0, st)
+        bias = torch.randn(Cout, device="cuda")
+        msk = (torch.rand(B, Cout, device="cuda") > 0.1).float() if kind == "a" else None
+        f = lambda: H.call("yogo_conv2d_fwd_bf16", x8, packed, bias, y8, None, msk, None if kind == "a" else stats, B, Cin, Cout, IH, IW,
+                           k, s, 1 if kind == "a" else 0, st)
         nbytes = B * 16 * (blocks(Cin) * IH * IW + blocks(Cout) * OH * OW)
     else:
-        f = lambda: H.call("yogo_conv2d_dgrad_bf16", y8, packed, x8, None, 0, None, B, Cin, Cout, IH, IW, k, s, st)
-        nbytes = B * 16 * (blocks(Cin) * IH * IW + blocks(Cout) * OH * OW)
+        ref = torch.randn(B, blocks(Cin), IH, IW, 8, device="cuda").to(torch.bfloat16) if kind == "r" else None
+        msk = (torch.rand(B, Cin, device="cuda") > 0.1).float() if kind == "r" else None
+        f = lambda: H.call("yogo_conv2d_dgrad_bf16", y8, packed, x8, ref, 1 if kind == "r" else 0, msk, B, Cin, Cout, IH, IW, k, s, st)
+        nbytes = B * 16 * (blocks(Cin) * IH * IW * (2 if kind == "r" else 1) + blocks(Cout) * OH * OW)
     for _ in range(2):
         f()
     torch.cuda.synchronize()

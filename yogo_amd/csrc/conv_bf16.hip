@@ -47,7 +47,7 @@ struct ConvBf16Params {
   // dma = 1: a chunk fits the kernel's PF slots and two LDS buffers -> chunk c+1 streams into the other buffer by LDS-DMA
   // while the matrix cores work on chunk c.  ni_slots / n_slots: input / all slots of a chunk; bufu: units per buffer.
   int dma, ni_slots, n_slots, bufu;
-  int dbg;  // experiments (YOGO_BF16_DBG): 1 = no output stores, 2 = no MFMA loop, 4 = no DMA
+  int dbg;  // experiments (YOGO_BF16_DBG): 1 = no output stores, 2 = no MFMA loop, 4 = no DMA, 8 / 16 = no input / weight DMA
   unsigned long long* stamps;  // experiments (YOGO_BF16_STAMPS): [workgroup][4] s_memtime at start / loop / epilogue / end
 };
 
@@ -150,6 +150,11 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
   }
 
   f32x16 acc[NC][MW][NW];
+  // per-lane unit offsets of the operand reads: weights (channel pair half, output channel), input (pixel, channel pair half)
+  const int a_vu = half * BM + l31;
+  int b_vu[NW];
+#pragma unroll
+  for (int n = 0; n < NW; ++n) b_vu[n] = boff[n] + half * ((i_hi - i_lo) * p.a + span_y) * lw;
 #pragma unroll
   for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -215,35 +220,44 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
   }
 #define LAUNDER_TID(T) int T = tid; asm volatile("" : "+v"(T));
 
+// operand fetch of step S: everything that depends on the step is scalar (tap, channel pair), the per-lane parts (a_vu, b_vu)
+// are fixed for the whole kernel -- one vector add per ds_read_b128 address
 #define BF_LOAD(AV, BV, S, SEND)                                                                  \
   {                                                                                               \
     const int s_ = min((S), (SEND)-1);                                                            \
     const int t_ = s_ >> hk_shift;                                                                \
-    const int kb_ = 2 * (s_ & (hk - 1)) + half;                                                   \
-    const u32x4* wI_ = ldsI + kb_ * per_kb + __builtin_amdgcn_readlane(toff_lane, t_);            \
-    const u32x4* wW_ = ldsW + ((t_ << p.ckb_shift) + kb_) * BM + l31;                             \
-    _Pragma("unroll") for (int mb = 0; mb < MW; ++mb) AV[mb] = wW_[mb * 32];                      \
-    _Pragma("unroll") for (int n = 0; n < NW; ++n) BV[n] = wI_[boff[n]];                          \
+    const int k2_ = 2 * (s_ & (hk - 1));                                                          \
+    const u32x4* wI_ = ldsI + (k2_ * per_kb + __builtin_amdgcn_readlane(toff_lane, t_));          \
+    const u32x4* wW_ = ldsW + ((t_ << p.ckb_shift) + k2_) * BM;                                   \
+    if (!(p.dbg & 32)) {                                                                          \
+    _Pragma("unroll") for (int mb = 0; mb < MW; ++mb) AV[mb] = wW_[a_vu + mb * 32];               \
+    _Pragma("unroll") for (int n = 0; n < NW; ++n) BV[n] = wI_[b_vu[n]];                          \
+    }                                                                                             \
   }
 #define BF_MFMA(CI, AV, BV)                                                                       \
   _Pragma("unroll") for (int mb = 0; mb < MW; ++mb)                                               \
   _Pragma("unroll") for (int n = 0; n < NW; ++n)                                                  \
     acc[CI][mb][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, AV[mb]),  \
                                                              __builtin_bit_cast(bf16x8, BV[n]), acc[CI][mb][n], 0, 0, 0);
-// MFMA over steps [SBEG, SEND) = (tap, 16-channel step); operands of step s+1 are read before the MFMAs of step s
+// MFMA over steps [SBEG, SEND) = (tap, 16-channel step); operands of step s+1 are read before the MFMAs of step s.  The MFMA
+// cluster runs at raised priority so that the two wavefronts of a SIMD fall out of phase (one fetches while the other multiplies)
 #define BF_RUN(CI, SBEG, SEND)                                                                    \
   {                                                                                               \
-    u32x4 a0[MW], b0[NW], a1[MW], b1[NW];                                                         \
+    u32x4 a0[MW] = {}, b0[NW] = {}, a1[MW] = {}, b1[NW] = {};                                     \
     int s = (SBEG);                                                                               \
     BF_LOAD(a0, b0, s, SEND);                                                                     \
     for (; s + 1 < (SEND); s += 2) {                                                              \
       BF_LOAD(a1, b1, s + 1, SEND);                                                               \
       __builtin_amdgcn_sched_barrier(0);                                                          \
+      __builtin_amdgcn_s_setprio(1);                                                              \
       BF_MFMA(CI, a0, b0);                                                                        \
+      __builtin_amdgcn_s_setprio(0);                                                              \
       __builtin_amdgcn_sched_barrier(0);                                                          \
       BF_LOAD(a0, b0, s + 2, SEND);                                                               \
       __builtin_amdgcn_sched_barrier(0);                                                          \
+      __builtin_amdgcn_s_setprio(1);                                                              \
       BF_MFMA(CI, a1, b1);                                                                        \
+      __builtin_amdgcn_s_setprio(0);                                                              \
       __builtin_amdgcn_sched_barrier(0);                                                          \
     }                                                                                             \
     if (s < (SEND)) BF_MFMA(CI, a0, b0);                                                          \
@@ -291,8 +305,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
   {                                                                                                                    \
     u32x4* lb_ = smem4 + ((C) & 1) * p.bufu + wave * 64;                                                               \
     _Pragma("unroll") for (int i = 0; i < PF; ++i) {                                                                   \
-      if (i < ni) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_i, (lds_ptr_t)(lb_ + i * NT), 16, voff[i], (C) * so_i, 0, 0); \
-      else if (i < ns) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(lb_ + i * NT), 16, voff[i], (C) * so_w, 0, 0); \
+      if (i < ni) { if (!(p.dbg & 8)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_i, (lds_ptr_t)(lb_ + i * NT), 16, voff[i], (C) * so_i, 0, 0); } \
+      else if (i < ns) { if (!(p.dbg & 16)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(lb_ + i * NT), 16, voff[i], (C) * so_w, 0, 0); } \
     }                                                                                                                  \
   }
 #else
@@ -374,7 +388,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
       }
     }
   } else {
-    const bool plain = p.act == ACT_NONE && p.act_ref == nullptr;
+    const bool has_ref = p.act_ref != nullptr;
     const int plane16 = (int)plane * 16;
     const auto rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (size_t)b * p.Mb * plane * 2), (short)0, p.Mb * plane16, 0x00020000);
     int vo[NC][NW];  // byte offset of this lane's unit inside its image: lanes 32-63 write the next channel block
@@ -385,6 +399,28 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
         const bool valid = (c == 0 ? pvalid[n] : pvalid1[n]) && !(p.dbg & 1);
         vo[c][n] = valid ? (opix[n] + c) * 16 + half * plane16 : (int)0x80000000u;
       }
+    // training dgrad into a block without BatchNorm: act'(ref).  All of this lane's reference values (8 bytes per group) are
+    // requested up front so that their latency is paid once, behind the LDS hand-over above.
+    u32x2 rf[MW][2][NC][NW][2];
+    if (has_ref) {
+      const auto rs_r = __builtin_amdgcn_make_buffer_rsrc((void*)(p.act_ref + (size_t)b * p.Mb * plane * 2), (short)0, p.Mb * plane16, 0x00020000);
+#pragma unroll
+      for (int mb = 0; mb < MW; ++mb)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          const int cb = (m0 >> 3) + mb * 4 + 2 * gp;
+          if (cb >= p.Mb) continue;
+#pragma unroll
+          for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int n = 0; n < NW; ++n) {
+              const bool valid = c == 0 ? pvalid[n] : pvalid1[n];
+              const int vr = valid ? (opix[n] + c) * 16 + half * 8 + cb * plane16 : (int)0x80000000u;
+              rf[mb][gp][c][n][0] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_r, vr, 0, 0));
+              rf[mb][gp][c][n][1] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_r, vr + plane16, 0, 0));
+            }
+        }
+    }
 #pragma unroll
     for (int mb = 0; mb < MW; ++mb) {
 #pragma unroll
@@ -413,23 +449,28 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
                 q8[i] += vm * v[i];
               }
             }
-            if (!plain) {
-              if (p.act_ref != nullptr) {
-                const bool valid = c == 0 ? pvalid[n] : pvalid1[n];
-                if (valid) {
-                  const size_t h0 = (((size_t)b * p.Mb + cb) * plane + opix[n] + c) * 2 + half;
-                  const bf16x4 r0 = __builtin_bit_cast(bf16x4, p.act_ref[h0]);
-                  const bf16x4 r1 = __builtin_bit_cast(bf16x4, p.act_ref[h0 + plane * 2]);
+            if (has_ref) {
+              const bf16x4 r0 = __builtin_bit_cast(bf16x4, rf[mb][gp][c][n][0]);
+              const bf16x4 r1 = __builtin_bit_cast(bf16x4, rf[mb][gp][c][n][1]);
+              if (p.ref_act == ACT_LEAKY) {
 #pragma unroll
-                  for (int i = 0; i < 4; ++i) {
-                    v[i] *= act_bwd_factor((float)r0[i], p.ref_act);
-                    v[4 + i] *= act_bwd_factor((float)r1[i], p.ref_act);
-                  }
+                for (int i = 0; i < 4; ++i) {
+                  v[i] *= (float)r0[i] > 0.f ? 1.f : LEAKY_SLOPE;
+                  v[4 + i] *= (float)r1[i] > 0.f ? 1.f : LEAKY_SLOPE;
                 }
               } else {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = act_fwd(v[i], p.act);
+                for (int i = 0; i < 4; ++i) {
+                  v[i] *= act_bwd_factor((float)r0[i], p.ref_act);
+                  v[4 + i] *= act_bwd_factor((float)r1[i], p.ref_act);
+                }
               }
+            } else if (p.act == ACT_LEAKY) {
+#pragma unroll
+              for (int i = 0; i < 8; ++i) v[i] = v[i] > 0.f ? v[i] : LEAKY_SLOPE * v[i];
+            } else if (p.act == ACT_SILU) {
+#pragma unroll
+              for (int i = 0; i < 8; ++i) v[i] = act_fwd(v[i], ACT_SILU);
             }
             bf16x8 o;
 #pragma unroll
