@@ -7,8 +7,14 @@
 // channel.  The transpose is done by the LDS hardware: tiles are staged as [pixel][32 channels] bf16 (64 B per pixel, plain
 // 16-byte copies of the global units) and read with ds_read_b64_tr_b16, which hands each lane 4 pixels of "its" channel per
 // instruction; tap shifts move the address by whole 64-byte pixels, so every read stays aligned.
-// Work decomposition as in the fp32 kernel: 12 wavefronts = MBW co-blocks x NBW ci-blocks x KS pixel-splits x 3 kernel rows,
-// each owning 3 accumulator tiles; split-K slabs + the same fixed-order reduction (clamp, OIHW, bias) finish the gradient.
+//
+// Work decomposition: a "unit" is R output rows x one column chunk of one image.  A workgroup owns MBW co-blocks x
+// (NBW * NPW) ci-blocks of 32 channels and walks its share of the units (split-K over pixels); its wavefronts are
+// MBW x NBW x KS pixel-splits x 3 kernel rows, each holding NPW x 3 accumulator tiles.  Units stream through two LDS buffers
+// by LDS-DMA (buffer_load ... lds): every lane owns a fixed set of 16-byte elements of the tile image, their source offsets
+// are decoded once, per unit only the unit's origin is added and the image / chunk borders are turned into out-of-range
+// offsets (which the buffer unit writes as zeros).  One barrier per unit, up to two units in flight ahead of the MFMAs.  Split-K slabs + the fixed-order reduction of
+// wgrad_f32.hip (clamp, OIHW, bias) finish the gradient.
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -16,23 +22,51 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-#define WGB_LDS_BUDGET (150 * 1024)
-#define WGB_ROWS(S) ((S) == 1 ? 4 : 2)  // output rows per unit (stride 2 stages a 2x larger input tile per row)
+#define WGB_LDS_MAX (160 * 1024)
+#define WGB_GSLOTS 4  // LDS-DMA slots per lane and unit: gradient tile
+#define WGB_XSLOTS 6  // ... input tile
 
 struct WgradBf16Params {
   const u32x4* x;   // [B][Nb][IH][IW] units
   const u32x4* g;   // [B][Mbk][OH][OW] units
   float* slab;      // [nsplit*KS][T][Mpad][Npad]
-  float* bias_part; // optional [nsplit][Mpad]
+  float* bias_part; // optional [nsplit*KS][Mpad]
   int B, Nb, Mbk, Npad, Mpad, IH, IW, OH, OW, pad;
   int nchunk_w, base_w, rem_w, wce;   // column chunks per row (balanced), staged chunk width (multiple of 16, zero padded)
-  int nrowg;                          // row groups per image (WGB_ROWS output rows each)
-  int xw, xrows;                      // staged input columns / rows per unit
-  unsigned inv_wce, inv_grow, inv_xw, inv_xrow;  // magic numbers: / wce, / (WGB_ROWS*wce), / xw, / (xrows*xw)
+  int nrowg;                          // row groups per image (R output rows each)
+  int xw;                             // staged input columns per unit
   int units, units_per_split;
-  int x_off;                          // byte offset of the x tile in LDS
-  int lds_dummy;                      // byte offset of a scratch unit
+  int ngs, nxs, bufu;                 // g / x slots in use, 16-byte units per LDS buffer
+  int depth;                          // LDS buffers in the ring (2 or 3): units in flight ahead of the MFMAs = depth - 1
 };
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// One LDS-DMA piece: 64 lanes x 16 bytes from (descriptor, per-lane byte offset) to LDS bytes [lds_addr, lds_addr + 1024).
+// Issued from inline asm on purpose: hipcc (ROCm 7.2) makes every later LDS read wait for ALL of its own LDS-DMA loads
+// (vmcnt(0)), which would serialise the ring; these loads are invisible to it and are retired by wait_dma() below.
+__device__ __forceinline__ void dma16(i32x4 rsrc, unsigned lds_addr, int voff) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(lds_addr), "s"(rsrc)
+               : "memory");
+}
+// descriptor of `bytes` bytes at `ptr` (raw buffer, no swizzle)
+__device__ __forceinline__ i32x4 make_rsrc(const void* ptr, int bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
+  return i32x4{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xFFFFu), bytes, 0x00020000};
+}
+
+// counted wait for this wavefront's LDS-DMA: at most n of its newest loads may still be in flight
+__device__ __forceinline__ void wait_dma(int n) {
+  switch (n) {
+#define WD_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    WD_CASE(1) WD_CASE(2) WD_CASE(3) WD_CASE(4) WD_CASE(5) WD_CASE(6) WD_CASE(7) WD_CASE(8) WD_CASE(9) WD_CASE(10)
+#undef WD_CASE
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
 
 __device__ __forceinline__ bf16x8 lds_tr8(const unsigned char* base, int off0, int off1) {
   typedef bf16x4 __attribute__((address_space(3))) * lds_v4;
@@ -41,20 +75,14 @@ __device__ __forceinline__ bf16x8 lds_tr8(const unsigned char* base, int off0, i
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int MBW, int NBW, int KS, int T, int S>
+template <int MBW, int NBW, int NPW, int KS, int T, int S, int R>
 __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_bf16_kernel(const WgradBf16Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
   constexpr int TG = (T == 1) ? 1 : 3;
   constexpr int TT = T / TG;
   constexpr int NT = 64 * MBW * NBW * KS * TG;
-  constexpr int R = WGB_ROWS(S);
-  constexpr int WC = 64;  // max staged chunk width
   constexpr int XR = (T == 1) ? R : (R - 1) * S + 3;
-  constexpr int XWMAX = (WC - 1) * S + ((T == 1) ? 1 : 3);
-  constexpr int NGU = (MBW * 4 * R * WC + NT - 1) / NT;    // g units per lane
-  constexpr int NXU = (NBW * 4 * XR * XWMAX + NT - 1) / NT;  // x units per lane
-  unsigned char* ldsG = smem_b;            // [MBW][R][wce][32 ch] bf16
-  unsigned char* ldsX = smem_b + p.x_off;  // [NBW][xrows][xw][32 ch] bf16
+  constexpr unsigned OOB = 0x80000000u;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tg = wave % TG;
@@ -62,90 +90,84 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
   const int nb = (wave / (TG * KS)) % NBW;
   const int mb = wave / (TG * KS * NBW);
   const int split = blockIdx.x;
-  const int n0b = blockIdx.y * (NBW * 4);  // first channel BLOCK (of 8) of this workgroup's ci range
+  const int n0b = blockIdx.y * (NBW * NPW * 4);  // first channel BLOCK (of 8) of this workgroup's ci range
   const int m0b = blockIdx.z * (MBW * 4);
 
-  f32x16 acc[TT];
+  f32x16 acc[NPW][TT];
 #pragma unroll
-  for (int t = 0; t < TT; ++t)
+  for (int q = 0; q < NPW; ++q)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][t][r] = 0.f;
   float bsum = 0.f;
+  const bool do_bias = p.bias_part != nullptr && blockIdx.y == 0 && tg == 0 && nb == 0;
 
   const int u_begin = split * p.units_per_split;
   const int u_end = min(p.units, u_begin + p.units_per_split);
   const int gplane = p.OH * p.OW, xplane = p.IH * p.IW;
-  const int growsz = R * p.wce;          // g units per 8-channel block and unit
-  const int xrowsz = p.xrows * p.xw;     // x units per 8-channel block and unit
-  const int gtotal = MBW * 4 * growsz;
-  const int xtotal = NBW * 4 * xrowsz;
-  u32x4 gu[NGU], xu[NXU];
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
-#define WB_UNIT(U, B_, OY0_, OX0_, WCR_)                                  \
-  const int cwu_ = (U) % p.nchunk_w;                                      \
-  const int rgu_ = ((U) / p.nchunk_w) % p.nrowg;                          \
-  const int B_ = (U) / (p.nchunk_w * p.nrowg);                            \
-  const int OY0_ = rgu_ * R;                                              \
-  const int OX0_ = cwu_ * p.base_w + min(cwu_, p.rem_w);                  \
-  const int WCR_ = p.base_w + (cwu_ < p.rem_w ? 1 : 0);
-
-  // element e of the g tile -> (channel block cb, row r, column c); of the x tile likewise
-#define WB_GDEC(E)                                                        \
-  const int cb_ = __umulhi((unsigned)(E), p.inv_grow);                    \
-  const int rm_ = (E) - cb_ * growsz;                                     \
-  const int r_ = __umulhi((unsigned)rm_, p.inv_wce);                      \
-  const int c_ = rm_ - r_ * p.wce;
-#define WB_XDEC(E)                                                        \
-  const int cb_ = __umulhi((unsigned)(E), p.inv_xrow);                    \
-  const int rm_ = (E) - cb_ * xrowsz;                                     \
-  const int r_ = __umulhi((unsigned)rm_, p.inv_xw);                       \
-  const int c_ = rm_ - r_ * p.xw;
-
-#define WB_ISSUE(U)                                                                                         \
-  {                                                                                                         \
-    WB_UNIT(U, b_, oy0_, ox0_, wc_)                                                                         \
-    const u32x4* gb_ = p.g + (size_t)b_ * p.Mbk * gplane;                                                   \
-    _Pragma("unroll") for (int i = 0; i < NGU; ++i) {                                                       \
-      const int e_ = min(tid + NT * i, gtotal - 1);                                                         \
-      WB_GDEC(e_)                                                                                           \
-      const int oy_ = oy0_ + r_;                                                                            \
-      const bool ok_ = (m0b + cb_ < p.Mbk) && (c_ < wc_) && (oy_ < p.OH);                                   \
-      gu[i] = gb_[ok_ ? (m0b + cb_) * gplane + oy_ * p.OW + ox0_ + c_ : 0];                                 \
-    }                                                                                                       \
-    const u32x4* xb_ = p.x + (size_t)b_ * p.Nb * xplane;                                                    \
-    const int iy0_ = oy0_ * S - p.pad, ix0_ = ox0_ * S - p.pad;                                             \
-    _Pragma("unroll") for (int i = 0; i < NXU; ++i) {                                                       \
-      const int e_ = min(tid + NT * i, xtotal - 1);                                                         \
-      WB_XDEC(e_)                                                                                           \
-      const int iy_ = iy0_ + r_, ix_ = ix0_ + c_;                                                           \
-      const bool ok_ = (n0b + cb_ < p.Nb) && (iy_ >= 0) && (iy_ < p.IH) && (ix_ >= 0) && (ix_ < p.IW);      \
-      xu[i] = xb_[ok_ ? (n0b + cb_) * xplane + iy_ * p.IW + ix_ : 0];                                       \
-    }                                                                                                       \
+  // ---- this lane's elements of the tile image: slot i covers LDS unit i*NT + tid -------------------------------------------
+  // g image [MBW][R][wce][4 channel blocks], x image [NBW*NPW][XR][xw][4 channel blocks]; element -> (cb, r, c).
+  // lc = byte offset inside the image for unit origin (0, 0), rc = r << 16 | c (all ones: never valid)
+  int glc[WGB_GSLOTS], xlc[WGB_XSLOTS];
+  unsigned grc[WGB_GSLOTS], xrc[WGB_XSLOTS];
+  {
+    const int gtot = MBW * 4 * R * p.wce, xtot = NBW * NPW * 4 * XR * p.xw;
+#pragma unroll
+    for (int i = 0; i < WGB_GSLOTS; ++i) {
+      const int e = tid + i * NT;
+      const int cb3 = e & 3, pix = e >> 2;
+      const int rr = pix / p.wce, c = pix - rr * p.wce;
+      const int cbg = rr / R, r = rr - cbg * R;
+      const int cb = m0b + cbg * 4 + cb3;
+      const bool ok = e < gtot && cb < p.Mbk;
+      glc[i] = (cb * gplane + r * p.OW + c) * 16;
+      grc[i] = ok ? (unsigned)(r << 16 | c) : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int i = 0; i < WGB_XSLOTS; ++i) {
+      const int e = tid + i * NT;
+      const int cb3 = e & 3, pix = e >> 2;
+      const int rr = pix / p.xw, c = pix - rr * p.xw;
+      const int cbg = rr / XR, r = rr - cbg * XR;
+      const int cb = n0b + cbg * 4 + cb3;
+      const bool ok = e < xtot && cb < p.Nb;
+      xlc[i] = (cb * xplane + r * p.IW + c) * 16;
+      xrc[i] = ok ? (unsigned)(r << 16 | c) : 0xFFFFFFFFu;
+    }
   }
-  // commit: unit (cb, r, c) -> LDS [cb/4][r][c][32 ch], 16 bytes at channel offset (cb%4)*8; out-of-range units are zero
-#define WB_COMMIT(U)                                                                                        \
-  {                                                                                                         \
-    WB_UNIT(U, b_, oy0_, ox0_, wc_)                                                                         \
-    (void)b_;                                                                                               \
-    _Pragma("unroll") for (int i = 0; i < NGU; ++i) {                                                       \
-      const int e_ = tid + NT * i;                                                                          \
-      const int ec_ = min(e_, gtotal - 1);                                                                  \
-      WB_GDEC(ec_)                                                                                          \
-      const bool ok_ = (m0b + cb_ < p.Mbk) && (c_ < wc_) && (oy0_ + r_ < p.OH);                             \
-      const int off_ = (((cb_ >> 2) * R + r_) * p.wce + c_) * 64 + (cb_ & 3) * 16;                          \
-      *reinterpret_cast<u32x4*>(smem_b + (e_ < gtotal ? off_ : p.lds_dummy)) = ok_ ? gu[i] : zero4;         \
-    }                                                                                                       \
-    const int iy0_ = oy0_ * S - p.pad, ix0_ = ox0_ * S - p.pad;                                             \
-    _Pragma("unroll") for (int i = 0; i < NXU; ++i) {                                                       \
-      const int e_ = tid + NT * i;                                                                          \
-      const int ec_ = min(e_, xtotal - 1);                                                                  \
-      WB_XDEC(ec_)                                                                                          \
-      const int iy_ = iy0_ + r_, ix_ = ix0_ + c_;                                                           \
-      const bool ok_ = (n0b + cb_ < p.Nb) && (iy_ >= 0) && (iy_ < p.IH) && (ix_ >= 0) && (ix_ < p.IW);      \
-      const int off_ = p.x_off + (((cb_ >> 2) * p.xrows + r_) * p.xw + c_) * 64 + (cb_ & 3) * 16;           \
-      *reinterpret_cast<u32x4*>(smem_b + (e_ < xtotal ? off_ : p.lds_dummy)) = ok_ ? xu[i] : zero4;         \
-    }                                                                                                       \
+
+  // the unit whose DMA is issued next: (image, row group, column chunk), stepped without divisions
+  int iu_cw = u_begin % p.nchunk_w, iu_rg = (u_begin / p.nchunk_w) % p.nrowg, iu_b = u_begin / (p.nchunk_w * p.nrowg);
+#define WB_ISSUE(BUF)                                                                                                 \
+  {                                                                                                                   \
+    const int b_ = iu_b, oy0_ = iu_rg * R, ox0_ = iu_cw * p.base_w + min(iu_cw, p.rem_w);                             \
+    const int wc_ = p.base_w + (iu_cw < p.rem_w ? 1 : 0);                                                             \
+    if (++iu_cw == p.nchunk_w) {                                                                                      \
+      iu_cw = 0;                                                                                                      \
+      if (++iu_rg == p.nrowg) { iu_rg = 0; ++iu_b; }                                                                  \
+    }                                                                                                                 \
+    const i32x4 rs_g = make_rsrc(p.g + (size_t)b_ * p.Mbk * gplane, p.Mbk * gplane * 16);                             \
+    const i32x4 rs_x = make_rsrc(p.x + (size_t)b_ * p.Nb * xplane, p.Nb * xplane * 16);                               \
+    const unsigned lb_ = (unsigned)(((BUF) * p.bufu + wave * 64) * 16);  /* the dynamic LDS block starts at LDS address 0 */ \
+    const int gorg_ = (oy0_ * p.OW + ox0_) * 16, rmax_ = p.OH - oy0_;                                                 \
+    _Pragma("unroll") for (int i = 0; i < WGB_GSLOTS; ++i) {                                                          \
+      if (i < p.ngs) {                                                                                                \
+        const int c_ = (int)(grc[i] & 0xFFFFu), r_ = (int)(grc[i] >> 16);                                             \
+        const bool ok_ = (c_ < wc_) && (r_ < rmax_);                                                                  \
+        dma16(rs_g, lb_ + i * NT * 16, ok_ ? glc[i] + gorg_ : (int)OOB);                                              \
+      }                                                                                                               \
+    }                                                                                                                 \
+    const int iy0_ = oy0_ * S - p.pad, ix0_ = ox0_ * S - p.pad;                                                       \
+    const int xorg_ = (iy0_ * p.IW + ix0_) * 16;                                                                      \
+    _Pragma("unroll") for (int i = 0; i < WGB_XSLOTS; ++i) {                                                          \
+      if (i < p.nxs) {                                                                                                \
+        const int c_ = (int)(xrc[i] & 0xFFFFu), r_ = (int)(xrc[i] >> 16);                                             \
+        const bool ok_ = ((unsigned)(iy0_ + r_) < (unsigned)p.IH) && ((unsigned)(ix0_ + c_) < (unsigned)p.IW);        \
+        dma16(rs_x, lb_ + (p.ngs + i) * NT * 16, ok_ ? xlc[i] + xorg_ : (int)OOB);                                    \
+      }                                                                                                               \
+    }                                                                                                                 \
   }
 
   // ---- per-lane operand addressing for the transposed reads ----------------------------------------------------------
@@ -157,8 +179,9 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
   const int ksteps_row = p.wce >> 4;
   const int nsteps = R * ksteps_row;
   const int cnt = (nsteps - ks + KS - 1) / KS;
+  const int xblk = XR * p.xw * 64;                        // bytes of one 32-channel block of the x image
   const int gbase = mb * (R * p.wce * 64) + lane_ch_off;
-  const int xbase = nb * (p.xrows * p.xw * 64) + lane_ch_off;
+  const int xbase = p.ngs * NT * 16 + nb * NPW * xblk + lane_ch_off;
 
 #define WB_LOAD(AV, BV, I)                                                                                      \
   {                                                                                                             \
@@ -166,73 +189,96 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
     const int r_ = st_ / ksteps_row;                                                                            \
     const int px_ = (st_ - r_ * ksteps_row) * 16 + lane_px;                                                     \
     const int ga_ = gbase + (r_ * p.wce + px_) * 64;                                                            \
-    AV = lds_tr8(ldsG, ga_, ga_ + 4 * 64);                                                                      \
+    AV = lds_tr8(buf, ga_, ga_ + 4 * 64);                                                                       \
+    _Pragma("unroll") for (int q = 0; q < NPW; ++q)                                                             \
     _Pragma("unroll") for (int t = 0; t < TT; ++t) {                                                            \
-      const int xa_ = xbase + (((r_ * S + (T == 1 ? 0 : tg)) * p.xw) + px_ * S + t) * 64;                       \
-      BV[t] = lds_tr8(ldsX, xa_, xa_ + 4 * S * 64);                                                             \
+      const int xa_ = xbase + q * xblk + (((r_ * S + (T == 1 ? 0 : tg)) * p.xw) + px_ * S + t) * 64;            \
+      BV[q][t] = lds_tr8(buf, xa_, xa_ + 4 * S * 64);                                                           \
     }                                                                                                           \
   }
-#define WB_MFMA(AV, BV) \
-  _Pragma("unroll") for (int t = 0; t < TT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AV, BV[t], acc[t], 0, 0, 0);
+// bias gradient: the A operand already holds 8 pixels of "this lane's" output channel (padding pixels are zeros)
+#define WB_BIAS(AV)                                                             \
+  if (do_bias) {                                                                \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) bsum += (float)AV[j];         \
+  }
+#define WB_MFMA(AV, BV)                                           \
+  _Pragma("unroll") for (int q = 0; q < NPW; ++q)                 \
+  _Pragma("unroll") for (int t = 0; t < TT; ++t)                  \
+    acc[q][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AV, BV[q][t], acc[q][t], 0, 0, 0);
 
-  if (u_begin < u_end) {
-    WB_ISSUE(u_begin);
-    WB_COMMIT(u_begin);
-  }
-  __syncthreads();
+  // ring of p.depth LDS buffers: unit u + depth - 1 streams in while unit u is multiplied.  Ordering (LDS-DMA is invisible to
+  // the barrier): every wave waits for ITS loads of unit u with a counted vmcnt, then the barrier makes all of them visible and
+  // proves that nobody still reads the buffer the next issue overwrites.
+  const int nslots = p.ngs + p.nxs;
+  if (u_begin < u_end) WB_ISSUE(0)
+  if (p.depth == 3 && u_begin + 1 < u_end) WB_ISSUE(1)
+  int ib = 0;
   for (int u = u_begin; u < u_end; ++u) {
-    const bool more = u + 1 < u_end;
-    if (more) WB_ISSUE(u + 1);
-    // bias partial: sum over the staged pixels of channel tid (padding pixels / rows hold zeros)
-    if (p.bias_part != nullptr && blockIdx.y == 0 && tid < MBW * 32) {
-      const __bf16* gp = reinterpret_cast<const __bf16*>(ldsG) + (tid >> 5) * (R * p.wce * 32) + (tid & 31);
-      float s = 0.f;
-      for (int px = 0; px < R * p.wce; ++px) s += (float)gp[px * 32];
-      bsum += s;
+    wait_dma((p.depth == 3 && u + 1 < u_end) ? nslots : 0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const int ahead = p.depth - 1;
+    if (u + ahead < u_end) {
+      int nb_ = ib + ahead;
+      nb_ = nb_ >= p.depth ? nb_ - p.depth : nb_;
+      WB_ISSUE(nb_)
     }
+    const unsigned char* buf = smem_b + ib * p.bufu * 16;
+    ib = ib + 1 == p.depth ? 0 : ib + 1;
     if (cnt > 0) {
-      bf16x8 a0, a1, b0[TT], b1[TT];
-      WB_LOAD(a0, b0, 0);
-      int i = 0;
-      for (; i + 1 < cnt; i += 2) {
-        WB_LOAD(a1, b1, i + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        WB_MFMA(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        WB_LOAD(a0, b0, i + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        WB_MFMA(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
+      if constexpr (NPW == 1) {  // operands of step i+1 are fetched before the MFMAs of step i
+        bf16x8 a0, a1, b0[NPW][TT], b1[NPW][TT];
+        WB_LOAD(a0, b0, 0);
+        int i = 0;
+        for (; i + 1 < cnt; i += 2) {
+          WB_LOAD(a1, b1, i + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          WB_MFMA(a0, b0);
+          WB_BIAS(a0)
+          __builtin_amdgcn_sched_barrier(0);
+          WB_LOAD(a0, b0, i + 2);
+          __builtin_amdgcn_sched_barrier(0);
+          WB_MFMA(a1, b1);
+          WB_BIAS(a1)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (i < cnt) {
+          WB_MFMA(a0, b0);
+          WB_BIAS(a0)
+        }
+      } else {  // 6 accumulator tiles: one operand set (the three wavefronts of a SIMD hide each other's LDS latency)
+        for (int i = 0; i < cnt; ++i) {
+          bf16x8 a0, b0[NPW][TT];
+          WB_LOAD(a0, b0, i);
+          WB_MFMA(a0, b0);
+          WB_BIAS(a0)
+        }
       }
-      if (i < cnt) WB_MFMA(a0, b0);
-    }
-    __syncthreads();
-    if (more) {
-      WB_COMMIT(u + 1);
-      __syncthreads();
     }
   }
-#undef WB_UNIT
-#undef WB_GDEC
-#undef WB_XDEC
 #undef WB_ISSUE
-#undef WB_COMMIT
 #undef WB_LOAD
 #undef WB_MFMA
+#undef WB_BIAS
 
   // ---- write the slab: [split*KS + ks][t][m][n] ----------------------------------------------------------------------
   float* sl = p.slab + (size_t)(split * KS + ks) * T * p.Mpad * p.Npad;
   const int m0 = m0b * 8, n0 = n0b * 8;
 #pragma unroll
-  for (int t = 0; t < TT; ++t) {
+  for (int q = 0; q < NPW; ++q)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      const int n = n0 + nb * 32 + l31;
-      sl[((size_t)(tg * TT + t) * p.Mpad + m) * p.Npad + n] = acc[t][r];
+    for (int t = 0; t < TT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int n = n0 + (nb * NPW + q) * 32 + l31;
+        sl[((size_t)(tg * TT + t) * p.Mpad + m) * p.Npad + n] = acc[q][t][r];
+      }
     }
+  if (do_bias) {  // lane l31 and lane l31 + 32 hold the two pixel halves of channel mb*32 + l31
+    const float tot = bsum + __shfl_xor(bsum, 32, 64);
+    if (half == 0) p.bias_part[(size_t)(split * KS + ks) * p.Mpad + m0 + mb * 32 + l31] = tot;
   }
-  if (p.bias_part != nullptr && blockIdx.y == 0 && tid < MBW * 32) p.bias_part[(size_t)split * p.Mpad + m0 + tid] = bsum;
 }
 
 // defined in wgrad_f32.hip (the fixed-order slab reduction is shared)
@@ -242,12 +288,10 @@ extern "C" int yogo_internal_wgrad_reduce(const float* slab, int nslab, int T, i
 namespace {
 
 struct WbPlan {
-  int MBW, NBW, KS, Mpad, Npad, nchunk_w, base_w, rem_w, wce, nrowg, xw, xrows, units, nsplit, units_per_split, x_off, lds_dummy,
-      lds_bytes;
+  int MBW, NBW, NPW, KS, R, Mpad, Npad, nchunk_w, base_w, rem_w, wce, nrowg, xw, units, nsplit, units_per_split, ngs, nxs, bufu,
+      depth, lds_bytes;
   dim3 grid;
 };
-
-unsigned wb_magic(int d) { return (unsigned)(((1ull << 32) + (unsigned long long)d - 1ull) / (unsigned long long)d); }
 
 bool wb_plan(int B, int N, int M, int IH, int IW, int ks, int stride, WbPlan* pl) {
   const int pad = ks == 3 ? 1 : 0;
@@ -257,32 +301,45 @@ bool wb_plan(int B, int N, int M, int IH, int IW, int ks, int stride, WbPlan* pl
   if (MBW == 3) MBW = 2;
   int NBW = min(4 / MBW, nblocks);
   if (NBW == 3) NBW = 2;
-  pl->MBW = MBW; pl->NBW = NBW; pl->KS = 4 / (MBW * NBW);
+  // 128 output channels x >= 64 input channels: two ci-blocks per wavefront, so the gradient tile is staged once per 64 (not
+  // 32) input channels
+  const int NPW = (MBW == 4 && NBW == 1 && nblocks >= 2 && ks == 3) ? 2 : 1;
+  const int KS = 4 / (MBW * NBW);
+  const int R = NPW == 2 ? (stride == 1 ? 3 : 2) : (stride == 1 ? 4 : 2);
+  pl->MBW = MBW; pl->NBW = NBW; pl->NPW = NPW; pl->KS = KS; pl->R = R;
   pl->Mpad = round_up(M, 32 * MBW);
-  pl->Npad = round_up(N, 32 * NBW);
-  // column chunks: <= 64 staged pixels, multiple of 16; pick the count with the least zero padding
-  int best_nc = cdiv(OW, 64), best_waste = 1 << 30;
-  for (int nc = cdiv(OW, 64); nc <= cdiv(OW, 64) + 4 && nc <= OW; ++nc) {
-    const int w = round_up(cdiv(OW, nc), 16);
-    if (w > 64) continue;
-    const int waste = nc * w - OW;
-    if (waste < best_waste) { best_waste = waste; best_nc = nc; }
+  pl->Npad = round_up(N, 32 * NBW * NPW);
+  const int TG = ks == 3 ? 3 : 1;
+  const int NT = 64 * MBW * NBW * KS * TG;
+  const int XR = ks == 3 ? (R - 1) * stride + 3 : R;
+  // column chunks: staged width a multiple of 16, at most 64; the widest that fits the slots and two LDS buffers, then the
+  // count with the least zero padding
+  bool found = false;
+  int best_waste = 1 << 30;
+  for (int wmax = 64; wmax >= 16 && !found; wmax -= 16) {
+    for (int nc = cdiv(OW, wmax); nc <= cdiv(OW, wmax) + 4 && nc <= OW; ++nc) {
+      const int w = round_up(cdiv(OW, nc), 16);
+      if (w > wmax) continue;
+      const int xw = (w - 1) * stride + (ks == 3 ? 3 : 1);
+      const int ngs = cdiv(MBW * 4 * R * w, NT), nxs = cdiv(NBW * NPW * 4 * XR * xw, NT);
+      const int bufu = (ngs + nxs) * NT;
+      if (ngs > WGB_GSLOTS || nxs > WGB_XSLOTS || 2 * bufu * 16 > WGB_LDS_MAX) continue;
+      const int waste = nc * w - OW;
+      if (waste < best_waste) {
+        best_waste = waste;
+        pl->nchunk_w = nc; pl->wce = w; pl->xw = xw; pl->ngs = ngs; pl->nxs = nxs; pl->bufu = bufu;
+        found = true;
+      }
+    }
   }
-  pl->nchunk_w = best_nc;
-  pl->base_w = OW / best_nc;
-  pl->rem_w = OW - pl->base_w * best_nc;
-  pl->wce = round_up(pl->base_w + (pl->rem_w > 0 ? 1 : 0), 16);
-  if (pl->wce > 64) return false;
-  const int R = WGB_ROWS(stride);
+  if (!found) return false;
+  pl->base_w = OW / pl->nchunk_w;
+  pl->rem_w = OW - pl->base_w * pl->nchunk_w;
+  pl->depth = 3 * pl->bufu * 16 <= WGB_LDS_MAX ? 3 : 2;
+  pl->lds_bytes = pl->depth * pl->bufu * 16;
   pl->nrowg = cdiv(OH, R);
-  pl->xw = (pl->wce - 1) * stride + (ks == 3 ? 3 : 1);
-  pl->xrows = ks == 3 ? (R - 1) * stride + 3 : R;
-  pl->x_off = MBW * R * pl->wce * 64;
-  pl->lds_dummy = pl->x_off + NBW * pl->xrows * pl->xw * 64;
-  pl->lds_bytes = pl->lds_dummy + 16;
-  if (pl->lds_bytes > WGB_LDS_BUDGET) return false;
   pl->units = B * pl->nrowg * pl->nchunk_w;
-  const int gy = pl->Npad / (32 * NBW), gz = pl->Mpad / (32 * MBW);
+  const int gy = pl->Npad / (32 * NBW * NPW), gz = pl->Mpad / (32 * MBW);
   int nsplit = max(1, min(pl->units, 256 / max(1, gy * gz)));
   pl->units_per_split = cdiv(pl->units, nsplit);
   pl->nsplit = cdiv(pl->units, pl->units_per_split);
@@ -290,23 +347,23 @@ bool wb_plan(int B, int N, int M, int IH, int IW, int ks, int stride, WbPlan* pl
   return true;
 }
 
-template <int MBW, int NBW, int KS, int T, int S>
+template <int MBW, int NBW, int NPW, int KS, int T, int S, int R>
 void wb_launch_one(const WgradBf16Params& p, const WbPlan& pl, hipStream_t stream) {
   static bool s = false;
   if (!s) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<MBW, NBW, KS, T, S>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, WGB_LDS_BUDGET);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<MBW, NBW, NPW, KS, T, S, R>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, WGB_LDS_MAX);
     s = true;
   }
-  hipLaunchKernelGGL((wgrad_bf16_kernel<MBW, NBW, KS, T, S>), pl.grid, dim3(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)), pl.lds_bytes,
-                     stream, p);
+  hipLaunchKernelGGL((wgrad_bf16_kernel<MBW, NBW, NPW, KS, T, S, R>), pl.grid, dim3(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)),
+                     pl.lds_bytes, stream, p);
 }
 
 template <int MBW, int NBW, int KS>
 void wb_launch(const WgradBf16Params& p, const WbPlan& pl, int T, int stride, hipStream_t stream) {
-  if (T == 1) wb_launch_one<MBW, NBW, KS, 1, 1>(p, pl, stream);
-  else if (stride == 1) wb_launch_one<MBW, NBW, KS, 9, 1>(p, pl, stream);
-  else wb_launch_one<MBW, NBW, KS, 9, 2>(p, pl, stream);
+  if (T == 1) wb_launch_one<MBW, NBW, 1, KS, 1, 1, 4>(p, pl, stream);
+  else if (stride == 1) wb_launch_one<MBW, NBW, 1, KS, 9, 1, 4>(p, pl, stream);
+  else wb_launch_one<MBW, NBW, 1, KS, 9, 2, 2>(p, pl, stream);
 }
 
 }  // namespace
@@ -316,7 +373,7 @@ extern "C" int yogo_conv2d_wgrad_bf16_workspace_bytes(int B, int Cin, int Cout, 
                  "wgrad_bf16_workspace_bytes: bad arguments");
   WbPlan pl;
   YOGO_CHECK_ARG(wb_plan(B, Cin, Cout, IH, IW, ks, stride, &pl), "wgrad_bf16: no LDS plan");
-  *bytes = ((size_t)pl.nsplit * pl.KS * ks * ks * pl.Mpad * pl.Npad + (size_t)pl.nsplit * pl.Mpad) * sizeof(float);
+  *bytes = ((size_t)pl.nsplit * pl.KS * ks * ks * pl.Mpad * pl.Npad + (size_t)pl.nsplit * pl.KS * pl.Mpad) * sizeof(float);
   return YOGO_OK;
 }
 
@@ -336,23 +393,34 @@ extern "C" int yogo_conv2d_wgrad_bf16(const void* x, const void* g, float* dw, f
   p.B = B; p.Nb = ((Cin + 15) / 16) * 2; p.Mbk = ((Cout + 15) / 16) * 2; p.Npad = pl.Npad; p.Mpad = pl.Mpad;
   p.IH = IH; p.IW = IW; p.OH = (IH + 2 * pad - ks) / stride + 1; p.OW = (IW + 2 * pad - ks) / stride + 1; p.pad = pad;
   p.nchunk_w = pl.nchunk_w; p.base_w = pl.base_w; p.rem_w = pl.rem_w; p.wce = pl.wce; p.nrowg = pl.nrowg;
-  p.xw = pl.xw; p.xrows = pl.xrows;
-  p.inv_wce = wb_magic(pl.wce); p.inv_grow = wb_magic(WGB_ROWS(stride) * pl.wce); p.inv_xw = wb_magic(pl.xw);
-  p.inv_xrow = wb_magic(pl.xrows * pl.xw);
-  p.units = pl.units; p.units_per_split = pl.units_per_split; p.x_off = pl.x_off; p.lds_dummy = pl.lds_dummy;
-  const int cfg = pl.MBW * 100 + pl.NBW * 10 + pl.KS;
-  switch (cfg) {
-    case 411: wb_launch<4, 1, 1>(p, pl, T, stride, stream); break;
-    case 221: wb_launch<2, 2, 1>(p, pl, T, stride, stream); break;
-    case 212: wb_launch<2, 1, 2>(p, pl, T, stride, stream); break;
-    case 141: wb_launch<1, 4, 1>(p, pl, T, stride, stream); break;
-    case 122: wb_launch<1, 2, 2>(p, pl, T, stride, stream); break;
-    case 114: wb_launch<1, 1, 4>(p, pl, T, stride, stream); break;
-    default:
-      yogo_set_error("wgrad_bf16: unsupported wave layout %d", cfg);
-      return YOGO_ERR_ARG;
+  p.xw = pl.xw;
+  p.units = pl.units; p.units_per_split = pl.units_per_split; p.ngs = pl.ngs; p.nxs = pl.nxs; p.bufu = pl.bufu; p.depth = pl.depth;
+  {
+    static int verbose = -1;
+    if (verbose < 0) verbose = getenv("YOGO_IGEMM_VERBOSE") ? 1 : 0;
+    if (verbose)
+      fprintf(stderr, "[wgrad bf16] N=%d M=%d in=%dx%d s=%d T=%d | MBW=%d NBW=%d NPW=%d KS=%d R=%d wce=%d x%d chunks xw=%d slots=%d+%d depth=%d lds=%d units=%d grid=%ux%ux%u\n",
+              Cin, Cout, IH, IW, stride, T, pl.MBW, pl.NBW, pl.NPW, pl.KS, pl.R, pl.wce, pl.nchunk_w, pl.xw, pl.ngs, pl.nxs, pl.depth, pl.lds_bytes,
+              pl.units, pl.grid.x, pl.grid.y, pl.grid.z);
+  }
+  if (pl.NPW == 2) {
+    if (stride == 1) wb_launch_one<4, 1, 2, 1, 9, 1, 3>(p, pl, stream);
+    else wb_launch_one<4, 1, 2, 1, 9, 2, 2>(p, pl, stream);
+  } else {
+    const int cfg = pl.MBW * 100 + pl.NBW * 10 + pl.KS;
+    switch (cfg) {
+      case 411: wb_launch<4, 1, 1>(p, pl, T, stride, stream); break;
+      case 221: wb_launch<2, 2, 1>(p, pl, T, stride, stream); break;
+      case 212: wb_launch<2, 1, 2>(p, pl, T, stride, stream); break;
+      case 141: wb_launch<1, 4, 1>(p, pl, T, stride, stream); break;
+      case 122: wb_launch<1, 2, 2>(p, pl, T, stride, stream); break;
+      case 114: wb_launch<1, 1, 4>(p, pl, T, stride, stream); break;
+      default:
+        yogo_set_error("wgrad_bf16: unsupported wave layout %d", cfg);
+        return YOGO_ERR_ARG;
+    }
   }
   YOGO_CHECK_LAUNCH("conv2d_wgrad_bf16");
-  return yogo_internal_wgrad_reduce(p.slab, pl.nsplit * pl.KS, T, Cout, Cin, pl.Mpad, pl.Npad, clip, dw, p.bias_part, pl.nsplit, db,
+  return yogo_internal_wgrad_reduce(p.slab, pl.nsplit * pl.KS, T, Cout, Cin, pl.Mpad, pl.Npad, clip, dw, p.bias_part, pl.nsplit * pl.KS, db,
                                     stream);
 }
