@@ -47,6 +47,7 @@ struct ConvBf16Params {
   // dma = 1: a chunk fits the kernel's PF slots and two LDS buffers -> chunk c+1 streams into the other buffer by LDS-DMA
   // while the matrix cores work on chunk c.  ni_slots / n_slots: input / all slots of a chunk; bufu: units per buffer.
   int dma, ni_slots, n_slots, bufu;
+  int bufs;  // LDS units between the buffers of consecutive chunks: bufu (two buffers) or 0 (dma = 2: one buffer, see below)
   int dbg;  // experiments (YOGO_BF16_DBG): 1 = no output stores, 2 = no MFMA loop, 4 = no DMA, 8 / 16 = no input / weight DMA
   unsigned long long* stamps;  // experiments (YOGO_BF16_STAMPS): [workgroup][4] s_memtime at start / loop / epilogue / end
 };
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define DMA_ISSUE(C)                                                                                                   \
   {                                                                                                                    \
-    u32x4* lb_ = smem4 + ((C) & 1) * p.bufu + wave * 64;                                                               \
+    u32x4* lb_ = smem4 + ((C) & 1) * p.bufs + wave * 64;                                                               \
     _Pragma("unroll") for (int i = 0; i < PF; ++i) {                                                                   \
       if (i < ni) { if (!(p.dbg & 8)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_i, (lds_ptr_t)(lb_ + i * NT), 16, voff[i], (C) * so_i, 0, 0); } \
       else if (i < ns) { if (!(p.dbg & 16)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(lb_ + i * NT), 16, voff[i], (C) * so_w, 0, 0); } \
@@ -314,9 +315,15 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
 #endif
     DMA_ISSUE(0)
     for (int c = 0; c < p.nchunk; ++c) {
+      // dma = 2 (at most two chunks): ONE buffer, the next chunk is fetched after the MFMAs -- half the LDS, so more
+      // workgroups per CU cover each other's latencies, which matters more than overlap inside a workgroup that short
+      if (p.dma == 2 && c > 0) {
+        __syncthreads();
+        DMA_ISSUE(c)
+      }
       __syncthreads();  // chunk c has landed (every wave drained its DMA) and nobody reads the other buffer any more
-      if (c + 1 < p.nchunk && !(p.dbg & 4)) { DMA_ISSUE(c + 1) }
-      const u32x4* ldsI = smem4 + (c & 1) * p.bufu;
+      if (p.dma == 1 && c + 1 < p.nchunk && !(p.dbg & 4)) { DMA_ISSUE(c + 1) }
+      const u32x4* ldsI = smem4 + (c & 1) * p.bufs;
       const u32x4* ldsW = ldsI + p.ldsw_off;
       __builtin_amdgcn_sched_barrier(0);
       if (!(p.dbg & 2)) BF_COMPUTE()
@@ -629,13 +636,14 @@ bool bf_plan(int OH, int OW, int a, int T, int span, int Kb, int MW, int NW, int
       const int ni = cdiv(CKb * chs, NT), nw = cdiv(T * CKb * BM, NT);
       const int ldsw_off = ni * NT;  // slot-aligned, so a DMA slot is all input or all weights
       const int bufu = (ni + nw) * NT;
-      const int dma = (ni + nw <= PF && 2 * bufu * 16 <= budget) ? 1 : 0;
+      const int nbuf = Kb / CKb <= 2 ? 1 : 2;  // short contractions: one buffer (more workgroups per CU)
+      const int dma = (ni + nw <= PF && nbuf * bufu * 16 <= budget) ? (nbuf == 1 ? 2 : 1) : 0;
       const int dummy = ldsw_off + T * CKb * BM;
-      const int bytes = dma ? 2 * bufu * 16 : (dummy + 1) * 16;
+      const int bytes = dma ? nbuf * bufu * 16 : (dummy + 1) * 16;
       if (bytes > budget) continue;
       // pipelined chunks first, then deep chunks, then the least staged input over the whole image (halo overhead)
       const long long staged = (long long)ncb * cdiv(OH * TW, PT) * rows_max * LW;  // units per channel block and image
-      const long long score = dma * 100000000000000LL + (long long)CKb * 100000000000LL - staged * 100 - ncb;
+      const long long score = (dma ? 1 : 0) * 100000000000000LL + (long long)CKb * 100000000000LL - staged * 100 - ncb;
       if (best_score < 0 || score > best_score) {
         best_score = score;
         best = BfTiling{ncb, TW, cdiv(OH * TW, PT), CKb, rows_max, LW, ldsw_off, dummy, bytes, dma, ni, ni + nw, bufu};
@@ -698,7 +706,13 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
   BfTiling tl;
   // 4-wavefront workgroups: two per CU when the pipelined tiling fits half the LDS
   bool planned = false;
-  if (NWV == 4) planned = bf_plan(OHt, OWt, s2d ? 1 : a, s2d ? 6 : T, s2d ? 2 : ks, Kb, MW, NW, NWV, PF, BF_LDS_BUDGET, &tl) && tl.dma;
+  if (NWV == 4) {  // as many workgroups per CU as a pipelined tiling allows: 4, 3, 2
+    static int ladder_env = -1;
+    if (ladder_env < 0) ladder_env = getenv("YOGO_BF16_LDS_LADDER") ? atoi(getenv("YOGO_BF16_LDS_LADDER")) : 0;
+    const int ladder[3] = {40 * 1024, 53 * 1024, BF_LDS_BUDGET};
+    for (int i = ladder_env; i < 3 && !planned; ++i)
+      planned = bf_plan(OHt, OWt, s2d ? 1 : a, s2d ? 6 : T, s2d ? 2 : ks, Kb, MW, NW, NWV, PF, ladder[i], &tl) && tl.dma;
+  }
   if (!planned) planned = bf_plan(OHt, OWt, s2d ? 1 : a, s2d ? 6 : T, s2d ? 2 : ks, Kb, MW, NW, NWV, PF, BF_LDS_MAX, &tl);
   if (!planned) {
     yogo_set_error("conv_bf16: no LDS tiling fits (K=%d M=%d OW=%d a=%d)", K, M, OW, a);
@@ -722,7 +736,7 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
   p.ncb = tl.ncb; p.TW = tl.TW; p.tiles_per_band = tl.tiles_per_band;
   p.CKb = tl.CKb; p.ckb_shift = tl.CKb == 8 ? 3 : (tl.CKb == 4 ? 2 : 1); p.nchunk = Kb / tl.CKb;
   p.ldsw_off = tl.ldsw_off; p.lds_dummy = tl.lds_dummy; p.act = act;
-  p.dma = tl.dma; p.ni_slots = tl.ni_slots; p.n_slots = tl.n_slots; p.bufu = tl.bufu;
+  p.dma = tl.dma; p.ni_slots = tl.ni_slots; p.n_slots = tl.n_slots; p.bufu = tl.bufu; p.bufs = tl.dma == 1 ? tl.bufu : 0;
   {
     static int nopf = -1;
     if (nopf < 0) nopf = getenv("YOGO_BF16_NO_DMA") ? 1 : 0;  // experiments: synchronous staging through registers
