@@ -118,6 +118,132 @@ __global__ __launch_bounds__(CF_THREADS) void conv_first_kernel(const ConvFirstP
   }
 }
 
+// Training variant with bf16 NCHW8c output: weights (transposed to [tap][16 channels]) and bias sit in LDS and are read as
+// broadcast ds_read_b128 -- once per tap for the lane's CF_PPT register-blocked pixels; input reads are branch-free (clamped
+// address + select); the BatchNorm sums are formed from the accumulators at the end and reduced with DPP adds.
+template <typename TIn, int CIN>
+__global__ __launch_bounds__(CF_THREADS) void conv_first_train_bf16_kernel(const ConvFirstParams p) {
+  constexpr int NJ = CIN * 9;
+  __shared__ __attribute__((aligned(16))) float wsh[NJ][CF_COCHUNK];
+  __shared__ __attribute__((aligned(16))) float bsh[CF_COCHUNK], csh[CF_COCHUNK];
+  __shared__ float red[4][2 * CF_COCHUNK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y;
+  const int npix = p.OH * p.OW;
+  const int pbase = blockIdx.x * (CF_THREADS * CF_PPT);
+  const TIn* inb = reinterpret_cast<const TIn*>(p.in) + (size_t)b * CIN * p.IH * p.IW;
+  bool okk[CF_PPT];
+  int oy[CF_PPT], ox[CF_PPT];
+#pragma unroll
+  for (int k = 0; k < CF_PPT; ++k) {
+    const int pix = pbase + k * CF_THREADS + tid;
+    okk[k] = pix < npix;
+    const int pc = okk[k] ? pix : 0;
+    oy[k] = pc / p.OW;
+    ox[k] = pc - oy[k] * p.OW;
+  }
+  for (int co0 = 0; co0 < p.Mb * 8; co0 += CF_COCHUNK) {
+    __syncthreads();
+    for (int e = tid; e < NJ * CF_COCHUNK; e += CF_THREADS) {
+      const int j = e / CF_COCHUNK, c = e - j * CF_COCHUNK;
+      wsh[j][c] = co0 + c < p.Cout ? p.w[(size_t)(co0 + c) * NJ + j] : 0.f;
+    }
+    if (tid < CF_COCHUNK) {
+      const int co = co0 + tid;
+      bsh[tid] = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f;
+      csh[tid] = co < p.Cout ? (p.chan_scale != nullptr ? p.chan_scale[(size_t)b * p.Cout + co] : 1.f) : 0.f;
+    }
+    __syncthreads();
+    float acc[CF_PPT][CF_COCHUNK];
+#pragma unroll
+    for (int c4 = 0; c4 < CF_COCHUNK; c4 += 4) {
+      const float4 bv = *reinterpret_cast<const float4*>(&bsh[c4]);
+#pragma unroll
+      for (int k = 0; k < CF_PPT; ++k) {
+        acc[k][c4] = bv.x; acc[k][c4 + 1] = bv.y; acc[k][c4 + 2] = bv.z; acc[k][c4 + 3] = bv.w;
+      }
+    }
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int j = (ci * 3 + kh) * 3 + kw;
+          float x[CF_PPT];
+#pragma unroll
+          for (int k = 0; k < CF_PPT; ++k) {
+            const int iy = oy[k] * p.stride + kh - 1, ix = ox[k] * p.stride + kw - 1;
+            const bool in = iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+            const float v = (float)inb[in ? ((size_t)ci * p.IH + iy) * p.IW + ix : 0];
+            x[k] = in ? v : 0.f;
+          }
+#pragma unroll
+          for (int c4 = 0; c4 < CF_COCHUNK; c4 += 4) {
+            const float4 wv = *reinterpret_cast<const float4*>(&wsh[j][c4]);
+#pragma unroll
+            for (int k = 0; k < CF_PPT; ++k) {
+              acc[k][c4] = fmaf(wv.x, x[k], acc[k][c4]);
+              acc[k][c4 + 1] = fmaf(wv.y, x[k], acc[k][c4 + 1]);
+              acc[k][c4 + 2] = fmaf(wv.z, x[k], acc[k][c4 + 2]);
+              acc[k][c4 + 3] = fmaf(wv.w, x[k], acc[k][c4 + 3]);
+            }
+          }
+        }
+    // BatchNorm partial sums of the pre-activation (tail pixels masked out)
+    if (p.stats_part != nullptr) {
+#pragma unroll
+      for (int c = 0; c < CF_COCHUNK; ++c) {
+        float sc = 0.f, qc = 0.f;
+#pragma unroll
+        for (int k = 0; k < CF_PPT; ++k) {
+          const float vm = okk[k] ? acc[k][c] : 0.f;
+          sc += vm;
+          qc += vm * vm;
+        }
+        const float ss = wave_sum(sc), qq = wave_sum(qc);
+        if (lane == 0) {
+          red[wave][2 * c] = ss;
+          red[wave][2 * c + 1] = qq;
+        }
+      }
+    }
+    // activation + channel scale + bf16 store
+    const float4 c0 = *reinterpret_cast<const float4*>(&csh[0]), c1 = *reinterpret_cast<const float4*>(&csh[4]);
+    const float4 c2 = *reinterpret_cast<const float4*>(&csh[8]), c3 = *reinterpret_cast<const float4*>(&csh[12]);
+    const float cs[16] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
+#pragma unroll
+    for (int k = 0; k < CF_PPT; ++k) {
+      const int pix = pbase + k * CF_THREADS + tid;
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+        const int cb = (co0 >> 3) + hb;
+        if (cb < p.Mb && okk[k]) {
+          cf_bf16x8 o;
+          if (p.act == ACT_NONE) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (__bf16)(acc[k][hb * 8 + j] * cs[hb * 8 + j]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (__bf16)(act_fwd(acc[k][hb * 8 + j], p.act) * cs[hb * 8 + j]);
+          }
+          p.out_bf16[((size_t)b * p.Mb + cb) * npix + pix] = __builtin_bit_cast(cf_u32x4, o);
+        }
+      }
+    }
+    if (p.stats_part != nullptr) {
+      __syncthreads();
+      if (tid < 2 * CF_COCHUNK) {
+        const int c = tid >> 1;
+        if (co0 + c < p.Cout) {
+          const float v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+          p.stats_part[((size_t)(b * gridDim.x + blockIdx.x) * p.Cout + co0 + c) * 2 + (tid & 1)] = v;
+        }
+      }
+    }
+  }
+}
+
 // dW[co][ci][kh][kw] = sum_{b,pix} dy[b][co][pix] * x[b][ci][pix*stride + tap]; db likewise without x.
 // One workgroup per (pixel tile, image); partials [rows][Cout][CIN*9 + 1] are summed by channel_partials_reduce.
 struct ConvFirstWgradParams {
@@ -272,6 +398,14 @@ static int conv_first_fwd_impl(const void* in, int in_dtype, const float* w, con
   p.OH = (IH - 1) / stride + 1; p.OW = (IW - 1) / stride + 1;
   if (B == 0) return YOGO_OK;
   dim3 grid(first_tiles(p.OH, p.OW), B);
+  if (out_bf16 != nullptr) {  // training, bf16 NCHW8c output
+    if (in_dtype == 0 && Cin == 1) hipLaunchKernelGGL((conv_first_train_bf16_kernel<uint8_t, 1>), grid, dim3(CF_THREADS), 0, stream, p);
+    else if (in_dtype == 0) hipLaunchKernelGGL((conv_first_train_bf16_kernel<uint8_t, 3>), grid, dim3(CF_THREADS), 0, stream, p);
+    else if (Cin == 1) hipLaunchKernelGGL((conv_first_train_bf16_kernel<float, 1>), grid, dim3(CF_THREADS), 0, stream, p);
+    else hipLaunchKernelGGL((conv_first_train_bf16_kernel<float, 3>), grid, dim3(CF_THREADS), 0, stream, p);
+    YOGO_CHECK_LAUNCH("conv_first_fwd");
+    return YOGO_OK;
+  }
   if (in_dtype == 0 && Cin == 1) hipLaunchKernelGGL((conv_first_kernel<uint8_t, 1>), grid, dim3(CF_THREADS), 0, stream, p);
   else if (in_dtype == 0) hipLaunchKernelGGL((conv_first_kernel<uint8_t, 3>), grid, dim3(CF_THREADS), 0, stream, p);
   else if (Cin == 1) hipLaunchKernelGGL((conv_first_kernel<float, 1>), grid, dim3(CF_THREADS), 0, stream, p);

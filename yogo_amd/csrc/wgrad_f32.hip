@@ -291,40 +291,70 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
 }
 
 // dW[co][ci][t] = clamp(sum_s slab[s][t][co][ci]);  db[co] = clamp(sum_s bias_part[s][co])
-// 64 consecutive slab elements per workgroup (coalesced 256-B reads); the four wavefronts each add a fixed
-// quarter of the slabs in fp64, then combine in a fixed order -> bitwise reproducible.
+// 256 consecutive slab elements per workgroup, four per lane (16-byte loads, eight slabs in flight per lane); the four
+// wavefronts each add a fixed quarter of the slabs in fp64, then combine in a fixed order -> bitwise reproducible.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, int T, int M, int N,
                                                            int Mpad, int Npad, float clip, float* __restrict__ dw,
                                                            const float* __restrict__ bias_part, int nbias,
                                                            float* __restrict__ db) {
-  __shared__ double sh[4][64];
+  __shared__ double sh[4][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const size_t stride = (size_t)T * Mpad * Npad;
-  const int nw = (int)(stride / 64);  // Npad is a multiple of 32, Mpad*Npad of 64
+  const size_t stride = (size_t)T * Mpad * Npad;  // Npad is a multiple of 32, Mpad*Npad of 1024
+  const int nw = (int)((stride + 255) / 256);
   if ((int)blockIdx.x < nw) {
-    const size_t e = (size_t)blockIdx.x * 64 + lane;
+    const size_t e0 = (size_t)blockIdx.x * 256 + lane * 4;
+    const bool in = e0 < stride;  // stride is a multiple of 4
     const int per = (nslab + 3) / 4;
     const int k0 = wave * per, k1 = min(nslab, k0 + per);
-    double s = 0.0;
-    for (int k = k0; k < k1; ++k) s += (double)slab[(size_t)k * stride + e];
-    sh[wave][lane] = s;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (in) {
+      const float4* src = reinterpret_cast<const float4*>(slab + e0);
+      const size_t st4 = stride / 4;
+      int k = k0;
+      for (; k + 8 <= k1; k += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(k + j) * st4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          s0 += (double)v[j].x; s1 += (double)v[j].y; s2 += (double)v[j].z; s3 += (double)v[j].w;
+        }
+      }
+      for (; k < k1; ++k) {
+        const float4 v = src[(size_t)k * st4];
+        s0 += (double)v.x; s1 += (double)v.y; s2 += (double)v.z; s3 += (double)v.w;
+      }
+    }
+    sh[wave][lane * 4 + 0] = s0; sh[wave][lane * 4 + 1] = s1; sh[wave][lane * 4 + 2] = s2; sh[wave][lane * 4 + 3] = s3;
     __syncthreads();
-    if (wave == 0) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < stride) {
       const int n = (int)(e % Npad);
       const int m = (int)((e / Npad) % Mpad);
       const int t = (int)(e / ((size_t)Npad * Mpad));
       if (m < M && n < N) {
-        float v = (float)(sh[0][lane] + sh[1][lane] + sh[2][lane] + sh[3][lane]);
+        const int i = threadIdx.x;
+        float v = (float)(sh[0][i] + sh[1][i] + sh[2][i] + sh[3][i]);
         if (clip > 0.f) v = fminf(fmaxf(v, -clip), clip);
         dw[((size_t)m * N + n) * T + t] = v;
       }
     }
   } else if (db != nullptr) {
-    const int e = ((int)blockIdx.x - nw) * 256 + threadIdx.x;
-    if (e < M) {
-      double s = 0.0;
-      for (int k = 0; k < nbias; ++k) s += (double)bias_part[(size_t)k * Mpad + e];
-      float v = (float)s;
+    // bias: 16 channels per workgroup, 16 lanes per channel each adding every 16th partial row (independent loads), then a
+    // fixed-order combine
+    double* shb = &sh[0][0];  // [16 parts][16 channels]
+    const int c = threadIdx.x & 15, part = threadIdx.x >> 4;
+    const int e = ((int)blockIdx.x - nw) * 16 + c;
+    double s = 0.0;
+    if (e < M)
+      for (int k = part; k < nbias; k += 16) s += (double)bias_part[(size_t)k * Mpad + e];
+    shb[part * 16 + c] = s;
+    __syncthreads();
+    if (threadIdx.x < 16 && e < M) {
+      double t = 0.0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) t += shb[q * 16 + c];
+      float v = (float)t;
       if (clip > 0.f) v = fminf(fmaxf(v, -clip), clip);
       db[e] = v;
     }
@@ -334,8 +364,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // slab reduction shared with wgrad_bf16.hip (kernels cannot be launched across translation units without RDC)
 extern "C" int yogo_internal_wgrad_reduce(const float* slab, int nslab, int T, int M, int N, int Mpad, int Npad, float clip, float* dw,
                                           const float* bias_part, int nbias, float* db, hipStream_t stream) {
-  const int nw = (int)(((size_t)T * Mpad * Npad) / 64);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nw + (db ? cdiv(M, 256) : 0)), dim3(256), 0, stream, slab, nslab, T, M, N, Mpad, Npad,
+  const int nw = (int)(((size_t)T * Mpad * Npad + 255) / 256);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nw + (db ? cdiv(M, 16) : 0)), dim3(256), 0, stream, slab, nslab, T, M, N, Mpad, Npad,
                      clip, dw, bias_part, nbias, db);
   YOGO_CHECK_LAUNCH("wgrad_reduce");
   return YOGO_OK;
