@@ -400,7 +400,8 @@ def forward_bf16_train(eng: Engine, x: torch.Tensor) -> Tuple[torch.Tensor, List
             pk = _packed_bf16(eng, i, 0)
             # algorithmic bytes: input + output once at storage precision (bf16 NCHW8c, channels padded to 16; fp32 head)
             nbytes = B * (_blocks(L.cin) * 8 * H * W * 2 + (L.cout * OH * OW * 4 if last else _blocks(L.cout) * 8 * OH * OW * 2))
-            eng._tick("fwd", i, 2.0 * B * L.cout * L.cin * L.k * L.k * OH * OW, mw=30, nbytes=nbytes)
+            # mw tags the kernel variant for bench.py: 34 = conv_bf16_kernel<4,2,8,...> (128 output channels, stride 1)
+            eng._tick("fwd", i, 2.0 * B * L.cout * L.cin * L.k * L.k * OH * OW, mw=34 if (L.cout > 64 and L.s == 1) else 30, nbytes=nbytes)
             _hip.call("yogo_conv2d_fwd_bf16", cur, pk, bias, out8, out32, mask, stats, B, L.cin, L.cout, H, W, L.k, L.s, fused_act, st)
             eng._tock()
         if has_bn:
@@ -511,7 +512,7 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
             dx = torch.empty(B, _blocks(L.cin), IH, IW, 8, dtype=torch.bfloat16, device=dev)
             pk = _packed_bf16(eng, i, 2 if (L.s == 2 and L.k == 3) else 1)
             nbytes = B * 2 * 8 * (_blocks(L.cout) * OH * OW + _blocks(L.cin) * IH * IW * (2 if act_ref is not None else 1))
-            eng._tick("dgrad", i, 2.0 * B * L.cout * L.cin * L.k * L.k * OH * OW, mw=30, nbytes=nbytes)
+            eng._tick("dgrad", i, 2.0 * B * L.cout * L.cin * L.k * L.k * OH * OW, mw=34 if (L.cin > 64 and L.s == 1) else 30, nbytes=nbytes)
             _hip.call("yogo_conv2d_dgrad_bf16", g, pk, dx, act_ref, ref_act, Sp.mask, B, L.cin, L.cout, IH, IW, L.k, L.s, st)
             eng._tock()
             g = dx
