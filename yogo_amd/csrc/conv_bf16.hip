@@ -440,48 +440,64 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
         const float ba[8] = {bA.x, bA.y, bA.z, bA.w, bB.x, bB.y, bB.z, bB.w};
         const float sa[8] = {sA.x, sA.y, sA.z, sA.w, sB.x, sB.y, sB.z, sB.w};
         float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, q8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float bs[8], sl[8];  // bias * scale, leaky slope * scale
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          bs[i] = ba[i] * sa[i];
+          sl[i] = LEAKY_SLOPE * sa[i];
+        }
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
 #pragma unroll
           for (int n = 0; n < NW; ++n) {
+            // out = act(acc + bias) * scale, or (acc + bias) * act'(ref) * scale.  The channel scale is >= 0 (Dropout2d mask /
+            // zero for padding channels), so LeakyReLU commutes with it: one FMA + mul + max per value.
             float v[8];
+            if (do_stats || p.act == ACT_SILU || (has_ref && p.ref_act != ACT_LEAKY)) {  // general order of operations
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = acc[c][mb][n][8 * gp + i] + ba[i];
-            if (do_stats) {
-              const float m = pvalid[n] ? 1.f : 0.f;
+              for (int i = 0; i < 8; ++i) v[i] = acc[c][mb][n][8 * gp + i] + ba[i];
+              if (do_stats) {
+                const float m = pvalid[n] ? 1.f : 0.f;
 #pragma unroll
-              for (int i = 0; i < 8; ++i) {
-                const float vm = v[i] * m;
-                s8[i] += vm;
-                q8[i] += vm * v[i];
-              }
-            }
-            if (has_ref) {
-              const bf16x4 r0 = __builtin_bit_cast(bf16x4, rf[mb][gp][c][n][0]);
-              const bf16x4 r1 = __builtin_bit_cast(bf16x4, rf[mb][gp][c][n][1]);
-              if (p.ref_act == ACT_LEAKY) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                  v[i] *= (float)r0[i] > 0.f ? 1.f : LEAKY_SLOPE;
-                  v[4 + i] *= (float)r1[i] > 0.f ? 1.f : LEAKY_SLOPE;
+                for (int i = 0; i < 8; ++i) {
+                  const float vm = v[i] * m;
+                  s8[i] += vm;
+                  q8[i] += vm * v[i];
                 }
-              } else {
+              }
+              if (has_ref) {
+                const bf16x4 r0 = __builtin_bit_cast(bf16x4, rf[mb][gp][c][n][0]);
+                const bf16x4 r1 = __builtin_bit_cast(bf16x4, rf[mb][gp][c][n][1]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                   v[i] *= act_bwd_factor((float)r0[i], p.ref_act);
                   v[4 + i] *= act_bwd_factor((float)r1[i], p.ref_act);
                 }
+              } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = act_fwd(v[i], p.act);
               }
-            } else if (p.act == ACT_LEAKY) {
 #pragma unroll
-              for (int i = 0; i < 8; ++i) v[i] = v[i] > 0.f ? v[i] : LEAKY_SLOPE * v[i];
-            } else if (p.act == ACT_SILU) {
+              for (int i = 0; i < 8; ++i) v[i] *= sa[i];
+            } else if (has_ref) {  // LeakyReLU backward: factor = ref > 0 ? scale : 0.01 * scale
+              const bf16x4 r0 = __builtin_bit_cast(bf16x4, rf[mb][gp][c][n][0]);
+              const bf16x4 r1 = __builtin_bit_cast(bf16x4, rf[mb][gp][c][n][1]);
 #pragma unroll
-              for (int i = 0; i < 8; ++i) v[i] = act_fwd(v[i], ACT_SILU);
+              for (int i = 0; i < 4; ++i) {
+                v[i] = (acc[c][mb][n][8 * gp + i] + ba[i]) * ((float)r0[i] > 0.f ? sa[i] : sl[i]);
+                v[4 + i] = (acc[c][mb][n][8 * gp + 4 + i] + ba[4 + i]) * ((float)r1[i] > 0.f ? sa[4 + i] : sl[4 + i]);
+              }
+            } else {
+#pragma unroll
+              for (int i = 0; i < 8; ++i) v[i] = fmaf(acc[c][mb][n][8 * gp + i], sa[i], bs[i]);
+              if (p.act == ACT_LEAKY) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], LEAKY_SLOPE * v[i]);
+              }
             }
             bf16x8 o;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) o[i] = (__bf16)(v[i] * sa[i]);
+            for (int i = 0; i < 8; ++i) o[i] = (__bf16)v[i];
             u32x4 w = __builtin_bit_cast(u32x4, o);  // (x, y) = group A, (z, w) = group B of this lane's pixel
             // lanes 32-63 hand their group A down, lanes 0-31 hand their group B up
             const auto r0 = __builtin_amdgcn_permlane32_swap(w.x, w.z, false, false);
@@ -697,8 +713,13 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
   const int T = ks * ks, pad = ks == 3 ? 1 : 0;
   const int MW = bf_pick_mw(M);
   const bool small_n = s2d || a == 2;  // two accumulator sets / four-fold input tile: half the pixel groups per wavefront
-  const int NW = MW == 1 ? (small_n ? 2 : 4) : (small_n ? 1 : 2);
-  const int NWV = (MW == 4) ? 8 : 4;  // 128-channel tiles: 8 wavefronts share the staged weight slice
+  // 64 GEMM rows at stride 1 with a long contraction: 8 wavefronts x 4 pixel groups (64 rows x 1024 px), the same staged
+  // bytes per MFMA as the 128-row tile; everything else with <= 64 rows stays on 4-wavefront workgroups
+  static int wide64_env = -1;
+  if (wide64_env < 0) wide64_env = getenv("YOGO_BF16_WIDE64") ? atoi(getenv("YOGO_BF16_WIDE64")) : 1;
+  const bool wide64 = wide64_env && MW == 2 && !small_n && K >= 64 && OH * OW >= 4096;
+  const int NW = MW == 1 ? (small_n ? 2 : 4) : (small_n ? 1 : (wide64 ? 4 : 2));
+  const int NWV = (MW == 4 || wide64) ? 8 : 4;  // 128-channel tiles: 8 wavefronts share the staged weight slice
   const int PF = NWV == 8 ? 10 : 16;  // = 160 KB / 128 KB of LDS for the two buffers at most
   const int Kb = bf_kb_of(K), Mpad = bf_mpad_of(M);
   // the grid the workgroups tile: output pixels, or 2x2 output quads of one row parity
@@ -788,6 +809,7 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
     else BFLAUNCH(1, 2, 4, false, 16);
   } else {
     if (MW == 4) BFLAUNCH(4, 2, 8, false, 10);
+    else if (MW == 2 && wide64) BFLAUNCH(2, 4, 8, false, 10);
     else if (MW == 2) BFLAUNCH(2, 2, 4, false, 16);
     else BFLAUNCH(1, 4, 4, false, 16);
   }
