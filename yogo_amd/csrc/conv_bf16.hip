@@ -77,7 +77,7 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 // PF: slots (16-byte elements per lane and chunk) of the LDS-DMA pipeline.  When a chunk fits (p.dma) the kernel runs
 //   barrier -> issue DMA(c+1 -> buffer (c+1)&1) -> MFMA(c from buffer c&1): one barrier per chunk, no staging registers, no
 //   ds_write, no vector-ALU address work inside the loop (every lane's source offsets are decoded once per workgroup).
-template <int MW, int NW, int NWV, bool S2D, int PF, bool OUT_F32>
+template <int MW, int NW, int NWV, bool S2D, int PF, bool OUT_F32, bool REF>
 __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Params p) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem4[];
   constexpr int BM = 32 * MW;
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
       }
     }
   } else {
-    const bool has_ref = p.act_ref != nullptr;
+    constexpr bool has_ref = REF;  // act'(ref) epilogue (training data gradient into a block without BatchNorm)
     const int plane16 = (int)plane * 16;
     const auto rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (size_t)b * p.Mb * plane * 2), (short)0, p.Mb * plane16, 0x00020000);
     int vo[NC][NW];  // byte offset of this lane's unit inside its image: lanes 32-63 write the next channel block
@@ -408,8 +408,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
       }
     // training dgrad into a block without BatchNorm: act'(ref).  All of this lane's reference values (8 bytes per group) are
     // requested up front so that their latency is paid once, behind the LDS hand-over above.
-    u32x2 rf[MW][2][NC][NW][2];
-    if (has_ref) {
+    u32x2 rf[REF ? MW : 1][2][NC][NW][2];
+    if constexpr (has_ref) {
       const auto rs_r = __builtin_amdgcn_make_buffer_rsrc((void*)(p.act_ref + (size_t)b * p.Mb * plane * 2), (short)0, p.Mb * plane16, 0x00020000);
 #pragma unroll
       for (int mb = 0; mb < MW; ++mb)
@@ -423,8 +423,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
             for (int n = 0; n < NW; ++n) {
               const bool valid = c == 0 ? pvalid[n] : pvalid1[n];
               const int vr = valid ? (opix[n] + c) * 16 + half * 8 + cb * plane16 : (int)0x80000000u;
-              rf[mb][gp][c][n][0] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_r, vr, 0, 0));
-              rf[mb][gp][c][n][1] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_r, vr + plane16, 0, 0));
+              rf[REF ? mb : 0][gp][c][n][0] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_r, vr, 0, 0));
+              rf[REF ? mb : 0][gp][c][n][1] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_r, vr + plane16, 0, 0));
             }
         }
     }
@@ -466,8 +466,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
                 }
               }
               if (has_ref) {
-                const bf16x4 r0 = __builtin_bit_cast(bf16x4, rf[mb][gp][c][n][0]);
-                const bf16x4 r1 = __builtin_bit_cast(bf16x4, rf[mb][gp][c][n][1]);
+                const bf16x4 r0 = __builtin_bit_cast(bf16x4, rf[REF ? mb : 0][gp][c][n][0]);
+                const bf16x4 r1 = __builtin_bit_cast(bf16x4, rf[REF ? mb : 0][gp][c][n][1]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                   v[i] *= act_bwd_factor((float)r0[i], p.ref_act);
@@ -480,8 +480,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
 #pragma unroll
               for (int i = 0; i < 8; ++i) v[i] *= sa[i];
             } else if (has_ref) {  // LeakyReLU backward: factor = ref > 0 ? scale : 0.01 * scale
-              const bf16x4 r0 = __builtin_bit_cast(bf16x4, rf[mb][gp][c][n][0]);
-              const bf16x4 r1 = __builtin_bit_cast(bf16x4, rf[mb][gp][c][n][1]);
+              const bf16x4 r0 = __builtin_bit_cast(bf16x4, rf[REF ? mb : 0][gp][c][n][0]);
+              const bf16x4 r1 = __builtin_bit_cast(bf16x4, rf[REF ? mb : 0][gp][c][n][1]);
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
                 v[i] = (acc[c][mb][n][8 * gp + i] + ba[i]) * ((float)r0[i] > 0.f ? sa[i] : sl[i]);
@@ -784,15 +784,20 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
               K, M, IH, IW, a, s2d, T, MW, NW, NWV, tl.ncb, tl.TW, tl.CKb, tl.rows_max, tl.LW, lds_bytes, p.dma, tl.ni_slots,
               tl.n_slots - tl.ni_slots, grid.x, grid.y, grid.z);
   }
-#define BFLAUNCH_(MW_, NW_, NWV_, S2D_, PF_, F32_)                                                                          \
+#define BFLAUNCH__(MW_, NW_, NWV_, S2D_, PF_, F32_, REF_)                                                                          \
   do {                                                                                                                 \
     static bool attr_set = false;                                                                                      \
     if (!attr_set) {                                                                                                   \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<MW_, NW_, NWV_, S2D_, PF_, F32_>),     \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<MW_, NW_, NWV_, S2D_, PF_, F32_, REF_>), \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, BF_LDS_MAX);                               \
       attr_set = true;                                                                                                 \
     }                                                                                                                  \
-    hipLaunchKernelGGL((conv_bf16_kernel<MW_, NW_, NWV_, S2D_, PF_, F32_>), grid, dim3(64 * NWV_), lds_bytes, stream, p); \
+    hipLaunchKernelGGL((conv_bf16_kernel<MW_, NW_, NWV_, S2D_, PF_, F32_, REF_>), grid, dim3(64 * NWV_), lds_bytes, stream, p); \
+  } while (0)
+#define BFLAUNCH_(MW_, NW_, NWV_, S2D_, PF_, F32_)                             \
+  do {                                                                         \
+    if (act_ref != nullptr) BFLAUNCH__(MW_, NW_, NWV_, S2D_, PF_, false, true); \
+    else BFLAUNCH__(MW_, NW_, NWV_, S2D_, PF_, F32_, false);                   \
   } while (0)
 #define BFLAUNCH(MW_, NW_, NWV_, S2D_, PF_)                                    \
   do {                                                                         \
@@ -815,6 +820,7 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
   }
 #undef BFLAUNCH
 #undef BFLAUNCH_
+#undef BFLAUNCH__
   YOGO_CHECK_LAUNCH("conv_bf16");
   if (p.stamps) {  // experiments: mean cycles per phase over the workgroups
     const size_t nwg = (size_t)grid.x * grid.y * grid.z;
