@@ -339,6 +339,16 @@ def _blocks(c: int) -> int:
 import os as _os
 
 _WGRAD_BF16_MFMA = _os.environ.get("YOGO_WGRAD_BF16", "1") != "0"   # 0: fp32-MFMA weight gradients on the widened inputs
+# 1: weight gradients run on a second HIP stream, beside the data-gradient / BatchNorm-backward chain they do not feed
+_WGRAD_SIDE_STREAM = _os.environ.get("YOGO_WGRAD_STREAM", "1") != "0"
+_SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def _side_stream(dev: torch.device) -> "torch.cuda.Stream":
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _SIDE_STREAMS[key]
 
 
 def _packed_bf16(eng: Engine, i: int, mode: int) -> torch.Tensor:
@@ -469,36 +479,45 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
             if bn.weight is not None:
                 grads[id(bn.weight)] = dgamma
                 grads[id(bn.bias)] = dbeta
-        dw = dst(L.conv.weight)
-        has_bias = L.conv.bias is not None
-        if i == 0:
-            rows = _hip.query_ints("yogo_conv_first_wgrad_rows", 1, B, IH, IW, L.s)[0]
-            nj = L.cin * 9 + 1
-            part = torch.empty(rows * L.cout * nj, dtype=torch.float32, device=dev)
-            _hip.call("yogo_conv_first_wgrad_bf16g", S.x_in, 0 if S.x_in.dtype == torch.uint8 else 1, g, part, B, L.cin, L.cout, IH, IW,
-                      L.s, st)
-            red = torch.empty(L.cout, nj, dtype=torch.float32, device=dev)
-            _hip.call("yogo_partials_reduce", part, rows, L.cout * nj, clip, red, st)
-            dw.copy_(red[:, : nj - 1].reshape(dw.shape))
-            if has_bias:
-                db = dst(L.conv.bias)
-                db.copy_(red[:, nj - 1])
-                grads[id(L.conv.bias)] = db
-        else:
-            db = dst(L.conv.bias) if has_bias else None
-            eng._tick("wgrad", i, 2.0 * B * L.cout * L.cin * L.k * L.k * OH * OW, mw=30,
-                      nbytes=B * 2 * 8 * (_blocks(L.cout) * OH * OW + _blocks(L.cin) * IH * IW))
-            if _WGRAD_BF16_MFMA:
-                wsb = _hip.query_size("yogo_conv2d_wgrad_bf16_workspace_bytes", B, L.cin, L.cout, IH, IW, L.k, L.s)
-                ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
-                _hip.call("yogo_conv2d_wgrad_bf16", S.x_in, g, dw, db, ws, B, L.cin, L.cout, IH, IW, L.k, L.s, clip, st)
-            else:   # exact fp32 MFMA on the widened bf16 inputs
-                wsb = _hip.query_size("yogo_conv2d_wgrad_workspace_bytes", B, L.cin, L.cout, IH, IW, L.k, L.s)
-                ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
-                _hip.call("yogo_conv2d_wgrad_bf16in", S.x_in, g, dw, db, ws, B, L.cin, L.cout, IH, IW, L.k, L.s, clip, st)
-            eng._tock()
-            if has_bias:
-                grads[id(L.conv.bias)] = db
+        # ---- weight / bias gradient: independent of everything downstream -> second stream -------------------------------
+        main = torch.cuda.current_stream()
+        wstream = _side_stream(dev) if _WGRAD_SIDE_STREAM else main
+        if wstream is not main:
+            wstream.wait_stream(main)           # g (= dz of this layer) is complete
+            for t in (g, S.x_in):
+                t.record_stream(wstream)
+        with torch.cuda.stream(wstream):
+            wst = _hip.stream_ptr()
+            dw = dst(L.conv.weight)
+            has_bias = L.conv.bias is not None
+            if i == 0:
+                rows = _hip.query_ints("yogo_conv_first_wgrad_rows", 1, B, IH, IW, L.s)[0]
+                nj = L.cin * 9 + 1
+                part = torch.empty(rows * L.cout * nj, dtype=torch.float32, device=dev)
+                _hip.call("yogo_conv_first_wgrad_bf16g", S.x_in, 0 if S.x_in.dtype == torch.uint8 else 1, g, part, B, L.cin, L.cout, IH, IW,
+                          L.s, wst)
+                red = torch.empty(L.cout, nj, dtype=torch.float32, device=dev)
+                _hip.call("yogo_partials_reduce", part, rows, L.cout * nj, clip, red, wst)
+                dw.copy_(red[:, : nj - 1].reshape(dw.shape))
+                if has_bias:
+                    db = dst(L.conv.bias)
+                    db.copy_(red[:, nj - 1])
+                    grads[id(L.conv.bias)] = db
+            else:
+                db = dst(L.conv.bias) if has_bias else None
+                eng._tick("wgrad", i, 2.0 * B * L.cout * L.cin * L.k * L.k * OH * OW, mw=30,
+                          nbytes=B * 2 * 8 * (_blocks(L.cout) * OH * OW + _blocks(L.cin) * IH * IW))
+                if _WGRAD_BF16_MFMA:
+                    wsb = _hip.query_size("yogo_conv2d_wgrad_bf16_workspace_bytes", B, L.cin, L.cout, IH, IW, L.k, L.s)
+                    ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
+                    _hip.call("yogo_conv2d_wgrad_bf16", S.x_in, g, dw, db, ws, B, L.cin, L.cout, IH, IW, L.k, L.s, clip, wst)
+                else:   # exact fp32 MFMA on the widened bf16 inputs
+                    wsb = _hip.query_size("yogo_conv2d_wgrad_workspace_bytes", B, L.cin, L.cout, IH, IW, L.k, L.s)
+                    ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
+                    _hip.call("yogo_conv2d_wgrad_bf16in", S.x_in, g, dw, db, ws, B, L.cin, L.cout, IH, IW, L.k, L.s, clip, wst)
+                eng._tock()
+                if has_bias:
+                    grads[id(L.conv.bias)] = db
         grads[id(L.conv.weight)] = dw
         if i > 0:
             Lp, Sp = eng.layers[i - 1], saved[i - 1]
@@ -516,6 +535,8 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
             _hip.call("yogo_conv2d_dgrad_bf16", g, pk, dx, act_ref, ref_act, Sp.mask, B, L.cin, L.cout, IH, IW, L.k, L.s, st)
             eng._tock()
             g = dx
+    if _WGRAD_SIDE_STREAM:
+        torch.cuda.current_stream().wait_stream(_side_stream(dev))
     bb = eng.backbone_ref()
     return [grads.get(id(p)) for p in bb.parameters()]
 
