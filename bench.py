@@ -154,7 +154,7 @@ def main():
     model = YOGO((H, W), ANCHOR_W, ANCHOR_H, NUM_CLASSES).to(dev)
     model.train()
     B = args.batch
-    trainer = HipTrainer(model, YOGOLoss().to(dev), total_steps=args.steps + args.warmup + 1, half=(args.dtype == "bf16"))
+    trainer = HipTrainer(model, YOGOLoss().to(dev), total_steps=args.steps + args.warmup + 41, half=(args.dtype == "bf16"))
     trainer.broadcast_parameters()
     imgs = synthetic_images(B, H, W, device=dev, seed=100 + rank)
     labels = synthetic_labels(B, model.Sx, model.Sy, K=64, num_classes=NUM_CLASSES, device=dev, seed=200 + rank)
@@ -163,6 +163,23 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
+    # device spin-up (untimed, before the W warm-up steps): a cold MI355X ramps its clocks and the caching allocator grows its
+    # pools over the first steps -- on this pool the first dozen steps of a fresh process run up to 2x slower.  Step until
+    # three consecutive steps agree within 5 % (at most 40 steps); every rank runs the same count so collectives stay matched.
+    spin = []
+    for i in range(40):
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        trainer.step(imgs, labels)
+        torch.cuda.synchronize()
+        spin.append(time.perf_counter() - ts)
+        done = len(spin) >= 6 and max(spin[-3:]) < 1.05 * min(spin[-3:])
+        if world > 1:
+            flag = torch.tensor([1.0 if done else 0.0], device=dev)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            done = bool(flag.item() > 0.5)
+        if done:
+            break
     for _ in range(args.warmup):
         trainer.step(imgs, labels)
     torch.cuda.synchronize()

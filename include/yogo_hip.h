@@ -141,6 +141,17 @@ int yogo_conv_first_fwd_train_bf16(const void* in, int in_dtype, const float* w,
                                    int stride, int act, yogo_stream_t stream);
 int yogo_conv_first_wgrad_bf16g(const void* in, int in_dtype, const void* dy_bf16, float* part, int B, int Cin, int Cout,
                                 int IH, int IW, int stride, yogo_stream_t stream);
+/* Layer-0 backward in one pass: BatchNorm backward (model_defns.py:35) + activation derivative + weight gradient of the first
+ * convolution; g = gradient w.r.t. the block output, z = saved conv output, both bf16 NCHW8c.  part: rows
+ * (yogo_conv_first_wgrad_rows) x cols (yogo_conv_first_bn_wgrad_cols) floats; then yogo_partials_reduce(part, rows, cols, 0,
+ * sums) and yogo_conv_first_bn_wgrad_finalize (dw OIHW, dgamma, dbeta, clamped to +-clip). */
+int yogo_conv_first_bn_wgrad_cols(int Cin, int Cout, int* cols);
+int yogo_conv_first_bn_wgrad_bf16(const void* in, int in_dtype, const void* g, const void* z, const float* mean,
+                                  const float* invstd, const float* gamma, const float* beta, float* part, int B, int Cin,
+                                  int Cout, int IH, int IW, int stride, int act, yogo_stream_t stream);
+int yogo_conv_first_bn_wgrad_finalize(const float* sums, const float* invstd, const float* gamma, float* dw, float* dgamma,
+                                      float* dbeta, int B, int Cin, int Cout, int IH, int IW, int stride, int training,
+                                      float clip, yogo_stream_t stream);
 int yogo_bn_apply_act_bf16(const void* z, void* y, const float* mean, const float* invstd_or_var, int stat_is_var, float eps,
                            const float* gamma, const float* beta, int B, int C, int HW, int act, yogo_stream_t stream);
 int yogo_bn_bwd_bf16_rows(int B, int HW, int* rows);

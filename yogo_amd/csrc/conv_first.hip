@@ -344,6 +344,166 @@ __global__ __launch_bounds__(CF_THREADS) void conv_first_wgrad_kernel(const Conv
   }
 }
 
+// =========================================================================================================
+// Layer-0 backward in ONE pass over (image, gradient, saved conv output): BatchNorm backward + LeakyReLU derivative + weight
+// gradient of the first convolution (the layer has no data gradient and, in the reference's architectures, no conv bias).
+// With xh = (z - mean) * invstd, gb = g * act'(gamma * xh + beta), c1 = gamma * invstd, N = B*OH*OW:
+//   dz = c1 * (gb - S1/N - xh * S2/N),  S1 = sum gb (= dbeta),  S2 = sum gb * xh (= dgamma)      [batch statistics]
+//   dW[c][j] = sum dz[c] * patch_j = c1 * (A1[c][j] - S1/N * P[j] - S2/N * A2[c][j])
+//   A1 = sum gb * patch_j,  A2 = sum xh * patch_j,  P = sum patch_j
+// so every sum is accumulated in the same sweep and dz never goes to memory (replaces bn_bwd_reduce + bn_bwd_apply +
+// conv_first_wgrad: 5 tensor passes -> 2).  Partials [rows][Cout*(2*NJ+2) + NJ], finished by yogo_partials_reduce +
+// conv_first_bn_wgrad_finalize.
+struct ConvFirstBnWgradParams {
+  const void* in;
+  const cf_u32x4* g;   // gradient w.r.t. the block output, bf16 NCHW8c [B][Mb][OH][OW]
+  const cf_u32x4* z;   // saved conv output (pre-BatchNorm), same layout
+  const float *mean, *invstd, *gamma, *beta;
+  float* part;
+  int B, Cin, Cout, Mb, IH, IW, OH, OW, stride, act;
+};
+
+template <typename TIn, int CIN, int COC>
+__global__ __launch_bounds__(CF_THREADS) void conv_first_bn_wgrad_kernel(const ConvFirstBnWgradParams p) {
+  constexpr int NJ = CIN * 9;
+  constexpr int PER = 2 * NJ + 2;  // per channel: A1[NJ], A2[NJ], S1, S2
+  __shared__ float red[4][COC * PER + NJ];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y;
+  const int npix = p.OH * p.OW;
+  const int pbase = blockIdx.x * (CF_THREADS * CFW_PPT);
+  const int ncol = p.Cout * PER + NJ;
+  const TIn* inb = reinterpret_cast<const TIn*>(p.in) + (size_t)b * CIN * p.IH * p.IW;
+  float* prow = p.part + (size_t)(b * gridDim.x + blockIdx.x) * ncol;
+  for (int co0 = 0; co0 < p.Cout; co0 += COC) {
+    float a1[COC][NJ], a2[COC][NJ], s1[COC], s2[COC], ps[NJ];
+    float mu[COC], is[COC], ga[COC], be[COC];
+#pragma unroll
+    for (int c = 0; c < COC; ++c) {
+      const int co = min(co0 + c, p.Cout - 1);
+      mu[c] = p.mean[co]; is[c] = p.invstd[co]; ga[c] = p.gamma[co]; be[c] = p.beta[co];
+      s1[c] = s2[c] = 0.f;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) a1[c][j] = a2[c][j] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) ps[j] = 0.f;
+    for (int k = 0; k < CFW_PPT; ++k) {
+      const int pix = pbase + k * CF_THREADS + tid;
+      const bool ok = pix < npix;
+      const int pc = ok ? pix : 0;
+      const int oy = pc / p.OW, ox = pc - oy * p.OW;
+      float x[NJ];
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int iy = oy * p.stride + kh - 1, ix = ox * p.stride + kw - 1;
+            const bool in = ok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+            const float v = (float)inb[in ? ((size_t)ci * p.IH + iy) * p.IW + ix : 0];
+            x[(ci * 3 + kh) * 3 + kw] = in ? v : 0.f;
+          }
+      // COC consecutive channels live inside one 8-channel unit (COC divides 8)
+      const size_t u = ((size_t)b * p.Mb + (co0 >> 3)) * npix + pc;
+      const cf_bf16x8 gu = __builtin_bit_cast(cf_bf16x8, p.g[u]);
+      const cf_bf16x8 zu = __builtin_bit_cast(cf_bf16x8, p.z[u]);
+#pragma unroll
+      for (int c = 0; c < COC; ++c) {
+        float gv = 0.f, zv = 0.f;
+        if constexpr (COC == 8) {  // a pass = one whole 8-channel unit
+          gv = (float)gu[c];
+          zv = (float)zu[c];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const bool pick = ((co0 & 7) + c) == j;
+            gv = pick ? (float)gu[j] : gv;
+            zv = pick ? (float)zu[j] : zv;
+          }
+        }
+        const bool cok = ok && co0 + c < p.Cout;
+        const float xh = cok ? (zv - mu[c]) * is[c] : 0.f;
+        const float yb = fmaf(ga[c], xh, be[c]);
+        float gb = cok ? gv : 0.f;
+        if (p.act == ACT_LEAKY) gb *= yb > 0.f ? 1.f : LEAKY_SLOPE;
+        else if (p.act == ACT_SILU) gb *= act_bwd_factor(yb, ACT_SILU);
+        s1[c] += gb;
+        s2[c] = fmaf(gb, xh, s2[c]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          a1[c][j] = fmaf(gb, x[j], a1[c][j]);
+          a2[c][j] = fmaf(xh, x[j], a2[c][j]);
+        }
+      }
+      if (co0 == 0) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) ps[j] += x[j];
+      }
+    }
+    // cross-lane sums (DPP), then the four wavefronts through LDS
+#pragma unroll
+    for (int c = 0; c < COC; ++c) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const float v1 = wave_sum(a1[c][j]), v2 = wave_sum(a2[c][j]);
+        if (lane == 0) {
+          red[wave][c * PER + j] = v1;
+          red[wave][c * PER + NJ + j] = v2;
+        }
+      }
+      const float t1 = wave_sum(s1[c]), t2 = wave_sum(s2[c]);
+      if (lane == 0) {
+        red[wave][c * PER + 2 * NJ] = t1;
+        red[wave][c * PER + 2 * NJ + 1] = t2;
+      }
+    }
+    if (co0 == 0) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const float v = wave_sum(ps[j]);
+        if (lane == 0) red[wave][COC * PER + j] = v;
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < COC * PER + (co0 == 0 ? NJ : 0); e += CF_THREADS) {
+      const float v = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+      if (e < COC * PER) {
+        const int c = e / PER;
+        if (co0 + c < p.Cout) prow[(co0 + c) * PER + (e - c * PER)] = v;
+      } else {
+        prow[p.Cout * PER + (e - COC * PER)] = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// sums [Cout*(2*NJ+2) + NJ] -> dW (OIHW), dgamma, dbeta, each clamped to +-clip when clip > 0
+__global__ void conv_first_bn_wgrad_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ invstd,
+                                                    const float* __restrict__ gamma, float* __restrict__ dw,
+                                                    float* __restrict__ dgamma, float* __restrict__ dbeta, int Cout, int NJ,
+                                                    float inv_count, int training, float clip) {
+  const int PER = 2 * NJ + 2;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= Cout * (NJ + 2)) return;
+  const int c = e / (NJ + 2), j = e - c * (NJ + 2);
+  const float* sc = sums + c * PER;
+  const float S1 = sc[2 * NJ], S2 = sc[2 * NJ + 1];
+  float v;
+  if (j < NJ) {
+    const float c1 = gamma[c] * invstd[c];
+    v = training ? c1 * (sc[j] - S1 * inv_count * sums[Cout * PER + j] - S2 * inv_count * sc[NJ + j]) : c1 * sc[j];
+  } else {
+    v = j == NJ ? S2 : S1;
+  }
+  if (clip > 0.f) v = fminf(fmaxf(v, -clip), clip);
+  if (j < NJ) dw[c * NJ + j] = v;
+  else if (j == NJ) dgamma[c] = v;
+  else dbeta[c] = v;
+}
+
 static int first_tiles(int OH, int OW) { return cdiv(OH * OW, CF_THREADS * CF_PPT); }
 static int first_wgrad_tiles(int OH, int OW) { return cdiv(OH * OW, CF_THREADS * CFW_PPT); }
 
@@ -452,5 +612,47 @@ static int conv_first_wgrad_impl(const void* in, int in_dtype, const float* dy, 
   else CFW_LAUNCH(float, 3);
 #undef CFW_LAUNCH
   YOGO_CHECK_LAUNCH("conv_first_wgrad");
+  return YOGO_OK;
+}
+
+// ---- fused layer-0 backward (BatchNorm + activation + first-conv weight gradient), bf16 NCHW8c g / z ----------------------
+extern "C" int yogo_conv_first_bn_wgrad_cols(int Cin, int Cout, int* cols) {
+  YOGO_CHECK_ARG(cols && (Cin == 1 || Cin == 3) && Cout > 0, "conv_first_bn_wgrad_cols: bad arguments");
+  *cols = Cout * (2 * Cin * 9 + 2) + Cin * 9;
+  return YOGO_OK;
+}
+
+// part: rows (yogo_conv_first_wgrad_rows) x cols floats.  Follow with yogo_partials_reduce(part, rows, cols, 0, sums) and
+// yogo_conv_first_bn_wgrad_finalize.
+extern "C" int yogo_conv_first_bn_wgrad_bf16(const void* in, int in_dtype, const void* g, const void* z, const float* mean,
+                                             const float* invstd, const float* gamma, const float* beta, float* part, int B,
+                                             int Cin, int Cout, int IH, int IW, int stride, int act, hipStream_t stream) {
+  YOGO_CHECK_ARG(in && g && z && mean && invstd && gamma && beta && part, "conv_first_bn_wgrad_bf16: null pointer");
+  YOGO_CHECK_ARG((Cin == 1 || Cin == 3) && Cout > 0 && (stride == 1 || stride == 2) && (in_dtype == 0 || in_dtype == 1),
+                 "conv_first_bn_wgrad_bf16: unsupported shape");
+  ConvFirstBnWgradParams p{};
+  p.in = in; p.g = reinterpret_cast<const cf_u32x4*>(g); p.z = reinterpret_cast<const cf_u32x4*>(z);
+  p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta; p.part = part;
+  p.B = B; p.Cin = Cin; p.Cout = Cout; p.Mb = ((Cout + 15) / 16) * 2; p.IH = IH; p.IW = IW; p.stride = stride; p.act = act;
+  p.OH = (IH - 1) / stride + 1; p.OW = (IW - 1) / stride + 1;
+  if (B == 0) return YOGO_OK;
+  dim3 grid(first_wgrad_tiles(p.OH, p.OW), B);
+  if (in_dtype == 0 && Cin == 1) hipLaunchKernelGGL((conv_first_bn_wgrad_kernel<uint8_t, 1, 8>), grid, dim3(CF_THREADS), 0, stream, p);
+  else if (in_dtype == 0) hipLaunchKernelGGL((conv_first_bn_wgrad_kernel<uint8_t, 3, 2>), grid, dim3(CF_THREADS), 0, stream, p);
+  else if (Cin == 1) hipLaunchKernelGGL((conv_first_bn_wgrad_kernel<float, 1, 8>), grid, dim3(CF_THREADS), 0, stream, p);
+  else hipLaunchKernelGGL((conv_first_bn_wgrad_kernel<float, 3, 2>), grid, dim3(CF_THREADS), 0, stream, p);
+  YOGO_CHECK_LAUNCH("conv_first_bn_wgrad_bf16");
+  return YOGO_OK;
+}
+
+extern "C" int yogo_conv_first_bn_wgrad_finalize(const float* sums, const float* invstd, const float* gamma, float* dw,
+                                                 float* dgamma, float* dbeta, int B, int Cin, int Cout, int IH, int IW,
+                                                 int stride, int training, float clip, hipStream_t stream) {
+  YOGO_CHECK_ARG(sums && invstd && gamma && dw && dgamma && dbeta, "conv_first_bn_wgrad_finalize: null pointer");
+  const int OH = (IH - 1) / stride + 1, OW = (IW - 1) / stride + 1, NJ = Cin * 9;
+  const int n = Cout * (NJ + 2);
+  hipLaunchKernelGGL(conv_first_bn_wgrad_finalize_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, sums, invstd, gamma, dw,
+                     dgamma, dbeta, Cout, NJ, 1.0f / ((float)B * (float)OH * (float)OW), training, clip);
+  YOGO_CHECK_LAUNCH("conv_first_bn_wgrad_finalize");
   return YOGO_OK;
 }

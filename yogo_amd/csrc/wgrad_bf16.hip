@@ -305,7 +305,9 @@ bool wb_plan(int B, int N, int M, int IH, int IW, int ks, int stride, WbPlan* pl
   // 32) input channels
   const int NPW = (MBW == 4 && NBW == 1 && nblocks >= 2 && ks == 3) ? 2 : 1;
   const int KS = 4 / (MBW * NBW);
-  const int R = NPW == 2 ? (stride == 1 ? 3 : 2) : (stride == 1 ? 4 : 2);
+  // rows per unit: few channels -> little MFMA work per row, so take more rows per barrier
+  const bool tall = MBW == 1 && NBW == 1 && ks == 3 && stride == 1 && OH >= 64;
+  const int R = NPW == 2 ? (stride == 1 ? 3 : 2) : (stride == 1 ? (tall ? 8 : 4) : 2);
   pl->MBW = MBW; pl->NBW = NBW; pl->NPW = NPW; pl->KS = KS; pl->R = R;
   pl->Mpad = round_up(M, 32 * MBW);
   pl->Npad = round_up(N, 32 * NBW * NPW);
@@ -408,6 +410,9 @@ extern "C" int yogo_conv2d_wgrad_bf16(const void* x, const void* g, float* dw, f
     else wb_launch_one<4, 1, 2, 1, 9, 2, 2>(p, pl, stream);
   } else {
     const int cfg = pl.MBW * 100 + pl.NBW * 10 + pl.KS;
+    if (pl.R == 8) {
+      wb_launch_one<1, 1, 1, 4, 9, 1, 8>(p, pl, stream);
+    } else
     switch (cfg) {
       case 411: wb_launch<4, 1, 1>(p, pl, T, stride, stream); break;
       case 221: wb_launch<2, 2, 1>(p, pl, T, stride, stream); break;

@@ -341,6 +341,7 @@ import os as _os
 _WGRAD_BF16_MFMA = _os.environ.get("YOGO_WGRAD_BF16", "1") != "0"   # 0: fp32-MFMA weight gradients on the widened inputs
 # 1: weight gradients run on a second HIP stream, beside the data-gradient / BatchNorm-backward chain they do not feed
 _WGRAD_SIDE_STREAM = _os.environ.get("YOGO_WGRAD_STREAM", "1") != "0"
+_FUSE_LAYER0_BWD = _os.environ.get("YOGO_FUSE_LAYER0_BWD", "1") != "0"   # 0: separate BatchNorm-backward + weight-gradient passes
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
 
@@ -455,6 +456,7 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
 
     graw = _f32(graw)
     B, P, Sy, Sx = graw.shape
+    keep: list = []   # tensors in use on the weight-gradient stream
     g = torch.empty(B, _blocks(P), Sy, Sx, 8, dtype=torch.bfloat16, device=dev)
     _hip.call("yogo_nchw_f32_to_bf16_8c", graw, g, B, P, Sy * Sx, st)
     n = len(eng.layers)
@@ -465,7 +467,10 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
             IH, IW = int(S.x_in.shape[2]), int(S.x_in.shape[3])
         else:
             IH, IW = int(S.x_in.shape[2]), int(S.x_in.shape[3])   # NCHW8c: [B, Cb, H, W, 8]
-        if L.bn is not None:
+        # layer 0 with BatchNorm and no conv bias: BatchNorm backward, activation derivative and the weight gradient share ONE
+        # sweep over (image, g, z) -- dz is never written (see conv_first_bn_wgrad_kernel)
+        fuse0 = _FUSE_LAYER0_BWD and i == 0 and L.bn is not None and L.conv.bias is None and L.act in (ACT_NONE, ACT_LEAKY)
+        if L.bn is not None and not fuse0:
             bn = L.bn
             gamma = _f32(bn.weight.detach()) if bn.weight is not None else torch.ones(L.cout, device=dev)
             beta = _f32(bn.bias.detach()) if bn.bias is not None else torch.zeros(L.cout, device=dev)
@@ -480,44 +485,66 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
                 grads[id(bn.weight)] = dgamma
                 grads[id(bn.bias)] = dbeta
         # ---- weight / bias gradient: independent of everything downstream -> second stream -------------------------------
+        # Everything the side stream touches is allocated here, from the MAIN stream's pool, and kept alive until the main
+        # stream has waited for the side stream (end of this function): no record_stream bookkeeping, no allocator stalls.
         main = torch.cuda.current_stream()
         wstream = _side_stream(dev) if _WGRAD_SIDE_STREAM else main
+        dw = dst(L.conv.weight)
+        has_bias = L.conv.bias is not None
+        db = dst(L.conv.bias) if has_bias else None
+        if fuse0:
+            bn = L.bn
+            gamma = _f32(bn.weight.detach()) if bn.weight is not None else torch.ones(L.cout, device=dev)
+            beta = _f32(bn.bias.detach()) if bn.bias is not None else torch.zeros(L.cout, device=dev)
+            dgamma = dst(bn.weight) if bn.weight is not None else torch.empty(L.cout, dtype=torch.float32, device=dev)
+            dbeta = dst(bn.bias) if bn.bias is not None else torch.empty(L.cout, dtype=torch.float32, device=dev)
+            rows = _hip.query_ints("yogo_conv_first_wgrad_rows", 1, B, IH, IW, L.s)[0]
+            cols = _hip.query_ints("yogo_conv_first_bn_wgrad_cols", 1, L.cin, L.cout)[0]
+            part = torch.empty(rows * cols, dtype=torch.float32, device=dev)
+            sums = torch.empty(cols, dtype=torch.float32, device=dev)
+            keep.extend((gamma, beta, dgamma, dbeta, part, sums))
+        elif i == 0:
+            rows = _hip.query_ints("yogo_conv_first_wgrad_rows", 1, B, IH, IW, L.s)[0]
+            nj = L.cin * 9 + 1
+            part = torch.empty(rows * L.cout * nj, dtype=torch.float32, device=dev)
+            red = torch.empty(L.cout, nj, dtype=torch.float32, device=dev)
+            keep.extend((part, red))
+        else:
+            wname = "yogo_conv2d_wgrad_bf16_workspace_bytes" if _WGRAD_BF16_MFMA else "yogo_conv2d_wgrad_workspace_bytes"
+            ws = torch.empty(_hip.query_size(wname, B, L.cin, L.cout, IH, IW, L.k, L.s) // 4, dtype=torch.float32, device=dev)
+            keep.append(ws)
+        keep.extend((g, S.x_in, dw))
         if wstream is not main:
             wstream.wait_stream(main)           # g (= dz of this layer) is complete
-            for t in (g, S.x_in):
-                t.record_stream(wstream)
         with torch.cuda.stream(wstream):
             wst = _hip.stream_ptr()
-            dw = dst(L.conv.weight)
-            has_bias = L.conv.bias is not None
-            if i == 0:
-                rows = _hip.query_ints("yogo_conv_first_wgrad_rows", 1, B, IH, IW, L.s)[0]
-                nj = L.cin * 9 + 1
-                part = torch.empty(rows * L.cout * nj, dtype=torch.float32, device=dev)
-                _hip.call("yogo_conv_first_wgrad_bf16g", S.x_in, 0 if S.x_in.dtype == torch.uint8 else 1, g, part, B, L.cin, L.cout, IH, IW,
-                          L.s, wst)
-                red = torch.empty(L.cout, nj, dtype=torch.float32, device=dev)
+            xdt = 0 if S.x_in.dtype == torch.uint8 else 1
+            if fuse0:
+                keep.append(S.z)
+                _hip.call("yogo_conv_first_bn_wgrad_bf16", S.x_in, xdt, g, S.z, S.mean, S.invstd, gamma, beta, part, B, L.cin, L.cout,
+                          IH, IW, L.s, L.act, wst)
+                _hip.call("yogo_partials_reduce", part, rows, cols, 0.0, sums, wst)
+                _hip.call("yogo_conv_first_bn_wgrad_finalize", sums, S.invstd, gamma, dw, dgamma, dbeta, B, L.cin, L.cout, IH, IW,
+                          L.s, 1 if S.bn_train else 0, clip, wst)
+                if bn.weight is not None:
+                    grads[id(bn.weight)] = dgamma
+                    grads[id(bn.bias)] = dbeta
+            elif i == 0:
+                _hip.call("yogo_conv_first_wgrad_bf16g", S.x_in, xdt, g, part, B, L.cin, L.cout, IH, IW, L.s, wst)
                 _hip.call("yogo_partials_reduce", part, rows, L.cout * nj, clip, red, wst)
-                dw.copy_(red[:, : nj - 1].reshape(dw.shape))
+                dw.view(L.cout, nj - 1).copy_(red[:, : nj - 1])
                 if has_bias:
-                    db = dst(L.conv.bias)
                     db.copy_(red[:, nj - 1])
-                    grads[id(L.conv.bias)] = db
             else:
-                db = dst(L.conv.bias) if has_bias else None
                 eng._tick("wgrad", i, 2.0 * B * L.cout * L.cin * L.k * L.k * OH * OW, mw=30,
                           nbytes=B * 2 * 8 * (_blocks(L.cout) * OH * OW + _blocks(L.cin) * IH * IW))
                 if _WGRAD_BF16_MFMA:
-                    wsb = _hip.query_size("yogo_conv2d_wgrad_bf16_workspace_bytes", B, L.cin, L.cout, IH, IW, L.k, L.s)
-                    ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
                     _hip.call("yogo_conv2d_wgrad_bf16", S.x_in, g, dw, db, ws, B, L.cin, L.cout, IH, IW, L.k, L.s, clip, wst)
                 else:   # exact fp32 MFMA on the widened bf16 inputs
-                    wsb = _hip.query_size("yogo_conv2d_wgrad_workspace_bytes", B, L.cin, L.cout, IH, IW, L.k, L.s)
-                    ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
                     _hip.call("yogo_conv2d_wgrad_bf16in", S.x_in, g, dw, db, ws, B, L.cin, L.cout, IH, IW, L.k, L.s, clip, wst)
                 eng._tock()
-                if has_bias:
-                    grads[id(L.conv.bias)] = db
+        if has_bias:
+            grads[id(L.conv.bias)] = db
         grads[id(L.conv.weight)] = dw
         if i > 0:
             Lp, Sp = eng.layers[i - 1], saved[i - 1]
@@ -537,6 +564,7 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
             g = dx
     if _WGRAD_SIDE_STREAM:
         torch.cuda.current_stream().wait_stream(_side_stream(dev))
+    keep.clear()
     bb = eng.backbone_ref()
     return [grads.get(id(p)) for p in bb.parameters()]
 
