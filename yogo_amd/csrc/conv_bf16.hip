@@ -240,6 +240,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
   _Pragma("unroll") for (int n = 0; n < NW; ++n)                                                  \
     acc[CI][mb][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, AV[mb]),  \
                                                              __builtin_bit_cast(bf16x8, BV[n]), acc[CI][mb][n], 0, 0, 0);
+#define BF_HOOK()
 // MFMA over steps [SBEG, SEND) = (tap, 16-channel step); operands of step s+1 are read before the MFMAs of step s.  The MFMA
 // cluster runs at raised priority so that the two wavefronts of a SIMD fall out of phase (one fetches while the other multiplies)
 #define BF_RUN(CI, SBEG, SEND)                                                                    \
@@ -253,15 +254,20 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
       __builtin_amdgcn_s_setprio(1);                                                              \
       BF_MFMA(CI, a0, b0);                                                                        \
       __builtin_amdgcn_s_setprio(0);                                                              \
+      BF_HOOK()                                                                                   \
       __builtin_amdgcn_sched_barrier(0);                                                          \
       BF_LOAD(a0, b0, s + 2, SEND);                                                               \
       __builtin_amdgcn_sched_barrier(0);                                                          \
       __builtin_amdgcn_s_setprio(1);                                                              \
       BF_MFMA(CI, a1, b1);                                                                        \
       __builtin_amdgcn_s_setprio(0);                                                              \
+      BF_HOOK()                                                                                   \
       __builtin_amdgcn_sched_barrier(0);                                                          \
     }                                                                                             \
-    if (s < (SEND)) BF_MFMA(CI, a0, b0);                                                          \
+    if (s < (SEND)) {                                                                             \
+      BF_MFMA(CI, a0, b0);                                                                        \
+      BF_HOOK()                                                                                   \
+    }                                                                                             \
   }
 #define BF_COMPUTE()                                                                              \
   {                                                                                               \
@@ -310,9 +316,37 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
       else if (i < ns) { if (!(p.dbg & 16)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(lb_ + i * NT), 16, voff[i], (C) * so_w, 0, 0); } \
     }                                                                                                                  \
   }
+// one slot of chunk C, chosen at run time (the slot's registers need a compile-time index): issued between the MFMA clusters
+// of the previous chunk, so the DMA instructions never hold up the matrix cores
+#define DMA_ONE(I, C)                                                                                                  \
+  {                                                                                                                    \
+    u32x4* lb_ = smem4 + ((C) & 1) * p.bufs + wave * 64;                                                               \
+    switch (I) {                                                                                                       \
+      DMA_CASES(C)                                                                                                     \
+      default: break;                                                                                                  \
+    }                                                                                                                  \
+  }
+#define DMA_CASE(I_, C)                                                                                                \
+  case I_:                                                                                                             \
+    if constexpr (I_ < PF) {                                                                                           \
+      if (I_ < ni) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_i, (lds_ptr_t)(lb_ + I_ * NT), 16, voff[I_ < PF ? I_ : 0], (C) * so_i, 0, 0); \
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(lb_ + I_ * NT), 16, voff[I_ < PF ? I_ : 0], (C) * so_w, 0, 0); \
+    }                                                                                                                  \
+    break;
+#define DMA_CASES(C)                                                                                                   \
+  DMA_CASE(0, C) DMA_CASE(1, C) DMA_CASE(2, C) DMA_CASE(3, C) DMA_CASE(4, C) DMA_CASE(5, C) DMA_CASE(6, C) DMA_CASE(7, C)   \
+  DMA_CASE(8, C) DMA_CASE(9, C) DMA_CASE(10, C) DMA_CASE(11, C) DMA_CASE(12, C) DMA_CASE(13, C) DMA_CASE(14, C) DMA_CASE(15, C)
 #else
 #define DMA_ISSUE(C) (void)ns, (void)so_i, (void)so_w, (void)rs_i, (void)rs_w, (void)voff;
+#define DMA_ONE(I, C) (void)(I);
 #endif
+    int dnext = 0, dend = 0, dchunk = 0;
+#undef BF_HOOK
+#define BF_HOOK()                   \
+  if (dnext < dend) {               \
+    DMA_ONE(dnext, dchunk)          \
+    ++dnext;                        \
+  }
     DMA_ISSUE(0)
     for (int c = 0; c < p.nchunk; ++c) {
       // dma = 2 (at most two chunks): ONE buffer, the next chunk is fetched after the MFMAs -- half the LDS, so more
@@ -322,13 +356,25 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
         DMA_ISSUE(c)
       }
       __syncthreads();  // chunk c has landed (every wave drained its DMA) and nobody reads the other buffer any more
-      if (p.dma == 1 && c + 1 < p.nchunk && !(p.dbg & 4)) { DMA_ISSUE(c + 1) }
+      // two buffers: chunk c + 1 is requested slot by slot between the MFMA clusters of chunk c
+      dnext = 0;
+      dchunk = c + 1;
+      dend = (p.dma == 1 && c + 1 < p.nchunk && !(p.dbg & 4)) ? ns : 0;
       const u32x4* ldsI = smem4 + (c & 1) * p.bufs;
       const u32x4* ldsW = ldsI + p.ldsw_off;
       __builtin_amdgcn_sched_barrier(0);
       if (!(p.dbg & 2)) BF_COMPUTE()
+      while (dnext < dend) {  // fewer MFMA clusters than slots: the rest goes out now
+        DMA_ONE(dnext, dchunk)
+        ++dnext;
+      }
     }
 #undef DMA_ISSUE
+#undef DMA_ONE
+#undef DMA_CASE
+#undef DMA_CASES
+#undef BF_HOOK
+#define BF_HOOK()
   } else {
     for (int c = 0; c < p.nchunk; ++c) {
       const int kb0 = c * p.CKb;
@@ -353,6 +399,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
 #undef BF_MFMA
 #undef BF_RUN
 #undef BF_COMPUTE
+#undef BF_HOOK
 
   const unsigned long long t_epi = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
   // ---- epilogue: bias (+ BatchNorm partial sums of the fp32 pre-activation) + activation [or act'(ref)] + channel mask,
@@ -635,7 +682,8 @@ struct BfTiling {
 
 // (OH, OW): the grid the workgroups tile (output pixels; quads for the stride-2 data gradient), T: weight slices staged at
 // most, PF: DMA slots of the kernel variant.  LDS image of a chunk: input tile from unit 0, weight slices from ldsw_off.
-bool bf_plan(int OH, int OW, int a, int T, int span, int Kb, int MW, int NW, int NWV, int PF, int budget, BfTiling* out) {
+bool bf_plan(int OH, int OW, int a, int T, int span, int Kb, int MW, int NW, int NWV, int PF, int budget, BfTiling* out,
+             bool force_single = false) {
   const int BM = 32 * MW, PT = 32 * NWV * NW, NT = 64 * NWV;
   BfTiling best{};
   long long best_score = -1;
@@ -652,7 +700,7 @@ bool bf_plan(int OH, int OW, int a, int T, int span, int Kb, int MW, int NW, int
       const int ni = cdiv(CKb * chs, NT), nw = cdiv(T * CKb * BM, NT);
       const int ldsw_off = ni * NT;  // slot-aligned, so a DMA slot is all input or all weights
       const int bufu = (ni + nw) * NT;
-      const int nbuf = Kb / CKb <= 2 ? 1 : 2;  // short contractions: one buffer (more workgroups per CU)
+      const int nbuf = (Kb / CKb <= 2 || force_single) ? 1 : 2;  // short contractions: one buffer (more workgroups per CU)
       const int dma = (ni + nw <= PF && nbuf * bufu * 16 <= budget) ? (nbuf == 1 ? 2 : 1) : 0;
       const int dummy = ldsw_off + T * CKb * BM;
       const int bytes = dma ? nbuf * bufu * 16 : (dummy + 1) * 16;
@@ -719,7 +767,12 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
   if (wide64_env < 0) wide64_env = getenv("YOGO_BF16_WIDE64") ? atoi(getenv("YOGO_BF16_WIDE64")) : 1;
   const bool wide64 = wide64_env && MW == 2 && !small_n && K >= 64 && OH * OW >= 4096;
   const int NW = MW == 1 ? (small_n ? 2 : 4) : (small_n ? 1 : (wide64 ? 4 : 2));
-  const int NWV = (MW == 4 || wide64) ? 8 : 4;  // 128-channel tiles: 8 wavefronts share the staged weight slice
+  // experiment (YOGO_BF16_HALFWG=1): 128-row tiles on two 4-wavefront workgroups per CU with ONE LDS buffer each, so that one
+  // workgroup's staging / epilogue overlaps the other's MFMAs
+  static int halfwg_env = -1;
+  if (halfwg_env < 0) halfwg_env = getenv("YOGO_BF16_HALFWG") ? atoi(getenv("YOGO_BF16_HALFWG")) : 0;
+  const bool halfwg = halfwg_env && MW == 4 && !small_n;
+  const int NWV = ((MW == 4 && !halfwg) || wide64) ? 8 : 4;  // 128-channel tiles: 8 wavefronts share the staged weight slice
   const int PF = NWV == 8 ? 10 : 16;  // = 160 KB / 128 KB of LDS for the two buffers at most
   const int Kb = bf_kb_of(K), Mpad = bf_mpad_of(M);
   // the grid the workgroups tile: output pixels, or 2x2 output quads of one row parity
@@ -727,7 +780,8 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
   BfTiling tl;
   // 4-wavefront workgroups: two per CU when the pipelined tiling fits half the LDS
   bool planned = false;
-  if (NWV == 4) {  // as many workgroups per CU as a pipelined tiling allows: 4, 3, 2
+  if (halfwg) planned = bf_plan(OHt, OWt, a, T, ks, Kb, MW, NW, NWV, PF, BF_LDS_BUDGET, &tl, true) && tl.dma;
+  if (NWV == 4 && !planned) {  // as many workgroups per CU as a pipelined tiling allows: 4, 3, 2
     static int ladder_env = -1;
     if (ladder_env < 0) ladder_env = getenv("YOGO_BF16_LDS_LADDER") ? atoi(getenv("YOGO_BF16_LDS_LADDER")) : 0;
     const int ladder[3] = {40 * 1024, 53 * 1024, BF_LDS_BUDGET};
@@ -813,7 +867,8 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
     else if (MW == 2) BFLAUNCH(2, 1, 4, false, 16);
     else BFLAUNCH(1, 2, 4, false, 16);
   } else {
-    if (MW == 4) BFLAUNCH(4, 2, 8, false, 10);
+    if (MW == 4 && halfwg) BFLAUNCH(4, 2, 4, false, 16);
+    else if (MW == 4) BFLAUNCH(4, 2, 8, false, 10);
     else if (MW == 2 && wide64) BFLAUNCH(2, 4, 8, false, 10);
     else if (MW == 2) BFLAUNCH(2, 2, 4, false, 16);
     else BFLAUNCH(1, 4, 4, false, 16);
