@@ -230,10 +230,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
     const int k2_ = 2 * (s_ & (hk - 1));                                                          \
     const u32x4* wI_ = ldsI + (k2_ * per_kb + __builtin_amdgcn_readlane(toff_lane, t_));          \
     const u32x4* wW_ = ldsW + ((t_ << p.ckb_shift) + k2_) * BM;                                   \
-    if (!(p.dbg & 32)) {                                                                          \
     _Pragma("unroll") for (int mb = 0; mb < MW; ++mb) AV[mb] = wW_[a_vu + mb * 32];               \
     _Pragma("unroll") for (int n = 0; n < NW; ++n) BV[n] = wI_[b_vu[n]];                          \
-    }                                                                                             \
   }
 #define BF_MFMA(CI, AV, BV)                                                                       \
   _Pragma("unroll") for (int mb = 0; mb < MW; ++mb)                                               \
@@ -243,24 +241,31 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
 #define BF_HOOK()
 // MFMA over steps [SBEG, SEND) = (tap, 16-channel step); operands of step s+1 are read before the MFMAs of step s.  The MFMA
 // cluster runs at raised priority so that the two wavefronts of a SIMD fall out of phase (one fetches while the other multiplies)
+// interleave directive for one (operand fetch of the next step, MFMA cluster of this step) pair: one ds_read_b128 behind each
+// of the first MW + NW MFMAs, so a wavefront's own stream keeps the matrix pipe fed while its operands arrive
+#define BF_INTERLEAVE()                                                                           \
+  _Pragma("unroll") for (int q_ = 0; q_ < MW + NW; ++q_) {                                        \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                            \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                            \
+  }                                                                                               \
+  __builtin_amdgcn_sched_group_barrier(0x008, MW * NW - (MW + NW) > 0 ? MW * NW - (MW + NW) : 0, 0);
 #define BF_RUN(CI, SBEG, SEND)                                                                    \
   {                                                                                               \
     u32x4 a0[MW] = {}, b0[NW] = {}, a1[MW] = {}, b1[NW] = {};                                     \
     int s = (SBEG);                                                                               \
     BF_LOAD(a0, b0, s, SEND);                                                                     \
     for (; s + 1 < (SEND); s += 2) {                                                              \
-      BF_LOAD(a1, b1, s + 1, SEND);                                                               \
       __builtin_amdgcn_sched_barrier(0);                                                          \
-      __builtin_amdgcn_s_setprio(1);                                                              \
+      BF_LOAD(a1, b1, s + 1, SEND);                                                               \
       BF_MFMA(CI, a0, b0);                                                                        \
-      __builtin_amdgcn_s_setprio(0);                                                              \
+      if (MW * NW >= MW + NW) { BF_INTERLEAVE() }                                                 \
+      __builtin_amdgcn_sched_barrier(0);                                                          \
       BF_HOOK()                                                                                   \
       __builtin_amdgcn_sched_barrier(0);                                                          \
       BF_LOAD(a0, b0, s + 2, SEND);                                                               \
-      __builtin_amdgcn_sched_barrier(0);                                                          \
-      __builtin_amdgcn_s_setprio(1);                                                              \
       BF_MFMA(CI, a1, b1);                                                                        \
-      __builtin_amdgcn_s_setprio(0);                                                              \
+      if (MW * NW >= MW + NW) { BF_INTERLEAVE() }                                                 \
+      __builtin_amdgcn_sched_barrier(0);                                                          \
       BF_HOOK()                                                                                   \
       __builtin_amdgcn_sched_barrier(0);                                                          \
     }                                                                                             \
@@ -398,6 +403,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
 #undef BF_LOAD
 #undef BF_MFMA
 #undef BF_RUN
+#undef BF_INTERLEAVE
 #undef BF_COMPUTE
 #undef BF_HOOK
 
