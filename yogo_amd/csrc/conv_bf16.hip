@@ -23,6 +23,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 // native vector types (HIP's u32x4/u32x2 are structs and get spilled to scratch when selected/stored through pointers)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 #define BF_MAX_TAPS 9
 #define BF_LDS_BUDGET (80 * 1024)      // two 4-wavefront workgroups per CU
@@ -307,6 +308,9 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
       const int ii_ = (kc_ * p.IH + iy_) * p.IW + ix_;
       voff[i] = (i >= ni) ? (wok ? wi_ * 16 : (int)OOB) : (iok ? ii_ * 16 : (int)OOB);
     }
+    i32x16 voffv;  // the same offsets as a register vector that can be indexed at run time
+#pragma unroll
+    for (int i = 0; i < 16; ++i) voffv[i] = i < PF ? voff[i < PF ? i : 0] : 0;
     const int ibytes = p.Kb * p.IH * p.IW * 16, wbytes = p.T * p.Kb * p.Mpad * 16;
     const int so_i = p.CKb * p.IH * p.IW * 16, so_w = p.CKb * p.Mpad * 16;
     const auto rs_i = __builtin_amdgcn_make_buffer_rsrc((void*)inb, (short)0, ibytes, 0x00020000);
@@ -321,29 +325,20 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
       else if (i < ns) { if (!(p.dbg & 16)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(lb_ + i * NT), 16, voff[i], (C) * so_w, 0, 0); } \
     }                                                                                                                  \
   }
-// one slot of chunk C, chosen at run time (the slot's registers need a compile-time index): issued between the MFMA clusters
-// of the previous chunk, so the DMA instructions never hold up the matrix cores
+// one slot of chunk C, chosen at run time: issued between the MFMA clusters of the previous chunk, so the DMA instructions
+// never hold up the matrix cores.  The slot's offset comes out of the register array by relative indexing (voffv[I]), the
+// descriptor / scalar offset / LDS address are scalar selects -- no branches.
 #define DMA_ONE(I, C)                                                                                                  \
   {                                                                                                                    \
-    u32x4* lb_ = smem4 + ((C) & 1) * p.bufs + wave * 64;                                                               \
-    switch (I) {                                                                                                       \
-      DMA_CASES(C)                                                                                                     \
-      default: break;                                                                                                  \
-    }                                                                                                                  \
+    const int i_ = (I);                                                                                                \
+    const bool isw_ = i_ >= ni;                                                                                        \
+    const auto rs_ = __builtin_amdgcn_make_buffer_rsrc(isw_ ? (void*)p.wp : (void*)inb, (short)0, isw_ ? wbytes : ibytes, 0x00020000); \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_ptr_t)(smem4 + ((C) & 1) * p.bufs + wave * 64 + i_ * NT), 16, voffv[i_],   \
+                                             (C) * (isw_ ? so_w : so_i), 0, 0);                                        \
   }
-#define DMA_CASE(I_, C)                                                                                                \
-  case I_:                                                                                                             \
-    if constexpr (I_ < PF) {                                                                                           \
-      if (I_ < ni) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_i, (lds_ptr_t)(lb_ + I_ * NT), 16, voff[I_ < PF ? I_ : 0], (C) * so_i, 0, 0); \
-      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(lb_ + I_ * NT), 16, voff[I_ < PF ? I_ : 0], (C) * so_w, 0, 0); \
-    }                                                                                                                  \
-    break;
-#define DMA_CASES(C)                                                                                                   \
-  DMA_CASE(0, C) DMA_CASE(1, C) DMA_CASE(2, C) DMA_CASE(3, C) DMA_CASE(4, C) DMA_CASE(5, C) DMA_CASE(6, C) DMA_CASE(7, C)   \
-  DMA_CASE(8, C) DMA_CASE(9, C) DMA_CASE(10, C) DMA_CASE(11, C) DMA_CASE(12, C) DMA_CASE(13, C) DMA_CASE(14, C) DMA_CASE(15, C)
 #else
 #define DMA_ISSUE(C) (void)ns, (void)so_i, (void)so_w, (void)rs_i, (void)rs_w, (void)voff;
-#define DMA_ONE(I, C) (void)(I);
+#define DMA_ONE(I, C) (void)(I), (void)voffv;
 #endif
     int dnext = 0, dend = 0, dchunk = 0;
 #undef BF_HOOK
@@ -376,8 +371,6 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
     }
 #undef DMA_ISSUE
 #undef DMA_ONE
-#undef DMA_CASE
-#undef DMA_CASES
 #undef BF_HOOK
 #define BF_HOOK()
   } else {
