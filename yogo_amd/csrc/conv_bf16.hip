@@ -346,6 +346,10 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
   if (dnext < dend) {               \
     DMA_ONE(dnext, dchunk)          \
     ++dnext;                        \
+    if (dnext < dend) {             \
+      DMA_ONE(dnext, dchunk)        \
+      ++dnext;                      \
+    }                               \
   }
     DMA_ISSUE(0)
     for (int c = 0; c < p.nchunk; ++c) {
