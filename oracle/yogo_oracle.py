@@ -14,6 +14,7 @@ root):
 * Kaiming init + grad clamp            yogo/model.py:76-87
 * loss                                 yogo/yogo_loss.py:38-129
 * threshold + NMS post-process         yogo/utils/prediction_formatting.py:23-93
+* inference output rows / arrays       yogo/infer.py:39-124, yogo/utils/prediction_formatting.py:96-156
 * label rasteriser (synthetic labels)  yogo/data/yogo_dataset.py:24-46
 * AdamW + cosine LR (trainer glue)     yogo/train.py:206-223, 324-325
 
@@ -463,6 +464,31 @@ def get_prediction_class_counts(batch_preds, obj_thresh=0.5, iou_thresh=0.5, min
             continue
         tot += count_cells_for_formatted_preds(r[:, 5:])
     return tot
+
+
+def save_predictions_text(rows: torch.Tensor) -> str:
+    """text of one image's prediction file: one "class xc yc w h" line per kept row, class = first argmax over the class
+    columns, numbers printed as Python floats of the float32 values (yogo/infer.py:39-57, argmax helper :35-36)"""
+    lines = []
+    for pred in rows:
+        cls = pred[5:].tolist()
+        am = max(range(len(cls)), key=cls.__getitem__)
+        lines.append(f"{am} {pred[0].item()} {pred[1].item()} {pred[2].item()} {pred[3].item()}")
+    return "\n".join(lines)
+
+
+def format_to_numpy(img_id: int, prediction_tensor: np.ndarray, img_h: int, img_w: int, np_dtype=np.float32) -> np.ndarray:
+    """(8 + C) x N array: img id, x1*W, y1*H, x2*W, y2*H, objectness, argmax class, its probability, all class probabilities
+    (yogo/utils/prediction_formatting.py:96-156; default thresholds, box_format="xyxy")"""
+    fp = format_preds(torch.from_numpy(prediction_tensor), box_format="xyxy").numpy().T
+    n = fp.shape[1]
+    img_ids = np.ones(n).astype(np_dtype) * img_id
+    tlx, tly, brx, bry = fp[0, :] * img_w, fp[1, :] * img_h, fp[2, :] * img_w, fp[3, :] * img_h
+    objectness = fp[4, :].astype(np_dtype)
+    all_confs = fp[5:, :].astype(np_dtype)
+    pred_labels = np.argmax(all_confs, axis=0).astype(np.uint8)
+    pred_probs = fp[5:,][pred_labels, np.arange(n)]
+    return np.vstack((img_ids, tlx, tly, brx, bry, objectness, pred_labels.astype(np_dtype), pred_probs.astype(np_dtype), all_confs))
 
 
 # ---------------------------------------------------------------------------

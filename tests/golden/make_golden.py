@@ -282,6 +282,11 @@ def main():
     logits[5:] = torch.randn(7, 24, 33, generator=g) * 3     # Metrics path feeds raw logits (inference=False)
     fmt_case("fmt_logits_12x24x33.npz", logits, variants)
 
+    # ---- (vii) inference output arrays from the reference's format_to_numpy (prediction_formatting.py:96-156) --------
+    npsave("fnp_12x24x33.npz", sparse=sparse, dense=dense,
+           out_sparse=pf.format_to_numpy(3, sparse.numpy().copy(), 772, 1032),
+           out_dense=pf.format_to_numpy(7, dense.numpy().copy(), 193, 1032))
+
 
 if __name__ == "__main__":
     main()

@@ -224,6 +224,22 @@ def test_class_counts_match_oracle():
     assert torch.equal(got, want)
 
 
+def test_inference_writers_match_oracle(tmp_path):
+    """save_predictions / format_to_numpy (yogo/infer.py:39-57, prediction_formatting.py:96-156) over the batched kernel"""
+    from yogo_amd.utils import format_to_numpy, format_to_numpy_batched, save_predictions
+
+    preds = O.synthetic_predictions(3, 33, 24, num_classes=7, K=30, seed=77)
+    names = [str(tmp_path / f"img{i}.txt") for i in range(3)]
+    save_predictions(names, preds.cuda(), obj_thresh=0.5, iou_thresh=0.5)
+    for b, n in enumerate(names):
+        assert open(n).read() == O.save_predictions_text(O.format_preds(preds[b]))
+    arrs = format_to_numpy_batched([10, 11, 12], preds.cuda(), 772, 1032)
+    for b in range(3):
+        want = O.format_to_numpy(10 + b, preds[b].numpy(), 772, 1032)
+        assert arrs[b].dtype == want.dtype and np.array_equal(arrs[b], want)
+    assert np.array_equal(format_to_numpy(5, preds[1].numpy(), 193, 1032), O.format_to_numpy(5, preds[1].numpy(), 193, 1032))
+
+
 def test_trainer_steps_match_oracle():
     """two full optimisation steps (fwd, loss, bwd, clamp, AdamW with cosine LR) against the CPU oracle"""
     from yogo_amd.model import YOGO

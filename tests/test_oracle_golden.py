@@ -117,6 +117,38 @@ def test_format_preds_against_reference_control_flow(fix):
     assert i == 5
 
 
+def test_format_to_numpy_against_reference():
+    """inference output array of yogo/utils/prediction_formatting.py:96-156 (fixture written by the real function)"""
+    z = load_npz("fnp_12x24x33.npz")
+    for name, img_id, h, w in (("sparse", 3, 772, 1032), ("dense", 7, 193, 1032)):
+        got = O.format_to_numpy(img_id, np.array(z[name]), h, w)
+        want = z["out_" + name]
+        assert got.dtype == want.dtype and got.shape == want.shape and want.shape[0] == 8 + 7
+        assert np.array_equal(got, want), name
+
+
+def test_save_predictions_text_known_answer():
+    """row format of yogo/infer.py:52-55: first-argmax class, then xc yc w h printed as Python floats of the float32 values"""
+    rows = torch.tensor([[0.5, 0.25, 0.125, 0.0625, 0.9, 0.1, 0.7, 0.7, 0.0],
+                         [0.1, 0.2, 0.3, 0.4, 0.8, 0.6, 0.1, 0.1, 0.2]])
+    txt = O.save_predictions_text(rows)
+    assert txt.split("\n")[0] == "1 0.5 0.25 0.125 0.0625"            # tie between classes 1 and 2 -> the first
+    assert txt.split("\n")[1] == f"0 {float(np.float32(0.1))} {float(np.float32(0.2))} {float(np.float32(0.3))} {float(np.float32(0.4))}"
+    assert O.save_predictions_text(torch.zeros(0, 9)) == ""
+
+
+def test_host_side_writers_match_oracle():
+    """the product's host-side formatting (no GPU involved) against the oracle's restatement"""
+    from yogo_amd.utils.prediction_formatting import _rows_xyxy_to_numpy, prediction_rows_to_text
+
+    z = load_npz("fnp_12x24x33.npz")
+    pred = as_t(z["sparse"])
+    rows = O.format_preds(pred)
+    assert prediction_rows_to_text(rows) == O.save_predictions_text(rows)
+    rows_xyxy = O.format_preds(pred, box_format="xyxy")
+    assert np.array_equal(_rows_xyxy_to_numpy(3, rows_xyxy, 772, 1032, np.float32), z["out_sparse"])
+
+
 # ---- the reference's own known-answer tests (tests/test_utils_tensor_formatting.py:8-68) ------------------
 def _kat_tensors():
     none = torch.zeros(12, 4, 4)

@@ -102,3 +102,59 @@ def get_prediction_class_counts(batch_preds: torch.Tensor, obj_thresh=0.5, iou_t
             continue
         tot += count_cells_for_formatted_preds(r[:, 5:]).cpu()
     return tot
+
+
+def _argmax_first(vals) -> int:
+    return max(range(len(vals)), key=vals.__getitem__)
+
+
+def prediction_rows_to_text(rows: torch.Tensor) -> str:
+    """one image's prediction file: "class xc yc w h" per kept row, numbers as Python floats of the float32 values
+    (the f-string of yogo/infer.py:52-55; `rows` on the host)"""
+    out = []
+    for r in rows.tolist():
+        out.append(f"{_argmax_first(r[5:])} {r[0]} {r[1]} {r[2]} {r[3]}")
+    return "\n".join(out)
+
+
+def save_predictions(fnames, batch_preds: torch.Tensor, obj_thresh=0.5, iou_thresh=0.5) -> None:
+    """yogo/infer.py:39-57 with ONE batched threshold + NMS launch and one device->host copy for the whole batch"""
+    rows, _, counts = format_preds_batched(batch_preds, obj_thresh, iou_thresh)
+    host = rows.cpu()
+    for fname, n, r in zip(fnames, counts.cpu().tolist(), host):
+        with open(fname, "w") as f:
+            f.write(prediction_rows_to_text(r[:n]))
+
+
+def _rows_xyxy_to_numpy(img_id: int, rows_xyxy, img_h: int, img_w: int, np_dtype):
+    import numpy as np
+
+    fp = rows_xyxy.numpy().T
+    n = fp.shape[1]
+    img_ids = np.ones(n).astype(np_dtype) * img_id
+    tlx, tly, brx, bry = fp[0, :] * img_w, fp[1, :] * img_h, fp[2, :] * img_w, fp[3, :] * img_h
+    objectness = fp[4, :].astype(np_dtype)
+    all_confs = fp[5:, :].astype(np_dtype)
+    pred_labels = np.argmax(all_confs, axis=0).astype(np.uint8)
+    pred_probs = fp[5:,][pred_labels, np.arange(n)]
+    return np.vstack((img_ids, tlx, tly, brx, bry, objectness, pred_labels.astype(np_dtype), pred_probs.astype(np_dtype), all_confs))
+
+
+def format_to_numpy_batched(img_ids, batch_preds: torch.Tensor, img_h: int, img_w: int, np_dtype=None):
+    """`format_to_numpy` of every image of a device batch: one threshold + NMS launch, one copy; returns a list of
+    (8 + C) x N_b arrays (yogo/utils/prediction_formatting.py:96-156, call site yogo/infer.py:360-380)"""
+    import numpy as np
+
+    np_dtype = np.float32 if np_dtype is None else np_dtype
+    rows, _, counts = format_preds_batched(batch_preds, box_format="xyxy")
+    host = rows.cpu()
+    return [_rows_xyxy_to_numpy(i, host[b, :n], img_h, img_w, np_dtype)
+            for b, (i, n) in enumerate(zip(img_ids, counts.cpu().tolist()))]
+
+
+def format_to_numpy(img_id: int, prediction_tensor, img_h: int, img_w: int, np_dtype=None):
+    """reference signature (one image, numpy in / numpy out); the threshold + NMS runs on the MI355X"""
+    t = torch.from_numpy(prediction_tensor) if not isinstance(prediction_tensor, torch.Tensor) else prediction_tensor
+    if t.ndim != 3:
+        raise ValueError(f"argument to format_pred should be unbatched result - shape should be (pred_shape, Sy, Sx), got {t.shape}")
+    return format_to_numpy_batched([img_id], t.unsqueeze(0).cuda(), img_h, img_w, np_dtype)[0]
