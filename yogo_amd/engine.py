@@ -340,7 +340,9 @@ import os as _os
 
 _WGRAD_BF16_MFMA = _os.environ.get("YOGO_WGRAD_BF16", "1") != "0"   # 0: fp32-MFMA weight gradients on the widened inputs
 # 1: weight gradients run on a second HIP stream, beside the data-gradient / BatchNorm-backward chain they do not feed
-_WGRAD_SIDE_STREAM = _os.environ.get("YOGO_WGRAD_STREAM", "1") != "0"
+# (measured: -2 % step time).  Off by default: with two kernels sharing the chip the per-kernel HIP-event / rocprofv3 durations
+# that bench.py's roofline is built from stop being attributable to one kernel.
+_WGRAD_SIDE_STREAM = _os.environ.get("YOGO_WGRAD_STREAM", "0") != "0"
 _FUSE_LAYER0_BWD = _os.environ.get("YOGO_FUSE_LAYER0_BWD", "1") != "0"   # 0: separate BatchNorm-backward + weight-gradient passes
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
@@ -558,7 +560,7 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
             dx = torch.empty(B, _blocks(L.cin), IH, IW, 8, dtype=torch.bfloat16, device=dev)
             pk = _packed_bf16(eng, i, 2 if (L.s == 2 and L.k == 3) else 1)
             nbytes = B * 2 * 8 * (_blocks(L.cout) * OH * OW + _blocks(L.cin) * IH * IW * (2 if act_ref is not None else 1))
-            eng._tick("dgrad", i, 2.0 * B * L.cout * L.cin * L.k * L.k * OH * OW, mw=34 if (L.cin > 64 and L.s == 1) else 30, nbytes=nbytes)
+            eng._tick("dgrad", i, 2.0 * B * L.cout * L.cin * L.k * L.k * OH * OW, mw=34 if (L.cin > 64 and L.s == 1 and act_ref is None) else 30, nbytes=nbytes)
             _hip.call("yogo_conv2d_dgrad_bf16", g, pk, dx, act_ref, ref_act, Sp.mask, B, L.cin, L.cout, IH, IW, L.k, L.s, st)
             eng._tock()
             g = dx
