@@ -254,6 +254,13 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
   {                                                                                               \
     u32x4 a0[MW] = {}, b0[NW] = {}, a1[MW] = {}, b1[NW] = {};                                     \
     int s = (SBEG);                                                                               \
+    if constexpr (MW == 1) {  /* 32-row tiles are memory-bound: one operand set, fewer registers, more workgroups per CU */ \
+      for (; s < (SEND); ++s) {                                                                   \
+        BF_LOAD(a0, b0, s, SEND);                                                                 \
+        BF_MFMA(CI, a0, b0);                                                                      \
+        BF_HOOK()                                                                                 \
+      }                                                                                           \
+    } else {                                                                                      \
     BF_LOAD(a0, b0, s, SEND);                                                                     \
     for (; s + 1 < (SEND); s += 2) {                                                              \
       __builtin_amdgcn_sched_barrier(0);                                                          \
@@ -274,6 +281,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
       BF_MFMA(CI, a0, b0);                                                                        \
       BF_HOOK()                                                                                   \
     }                                                                                             \
+    }                                                                                             \
   }
 #define BF_COMPUTE()                                                                              \
   {                                                                                               \
@@ -290,7 +298,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
     constexpr unsigned OOB = 0x80000000u;
     const int ni = p.ni_slots, ns = p.n_slots;
     const int wtotal = total - itotal;
-    int voff[PF];
+    i32x16 voffv = {};  // the slot offsets: a register vector, so that a slot can also be picked at run time (relative indexing)
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
       const int e = tid + i * NT;
@@ -306,11 +314,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
       const int R_ = w_ >> BM_SHIFT;
       const int wi_ = ((tbase + (R_ >> p.ckb_shift)) * p.Kb + (R_ & (p.CKb - 1))) * p.Mpad + m0 + (w_ & (BM - 1));
       const int ii_ = (kc_ * p.IH + iy_) * p.IW + ix_;
-      voff[i] = (i >= ni) ? (wok ? wi_ * 16 : (int)OOB) : (iok ? ii_ * 16 : (int)OOB);
+      voffv[i] = (i >= ni) ? (wok ? wi_ * 16 : (int)OOB) : (iok ? ii_ * 16 : (int)OOB);
     }
-    i32x16 voffv;  // the same offsets as a register vector that can be indexed at run time
-#pragma unroll
-    for (int i = 0; i < 16; ++i) voffv[i] = i < PF ? voff[i < PF ? i : 0] : 0;
     const int ibytes = p.Kb * p.IH * p.IW * 16, wbytes = p.T * p.Kb * p.Mpad * 16;
     const int so_i = p.CKb * p.IH * p.IW * 16, so_w = p.CKb * p.Mpad * 16;
     const auto rs_i = __builtin_amdgcn_make_buffer_rsrc((void*)inb, (short)0, ibytes, 0x00020000);
@@ -321,8 +326,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
   {                                                                                                                    \
     u32x4* lb_ = smem4 + ((C) & 1) * p.bufs + wave * 64;                                                               \
     _Pragma("unroll") for (int i = 0; i < PF; ++i) {                                                                   \
-      if (i < ni) { if (!(p.dbg & 8)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_i, (lds_ptr_t)(lb_ + i * NT), 16, voff[i], (C) * so_i, 0, 0); } \
-      else if (i < ns) { if (!(p.dbg & 16)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(lb_ + i * NT), 16, voff[i], (C) * so_w, 0, 0); } \
+      if (i < ni) { if (!(p.dbg & 8)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_i, (lds_ptr_t)(lb_ + i * NT), 16, voffv[i], (C) * so_i, 0, 0); } \
+      else if (i < ns) { if (!(p.dbg & 16)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(lb_ + i * NT), 16, voffv[i], (C) * so_w, 0, 0); } \
     }                                                                                                                  \
   }
 // one slot of chunk C, chosen at run time: issued between the MFMA clusters of the previous chunk, so the DMA instructions
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
                                              (C) * (isw_ ? so_w : so_i), 0, 0);                                        \
   }
 #else
-#define DMA_ISSUE(C) (void)ns, (void)so_i, (void)so_w, (void)rs_i, (void)rs_w, (void)voff;
+#define DMA_ISSUE(C) (void)ns, (void)so_i, (void)so_w, (void)rs_i, (void)rs_w, (void)voffv;
 #define DMA_ONE(I, C) (void)(I), (void)voffv;
 #endif
     int dnext = 0, dend = 0, dchunk = 0;
