@@ -450,6 +450,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
       }
     }
   } else {
+    const bool full_tile = p1 - p0 == PT;  // uniform
     constexpr bool has_ref = REF;  // act'(ref) epilogue (training data gradient into a block without BatchNorm)
     const int plane16 = (int)plane * 16;
     const auto rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (size_t)b * p.Mb * plane * 2), (short)0, p.Mb * plane16, 0x00020000);
@@ -511,13 +512,21 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
             if (do_stats || p.act == ACT_SILU || (has_ref && p.ref_act != ACT_LEAKY)) {  // general order of operations
 #pragma unroll
               for (int i = 0; i < 8; ++i) v[i] = acc[c][mb][n][8 * gp + i] + ba[i];
-              if (do_stats) {
-                const float m = pvalid[n] ? 1.f : 0.f;
+              if (do_stats && !(p.dbg & 256)) {
+                if (full_tile) {  // every pixel of the workgroup's tile exists: no masking
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                  const float vm = v[i] * m;
-                  s8[i] += vm;
-                  q8[i] += vm * v[i];
+                  for (int i = 0; i < 8; ++i) {
+                    s8[i] += v[i];
+                    q8[i] = fmaf(v[i], v[i], q8[i]);
+                  }
+                } else {
+                  const float m = pvalid[n] ? 1.f : 0.f;
+#pragma unroll
+                  for (int i = 0; i < 8; ++i) {
+                    const float vm = v[i] * m;
+                    s8[i] += vm;
+                    q8[i] = fmaf(vm, v[i], q8[i]);
+                  }
                 }
               }
               if (has_ref) {
@@ -528,9 +537,12 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
                   v[i] *= act_bwd_factor((float)r0[i], p.ref_act);
                   v[4 + i] *= act_bwd_factor((float)r1[i], p.ref_act);
                 }
-              } else {
+              } else if (p.act == ACT_LEAKY) {  // (uniform branches: a select over all activations would evaluate SiLU's exp)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = act_fwd(v[i], p.act);
+                for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], LEAKY_SLOPE * v[i]);
+              } else if (p.act == ACT_SILU) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = act_fwd(v[i], ACT_SILU);
               }
 #pragma unroll
               for (int i = 0; i < 8; ++i) v[i] *= sa[i];
@@ -565,13 +577,19 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
           }
         }
         if (do_stats) {
+          // 16 independent DPP chains (the compiler interleaves them), then ONE predicated block of LDS writes
+          float sr[8], qr[8];
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            const float s = half_wave_sum(s8[i]), q = half_wave_sum(q8[i]);
-            if (l31 == 31) {
+            sr[i] = (p.dbg & 128) ? s8[i] : half_wave_sum(s8[i]);
+            qr[i] = (p.dbg & 128) ? q8[i] : half_wave_sum(q8[i]);
+          }
+          if (l31 == 31) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
               const int ch = cl + (i < 4 ? i : 4 + i);  // group B starts 8 channels above group A
-              red[(wave * BM + ch) * 2 + 0] = s;
-              red[(wave * BM + ch) * 2 + 1] = q;
+              red[(wave * BM + ch) * 2 + 0] = sr[i];
+              red[(wave * BM + ch) * 2 + 1] = qr[i];
             }
           }
         }
