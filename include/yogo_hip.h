@@ -149,9 +149,9 @@ int yogo_conv_first_bn_wgrad_cols(int Cin, int Cout, int* cols);
 int yogo_conv_first_bn_wgrad_bf16(const void* in, int in_dtype, const void* g, const void* z, const float* mean,
                                   const float* invstd, const float* gamma, const float* beta, float* part, int B, int Cin,
                                   int Cout, int IH, int IW, int stride, int act, yogo_stream_t stream);
-int yogo_conv_first_bn_wgrad_finalize(const float* sums, const float* invstd, const float* gamma, float* dw, float* dgamma,
-                                      float* dbeta, int B, int Cin, int Cout, int IH, int IW, int stride, int training,
-                                      float clip, yogo_stream_t stream);
+int yogo_conv_first_bn_wgrad_finalize(const float* sums, const float* mean, const float* invstd, const float* gamma,
+                                      const float* w_oihw, float* dw, float* dgamma, float* dbeta, int B, int Cin, int Cout,
+                                      int IH, int IW, int stride, int training, float clip, yogo_stream_t stream);
 int yogo_bn_apply_act_bf16(const void* z, void* y, const float* mean, const float* invstd_or_var, int stat_is_var, float eps,
                            const float* gamma, const float* beta, int B, int C, int HW, int act, yogo_stream_t stream);
 int yogo_bn_bwd_bf16_rows(int B, int HW, int* rows);

@@ -363,20 +363,88 @@ struct ConvFirstBnWgradParams {
   int B, Cin, Cout, Mb, IH, IW, OH, OW, stride, act;
 };
 
-template <typename TIn, int CIN, int COC>
-__global__ __launch_bounds__(CF_THREADS) void conv_first_bn_wgrad_kernel(const ConvFirstBnWgradParams p) {
+// GRAM (Cin = 1): z is the bias-free convolution of the patches, so A2[c][j] = invstd_c * (sum_j' W[c][j'] G[j'][j] - mean_c P[j])
+// with the 9x9 Gram matrix G = sum patch_j' patch_j of the input -- channel independent: 45 accumulators replace 16 x 9, the
+// A2 columns of the partial rows stay unwritten and the finalize kernel forms A2 from G (appended after P).
+template <typename TIn, int CIN, int COC, bool GRAM>
+__global__ __launch_bounds__(CF_THREADS, GRAM ? 3 : 2) void conv_first_bn_wgrad_kernel(const ConvFirstBnWgradParams p) {
   constexpr int NJ = CIN * 9;
   constexpr int PER = 2 * NJ + 2;  // per channel: A1[NJ], A2[NJ], S1, S2
-  __shared__ float red[4][COC * PER + NJ];
+  constexpr int NG = GRAM ? NJ * (NJ + 1) / 2 : 0;
+  __shared__ float red[4][(COC * PER + NJ > NJ + NG) ? COC * PER + NJ : NJ + NG];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y;
   const int npix = p.OH * p.OW;
   const int pbase = blockIdx.x * (CF_THREADS * CFW_PPT);
-  const int ncol = p.Cout * PER + NJ;
+  const int ncol = p.Cout * PER + NJ + (GRAM ? NJ * NJ : 0);
   const TIn* inb = reinterpret_cast<const TIn*>(p.in) + (size_t)b * CIN * p.IH * p.IW;
   float* prow = p.part + (size_t)(b * gridDim.x + blockIdx.x) * ncol;
+// this lane's k-th pixel: validity, pixel index and the input patch (zero outside the image / beyond the tail)
+#define CFB_PIXEL(K)                                                                                       \
+  const int pix = pbase + (K) * CF_THREADS + tid;                                                           \
+  const bool ok = pix < npix;                                                                              \
+  const int pc = ok ? pix : 0;                                                                             \
+  const int oy = pc / p.OW, ox = pc - oy * p.OW;                                                           \
+  float x[NJ];                                                                                             \
+  _Pragma("unroll") for (int ci = 0; ci < CIN; ++ci)                                                       \
+  _Pragma("unroll") for (int kh = 0; kh < 3; ++kh)                                                         \
+  _Pragma("unroll") for (int kw = 0; kw < 3; ++kw) {                                                       \
+    const int iy = oy * p.stride + kh - 1, ix = ox * p.stride + kw - 1;                                    \
+    const bool in = ok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;                                    \
+    const float v = (float)inb[in ? ((size_t)ci * p.IH + iy) * p.IW + ix : 0];                             \
+    x[(ci * 3 + kh) * 3 + kw] = in ? v : 0.f;                                                              \
+  }
+
+  if constexpr (GRAM) {
+    // ---- pass over the image alone: P[j] = sum patch_j, G[j][j2] = sum patch_j * patch_j2 (upper triangle) -------------
+    float ps[NJ], gm[NG];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) ps[j] = 0.f;
+#pragma unroll
+    for (int q = 0; q < NG; ++q) gm[q] = 0.f;
+    for (int k = 0; k < CFW_PPT; ++k) {
+      CFB_PIXEL(k)
+      int q = 0;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        ps[j] += x[j];
+#pragma unroll
+        for (int j2 = j; j2 < NJ; ++j2) {
+          gm[q] = fmaf(x[j], x[j2], gm[q]);
+          ++q;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const float v = wave_sum(ps[j]);
+      if (lane == 0) red[wave][j] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+      const float v = wave_sum(gm[q]);
+      if (lane == 0) red[wave][NJ + q] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < NJ + NG; e += CF_THREADS) {
+      const float v = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+      if (e < NJ) {
+        prow[p.Cout * PER + e] = v;
+      } else {  // packed upper triangle -> both halves of the full NJ x NJ matrix
+        int q = e - NJ, j = 0;
+        while (q >= NJ - j) {
+          q -= NJ - j;
+          ++j;
+        }
+        const int j2 = j + q;
+        prow[p.Cout * PER + NJ + j * NJ + j2] = v;
+        prow[p.Cout * PER + NJ + j2 * NJ + j] = v;
+      }
+    }
+    __syncthreads();
+  }
   for (int co0 = 0; co0 < p.Cout; co0 += COC) {
-    float a1[COC][NJ], a2[COC][NJ], s1[COC], s2[COC], ps[NJ];
+    float a1[COC][NJ], a2[GRAM ? 1 : COC][NJ], s1[COC], s2[COC], ps[GRAM ? 1 : NJ];
     float mu[COC], is[COC], ga[COC], be[COC];
 #pragma unroll
     for (int c = 0; c < COC; ++c) {
@@ -384,27 +452,17 @@ __global__ __launch_bounds__(CF_THREADS) void conv_first_bn_wgrad_kernel(const C
       mu[c] = p.mean[co]; is[c] = p.invstd[co]; ga[c] = p.gamma[co]; be[c] = p.beta[co];
       s1[c] = s2[c] = 0.f;
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) a1[c][j] = a2[c][j] = 0.f;
+      for (int j = 0; j < NJ; ++j) {
+        a1[c][j] = 0.f;
+        if constexpr (!GRAM) a2[c][j] = 0.f;
+      }
     }
+    if constexpr (!GRAM) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) ps[j] = 0.f;
+      for (int j = 0; j < NJ; ++j) ps[j] = 0.f;
+    }
     for (int k = 0; k < CFW_PPT; ++k) {
-      const int pix = pbase + k * CF_THREADS + tid;
-      const bool ok = pix < npix;
-      const int pc = ok ? pix : 0;
-      const int oy = pc / p.OW, ox = pc - oy * p.OW;
-      float x[NJ];
-#pragma unroll
-      for (int ci = 0; ci < CIN; ++ci)
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            const int iy = oy * p.stride + kh - 1, ix = ox * p.stride + kw - 1;
-            const bool in = ok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
-            const float v = (float)inb[in ? ((size_t)ci * p.IH + iy) * p.IW + ix : 0];
-            x[(ci * 3 + kh) * 3 + kw] = in ? v : 0.f;
-          }
+      CFB_PIXEL(k)
       // COC consecutive channels live inside one 8-channel unit (COC divides 8)
       const size_t u = ((size_t)b * p.Mb + (co0 >> 3)) * npix + pc;
       const cf_bf16x8 gu = __builtin_bit_cast(cf_bf16x8, p.g[u]);
@@ -434,12 +492,14 @@ __global__ __launch_bounds__(CF_THREADS) void conv_first_bn_wgrad_kernel(const C
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           a1[c][j] = fmaf(gb, x[j], a1[c][j]);
-          a2[c][j] = fmaf(xh, x[j], a2[c][j]);
+          if constexpr (!GRAM) a2[c][j] = fmaf(xh, x[j], a2[c][j]);
         }
       }
-      if (co0 == 0) {
+      if constexpr (!GRAM) {
+        if (co0 == 0) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) ps[j] += x[j];
+          for (int j = 0; j < NJ; ++j) ps[j] += x[j];
+        }
       }
     }
     // cross-lane sums (DPP), then the four wavefronts through LDS
@@ -447,10 +507,11 @@ __global__ __launch_bounds__(CF_THREADS) void conv_first_bn_wgrad_kernel(const C
     for (int c = 0; c < COC; ++c) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const float v1 = wave_sum(a1[c][j]), v2 = wave_sum(a2[c][j]);
-        if (lane == 0) {
-          red[wave][c * PER + j] = v1;
-          red[wave][c * PER + NJ + j] = v2;
+        const float v1 = wave_sum(a1[c][j]);
+        if (lane == 0) red[wave][c * PER + j] = v1;
+        if constexpr (!GRAM) {
+          const float v2 = wave_sum(a2[c][j]);
+          if (lane == 0) red[wave][c * PER + NJ + j] = v2;
         }
       }
       const float t1 = wave_sum(s1[c]), t2 = wave_sum(s2[c]);
@@ -459,32 +520,35 @@ __global__ __launch_bounds__(CF_THREADS) void conv_first_bn_wgrad_kernel(const C
         red[wave][c * PER + 2 * NJ + 1] = t2;
       }
     }
-    if (co0 == 0) {
+    const bool with_p = !GRAM && co0 == 0;
+    if (with_p) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const float v = wave_sum(ps[j]);
+        const float v = wave_sum(ps[GRAM ? 0 : j]);
         if (lane == 0) red[wave][COC * PER + j] = v;
       }
     }
     __syncthreads();
-    for (int e = tid; e < COC * PER + (co0 == 0 ? NJ : 0); e += CF_THREADS) {
+    for (int e = tid; e < COC * PER + (with_p ? NJ : 0); e += CF_THREADS) {
       const float v = red[0][e] + red[1][e] + red[2][e] + red[3][e];
       if (e < COC * PER) {
-        const int c = e / PER;
-        if (co0 + c < p.Cout) prow[(co0 + c) * PER + (e - c * PER)] = v;
+        const int c = e / PER, k = e - c * PER;
+        if (co0 + c < p.Cout && !(GRAM && k >= NJ && k < 2 * NJ)) prow[(co0 + c) * PER + k] = v;
       } else {
         prow[p.Cout * PER + (e - COC * PER)] = v;
       }
     }
     __syncthreads();
   }
+#undef CFB_PIXEL
 }
 
-// sums [Cout*(2*NJ+2) + NJ] -> dW (OIHW), dgamma, dbeta, each clamped to +-clip when clip > 0
-__global__ void conv_first_bn_wgrad_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ invstd,
-                                                    const float* __restrict__ gamma, float* __restrict__ dw,
+// sums [Cout*(2*NJ+2) + NJ (+ NJ*NJ)] -> dW (OIHW), dgamma, dbeta, each clamped to +-clip when clip > 0
+__global__ void conv_first_bn_wgrad_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ mean,
+                                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                    const float* __restrict__ w, float* __restrict__ dw,
                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int Cout, int NJ,
-                                                    float inv_count, int training, float clip) {
+                                                    float inv_count, int training, int gram, float clip) {
   const int PER = 2 * NJ + 2;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= Cout * (NJ + 2)) return;
@@ -494,7 +558,21 @@ __global__ void conv_first_bn_wgrad_finalize_kernel(const float* __restrict__ su
   float v;
   if (j < NJ) {
     const float c1 = gamma[c] * invstd[c];
-    v = training ? c1 * (sc[j] - S1 * inv_count * sums[Cout * PER + j] - S2 * inv_count * sc[NJ + j]) : c1 * sc[j];
+    if (training) {
+      const float Pj = sums[Cout * PER + j];
+      float a2;
+      if (gram) {  // sum xh * patch_j = invstd * (sum_j' W[c][j'] G[j'][j] - mean * P[j])
+        const float* G = sums + Cout * PER + NJ;
+        float t = 0.f;
+        for (int k = 0; k < NJ; ++k) t = fmaf(w[c * NJ + k], G[k * NJ + j], t);
+        a2 = invstd[c] * (t - mean[c] * Pj);
+      } else {
+        a2 = sc[NJ + j];
+      }
+      v = c1 * (sc[j] - S1 * inv_count * Pj - S2 * inv_count * a2);
+    } else {
+      v = c1 * sc[j];
+    }
   } else {
     v = j == NJ ? S2 : S1;
   }
@@ -618,7 +696,7 @@ static int conv_first_wgrad_impl(const void* in, int in_dtype, const float* dy, 
 // ---- fused layer-0 backward (BatchNorm + activation + first-conv weight gradient), bf16 NCHW8c g / z ----------------------
 extern "C" int yogo_conv_first_bn_wgrad_cols(int Cin, int Cout, int* cols) {
   YOGO_CHECK_ARG(cols && (Cin == 1 || Cin == 3) && Cout > 0, "conv_first_bn_wgrad_cols: bad arguments");
-  *cols = Cout * (2 * Cin * 9 + 2) + Cin * 9;
+  *cols = Cout * (2 * Cin * 9 + 2) + Cin * 9 + (Cin == 1 ? 81 : 0);  // Cin = 1: + the 9x9 Gram matrix of the patches
   return YOGO_OK;
 }
 
@@ -637,22 +715,23 @@ extern "C" int yogo_conv_first_bn_wgrad_bf16(const void* in, int in_dtype, const
   p.OH = (IH - 1) / stride + 1; p.OW = (IW - 1) / stride + 1;
   if (B == 0) return YOGO_OK;
   dim3 grid(first_wgrad_tiles(p.OH, p.OW), B);
-  if (in_dtype == 0 && Cin == 1) hipLaunchKernelGGL((conv_first_bn_wgrad_kernel<uint8_t, 1, 8>), grid, dim3(CF_THREADS), 0, stream, p);
-  else if (in_dtype == 0) hipLaunchKernelGGL((conv_first_bn_wgrad_kernel<uint8_t, 3, 2>), grid, dim3(CF_THREADS), 0, stream, p);
-  else if (Cin == 1) hipLaunchKernelGGL((conv_first_bn_wgrad_kernel<float, 1, 8>), grid, dim3(CF_THREADS), 0, stream, p);
-  else hipLaunchKernelGGL((conv_first_bn_wgrad_kernel<float, 3, 2>), grid, dim3(CF_THREADS), 0, stream, p);
+  if (in_dtype == 0 && Cin == 1) hipLaunchKernelGGL((conv_first_bn_wgrad_kernel<uint8_t, 1, 8, true>), grid, dim3(CF_THREADS), 0, stream, p);
+  else if (in_dtype == 0) hipLaunchKernelGGL((conv_first_bn_wgrad_kernel<uint8_t, 3, 2, false>), grid, dim3(CF_THREADS), 0, stream, p);
+  else if (Cin == 1) hipLaunchKernelGGL((conv_first_bn_wgrad_kernel<float, 1, 8, true>), grid, dim3(CF_THREADS), 0, stream, p);
+  else hipLaunchKernelGGL((conv_first_bn_wgrad_kernel<float, 3, 2, false>), grid, dim3(CF_THREADS), 0, stream, p);
   YOGO_CHECK_LAUNCH("conv_first_bn_wgrad_bf16");
   return YOGO_OK;
 }
 
-extern "C" int yogo_conv_first_bn_wgrad_finalize(const float* sums, const float* invstd, const float* gamma, float* dw,
-                                                 float* dgamma, float* dbeta, int B, int Cin, int Cout, int IH, int IW,
-                                                 int stride, int training, float clip, hipStream_t stream) {
-  YOGO_CHECK_ARG(sums && invstd && gamma && dw && dgamma && dbeta, "conv_first_bn_wgrad_finalize: null pointer");
+extern "C" int yogo_conv_first_bn_wgrad_finalize(const float* sums, const float* mean, const float* invstd, const float* gamma,
+                                                 const float* w_oihw, float* dw, float* dgamma, float* dbeta, int B, int Cin,
+                                                 int Cout, int IH, int IW, int stride, int training, float clip,
+                                                 hipStream_t stream) {
+  YOGO_CHECK_ARG(sums && mean && invstd && gamma && w_oihw && dw && dgamma && dbeta, "conv_first_bn_wgrad_finalize: null pointer");
   const int OH = (IH - 1) / stride + 1, OW = (IW - 1) / stride + 1, NJ = Cin * 9;
   const int n = Cout * (NJ + 2);
-  hipLaunchKernelGGL(conv_first_bn_wgrad_finalize_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, sums, invstd, gamma, dw,
-                     dgamma, dbeta, Cout, NJ, 1.0f / ((float)B * (float)OH * (float)OW), training, clip);
+  hipLaunchKernelGGL(conv_first_bn_wgrad_finalize_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, sums, mean, invstd, gamma,
+                     w_oihw, dw, dgamma, dbeta, Cout, NJ, 1.0f / ((float)B * (float)OH * (float)OW), training, Cin == 1 ? 1 : 0, clip);
   YOGO_CHECK_LAUNCH("conv_first_bn_wgrad_finalize");
   return YOGO_OK;
 }

@@ -526,8 +526,8 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
                 _hip.call("yogo_conv_first_bn_wgrad_bf16", S.x_in, xdt, g, S.z, S.mean, S.invstd, gamma, beta, part, B, L.cin, L.cout,
                           IH, IW, L.s, L.act, wst)
                 _hip.call("yogo_partials_reduce", part, rows, cols, 0.0, sums, wst)
-                _hip.call("yogo_conv_first_bn_wgrad_finalize", sums, S.invstd, gamma, dw, dgamma, dbeta, B, L.cin, L.cout, IH, IW,
-                          L.s, 1 if S.bn_train else 0, clip, wst)
+                _hip.call("yogo_conv_first_bn_wgrad_finalize", sums, S.mean, S.invstd, gamma, _f32(L.conv.weight.detach()), dw, dgamma,
+                          dbeta, B, L.cin, L.cout, IH, IW, L.s, 1 if S.bn_train else 0, clip, wst)
                 if bn.weight is not None:
                     grads[id(bn.weight)] = dgamma
                     grads[id(bn.bias)] = dbeta
