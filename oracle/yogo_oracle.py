@@ -466,6 +466,31 @@ def get_prediction_class_counts(batch_preds, obj_thresh=0.5, iou_thresh=0.5, min
     return tot
 
 
+def format_preds_and_labels_v2(pred: torch.Tensor, label: torch.Tensor, objectness_thresh: float = 0.5,
+                               min_class_confidence_threshold: float = 0.0):
+    """prediction <-> label matching for the metrics (yogo/utils/prediction_formatting.py:254-330): threshold + NMS
+    (iou 0.5, xyxy), pairwise IoU of labels x predictions, Hungarian assignment on 1 - IoU (scipy), then the matched rows
+    plus the unmatched labels / predictions.  Returns (preds, labels, missed_labels, extra_predictions)."""
+    from scipy.optimize import linear_sum_assignment
+
+    pred = pred.squeeze()
+    label = label.squeeze()
+    if pred.ndim != 3:
+        raise ValueError(f"argument to format_pred should be unbatched result - shape should be (pred_shape, Sy, Sx), got {pred.shape}")
+    fp = format_preds(pred, obj_thresh=objectness_thresh, iou_thresh=0.5, box_format="xyxy",
+                      min_class_confidence_threshold=min_class_confidence_threshold)
+    L, Sy, Sx = label.shape
+    labels = label.reshape(L, Sx * Sy).T
+    fl = labels[labels[:, 0].bool()]
+    M, N = fp.shape[0], fl.shape[0]
+    cost = 1 - box_iou(fl[:, 1:5], fp[:, :4]).numpy()
+    rows, cols = linear_sum_assignment(cost)
+    rows_t, cols_t = torch.tensor(rows, dtype=torch.long), torch.tensor(cols, dtype=torch.long)
+    un_p = torch.tensor([i for i in range(M) if i not in set(cols.tolist())], dtype=torch.long)
+    un_l = torch.tensor([i for i in range(N) if i not in set(rows.tolist())], dtype=torch.long)
+    return fp[cols_t], fl[rows_t], fl[un_l], fp[un_p]
+
+
 def save_predictions_text(rows: torch.Tensor) -> str:
     """text of one image's prediction file: one "class xc yc w h" line per kept row, class = first argmax over the class
     columns, numbers printed as Python floats of the float32 values (yogo/infer.py:39-57, argmax helper :35-36)"""

@@ -282,6 +282,14 @@ def main():
     logits[5:] = torch.randn(7, 24, 33, generator=g) * 3     # Metrics path feeds raw logits (inference=False)
     fmt_case("fmt_logits_12x24x33.npz", logits, variants)
 
+    # ---- (viii) prediction <-> label matching from the reference's format_preds_and_labels_v2 (:254-330) ---------------
+    lab = O.synthetic_labels(1, 33, 24, K=25, num_classes=7, seed=33)[0]
+    for nm, pr in (("sparse", sparse), ("dense", dense)):
+        for thr in (0.0, 0.9):
+            m = pf.format_preds_and_labels_v2(pr.clone(), lab.clone(), objectness_thresh=0.5, min_class_confidence_threshold=thr)
+            npsave(f"match_{nm}_{int(thr * 10)}.npz", pred=pr, label=lab, preds=m.preds, labels=m.labels,
+                   missed=m.missed_labels, extra=m.extra_predictions)
+
     # ---- (vii) inference output arrays from the reference's format_to_numpy (prediction_formatting.py:96-156) --------
     npsave("fnp_12x24x33.npz", sparse=sparse, dense=dense,
            out_sparse=pf.format_to_numpy(3, sparse.numpy().copy(), 772, 1032),

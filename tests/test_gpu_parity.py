@@ -240,6 +240,26 @@ def test_inference_writers_match_oracle(tmp_path):
     assert np.array_equal(format_to_numpy(5, preds[1].numpy(), 193, 1032), O.format_to_numpy(5, preds[1].numpy(), 193, 1032))
 
 
+def test_format_preds_and_labels_v2_matches_oracle():
+    """metrics-side matching over the batched kernel (prediction_formatting.py:254-330)"""
+    from yogo_amd.utils import PredictionLabelMatch, format_preds_and_labels_v2, format_preds_and_labels_v2_batched
+
+    preds = O.synthetic_predictions(3, 33, 24, num_classes=7, K=30, seed=78)
+    labels = O.synthetic_labels(3, 33, 24, K=25, num_classes=7, seed=79)
+    ms = format_preds_and_labels_v2_batched(preds.cuda(), labels, 0.5, 0.0)
+    for b, m in enumerate(ms):
+        want = O.format_preds_and_labels_v2(preds[b], labels[b], 0.5, 0.0)
+        for g, w in zip((m.preds, m.labels, m.missed_labels, m.extra_predictions), want):
+            assert torch.equal(g, w)
+    one = format_preds_and_labels_v2(preds[1].cuda(), labels[1], 0.5, 0.9)
+    want = O.format_preds_and_labels_v2(preds[1], labels[1], 0.5, 0.9)
+    assert torch.equal(one.preds, want[0]) and torch.equal(one.extra_predictions, want[3])
+    cat = PredictionLabelMatch.concat(ms)
+    assert cat.preds.shape[0] == sum(m.preds.shape[0] for m in ms)
+    conv = cat.convert_background_errors(8)
+    assert conv.preds.shape[1] == 5 + 8 and conv.labels.shape[1] == 6 and conv.missed_labels is None
+
+
 def test_trainer_steps_match_oracle():
     """two full optimisation steps (fwd, loss, bwd, clamp, AdamW with cosine LR) against the CPU oracle"""
     from yogo_amd.model import YOGO

@@ -117,6 +117,23 @@ def test_format_preds_against_reference_control_flow(fix):
     assert i == 5
 
 
+@pytest.mark.parametrize("fix", ["match_sparse_0", "match_sparse_9", "match_dense_0", "match_dense_9"])
+def test_format_preds_and_labels_v2_against_reference(fix):
+    """prediction <-> label matching (prediction_formatting.py:254-330); fixtures written by the real function"""
+    z = load_npz(fix + ".npz")
+    thr = 0.9 if fix.endswith("9") else 0.0
+    got = O.format_preds_and_labels_v2(as_t(z["pred"]), as_t(z["label"]), 0.5, thr)
+    for g, name in zip(got, ("preds", "labels", "missed", "extra")):
+        assert torch.equal(g, as_t(z[name]).reshape(g.shape)), (fix, name)
+    # the product's host-side matcher on the oracle's kept rows gives the same partition
+    from yogo_amd.utils.prediction_formatting import _match_rows_to_labels
+
+    rows = O.format_preds(as_t(z["pred"]), 0.5, 0.5, "xyxy", thr)
+    m = _match_rows_to_labels(rows, as_t(z["label"]))
+    for g, name in zip((m.preds, m.labels, m.missed_labels, m.extra_predictions), ("preds", "labels", "missed", "extra")):
+        assert torch.equal(g, as_t(z[name]).reshape(g.shape)), (fix, name)
+
+
 def test_format_to_numpy_against_reference():
     """inference output array of yogo/utils/prediction_formatting.py:96-156 (fixture written by the real function)"""
     z = load_npz("fnp_12x24x33.npz")

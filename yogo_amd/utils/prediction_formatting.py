@@ -158,3 +158,97 @@ def format_to_numpy(img_id: int, prediction_tensor, img_h: int, img_w: int, np_d
     if t.ndim != 3:
         raise ValueError(f"argument to format_pred should be unbatched result - shape should be (pred_shape, Sy, Sx), got {t.shape}")
     return format_to_numpy_batched([img_id], t.unsqueeze(0).cuda(), img_h, img_w, np_dtype)[0]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# prediction <-> label matching for the metrics (yogo/utils/prediction_formatting.py:165-330)
+# ---------------------------------------------------------------------------------------------------------------------
+from dataclasses import dataclass  # noqa: E402
+
+
+def _one_hot(idx: int, num_classes: int) -> torch.Tensor:
+    return torch.nn.functional.one_hot(torch.tensor(idx, dtype=torch.long), num_classes=num_classes)
+
+
+def _box_iou(b1: torch.Tensor, b2: torch.Tensor) -> torch.Tensor:
+    """pairwise IoU of xyxy boxes (torchvision.ops.box_iou's published algorithm)"""
+    a1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1])
+    a2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
+    lt = torch.max(b1[:, None, :2], b2[:, :2])
+    rb = torch.min(b1[:, None, 2:], b2[:, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[:, :, 0] * wh[:, :, 1]
+    return inter / (a1[:, None] + a2 - inter)
+
+
+@dataclass
+class PredictionLabelMatch:
+    """one-to-one matches plus the missed labels and the extra (background) predictions -- the reference's dataclass
+    (prediction_formatting.py:165-252), same fields and methods"""
+
+    preds: torch.Tensor
+    labels: torch.Tensor
+    missed_labels: Optional[torch.Tensor]
+    extra_predictions: Optional[torch.Tensor]
+
+    @staticmethod
+    def concat(preds_and_labels: List["PredictionLabelMatch"]) -> "PredictionLabelMatch":
+        missed = [p.missed_labels for p in preds_and_labels if p.missed_labels is not None]
+        extra = [p.extra_predictions for p in preds_and_labels if p.extra_predictions is not None]
+        return PredictionLabelMatch(
+            preds=torch.cat([p.preds for p in preds_and_labels]),
+            labels=torch.cat([p.labels for p in preds_and_labels]),
+            missed_labels=torch.cat(missed, dim=0) if missed else None,
+            extra_predictions=torch.cat(extra, dim=0) if extra else None,
+        )
+
+    def convert_background_errors(self, num_classes: int) -> "PredictionLabelMatch":
+        """missed labels become predictions of the (last) background class, extra predictions get a background label"""
+        new_preds, new_labels = [], []
+        for ml in ([] if self.missed_labels is None else self.missed_labels.tolist()):
+            new_preds.append(torch.tensor([*ml[1:5], 1, *_one_hot(num_classes - 1, num_classes).float()]))
+            new_labels.append(torch.tensor(ml))
+        for ep in ([] if self.extra_predictions is None else self.extra_predictions.tolist()):
+            new_preds.append(torch.tensor([*ep, 0]))
+            new_labels.append(torch.tensor([1, *ep[:4], num_classes - 1]))
+        new_preds_ten = torch.stack(new_preds).to(self.preds.device)
+        new_labels_ten = torch.stack(new_labels).to(self.labels.device)
+        self.preds = torch.cat([self.preds, torch.zeros(self.preds.shape[0], 1, device=self.preds.device)], dim=1)
+        return PredictionLabelMatch(preds=torch.cat([self.preds, new_preds_ten]), labels=torch.cat([self.labels, new_labels_ten]),
+                                    missed_labels=None, extra_predictions=None)
+
+
+def _match_rows_to_labels(rows_xyxy: torch.Tensor, label: torch.Tensor) -> PredictionLabelMatch:
+    """host side of format_preds_and_labels_v2: Hungarian assignment on 1 - IoU between the label boxes and the kept rows"""
+    from scipy.optimize import linear_sum_assignment
+
+    L, Sy, Sx = label.shape
+    labels = label.reshape(L, Sx * Sy).T
+    fl = labels[labels[:, 0].bool()]
+    M, N = rows_xyxy.shape[0], fl.shape[0]
+    cost = 1 - _box_iou(fl[:, 1:5], rows_xyxy[:, :4]).cpu().numpy()
+    r, c = linear_sum_assignment(cost)
+    rs, cs = set(r.tolist()), set(c.tolist())
+    un_p = torch.tensor([i for i in range(M) if i not in cs], dtype=torch.long, device=rows_xyxy.device)
+    un_l = torch.tensor([i for i in range(N) if i not in rs], dtype=torch.long, device=fl.device)
+    return PredictionLabelMatch(preds=rows_xyxy[torch.tensor(c, dtype=torch.long)], labels=fl[torch.tensor(r, dtype=torch.long)],
+                                missed_labels=fl[un_l], extra_predictions=rows_xyxy[un_p])
+
+
+def format_preds_and_labels_v2_batched(preds: torch.Tensor, labels: torch.Tensor, objectness_thresh: float = 0.5,
+                                       min_class_confidence_threshold: float = 0.0) -> List[PredictionLabelMatch]:
+    """the matching of every image of a batch: ONE threshold + NMS launch and one device->host copy, then the assignment per
+    image on the host (scipy, as the reference).  preds [B, 5+C, Sy, Sx] on the MI355X, labels [B, 6, Sy, Sx] anywhere."""
+    rows, _, counts = format_preds_batched(preds, objectness_thresh, 0.5, "xyxy", min_class_confidence_threshold)
+    host, lab = rows.cpu(), labels.detach().cpu()
+    return [_match_rows_to_labels(host[b, :n], lab[b]) for b, n in enumerate(counts.cpu().tolist())]
+
+
+def format_preds_and_labels_v2(pred: torch.Tensor, label: torch.Tensor, objectness_thresh: float = 0.5,
+                               min_class_confidence_threshold: float = 0.0) -> PredictionLabelMatch:
+    """reference signature (one image; prediction_formatting.py:254-330).  Results live on the host."""
+    pred = pred.squeeze()
+    label = label.squeeze()
+    if len(pred.shape) != 3:
+        raise ValueError(f"argument to format_pred should be unbatched result - shape should be (pred_shape, Sy, Sx), got {pred.shape}")
+    return format_preds_and_labels_v2_batched(pred.unsqueeze(0), label.unsqueeze(0), objectness_thresh, min_class_confidence_threshold)[0]
