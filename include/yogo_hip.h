@@ -123,6 +123,11 @@ int yogo_conv2d_fwd_bf16_stats_shape(int B, int Cin, int Cout, int IH, int IW, i
 int yogo_conv2d_fwd_bf16(const void* in, const void* packed, const float* bias, void* out, float* out_f32,
                          const float* chan_scale, float* stats_part, int B, int Cin, int Cout, int IH, int IW, int ksize,
                          int stride, int act, yogo_stream_t stream);
+/* as above plus a second bf16 NCHW8c output out_pre = conv + bias before the activation (SiLU blocks without BatchNorm keep it:
+ * the activation derivative of yogo/model_defns.py's nn.SiLU is a function of the pre-activation) */
+int yogo_conv2d_fwd_bf16_pre(const void* in, const void* packed, const float* bias, void* out, void* out_pre,
+                             const float* chan_scale, int B, int Cin, int Cout, int IH, int IW, int ksize, int stride, int act,
+                             yogo_stream_t stream);
 /* dx = conv_transpose(dy) * act'(act_ref) * chan_scale, everything bf16 NCHW8c; (IH, IW) = forward INPUT dims */
 int yogo_conv2d_dgrad_bf16(const void* dy, const void* packed_dgrad, void* dx, const void* act_ref, int ref_act,
                            const float* chan_scale, int B, int Cin, int Cout, int IH, int IW, int ksize, int stride,

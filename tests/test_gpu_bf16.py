@@ -235,3 +235,31 @@ def test_fused_layer0_backward_matches_separate_passes():
             assert float((a - b_).abs().max()) < 1e-2 * float(b_.abs().max()) + 1e-7, (n, float((a - b_).abs().max()), float(b_.abs().max()))
         else:                          # every other gradient comes from identical kernels on identical inputs
             assert torch.equal(a, b_), n
+
+
+@pytest.mark.parametrize("name,hw,rgb", [("silu_model", (96, 128), False), ("quarter_filters", (130, 70), True),
+                                         ("depth_ver_3", (96, 128), False), ("triple_filters", (64, 96), False)])
+def test_bf16_training_other_architectures(name, hw, rgb):
+    """two optimisation steps in bf16 against the same two steps in fp32 for other registered ModelDefns (SiLU blocks keep
+    their pre-activation for the backward pass; widths 4..384; rgb input): loss within 2 %"""
+    from yogo_amd.model import YOGO
+    from yogo_amd.model_defns import MODELS
+    from yogo_amd.train import HipTrainer
+    from yogo_amd.yogo_loss import YOGOLoss
+
+    H_, W_ = hw
+    losses = {}
+    for half in (False, True):
+        torch.manual_seed(1)
+        m = YOGO((H_, W_), 0.0425, 0.0555, 5, is_rgb=rgb, model_func=MODELS[name]).cuda()
+        m.train()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout2d):
+                mod.p = 0.0
+        x = torch.randint(0, 256, (2, 3 if rgb else 1, H_, W_), dtype=torch.uint8, generator=torch.Generator().manual_seed(2)).cuda()
+        lab = O.synthetic_labels(2, m.Sx, m.Sy, K=4, num_classes=5, seed=3).cuda()
+        tr = HipTrainer(m, YOGOLoss().cuda(), total_steps=4, half=half)
+        tr.step(x, lab)
+        tr.step(x, lab)
+        losses[half] = tr.loss_components()["loss"]
+    assert abs(losses[True] - losses[False]) < 2e-2 * abs(losses[False]), losses

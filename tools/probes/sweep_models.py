@@ -1,0 +1,39 @@
+"""every registered architecture through one fp32 and one bf16 training step at a few image sizes (experiments / smoke)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "oracle"))
+import torch
+import yogo_oracle as O
+from yogo_amd.model import YOGO
+from yogo_amd.model_defns import MODELS
+from yogo_amd.train import HipTrainer
+from yogo_amd.yogo_loss import YOGOLoss
+
+bad = 0
+for name, fn in MODELS.items():
+    if name == "convnext_small":
+        continue
+    for (H, W, B, rgb) in ((96, 128, 2, False), (193, 258, 3, False), (130, 70, 1, True)):
+        losses = {}
+        try:
+            for half in (False, True):
+                torch.manual_seed(1)
+                m = YOGO((H, W), 0.0425, 0.0555, 5, is_rgb=rgb, model_func=fn).cuda()
+                m.train()
+                for mod in m.modules():
+                    if isinstance(mod, torch.nn.Dropout2d):
+                        mod.p = 0.0
+                x = torch.randint(0, 256, (B, 3 if rgb else 1, H, W), dtype=torch.uint8, generator=torch.Generator().manual_seed(2)).cuda()
+                lab = O.synthetic_labels(B, m.Sx, m.Sy, K=4, num_classes=5, seed=3).cuda()
+                tr = HipTrainer(m, YOGOLoss().cuda(), total_steps=4, half=half)
+                tr.step(x, lab)
+                tr.step(x, lab)
+                losses[half] = tr.loss_components()["loss"]
+            rel = abs(losses[True] - losses[False]) / max(1e-6, abs(losses[False]))
+            flag = "" if rel < 5e-2 else "   <-- MISMATCH"
+            bad += rel >= 5e-2
+            print(f"{name:16s} {H}x{W} B={B} rgb={int(rgb)}: fp32 {losses[False]:.4f}  bf16 {losses[True]:.4f}  rel {rel:.3e}{flag}", flush=True)
+        except Exception as e:
+            bad += 1
+            print(f"{name:16s} {H}x{W} B={B} rgb={int(rgb)}: ERROR {type(e).__name__}: {str(e)[:150]}", flush=True)
+print("problems:", bad)

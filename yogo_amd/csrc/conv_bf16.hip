@@ -35,6 +35,7 @@ struct ConvBf16Params {
   const float* bias;  // [M] fp32 or null
   u32x2* out;         // bf16 8c viewed as 8-byte halves: [B][Mb][OH][OW][2]
   float* out_f32;     // when set: fp32 NCHW [B][M][OH][OW] instead of `out`
+  u32x2* out_pre;     // optional second bf16 output: conv + bias BEFORE the activation (SiLU blocks keep it for backward)
   const u32x2* act_ref;     // training dgrad: multiply by act'(ref); ref = bf16 tensor shaped like `out` (8-byte halves)
   const float* chan_scale;  // optional [B][M] Dropout2d channel mask (already scaled)
   float* stats_part;        // optional BatchNorm partial sums [B*gridDim.x][Mpad][2] of the fp32 pre-activation
@@ -509,7 +510,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
             // out = act(acc + bias) * scale, or (acc + bias) * act'(ref) * scale.  The channel scale is >= 0 (Dropout2d mask /
             // zero for padding channels), so LeakyReLU commutes with it: one FMA + mul + max per value.
             float v[8];
-            if (do_stats || p.act == ACT_SILU || (has_ref && p.ref_act != ACT_LEAKY)) {  // general order of operations
+            if (do_stats || p.act == ACT_SILU || p.out_pre != nullptr || (has_ref && p.ref_act != ACT_LEAKY)) {  // general order of operations
 #pragma unroll
               for (int i = 0; i < 8; ++i) v[i] = acc[c][mb][n][8 * gp + i] + ba[i];
               if (do_stats && !(p.dbg & 256)) {
@@ -528,6 +529,17 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
                     q8[i] = fmaf(vm, v[i], q8[i]);
                   }
                 }
+              }
+              if (p.out_pre != nullptr) {  // the pre-activation goes out through the same 16-byte-unit exchange
+                bf16x8 po;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) po[i] = (__bf16)v[i];
+                const u32x4 pw = __builtin_bit_cast(u32x4, po);
+                const auto q0 = __builtin_amdgcn_permlane32_swap(pw.x, pw.z, false, false);
+                const auto q1 = __builtin_amdgcn_permlane32_swap(pw.y, pw.w, false, false);
+                const u32x4 pst = {q0[0], q1[0], q0[1], q1[1]};
+                const auto rs_p = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out_pre + (size_t)b * p.Mb * plane * 2), (short)0, p.Mb * plane16, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(pst, rs_p, vo[c][n] + cb * plane16, 0, 0);
               }
               if (has_ref) {
                 const bf16x4 r0 = __builtin_bit_cast(bf16x4, rf[REF ? mb : 0][gp][c][n][0]);
@@ -781,7 +793,7 @@ namespace {
 // One launcher for forward and data-gradient.  (K, M) are the GEMM contraction / output channel counts, (IH, IW) the
 // physical input dims, (OH, OW) the output dims, `a` the input step per output pixel; s2d = 1: parity-decomposed data
 // gradient of a stride-2 3x3 convolution (input = dy, output = dx, weights packed with mode 2).
-int launch_conv_bf16(const void* in, const void* packed, const float* bias, void* out, float* out_f32, const void* act_ref,
+int launch_conv_bf16(const void* in, const void* packed, const float* bias, void* out, float* out_f32, void* out_pre, const void* act_ref,
                      int ref_act, const float* chan_scale, float* stats_part, int B, int K, int M, int IH, int IW, int OH,
                      int OW, int ks, int a, int s2d, int act, hipStream_t stream, int* stats_rows, int* stats_mpad) {
   const int T = ks * ks, pad = ks == 3 ? 1 : 0;
@@ -825,7 +837,7 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
   if (in == nullptr) return YOGO_OK;  // shape query only
   ConvBf16Params p{};
   p.in = reinterpret_cast<const u32x4*>(in); p.wp = reinterpret_cast<const u32x4*>(packed); p.bias = bias;
-  p.out = reinterpret_cast<u32x2*>(out); p.out_f32 = out_f32;
+  p.out = reinterpret_cast<u32x2*>(out); p.out_f32 = out_f32; p.out_pre = reinterpret_cast<u32x2*>(out_pre);
   p.act_ref = reinterpret_cast<const u32x2*>(act_ref); p.ref_act = ref_act; p.chan_scale = chan_scale; p.stats_part = stats_part;
   p.B = B; p.Kb = Kb; p.M = M; p.Mpad = Mpad; p.Mb = bf_kb_of(M);
   p.IH = IH; p.IW = IW; p.OH = OH; p.OW = OW; p.T = T;
@@ -932,7 +944,7 @@ int check_bf16_conv(int B, int Cin, int Cout, int IH, int IW, int ks, int stride
 extern "C" int yogo_conv2d_fwd_bf16_stats_shape(int B, int Cin, int Cout, int IH, int IW, int ks, int stride, int* rows, int* mpad) {
   if (int e = check_bf16_conv(B, Cin, Cout, IH, IW, ks, stride)) return e;
   const int pad = ks == 3 ? 1 : 0;
-  return launch_conv_bf16(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, B, Cin, Cout, IH, IW,
+  return launch_conv_bf16(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, B, Cin, Cout, IH, IW,
                           (IH + 2 * pad - ks) / stride + 1, (IW + 2 * pad - ks) / stride + 1, ks, stride, 0, 0, nullptr, rows, mpad);
 }
 
@@ -944,7 +956,20 @@ extern "C" int yogo_conv2d_fwd_bf16(const void* in, const void* packed, const fl
   YOGO_CHECK_ARG(in && packed && (out || out_f32), "conv2d_fwd_bf16: null pointer");
   if (int e = check_bf16_conv(B, Cin, Cout, IH, IW, ks, stride)) return e;
   const int pad = ks == 3 ? 1 : 0;
-  return launch_conv_bf16(in, packed, bias, out, out_f32, nullptr, 0, chan_scale, stats_part, B, Cin, Cout, IH, IW,
+  return launch_conv_bf16(in, packed, bias, out, out_f32, nullptr, nullptr, 0, chan_scale, stats_part, B, Cin, Cout, IH, IW,
+                          (IH + 2 * pad - ks) / stride + 1, (IW + 2 * pad - ks) / stride + 1, ks, stride, 0, act, stream,
+                          nullptr, nullptr);
+}
+
+// the same with a second bf16 output `out_pre` = conv + bias before the activation (what the backward pass of a SiLU block
+// without BatchNorm needs: silu'(z) is a function of the pre-activation); bf16 NCHW8c outputs only
+extern "C" int yogo_conv2d_fwd_bf16_pre(const void* in, const void* packed, const float* bias, void* out, void* out_pre,
+                                        const float* chan_scale, int B, int Cin, int Cout, int IH, int IW, int ks, int stride,
+                                        int act, hipStream_t stream) {
+  YOGO_CHECK_ARG(in && packed && out && out_pre, "conv2d_fwd_bf16_pre: null pointer");
+  if (int e = check_bf16_conv(B, Cin, Cout, IH, IW, ks, stride)) return e;
+  const int pad = ks == 3 ? 1 : 0;
+  return launch_conv_bf16(in, packed, bias, out, nullptr, out_pre, nullptr, 0, chan_scale, nullptr, B, Cin, Cout, IH, IW,
                           (IH + 2 * pad - ks) / stride + 1, (IW + 2 * pad - ks) / stride + 1, ks, stride, 0, act, stream,
                           nullptr, nullptr);
 }
@@ -959,7 +984,7 @@ extern "C" int yogo_conv2d_dgrad_bf16(const void* dy, const void* packed_dgrad, 
   if (int e = check_bf16_conv(B, Cin, Cout, IH, IW, ks, stride)) return e;
   const int pad = ks == 3 ? 1 : 0;
   const int OHf = (IH + 2 * pad - ks) / stride + 1, OWf = (IW + 2 * pad - ks) / stride + 1;
-  return launch_conv_bf16(dy, packed_dgrad, nullptr, dx, nullptr, act_ref, ref_act, chan_scale, nullptr, B, Cout, Cin, OHf, OWf,
+  return launch_conv_bf16(dy, packed_dgrad, nullptr, dx, nullptr, nullptr, act_ref, ref_act, chan_scale, nullptr, B, Cout, Cin, OHf, OWf,
                           IH, IW, ks, 1, (stride == 2 && ks == 3) ? 1 : 0, ACT_NONE, stream, nullptr, nullptr);
 }
 

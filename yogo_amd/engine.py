@@ -383,8 +383,9 @@ def forward_bf16_train(eng: Engine, x: torch.Tensor) -> Tuple[torch.Tensor, List
             raise RuntimeError(f"yogo_amd: image too small at layer {i}")
         last = i == n - 1
         has_bn = L.bn is not None
-        if L.act == ACT_SILU and not has_bn:
-            raise RuntimeError("yogo_amd: bf16 training of SiLU blocks without BatchNorm is not implemented (use fp32)")
+        silu_pre = L.act == ACT_SILU and not has_bn   # silu'(z) needs the pre-activation: the conv writes it next to the output
+        if silu_pre and (i == 0 or last):
+            raise RuntimeError("yogo_amd: bf16 training of a first / last SiLU block without BatchNorm is not implemented (use fp32)")
         bias = _f32(L.conv.bias.detach()) if L.conv.bias is not None else None
         S = Saved(x_in=cur)
         mask = None
@@ -415,7 +416,11 @@ def forward_bf16_train(eng: Engine, x: torch.Tensor) -> Tuple[torch.Tensor, List
             nbytes = B * (_blocks(L.cin) * 8 * H * W * 2 + (L.cout * OH * OW * 4 if last else _blocks(L.cout) * 8 * OH * OW * 2))
             # mw tags the kernel variant for bench.py: 34 = conv_bf16_kernel<4,2,8,...> (128 output channels, stride 1)
             eng._tick("fwd", i, 2.0 * B * L.cout * L.cin * L.k * L.k * OH * OW, mw=34 if (L.cout > 64 and L.s == 1) else 30, nbytes=nbytes)
-            _hip.call("yogo_conv2d_fwd_bf16", cur, pk, bias, out8, out32, mask, stats, B, L.cin, L.cout, H, W, L.k, L.s, fused_act, st)
+            if silu_pre:
+                S.pre = torch.empty_like(out8)
+                _hip.call("yogo_conv2d_fwd_bf16_pre", cur, pk, bias, out8, S.pre, mask, B, L.cin, L.cout, H, W, L.k, L.s, fused_act, st)
+            else:
+                _hip.call("yogo_conv2d_fwd_bf16", cur, pk, bias, out8, out32, mask, stats, B, L.cin, L.cout, H, W, L.k, L.s, fused_act, st)
             eng._tock()
         if has_bn:
             bn = L.bn
@@ -554,9 +559,9 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
             if Lp.bn is not None or Lp.act == ACT_NONE:
                 act_ref, ref_act = None, ACT_NONE
             elif Lp.act == ACT_LEAKY:
-                act_ref = Sp.y
+                act_ref = Sp.y        # sign of the output = sign of the pre-activation
             else:
-                raise RuntimeError("yogo_amd: bf16 training of SiLU blocks without BatchNorm is not implemented (use fp32)")
+                act_ref = Sp.pre      # SiLU: the pre-activation saved by yogo_conv2d_fwd_bf16_pre
             dx = torch.empty(B, _blocks(L.cin), IH, IW, 8, dtype=torch.bfloat16, device=dev)
             pk = _packed_bf16(eng, i, 2 if (L.s == 2 and L.k == 3) else 1)
             nbytes = B * 2 * 8 * (_blocks(L.cout) * OH * OW + _blocks(L.cin) * IH * IW * (2 if act_ref is not None else 1))
