@@ -465,8 +465,10 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
       }
     // training dgrad into a block without BatchNorm: act'(ref).  All of this lane's reference values (8 bytes per group) are
     // requested up front so that their latency is paid once, behind the LDS hand-over above.
-    u32x2 rf[REF ? MW : 1][2][NC][NW][2];
-    if constexpr (has_ref) {
+    // (32-row tiles fetch them per channel-block pair instead: half the registers keep four workgroups on a CU)
+    constexpr bool RF_PER_GP = MW == 1;
+    u32x2 rf[REF ? MW : 1][RF_PER_GP ? 1 : 2][NC][NW][2];
+    if constexpr (has_ref && !RF_PER_GP) {
       const auto rs_r = __builtin_amdgcn_make_buffer_rsrc((void*)(p.act_ref + (size_t)b * p.Mb * plane * 2), (short)0, p.Mb * plane16, 0x00020000);
 #pragma unroll
       for (int mb = 0; mb < MW; ++mb)
@@ -480,8 +482,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
             for (int n = 0; n < NW; ++n) {
               const bool valid = c == 0 ? pvalid[n] : pvalid1[n];
               const int vr = valid ? (opix[n] + c) * 16 + half * 8 + cb * plane16 : (int)0x80000000u;
-              rf[REF ? mb : 0][gp][c][n][0] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_r, vr, 0, 0));
-              rf[REF ? mb : 0][gp][c][n][1] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_r, vr + plane16, 0, 0));
+              rf[REF ? mb : 0][RF_PER_GP ? 0 : gp][c][n][0] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_r, vr, 0, 0));
+              rf[REF ? mb : 0][RF_PER_GP ? 0 : gp][c][n][1] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_r, vr + plane16, 0, 0));
             }
         }
     }
@@ -491,6 +493,18 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
       for (int gp = 0; gp < 2; ++gp) {
         const int cb = (m0 >> 3) + mb * 4 + 2 * gp;  // channel block the lower half-wave stores (uniform); Mb is even
         if (cb >= p.Mb) continue;
+        if constexpr (has_ref && RF_PER_GP) {
+          const auto rs_r = __builtin_amdgcn_make_buffer_rsrc((void*)(p.act_ref + (size_t)b * p.Mb * plane * 2), (short)0, p.Mb * plane16, 0x00020000);
+#pragma unroll
+          for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int n = 0; n < NW; ++n) {
+              const bool valid = c == 0 ? pvalid[n] : pvalid1[n];
+              const int vr = valid ? (opix[n] + c) * 16 + half * 8 + cb * plane16 : (int)0x80000000u;
+              rf[0][0][c][n][0] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_r, vr, 0, 0));
+              rf[0][0][c][n][1] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_r, vr + plane16, 0, 0));
+            }
+        }
         const int cl = mb * 32 + 16 * gp + 4 * half;  // local channel of group A; group B = cl + 8
         const float4 bA = *reinterpret_cast<const float4*>(eb + cl), bB = *reinterpret_cast<const float4*>(eb + cl + 8);
         const float4 sA = *reinterpret_cast<const float4*>(es + cl), sB = *reinterpret_cast<const float4*>(es + cl + 8);
@@ -542,8 +556,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
                 __builtin_amdgcn_raw_buffer_store_b128(pst, rs_p, vo[c][n] + cb * plane16, 0, 0);
               }
               if (has_ref) {
-                const bf16x4 r0 = __builtin_bit_cast(bf16x4, rf[REF ? mb : 0][gp][c][n][0]);
-                const bf16x4 r1 = __builtin_bit_cast(bf16x4, rf[REF ? mb : 0][gp][c][n][1]);
+                const bf16x4 r0 = __builtin_bit_cast(bf16x4, rf[REF ? mb : 0][RF_PER_GP ? 0 : gp][c][n][0]);
+                const bf16x4 r1 = __builtin_bit_cast(bf16x4, rf[REF ? mb : 0][RF_PER_GP ? 0 : gp][c][n][1]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                   v[i] *= act_bwd_factor((float)r0[i], p.ref_act);
@@ -559,8 +573,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
 #pragma unroll
               for (int i = 0; i < 8; ++i) v[i] *= sa[i];
             } else if (has_ref) {  // LeakyReLU backward: factor = ref > 0 ? scale : 0.01 * scale
-              const bf16x4 r0 = __builtin_bit_cast(bf16x4, rf[REF ? mb : 0][gp][c][n][0]);
-              const bf16x4 r1 = __builtin_bit_cast(bf16x4, rf[REF ? mb : 0][gp][c][n][1]);
+              const bf16x4 r0 = __builtin_bit_cast(bf16x4, rf[REF ? mb : 0][RF_PER_GP ? 0 : gp][c][n][0]);
+              const bf16x4 r1 = __builtin_bit_cast(bf16x4, rf[REF ? mb : 0][RF_PER_GP ? 0 : gp][c][n][1]);
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
                 v[i] = (acc[c][mb][n][8 * gp + i] + ba[i]) * ((float)r0[i] > 0.f ? sa[i] : sl[i]);
