@@ -37,6 +37,7 @@ struct WgradBf16Params {
   int xw;                             // staged input columns per unit
   int units, units_per_split;
   int ngs, nxs, bufu;                 // g / x slots in use, 16-byte units per LDS buffer
+  int xcb;                            // channel blocks per pixel of the staged x image: 4, or 2 for 16-channel inputs
   int depth;                          // LDS buffers in the ring (2 or 3): units in flight ahead of the MFMAs = depth - 1
 };
 
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
   int glc[WGB_GSLOTS], xlc[WGB_XSLOTS];
   unsigned grc[WGB_GSLOTS], xrc[WGB_XSLOTS];
   {
-    const int gtot = MBW * 4 * R * p.wce, xtot = NBW * NPW * 4 * XR * p.xw;
+    const int gtot = MBW * 4 * R * p.wce, xtot = NBW * NPW * p.xcb * XR * p.xw;
 #pragma unroll
     for (int i = 0; i < WGB_GSLOTS; ++i) {
       const int e = tid + i * NT;
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
 #pragma unroll
     for (int i = 0; i < WGB_XSLOTS; ++i) {
       const int e = tid + i * NT;
-      const int cb3 = e & 3, pix = e >> 2;
+      const int pix = p.xcb == 4 ? e >> 2 : e >> 1, cb3 = e - pix * p.xcb;
       const int rr = pix / p.xw, c = pix - rr * p.xw;
       const int cbg = rr / XR, r = rr - cbg * XR;
       const int cb = n0b + cbg * 4 + cb3;
@@ -179,9 +180,11 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
   const int ksteps_row = p.wce >> 4;
   const int nsteps = R * ksteps_row;
   const int cnt = (nsteps - ks + KS - 1) / KS;
-  const int xblk = XR * p.xw * 64;                        // bytes of one 32-channel block of the x image
+  const int xpb = p.xcb * 16;                             // bytes per pixel of the x image (64, or 32 for 16-channel inputs)
+  const int xblk = XR * p.xw * xpb;                       // bytes of one channel-block group of the x image
   const int gbase = mb * (R * p.wce * 64) + lane_ch_off;
-  const int xbase = p.ngs * NT * 16 + nb * NPW * xblk + lane_ch_off;
+  // 16-channel image: the lanes of channels 16-31 re-read channels 0-15 (those output columns lie beyond N and are dropped)
+  const int xbase = p.ngs * NT * 16 + nb * NPW * xblk + (lane_ch_off & (xpb - 1));
 
 #define WB_LOAD(AV, BV, I)                                                                                      \
   {                                                                                                             \
@@ -192,8 +195,8 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
     AV = lds_tr8(buf, ga_, ga_ + 4 * 64);                                                                       \
     _Pragma("unroll") for (int q = 0; q < NPW; ++q)                                                             \
     _Pragma("unroll") for (int t = 0; t < TT; ++t) {                                                            \
-      const int xa_ = xbase + q * xblk + (((r_ * S + (T == 1 ? 0 : tg)) * p.xw) + px_ * S + t) * 64;            \
-      BV[q][t] = lds_tr8(buf, xa_, xa_ + 4 * S * 64);                                                           \
+      const int xa_ = xbase + q * xblk + (((r_ * S + (T == 1 ? 0 : tg)) * p.xw) + px_ * S + t) * xpb;           \
+      BV[q][t] = lds_tr8(buf, xa_, xa_ + 4 * S * xpb);                                                          \
     }                                                                                                           \
   }
 // bias gradient: the A operand already holds 8 pixels of "this lane's" output channel (padding pixels are zeros)
@@ -289,7 +292,7 @@ namespace {
 
 struct WbPlan {
   int MBW, NBW, NPW, KS, R, Mpad, Npad, nchunk_w, base_w, rem_w, wce, nrowg, xw, units, nsplit, units_per_split, ngs, nxs, bufu,
-      depth, lds_bytes;
+      depth, lds_bytes, xcb;
   dim3 grid;
 };
 
@@ -314,6 +317,8 @@ bool wb_plan(int B, int N, int M, int IH, int IW, int ks, int stride, WbPlan* pl
   const int TG = ks == 3 ? 3 : 1;
   const int NT = 64 * MBW * NBW * KS * TG;
   const int XR = ks == 3 ? (R - 1) * stride + 3 : R;
+  const int xcb = (NBW * NPW == 1 && N <= 16) ? 2 : 4;  // 16-channel inputs: 32-byte pixels in the staged image
+  pl->xcb = xcb;
   // column chunks: staged width a multiple of 16, at most 64; the widest that fits the slots and two LDS buffers, then the
   // count with the least zero padding
   bool found = false;
@@ -323,7 +328,7 @@ bool wb_plan(int B, int N, int M, int IH, int IW, int ks, int stride, WbPlan* pl
       const int w = round_up(cdiv(OW, nc), 16);
       if (w > wmax) continue;
       const int xw = (w - 1) * stride + (ks == 3 ? 3 : 1);
-      const int ngs = cdiv(MBW * 4 * R * w, NT), nxs = cdiv(NBW * NPW * 4 * XR * xw, NT);
+      const int ngs = cdiv(MBW * 4 * R * w, NT), nxs = cdiv(NBW * NPW * xcb * XR * xw, NT);
       const int bufu = (ngs + nxs) * NT;
       if (ngs > WGB_GSLOTS || nxs > WGB_XSLOTS || 2 * bufu * 16 > WGB_LDS_MAX) continue;
       const int waste = nc * w - OW;
@@ -396,7 +401,7 @@ extern "C" int yogo_conv2d_wgrad_bf16(const void* x, const void* g, float* dw, f
   p.IH = IH; p.IW = IW; p.OH = (IH + 2 * pad - ks) / stride + 1; p.OW = (IW + 2 * pad - ks) / stride + 1; p.pad = pad;
   p.nchunk_w = pl.nchunk_w; p.base_w = pl.base_w; p.rem_w = pl.rem_w; p.wce = pl.wce; p.nrowg = pl.nrowg;
   p.xw = pl.xw;
-  p.units = pl.units; p.units_per_split = pl.units_per_split; p.ngs = pl.ngs; p.nxs = pl.nxs; p.bufu = pl.bufu; p.depth = pl.depth;
+  p.units = pl.units; p.units_per_split = pl.units_per_split; p.ngs = pl.ngs; p.nxs = pl.nxs; p.bufu = pl.bufu; p.depth = pl.depth; p.xcb = pl.xcb;
   {
     static int verbose = -1;
     if (verbose < 0) verbose = getenv("YOGO_IGEMM_VERBOSE") ? 1 : 0;
