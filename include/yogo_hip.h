@@ -160,6 +160,8 @@ int yogo_conv_first_bn_wgrad_finalize(const float* sums, const float* mean, cons
 int yogo_bn_apply_act_bf16(const void* z, void* y, const float* mean, const float* invstd_or_var, int stat_is_var, float eps,
                            const float* gamma, const float* beta, int B, int C, int HW, int act, yogo_stream_t stream);
 int yogo_bn_bwd_bf16_rows(int B, int HW, int* rows);
+/* batch statistics of a stored bf16 NCHW8c tensor: part [rows][C][2] (rows = yogo_bn_bwd_bf16_rows), then yogo_bn_finalize */
+int yogo_bn_stats_bf16(const void* z, float* part, int B, int C, int HW, yogo_stream_t stream);
 int yogo_bn_bwd_bf16(const void* g, const void* z, void* dz, const float* mean, const float* invstd, const float* gamma,
                      const float* beta, int act, float* dgamma, float* dbeta, float* part, float* sums, int B, int C, int HW,
                      int training, float clip, yogo_stream_t stream);

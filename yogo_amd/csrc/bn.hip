@@ -353,6 +353,43 @@ __global__ __launch_bounds__(256) void bn_apply_act_8c_kernel(const u32x4_t* __r
   }
 }
 
+// batch statistics of a stored bf16 tensor: partial (sum, sum of squares) per channel, rows = B * gridDim.x
+__global__ __launch_bounds__(256) void bn_stats_8c_kernel(const u32x4_t* __restrict__ z, float* __restrict__ part, int C, int Cb,
+                                                          int HW) {
+  __shared__ float sh[4][16];
+  const int plane = blockIdx.y;
+  const int cb = plane % Cb, b = plane / Cb;
+  const u32x4_t* zp = z + (size_t)plane * HW;
+  float s[8], t[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = t[j] = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+    const bf16x8_t zv = __builtin_bit_cast(bf16x8_t, zp[i]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = (float)zv[j];
+      s[j] += v;
+      t[j] = fmaf(v, v, t[j]);
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float a = wave_sum(s[j]), c = wave_sum(t[j]);
+    if (lane == 0) {
+      sh[wave][2 * j] = a;
+      sh[wave][2 * j + 1] = c;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    const int j = threadIdx.x >> 1;
+    if (cb * 8 + j < C)
+      part[((size_t)(b * gridDim.x + blockIdx.x) * C + cb * 8 + j) * 2 + (threadIdx.x & 1)] =
+          sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+  }
+}
+
 // partial sums of g' and g' * xhat per channel, g' = g * act'(xhat*gamma + beta)
 __global__ __launch_bounds__(256) void bn_bwd_reduce_8c_kernel(const u32x4_t* __restrict__ g, const u32x4_t* __restrict__ z,
                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -500,6 +537,18 @@ extern "C" int yogo_bn_bwd_bf16(const void* g, const void* z, void* dz, const fl
   hipLaunchKernelGGL(bn_bwd_apply_8c_kernel, dim3(nb, B * Cb), dim3(256), 0, stream, g4, z4, reinterpret_cast<u32x4_t*>(dz), mean,
                      invstd, gamma, beta, act, sums, sums + C, 1.0f / ((float)B * (float)HW), training, C, Cb, HW);
   YOGO_CHECK_LAUNCH("bn_bwd_bf16");
+  return YOGO_OK;
+}
+
+// batch statistics of a bf16 NCHW8c tensor (the stored convolution output) as partial rows for yogo_bn_finalize:
+// part [rows][C][2] with rows from yogo_bn_bwd_bf16_rows(B, HW).  Cheaper than carrying the sums through the convolution's
+// epilogue when that epilogue is on the critical path of a one-workgroup-per-CU kernel.
+extern "C" int yogo_bn_stats_bf16(const void* z, float* part, int B, int C, int HW, hipStream_t stream) {
+  YOGO_CHECK_ARG(z && part && B > 0 && C > 0 && HW > 0, "bn_stats_bf16: bad arguments");
+  const int Cb = cb_of(C), nb = plane_blocks(HW, 4);
+  YOGO_CHECK_ARG(B * Cb <= 65535, "bn_stats_bf16: batch * channel blocks exceeds 65535");
+  hipLaunchKernelGGL(bn_stats_8c_kernel, dim3(nb, B * Cb), dim3(256), 0, stream, reinterpret_cast<const u32x4_t*>(z), part, C, Cb, HW);
+  YOGO_CHECK_LAUNCH("bn_stats_bf16");
   return YOGO_OK;
 }
 

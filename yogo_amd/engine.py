@@ -343,7 +343,10 @@ _WGRAD_BF16_MFMA = _os.environ.get("YOGO_WGRAD_BF16", "1") != "0"   # 0: fp32-MF
 # (measured: -2 % step time).  Off by default: with two kernels sharing the chip the per-kernel HIP-event / rocprofv3 durations
 # that bench.py's roofline is built from stop being attributable to one kernel.
 _WGRAD_SIDE_STREAM = _os.environ.get("YOGO_WGRAD_STREAM", "0") != "0"
-_FUSE_LAYER0_BWD = _os.environ.get("YOGO_FUSE_LAYER0_BWD", "1") != "0"   # 0: separate BatchNorm-backward + weight-gradient passes
+_FUSE_LAYER0_BWD = _os.environ.get("YOGO_FUSE_LAYER0_BWD", "1") != "0"
+# 1: BatchNorm batch statistics of layers > 0 come from a separate sweep over the stored bf16 output (0.08 ms per 128-channel
+# layer) instead of the convolution's epilogue, which sits on the critical path of a one-workgroup-per-CU kernel (0.14-0.2 ms)
+_BN_STATS_PASS = _os.environ.get("YOGO_BN_STATS_PASS", "1") != "0"   # 0: separate BatchNorm-backward + weight-gradient passes
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
 
@@ -397,7 +400,8 @@ def forward_bf16_train(eng: Engine, x: torch.Tensor) -> Tuple[torch.Tensor, List
         fused_act = ACT_NONE if has_bn else L.act
         stats = None
         rows = mpad = 0
-        if bn_train:
+        stats_pass = bn_train and i > 0 and _BN_STATS_PASS   # statistics by a separate sweep over the stored output
+        if bn_train and not stats_pass:
             if i == 0:
                 rows, mpad = _hip.query_ints("yogo_conv_first_stats_rows", 1, B, H, W, L.s)[0], L.cout
             else:
@@ -428,6 +432,10 @@ def forward_bf16_train(eng: Engine, x: torch.Tensor) -> Tuple[torch.Tensor, List
             beta = _f32(bn.bias.detach()) if bn.bias is not None else torch.zeros(L.cout, device=dev)
             y = torch.empty_like(out8)
             if bn_train:
+                if stats_pass:
+                    rows, mpad = _hip.query_ints("yogo_bn_bwd_bf16_rows", 1, B, OH * OW)[0], L.cout
+                    stats = torch.empty(rows * mpad * 2, dtype=torch.float32, device=dev)
+                    _hip.call("yogo_bn_stats_bf16", out8, stats, B, L.cout, OH * OW, st)
                 mean = torch.empty(L.cout, dtype=torch.float32, device=dev)
                 invstd = torch.empty(L.cout, dtype=torch.float32, device=dev)
                 track = bn.track_running_stats and bn.running_mean is not None
