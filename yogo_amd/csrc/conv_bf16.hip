@@ -44,6 +44,9 @@ struct ConvBf16Params {
   int IH, IW, OH, OW, a, T;
   int dy_min, dx_min, span_y, span_x;
   int ncb, TW, tiles_per_band;
+  // ceil(2^32 / d) for the divisors of the prologue (exact for n * d < 2^32): grid x, grid x*y, grid y, tiles per band, band
+  // width (full / last band), staged row length (full / last band)
+  unsigned m_gx, m_gxy, m_gy, m_tpb, m_bw, m_bwl, m_lw, m_lwl;
   int CKb, ckb_shift, nchunk, ldsw_off, lds_dummy;
   int act;
   // dma = 1: a chunk fits the kernel's PF slots and two LDS buffers -> chunk c+1 streams into the other buffer by LDS-DMA
@@ -66,6 +69,9 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 #undef DPP_ADD
   return v;
 }
+
+// n / d through the precomputed magic number m = ceil(2^32 / d) (d = 1: m does not fit, n is returned)
+__device__ __forceinline__ int udivm(int n, int d, unsigned m) { return d == 1 ? n : (int)__umulhi((unsigned)n, m); }
 
 // NWV wavefronts per workgroup, each owning NW 32-pixel groups x all MW channel blocks: NWV = 8 shares one staged weight
 // slice between 512 output pixels (the weight slice is the larger part of the LDS traffic at 128 channels).
@@ -95,9 +101,11 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
   const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
   const unsigned xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
   const unsigned widx = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
-  const int bx = widx % gridDim.x;
-  const int by = (widx / gridDim.x) % gridDim.y;
-  const int b = widx / (gridDim.x * gridDim.y);
+  const int gx = gridDim.x, gy = gridDim.y;
+  const int b = udivm((int)widx, gx * gy, p.m_gxy);
+  const int rem_ = (int)widx - b * gx * gy;
+  const int by = udivm(rem_, gx, p.m_gx);
+  const int bx = rem_ - by * gx;
   const int py = S2D ? (by & 1) : 0;
   const int m0 = (S2D ? (by >> 1) : by) * BM;
   // S2D tiles the quad grid of this row parity; everything else tiles the output
@@ -107,7 +115,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
   const int tbase = S2D ? 3 * py : 0;       // first weight slice
   const int ntap = S2D ? 3 + 3 * py : p.T;  // weight slices this workgroup uses
   const int n0tap = S2D ? 1 + py : ntap;    // ... of which belong to column parity 0
-  const int cb = bx / p.tiles_per_band;
+  const int cb = udivm(bx, p.tiles_per_band, p.m_tpb);
   const int tb = bx - cb * p.tiles_per_band;
   const int j0 = cb * p.TW;
   const int bw = min(p.TW, OWt - j0);
@@ -128,7 +136,9 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
     scale_reg = p.chan_scale != nullptr ? p.chan_scale[(size_t)b * p.M + m0 + tid] : 1.f;
   }
   const int p1 = min(p0 + PT, NPb);
-  const int i_lo = p0 / bw, i_hi = (p1 - 1) / bw;
+  const bool lastband = cb == p.ncb - 1;
+  const unsigned m_bw = lastband ? p.m_bwl : p.m_bw;
+  const int i_lo = udivm(p0, bw, m_bw), i_hi = udivm(p1 - 1, bw, m_bw);
   const int rows_in = (i_hi - i_lo) * p.a + span_y;
   const int iy0 = i_lo * p.a + p.dy_min;
   const int ix0 = j0 * p.a + p.dx_min;
@@ -141,7 +151,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
     const int pp = p0 + (wave * NW + n) * 32 + l31;
     pvalid[n] = pp < p1;
     const int pc = pvalid[n] ? pp : (p1 - 1);
-    const int i = pc / bw, j = pc - i * bw;
+    const int i = udivm(pc, bw, m_bw), j = pc - i * bw;
     boff[n] = ((i - i_lo) * p.a) * lw + j * p.a;
     if constexpr (S2D) {
       opix[n] = (2 * i + py) * p.OW + 2 * (j0 + j);
@@ -158,14 +168,12 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
   int b_vu[NW];
 #pragma unroll
   for (int n = 0; n < NW; ++n) b_vu[n] = boff[n] + half * ((i_hi - i_lo) * p.a + span_y) * lw;
-#pragma unroll
-  for (int c = 0; c < NC; ++c)
-#pragma unroll
-    for (int mb = 0; mb < MW; ++mb)
-#pragma unroll
-      for (int n = 0; n < NW; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[c][mb][n][r] = 0.f;
+// zeroed after the first chunk's DMA is on its way (the 128 moves then cost nothing)
+#define ACC_ZERO()                                                                  \
+  _Pragma("unroll") for (int c = 0; c < NC; ++c)                                    \
+  _Pragma("unroll") for (int mb = 0; mb < MW; ++mb)                                 \
+  _Pragma("unroll") for (int n = 0; n < NW; ++n)                                    \
+  _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[c][mb][n][r] = 0.f;
 
   const u32x4* inb = p.in + (size_t)b * p.Kb * p.IH * p.IW;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
@@ -182,8 +190,9 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
   // a branch-free correction
   const int per_kb = rows_in * lw;
   const int one_lw = lw == 1, one_perkb = per_kb == 1;
-  const unsigned inv_lw = one_lw ? 0xFFFFFFFFu : (unsigned)(((1ull << 32) + (unsigned)lw - 1ull) / (unsigned)lw);
-  const unsigned inv_perkb = one_perkb ? 0xFFFFFFFFu : (unsigned)(((1ull << 32) + (unsigned)per_kb - 1ull) / (unsigned)per_kb);
+  const unsigned inv_lw = one_lw ? 0xFFFFFFFFu : (lastband ? p.m_lwl : p.m_lw);
+  // 0xFFFFFFFF / d + 1 = ceil(2^32 / d) for every d > 1 (a 32-bit division; d | 2^32 included)
+  const unsigned inv_perkb = one_perkb ? 0xFFFFFFFFu : 0xFFFFFFFFu / (unsigned)per_kb + 1u;
   const int hk_shift = p.ckb_shift - 1;  // k-steps (16 channels) per tap and chunk = CKb / 2
   const int hk = 1 << hk_shift;
   // one chunk = CKb channel blocks of the input tile (rows_in x lw units, zero padded) followed by the weight slices
@@ -358,6 +367,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
     }                               \
   }
     DMA_ISSUE(0)
+    ACC_ZERO()
     for (int c = 0; c < p.nchunk; ++c) {
       // dma = 2 (at most two chunks): ONE buffer, the next chunk is fetched after the MFMAs -- half the LDS, so more
       // workgroups per CU cover each other's latencies, which matters more than overlap inside a workgroup that short
@@ -384,6 +394,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
 #undef BF_HOOK
 #define BF_HOOK()
   } else {
+    ACC_ZERO()
     for (int c = 0; c < p.nchunk; ++c) {
       const int kb0 = c * p.CKb;
       const u32x4* ldsI = smem4;
@@ -408,6 +419,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
 #undef BF_RUN
 #undef BF_INTERLEAVE
 #undef BF_COMPUTE
+#undef ACC_ZERO
 #undef BF_HOOK
 
   const unsigned long long t_epi = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -861,6 +873,14 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
     p.a = a; p.dy_min = -pad; p.dx_min = -pad; p.span_y = ks; p.span_x = ks;
   }
   p.ncb = tl.ncb; p.TW = tl.TW; p.tiles_per_band = tl.tiles_per_band;
+  {
+    auto magic = [](int d) -> unsigned { return d <= 1 ? 0xFFFFFFFFu : (unsigned)(((1ull << 32) + (unsigned)d - 1ull) / (unsigned)d); };
+    const int a_ = s2d ? 1 : a, span_ = s2d ? 2 : ks;
+    const int bw_last = OWt - (tl.ncb - 1) * tl.TW;
+    p.m_gx = magic((int)grid.x); p.m_gy = magic((int)grid.y); p.m_gxy = magic((int)(grid.x * grid.y)); p.m_tpb = magic(tl.tiles_per_band);
+    p.m_bw = magic(tl.TW); p.m_bwl = magic(bw_last);
+    p.m_lw = magic((tl.TW - 1) * a_ + span_); p.m_lwl = magic((bw_last - 1) * a_ + span_);
+  }
   p.CKb = tl.CKb; p.ckb_shift = tl.CKb == 8 ? 3 : (tl.CKb == 4 ? 2 : 1); p.nchunk = Kb / tl.CKb;
   p.ldsw_off = tl.ldsw_off; p.lds_dummy = tl.lds_dummy; p.act = act;
   p.dma = tl.dma; p.ni_slots = tl.ni_slots; p.n_slots = tl.n_slots; p.bufu = tl.bufu; p.bufs = tl.dma == 1 ? tl.bufu : 0;
