@@ -309,22 +309,38 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
     const int ni = p.ni_slots, ns = p.n_slots;
     const int wtotal = total - itotal;
     i32x16 voffv = {};  // the slot offsets: a register vector, so that a slot can also be picked at run time (relative indexing)
+    {
+      // input element tid + i*NT -> (channel block kc, tile row r, tile column x): slot 0 by division, every further slot by
+      // stepping (NT = skc*per_kb + sr*lw + sx) with two carries -- adds and compares instead of quarter-rate multiplies
+      const int skc = (int)__umulhi((unsigned)NT, inv_perkb) + one_perkb;  // NT != 0
+      const int srm = NT - skc * per_kb;
+      const int sr = (int)__umulhi((unsigned)srm, inv_lw) + (one_lw & (srm != 0));
+      const int sx = srm - sr * lw;
+      int kc_ = (int)__umulhi((unsigned)tid, inv_perkb) + (one_perkb & (tid != 0));
+      const int rm0 = tid - kc_ * per_kb;
+      int r_ = (int)__umulhi((unsigned)rm0, inv_lw) + (one_lw & (rm0 != 0));
+      int x_ = rm0 - r_ * lw;
+      const int rowb = p.IW * 16, kcb = p.IH * p.IW * 16;
 #pragma unroll
-    for (int i = 0; i < PF; ++i) {
-      const int e = tid + i * NT;
-      const int ei_ = min(e, itotal - 1);
-      const int kc_ = (int)__umulhi((unsigned)ei_, inv_perkb) + (one_perkb & (ei_ != 0));
-      const int rm_ = ei_ - kc_ * per_kb;
-      const int r_ = (int)__umulhi((unsigned)rm_, inv_lw) + (one_lw & (rm_ != 0));
-      const int x_ = rm_ - r_ * lw;
-      const int iy_ = iy0 + r_, ix_ = ix0 + x_;
-      const bool iok = (e < itotal) && (iy_ >= 0) && (iy_ < p.IH) && (ix_ >= 0) && (ix_ < p.IW);
-      const int w_ = e - ni * NT;
-      const bool wok = (w_ >= 0) && (w_ < wtotal);
-      const int R_ = w_ >> BM_SHIFT;
-      const int wi_ = ((tbase + (R_ >> p.ckb_shift)) * p.Kb + (R_ & (p.CKb - 1))) * p.Mpad + m0 + (w_ & (BM - 1));
-      const int ii_ = (kc_ * p.IH + iy_) * p.IW + ix_;
-      voffv[i] = (i >= ni) ? (wok ? wi_ * 16 : (int)OOB) : (iok ? ii_ * 16 : (int)OOB);
+      for (int i = 0; i < PF; ++i) {
+        const int e = tid + i * NT;
+        if (i < ni) {  // uniform
+          const int iy_ = iy0 + r_, ix_ = ix0 + x_;
+          const bool iok = (e < itotal) && (iy_ >= 0) && (iy_ < p.IH) && (ix_ >= 0) && (ix_ < p.IW);
+          voffv[i] = iok ? kc_ * kcb + iy_ * rowb + ix_ * 16 : (int)OOB;
+          x_ += sx;
+          r_ += sr;
+          kc_ += skc;
+          if (x_ >= lw) { x_ -= lw; ++r_; }
+          if (r_ >= rows_in) { r_ -= rows_in; ++kc_; }
+        } else {
+          const int w_ = e - ni * NT;
+          const bool wok = w_ < wtotal;
+          const int R_ = w_ >> BM_SHIFT;
+          const int wi_ = ((tbase + (R_ >> p.ckb_shift)) * p.Kb + (R_ & (p.CKb - 1))) * p.Mpad + m0 + (w_ & (BM - 1));
+          voffv[i] = wok ? wi_ * 16 : (int)OOB;
+        }
+      }
     }
     const int ibytes = p.Kb * p.IH * p.IW * 16, wbytes = p.T * p.Kb * p.Mpad * 16;
     const int so_i = p.CKb * p.IH * p.IW * 16, so_w = p.CKb * p.Mpad * 16;
