@@ -128,6 +128,19 @@ int yogo_conv2d_fwd_bf16(const void* in, const void* packed, const float* bias, 
 int yogo_conv2d_fwd_bf16_pre(const void* in, const void* packed, const float* bias, void* out, void* out_pre,
                              const float* chan_scale, int B, int Cin, int Cout, int IH, int IW, int ksize, int stride, int act,
                              yogo_stream_t stream);
+/* LeakyReLU sign map of a bf16 NCHW8c tensor: [B][2][H][W][Cpad/16] bytes (Cpad = C rounded up to 32 / 64 / a multiple of 128
+ * for C <= 32 / <= 64 / more); byte (h, pixel, q), bit i + 4e = (channel 4h + i of channel block 2q + e > 0), h, e in {0, 1},
+ * i < 4; bytes of channel blocks beyond kb(C) are unspecified -- all the data gradient needs of a LeakyReLU block's output (torch's
+ * leaky_relu_backward reads the whole tensor), at 1/16 of its bytes */
+int yogo_bf16_signs_bytes(int B, int C, int H, int W, size_t* bytes);
+/* yogo_conv2d_fwd_bf16 (bf16 output) that also writes the sign map of its output */
+int yogo_conv2d_fwd_bf16_signs(const void* in, const void* packed, const float* bias, void* out, void* signs,
+                               const float* chan_scale, int B, int Cin, int Cout, int IH, int IW, int ksize, int stride, int act,
+                               yogo_stream_t stream);
+/* yogo_conv2d_dgrad_bf16 for a LeakyReLU reference given as its sign map: dx = conv_transpose(dy) * (bit ? 1 : 0.01) * chan_scale */
+int yogo_conv2d_dgrad_bf16_signs(const void* dy, const void* packed_dgrad, void* dx, const void* signs,
+                                 const float* chan_scale, int B, int Cin, int Cout, int IH, int IW, int ksize, int stride,
+                                 yogo_stream_t stream);
 /* dx = conv_transpose(dy) * act'(act_ref) * chan_scale, everything bf16 NCHW8c; (IH, IW) = forward INPUT dims */
 int yogo_conv2d_dgrad_bf16(const void* dy, const void* packed_dgrad, void* dx, const void* act_ref, int ref_act,
                            const float* chan_scale, int B, int Cin, int Cout, int IH, int IW, int ksize, int stride,

@@ -38,6 +38,24 @@ def bf(t):
     return t.to(torch.bfloat16).float()
 
 
+def sign_map(y8, C):
+    """include/yogo_hip.h, yogo_bf16_signs_bytes: [B][2][H][W][Cpad/16] bytes; byte (h, pixel, q), bit i + 4e = (channel 4h + i of
+    channel block 2q + e > 0)"""
+    B, Mb, Hh, W, _ = y8.shape
+    cpad = 32 if C <= 32 else (64 if C <= 64 else (C + 127) // 128 * 128)
+    pos = torch.zeros(B, cpad // 8, Hh, W, 8, dtype=torch.int64)
+    pos[:, :Mb] = (y8 > 0)
+    pos = pos.view(B, cpad // 16, 2, Hh, W, 2, 4).permute(0, 5, 3, 4, 1, 2, 6)   # [B][h][H][W][q][e][i]
+    wts = torch.tensor([[1, 2, 4, 8], [16, 32, 64, 128]])
+    return (pos * wts).sum((-1, -2)).to(torch.uint8).reshape(-1)
+
+
+def sign_bytes_used(t, C):
+    """the bytes of a sign map that belong to existing channel blocks (bytes of padding blocks are unspecified)"""
+    cpad = 32 if C <= 32 else (64 if C <= 64 else (C + 127) // 128 * 128)
+    return t.view(-1, cpad // 16)[:, : (C + 15) // 16]
+
+
 def test_layout_round_trip():
     g = torch.Generator().manual_seed(0)
     x = torch.randn(2, 12, 7, 9, generator=g)
@@ -104,6 +122,18 @@ def test_conv_bf16_fwd_dgrad_wgrad(case):
     h.call("yogo_conv2d_dgrad_bf16", gy8, pd, dx, to8c(refy), 1, cmask.cuda(), B, Cin, Cout, IH, IW, k, s, st)
     want = x.grad * torch.where(refy > 0, 1.0, 0.01) * cmask[:, :, None, None]
     assert rel_err(from8c(dx, Cin), want) < 8e-3, case
+    # LeakyReLU reference as a sign map: the forward writes it next to the (unchanged) output, the data gradient reads it in
+    # place of the reference tensor -- both bit-identical to the bf16-reference route
+    out_s = torch.full_like(out, float("nan"))
+    sg = torch.full((h.query_size("yogo_bf16_signs_bytes", B, Cout, OH, OW),), 0xA5, dtype=torch.uint8, device="cuda")
+    h.call("yogo_conv2d_fwd_bf16_signs", x8, packed, b.detach().cuda(), out_s, sg, mask.cuda(), B, Cin, Cout, IH, IW, k, s, 1, st)
+    out_p = torch.full_like(out, float("nan"))   # (the launch above took the order of operations of the BatchNorm sums)
+    h.call("yogo_conv2d_fwd_bf16", x8, packed, b.detach().cuda(), out_p, None, mask.cuda(), None, B, Cin, Cout, IH, IW, k, s, 1, st)
+    assert torch.equal(out_s.view(torch.int16), out_p.view(torch.int16)), case
+    assert torch.equal(sign_bytes_used(sg.cpu(), Cout), sign_bytes_used(sign_map(out_p.cpu().float(), Cout), Cout)), case
+    dx_ref = dx.clone()
+    h.call("yogo_conv2d_dgrad_bf16_signs", gy8, pd, dx, sign_map(to8c(refy).cpu().float(), Cin).cuda(), cmask.cuda(), B, Cin, Cout, IH, IW, k, s, st)
+    assert torch.equal(dx.view(torch.int16), dx_ref.view(torch.int16)), case
     # wgrad from bf16 inputs is exact fp32 MFMA on the widened values
     ws = torch.empty(h.query_size("yogo_conv2d_wgrad_workspace_bytes", B, Cin, Cout, IH, IW, k, s) // 4, device="cuda")
     dw = torch.full((Cout, Cin, k, k), float("nan"), device="cuda")

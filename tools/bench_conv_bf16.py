@@ -1,6 +1,7 @@
 """micro-benchmark of single bf16 conv launches (experiments; not part of the product).
 usage: bench_conv_bf16.py [B] [which]   which = comma list of layer names (l1..l7) x kind (f = fwd with BatchNorm sums, a = fwd with bias + leaky + channel mask,
-d = dgrad, r = dgrad with act'(ref) and channel mask), e.g. l5f,l4r"""
+s = as a plus the sign map, d = dgrad, r = dgrad with act'(ref) and channel mask, m = as r with the sign map as reference),
+e.g. l5f,l4r"""
 import os
 import sys
 
@@ -25,10 +26,21 @@ def bench(name, B, Cin, Cout, IH, IW, k, s, kind, reps=10):
     w = torch.randn(Cout, Cin, k, k, device="cuda") * 0.05
     x8 = torch.randn(B, blocks(Cin), IH, IW, 8, device="cuda").to(torch.bfloat16)
     y8 = torch.randn(B, blocks(Cout), OH, OW, 8, device="cuda").to(torch.bfloat16)
-    mode = 0 if kind in "fa" else (2 if (s == 2 and k == 3) else 1)
+    mode = 0 if kind in "fas" else (2 if (s == 2 and k == 3) else 1)
     packed = torch.empty(H.query_size("yogo_conv_bf16_packed_bytes", Cin, Cout, k, mode), dtype=torch.uint8, device="cuda")
     H.call("yogo_conv_bf16_pack", w, None, packed, Cin, Cout, k, mode, st)
-    if kind in "fa":
+    if kind == "s":
+        bias = torch.randn(Cout, device="cuda")
+        msk = (torch.rand(B, Cout, device="cuda") > 0.1).float()
+        sg = torch.empty(H.query_size("yogo_bf16_signs_bytes", B, Cout, OH, OW), dtype=torch.uint8, device="cuda")
+        f = lambda: H.call("yogo_conv2d_fwd_bf16_signs", x8, packed, bias, y8, sg, msk, B, Cin, Cout, IH, IW, k, s, 1, st)
+        nbytes = B * (16 * blocks(Cin) * IH * IW + 17 * blocks(Cout) * OH * OW)
+    elif kind == "m":
+        sg = torch.randint(0, 256, (H.query_size("yogo_bf16_signs_bytes", B, Cin, IH, IW),), dtype=torch.uint8, device="cuda")
+        msk = (torch.rand(B, Cin, device="cuda") > 0.1).float()
+        f = lambda: H.call("yogo_conv2d_dgrad_bf16_signs", y8, packed, x8, sg, msk, B, Cin, Cout, IH, IW, k, s, st)
+        nbytes = B * (17 * blocks(Cin) * IH * IW + 16 * blocks(Cout) * OH * OW)
+    elif kind in "fa":
         rows, mpad = H.query_ints("yogo_conv2d_fwd_bf16_stats_shape", 2, B, Cin, Cout, IH, IW, k, s)
         stats = torch.empty(rows * mpad * 2, device="cuda")
         bias = torch.randn(Cout, device="cuda")

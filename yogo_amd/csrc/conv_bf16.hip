@@ -37,6 +37,10 @@ struct ConvBf16Params {
   float* out_f32;     // when set: fp32 NCHW [B][M][OH][OW] instead of `out`
   u32x2* out_pre;     // optional second bf16 output: conv + bias BEFORE the activation (SiLU blocks keep it for backward)
   const u32x2* act_ref;     // training dgrad: multiply by act'(ref); ref = bf16 tensor shaped like `out` (8-byte halves)
+  // sign map of a LeakyReLU block's output, [B][2][OH][OW][Mpad/16] bytes in the epilogue's lane order: byte (h, pixel, q),
+  // bit i + 4e = (channel 4h + i of channel block 2q + e > 0), h, e in {0, 1}, i < 4.  The forward pass writes it (REF = 3), the data gradient reads it in place of act_ref
+  // (REF = 2): 1/16 of the bytes of the bf16 reference.
+  unsigned char* signs;
   const float* chan_scale;  // optional [B][M] Dropout2d channel mask (already scaled)
   float* stats_part;        // optional BatchNorm partial sums [B*gridDim.x][Mpad][2] of the fp32 pre-activation
   int ref_act;
@@ -85,7 +89,7 @@ __device__ __forceinline__ int udivm(int n, int d, unsigned m) { return d == 1 ?
 // PF: slots (16-byte elements per lane and chunk) of the LDS-DMA pipeline.  When a chunk fits (p.dma) the kernel runs
 //   barrier -> issue DMA(c+1 -> buffer (c+1)&1) -> MFMA(c from buffer c&1): one barrier per chunk, no staging registers, no
 //   ds_write, no vector-ALU address work inside the loop (every lane's source offsets are decoded once per workgroup).
-template <int MW, int NW, int NWV, bool S2D, int PF, bool OUT_F32, bool REF>
+template <int MW, int NW, int NWV, bool S2D, int PF, bool OUT_F32, int REF>
 __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Params p) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem4[];
   constexpr int BM = 32 * MW;
@@ -449,6 +453,37 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
   float* eb = reinterpret_cast<float*>(smem4);  // [BM] bias
   float* es = eb + BM;                          // [BM] channel scale (0 for padding channels)
   float* red = es + BM;                         // [NWV waves][BM][2]
+  // sign-map reference: this lane's bytes of a pixel (one per 16 channels of the tile) are contiguous -- one load per pixel,
+  // requested before the LDS hand-over so that the barriers hide its latency
+  constexpr int SW = MW == 4 ? 2 : 1;  // dwords holding the 2 * MW sign bytes of a pixel
+  const int sq = p.Mpad >> 4;          // sign bytes per (pixel, half-wave)
+  unsigned sg[(REF == 2 || REF == 3) ? NC : 1][NW][SW];
+  if constexpr (REF == 2) {
+    const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)(p.signs + (size_t)b * plane * 2 * sq), (short)0, (int)plane * 2 * sq, 0x00020000);
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int n = 0; n < NW; ++n) {
+        const bool valid = c == 0 ? pvalid[n] : pvalid1[n];
+        const int vs = valid ? (half * (int)plane + opix[n] + c) * sq + (m0 >> 4) : (int)0x80000000u;
+        if constexpr (MW == 4) {
+          const u32x2 t = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_s, vs, 0, 0));
+          sg[c][n][0] = t.x;
+          sg[c][n][SW - 1] = t.y;
+        } else if constexpr (MW == 2) {
+          sg[c][n][0] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs_s, vs, 0, 0);
+        } else {
+          sg[c][n][0] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs_s, vs, 0, 0);
+        }
+      }
+  } else if constexpr (REF == 3) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int n = 0; n < NW; ++n)
+#pragma unroll
+        for (int k = 0; k < SW; ++k) sg[c][n][k] = 0u;
+  }
   __syncthreads();  // the staged tiles are dead
   if (tid < BM) {
     eb[tid] = bias_reg;
@@ -480,7 +515,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
     }
   } else {
     const bool full_tile = p1 - p0 == PT;  // uniform
-    constexpr bool has_ref = REF;  // act'(ref) epilogue (training data gradient into a block without BatchNorm)
+    constexpr bool has_ref = REF == 1 || REF == 2;  // act'(ref) epilogue (training data gradient into a block without BatchNorm)
+    constexpr bool sign_ref = REF == 2;  // ... with the LeakyReLU sign map in place of the bf16 reference
     const int plane16 = (int)plane * 16;
     const auto rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (size_t)b * p.Mb * plane * 2), (short)0, p.Mb * plane16, 0x00020000);
     int vo[NC][NW];  // byte offset of this lane's unit inside its image: lanes 32-63 write the next channel block
@@ -495,8 +531,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
     // requested up front so that their latency is paid once, behind the LDS hand-over above.
     // (32-row tiles fetch them per channel-block pair instead: half the registers keep four workgroups on a CU)
     constexpr bool RF_PER_GP = MW == 1;
-    u32x2 rf[REF ? MW : 1][RF_PER_GP ? 1 : 2][NC][NW][2];
-    if constexpr (has_ref && !RF_PER_GP) {
+    u32x2 rf[REF == 1 ? MW : 1][RF_PER_GP ? 1 : 2][NC][NW][2];
+    if constexpr (REF == 1 && !RF_PER_GP) {
       const auto rs_r = __builtin_amdgcn_make_buffer_rsrc((void*)(p.act_ref + (size_t)b * p.Mb * plane * 2), (short)0, p.Mb * plane16, 0x00020000);
 #pragma unroll
       for (int mb = 0; mb < MW; ++mb)
@@ -510,8 +546,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
             for (int n = 0; n < NW; ++n) {
               const bool valid = c == 0 ? pvalid[n] : pvalid1[n];
               const int vr = valid ? (opix[n] + c) * 16 + half * 8 + cb * plane16 : (int)0x80000000u;
-              rf[REF ? mb : 0][RF_PER_GP ? 0 : gp][c][n][0] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_r, vr, 0, 0));
-              rf[REF ? mb : 0][RF_PER_GP ? 0 : gp][c][n][1] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_r, vr + plane16, 0, 0));
+              rf[REF == 1 ? mb : 0][RF_PER_GP ? 0 : gp][c][n][0] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_r, vr, 0, 0));
+              rf[REF == 1 ? mb : 0][RF_PER_GP ? 0 : gp][c][n][1] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_r, vr + plane16, 0, 0));
             }
         }
     }
@@ -521,7 +557,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
       for (int gp = 0; gp < 2; ++gp) {
         const int cb = (m0 >> 3) + mb * 4 + 2 * gp;  // channel block the lower half-wave stores (uniform); Mb is even
         if (cb >= p.Mb) continue;
-        if constexpr (has_ref && RF_PER_GP) {
+        if constexpr (REF == 1 && RF_PER_GP) {
           const auto rs_r = __builtin_amdgcn_make_buffer_rsrc((void*)(p.act_ref + (size_t)b * p.Mb * plane * 2), (short)0, p.Mb * plane16, 0x00020000);
 #pragma unroll
           for (int c = 0; c < NC; ++c)
@@ -583,9 +619,16 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
                 const auto rs_p = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out_pre + (size_t)b * p.Mb * plane * 2), (short)0, p.Mb * plane16, 0x00020000);
                 __builtin_amdgcn_raw_buffer_store_b128(pst, rs_p, vo[c][n] + cb * plane16, 0, 0);
               }
-              if (has_ref) {
-                const bf16x4 r0 = __builtin_bit_cast(bf16x4, rf[REF ? mb : 0][RF_PER_GP ? 0 : gp][c][n][0]);
-                const bf16x4 r1 = __builtin_bit_cast(bf16x4, rf[REF ? mb : 0][RF_PER_GP ? 0 : gp][c][n][1]);
+              if constexpr (sign_ref) {  // (the launcher only takes the sign map for LeakyReLU)
+                const unsigned m = sg[sign_ref ? c : 0][n][(mb * 2 + gp) >> 2] >> (8 * ((mb * 2 + gp) & 3));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  v[i] *= (m >> i) & 1u ? 1.f : LEAKY_SLOPE;
+                  v[4 + i] *= (m >> (4 + i)) & 1u ? 1.f : LEAKY_SLOPE;
+                }
+              } else if (has_ref) {
+                const bf16x4 r0 = __builtin_bit_cast(bf16x4, rf[REF == 1 ? mb : 0][RF_PER_GP ? 0 : gp][c][n][0]);
+                const bf16x4 r1 = __builtin_bit_cast(bf16x4, rf[REF == 1 ? mb : 0][RF_PER_GP ? 0 : gp][c][n][1]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                   v[i] *= act_bwd_factor((float)r0[i], p.ref_act);
@@ -600,9 +643,16 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
               }
 #pragma unroll
               for (int i = 0; i < 8; ++i) v[i] *= sa[i];
+            } else if constexpr (sign_ref) {  // LeakyReLU backward from the sign map
+              const unsigned m = sg[sign_ref ? c : 0][n][(mb * 2 + gp) >> 2] >> (8 * ((mb * 2 + gp) & 3));
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                v[i] = (acc[c][mb][n][8 * gp + i] + ba[i]) * ((m >> i) & 1u ? sa[i] : sl[i]);
+                v[4 + i] = (acc[c][mb][n][8 * gp + 4 + i] + ba[4 + i]) * ((m >> (4 + i)) & 1u ? sa[4 + i] : sl[4 + i]);
+              }
             } else if (has_ref) {  // LeakyReLU backward: factor = ref > 0 ? scale : 0.01 * scale
-              const bf16x4 r0 = __builtin_bit_cast(bf16x4, rf[REF ? mb : 0][RF_PER_GP ? 0 : gp][c][n][0]);
-              const bf16x4 r1 = __builtin_bit_cast(bf16x4, rf[REF ? mb : 0][RF_PER_GP ? 0 : gp][c][n][1]);
+              const bf16x4 r0 = __builtin_bit_cast(bf16x4, rf[REF == 1 ? mb : 0][RF_PER_GP ? 0 : gp][c][n][0]);
+              const bf16x4 r1 = __builtin_bit_cast(bf16x4, rf[REF == 1 ? mb : 0][RF_PER_GP ? 0 : gp][c][n][1]);
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
                 v[i] = (acc[c][mb][n][8 * gp + i] + ba[i]) * ((float)r0[i] > 0.f ? sa[i] : sl[i]);
@@ -614,6 +664,23 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
               if (p.act == ACT_LEAKY) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], LEAKY_SLOPE * v[i]);
+              }
+            }
+            if constexpr (REF == 3) {  // forward of a LeakyReLU block: the sign map the data gradient will read
+              unsigned mA = 0, mB = 0;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                mA |= (v[i] > 0.f ? 1u : 0u) << i;
+                mB |= (v[4 + i] > 0.f ? 1u : 0u) << i;
+              }
+              // one byte = this lane's 4 + 4 signs BEFORE the half-wave exchange of the data below: the data gradient's lanes
+              // hold the same channels
+              if constexpr (MW == 1) {  // (32-channel tiles: two byte stores instead of NW more live registers)
+                const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)(p.signs + (size_t)b * plane * 2 * sq), (short)0, (int)plane * 2 * sq, 0x00020000);
+                const int vs = vo[c][n] < 0 ? (int)0x80000000u : (vo[c][n] >> 4) * sq + (m0 >> 4) + gp;
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(mA | (mB << 4)), rs_s, vs, 0, 0);
+              } else {
+                sg[c][n][(mb * 2 + gp) >> 2] |= (mA | (mB << 4)) << (8 * ((mb * 2 + gp) & 3));
               }
             }
             bf16x8 o;
@@ -648,6 +715,21 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
           }
         }
       }
+    }
+    if constexpr (REF == 3 && MW > 1) {  // the sign bytes of a pixel go out together
+      const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)(p.signs + (size_t)b * plane * 2 * sq), (short)0, (int)plane * 2 * sq, 0x00020000);
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+          const int vs = vo[c][n] < 0 ? (int)0x80000000u : (vo[c][n] >> 4) * sq + (m0 >> 4);
+          if constexpr (MW == 4) {
+            const u32x2 t = {sg[c][n][0], sg[c][n][SW - 1]};
+            __builtin_amdgcn_raw_buffer_store_b64(t, rs_s, vs, 0, 0);
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b32(sg[c][n][0], rs_s, vs, 0, 0);
+          }
+        }
     }
   }
   if (do_stats) {
@@ -836,7 +918,7 @@ namespace {
 // physical input dims, (OH, OW) the output dims, `a` the input step per output pixel; s2d = 1: parity-decomposed data
 // gradient of a stride-2 3x3 convolution (input = dy, output = dx, weights packed with mode 2).
 int launch_conv_bf16(const void* in, const void* packed, const float* bias, void* out, float* out_f32, void* out_pre, const void* act_ref,
-                     int ref_act, const float* chan_scale, float* stats_part, int B, int K, int M, int IH, int IW, int OH,
+                     int ref_act, void* signs, bool signs_read, const float* chan_scale, float* stats_part, int B, int K, int M, int IH, int IW, int OH,
                      int OW, int ks, int a, int s2d, int act, hipStream_t stream, int* stats_rows, int* stats_mpad) {
   const int T = ks * ks, pad = ks == 3 ? 1 : 0;
   const int MW = bf_pick_mw(M);
@@ -880,7 +962,7 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
   ConvBf16Params p{};
   p.in = reinterpret_cast<const u32x4*>(in); p.wp = reinterpret_cast<const u32x4*>(packed); p.bias = bias;
   p.out = reinterpret_cast<u32x2*>(out); p.out_f32 = out_f32; p.out_pre = reinterpret_cast<u32x2*>(out_pre);
-  p.act_ref = reinterpret_cast<const u32x2*>(act_ref); p.ref_act = ref_act; p.chan_scale = chan_scale; p.stats_part = stats_part;
+  p.act_ref = reinterpret_cast<const u32x2*>(act_ref); p.ref_act = ref_act; p.signs = reinterpret_cast<unsigned char*>(signs); p.chan_scale = chan_scale; p.stats_part = stats_part;
   p.B = B; p.Kb = Kb; p.M = M; p.Mpad = Mpad; p.Mb = bf_kb_of(M);
   p.IH = IH; p.IW = IW; p.OH = OH; p.OW = OW; p.T = T;
   if (s2d) {
@@ -938,8 +1020,10 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
   } while (0)
 #define BFLAUNCH_(MW_, NW_, NWV_, S2D_, PF_, F32_)                             \
   do {                                                                         \
-    if (act_ref != nullptr) BFLAUNCH__(MW_, NW_, NWV_, S2D_, PF_, false, true); \
-    else BFLAUNCH__(MW_, NW_, NWV_, S2D_, PF_, F32_, false);                   \
+    if (act_ref != nullptr) BFLAUNCH__(MW_, NW_, NWV_, S2D_, PF_, false, 1);   \
+    else if (signs_read) BFLAUNCH__(MW_, NW_, NWV_, S2D_, PF_, false, 2);      \
+    else if (signs != nullptr) BFLAUNCH__(MW_, NW_, NWV_, S2D_, PF_, false, 3); \
+    else BFLAUNCH__(MW_, NW_, NWV_, S2D_, PF_, F32_, 0);                       \
   } while (0)
 #define BFLAUNCH(MW_, NW_, NWV_, S2D_, PF_)                                    \
   do {                                                                         \
@@ -994,7 +1078,7 @@ int check_bf16_conv(int B, int Cin, int Cout, int IH, int IW, int ks, int stride
 extern "C" int yogo_conv2d_fwd_bf16_stats_shape(int B, int Cin, int Cout, int IH, int IW, int ks, int stride, int* rows, int* mpad) {
   if (int e = check_bf16_conv(B, Cin, Cout, IH, IW, ks, stride)) return e;
   const int pad = ks == 3 ? 1 : 0;
-  return launch_conv_bf16(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, B, Cin, Cout, IH, IW,
+  return launch_conv_bf16(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, false, nullptr, nullptr, B, Cin, Cout, IH, IW,
                           (IH + 2 * pad - ks) / stride + 1, (IW + 2 * pad - ks) / stride + 1, ks, stride, 0, 0, nullptr, rows, mpad);
 }
 
@@ -1006,7 +1090,7 @@ extern "C" int yogo_conv2d_fwd_bf16(const void* in, const void* packed, const fl
   YOGO_CHECK_ARG(in && packed && (out || out_f32), "conv2d_fwd_bf16: null pointer");
   if (int e = check_bf16_conv(B, Cin, Cout, IH, IW, ks, stride)) return e;
   const int pad = ks == 3 ? 1 : 0;
-  return launch_conv_bf16(in, packed, bias, out, out_f32, nullptr, nullptr, 0, chan_scale, stats_part, B, Cin, Cout, IH, IW,
+  return launch_conv_bf16(in, packed, bias, out, out_f32, nullptr, nullptr, 0, nullptr, false, chan_scale, stats_part, B, Cin, Cout, IH, IW,
                           (IH + 2 * pad - ks) / stride + 1, (IW + 2 * pad - ks) / stride + 1, ks, stride, 0, act, stream,
                           nullptr, nullptr);
 }
@@ -1019,9 +1103,45 @@ extern "C" int yogo_conv2d_fwd_bf16_pre(const void* in, const void* packed, cons
   YOGO_CHECK_ARG(in && packed && out && out_pre, "conv2d_fwd_bf16_pre: null pointer");
   if (int e = check_bf16_conv(B, Cin, Cout, IH, IW, ks, stride)) return e;
   const int pad = ks == 3 ? 1 : 0;
-  return launch_conv_bf16(in, packed, bias, out, nullptr, out_pre, nullptr, 0, chan_scale, nullptr, B, Cin, Cout, IH, IW,
+  return launch_conv_bf16(in, packed, bias, out, nullptr, out_pre, nullptr, 0, nullptr, false, chan_scale, nullptr, B, Cin, Cout, IH, IW,
                           (IH + 2 * pad - ks) / stride + 1, (IW + 2 * pad - ks) / stride + 1, ks, stride, 0, act, stream,
                           nullptr, nullptr);
+}
+
+// bytes of the LeakyReLU sign map of a bf16 NCHW8c tensor with C channels: [B][2][H][W][Cpad/16] bytes, Cpad = C rounded up
+// to the channel tile (32 / 64 / 128 for C <= 32 / <= 64 / more); byte (h, pixel, q), bit i + 4e = (channel 4h + i of channel
+// block 2q + e > 0) -- the lane order of the conv epilogue, so a lane's signs of one pixel are one contiguous store
+extern "C" int yogo_bf16_signs_bytes(int B, int C, int H, int W, size_t* bytes) {
+  YOGO_CHECK_ARG(bytes && B >= 0 && C > 0 && H > 0 && W > 0, "bf16_signs_bytes: bad arguments");
+  *bytes = (size_t)B * H * W * (bf_mpad_of(C) / 8);
+  return YOGO_OK;
+}
+
+// yogo_conv2d_fwd_bf16 (bf16 output) that also writes the sign map of its output: what the data gradient of the NEXT layer
+// needs of a LeakyReLU block without BatchNorm (yogo_conv2d_dgrad_bf16_signs), at 1/16 of the bytes of the output itself
+extern "C" int yogo_conv2d_fwd_bf16_signs(const void* in, const void* packed, const float* bias, void* out, void* signs,
+                                          const float* chan_scale, int B, int Cin, int Cout, int IH, int IW, int ks, int stride,
+                                          int act, hipStream_t stream) {
+  YOGO_CHECK_ARG(in && packed && out && signs, "conv2d_fwd_bf16_signs: null pointer");
+  if (int e = check_bf16_conv(B, Cin, Cout, IH, IW, ks, stride)) return e;
+  const int pad = ks == 3 ? 1 : 0;
+  return launch_conv_bf16(in, packed, bias, out, nullptr, nullptr, nullptr, 0, signs, false, chan_scale, nullptr, B, Cin, Cout, IH, IW,
+                          (IH + 2 * pad - ks) / stride + 1, (IW + 2 * pad - ks) / stride + 1, ks, stride, 0, act, stream,
+                          nullptr, nullptr);
+}
+
+// yogo_conv2d_dgrad_bf16 with act = LeakyReLU and the sign map of the reference in place of the reference:
+// dx = conv_transpose(dy) * (sign bit ? 1 : 0.01) * chan_scale
+extern "C" int yogo_conv2d_dgrad_bf16_signs(const void* dy, const void* packed_dgrad, void* dx, const void* signs,
+                                            const float* chan_scale, int B, int Cin, int Cout, int IH, int IW, int ks, int stride,
+                                            hipStream_t stream) {
+  YOGO_CHECK_ARG(dy && packed_dgrad && dx && signs, "conv2d_dgrad_bf16_signs: null pointer");
+  if (int e = check_bf16_conv(B, Cin, Cout, IH, IW, ks, stride)) return e;
+  const int pad = ks == 3 ? 1 : 0;
+  const int OHf = (IH + 2 * pad - ks) / stride + 1, OWf = (IW + 2 * pad - ks) / stride + 1;
+  return launch_conv_bf16(dy, packed_dgrad, nullptr, dx, nullptr, nullptr, nullptr, ACT_LEAKY, const_cast<void*>(signs), true, chan_scale,
+                          nullptr, B, Cout, Cin, OHf, OWf, IH, IW, ks, 1, (stride == 2 && ks == 3) ? 1 : 0, ACT_NONE, stream, nullptr,
+                          nullptr);
 }
 
 // dx = conv_transpose(dy) * act'(act_ref) * chan_scale, all bf16 NCHW8c; (IH, IW) = the forward conv's INPUT dims.
@@ -1034,7 +1154,7 @@ extern "C" int yogo_conv2d_dgrad_bf16(const void* dy, const void* packed_dgrad, 
   if (int e = check_bf16_conv(B, Cin, Cout, IH, IW, ks, stride)) return e;
   const int pad = ks == 3 ? 1 : 0;
   const int OHf = (IH + 2 * pad - ks) / stride + 1, OWf = (IW + 2 * pad - ks) / stride + 1;
-  return launch_conv_bf16(dy, packed_dgrad, nullptr, dx, nullptr, nullptr, act_ref, ref_act, chan_scale, nullptr, B, Cout, Cin, OHf, OWf,
+  return launch_conv_bf16(dy, packed_dgrad, nullptr, dx, nullptr, nullptr, act_ref, ref_act, nullptr, false, chan_scale, nullptr, B, Cout, Cin, OHf, OWf,
                           IH, IW, ks, 1, (stride == 2 && ks == 3) ? 1 : 0, ACT_NONE, stream, nullptr, nullptr);
 }
 

@@ -59,6 +59,7 @@ class Saved:
     y: Optional[torch.Tensor] = None
     z: Optional[torch.Tensor] = None       # conv output of a BN block
     pre: Optional[torch.Tensor] = None     # pre-activation (SiLU blocks)
+    signs: Optional[torch.Tensor] = None   # sign map of y (LeakyReLU blocks without BatchNorm, bf16 path)
     mask: Optional[torch.Tensor] = None    # Dropout2d channel mask, already scaled
     mean: Optional[torch.Tensor] = None
     invstd: Optional[torch.Tensor] = None
@@ -346,6 +347,8 @@ _WGRAD_SIDE_STREAM = _os.environ.get("YOGO_WGRAD_STREAM", "0") != "0"
 _FUSE_LAYER0_BWD = _os.environ.get("YOGO_FUSE_LAYER0_BWD", "1") != "0"
 # 1: BatchNorm batch statistics of layers > 0 come from a separate sweep over the stored bf16 output (0.08 ms per 128-channel
 # layer) instead of the convolution's epilogue, which sits on the critical path of a one-workgroup-per-CU kernel (0.14-0.2 ms)
+# LeakyReLU blocks without BatchNorm hand the next layer's data gradient a 1-bit-per-value sign map instead of the bf16 output
+_LEAKY_SIGNS = _os.environ.get("YOGO_BF16_SIGNS", "1") != "0"
 _BN_STATS_PASS = _os.environ.get("YOGO_BN_STATS_PASS", "1") != "0"   # 0: separate BatchNorm-backward + weight-gradient passes
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
@@ -423,6 +426,9 @@ def forward_bf16_train(eng: Engine, x: torch.Tensor) -> Tuple[torch.Tensor, List
             if silu_pre:
                 S.pre = torch.empty_like(out8)
                 _hip.call("yogo_conv2d_fwd_bf16_pre", cur, pk, bias, out8, S.pre, mask, B, L.cin, L.cout, H, W, L.k, L.s, fused_act, st)
+            elif _LEAKY_SIGNS and L.act == ACT_LEAKY and not has_bn and not last:
+                S.signs = torch.empty(_hip.query_size("yogo_bf16_signs_bytes", B, L.cout, OH, OW), dtype=torch.uint8, device=dev)
+                _hip.call("yogo_conv2d_fwd_bf16_signs", cur, pk, bias, out8, S.signs, mask, B, L.cin, L.cout, H, W, L.k, L.s, fused_act, st)
             else:
                 _hip.call("yogo_conv2d_fwd_bf16", cur, pk, bias, out8, out32, mask, stats, B, L.cin, L.cout, H, W, L.k, L.s, fused_act, st)
             eng._tock()
@@ -573,8 +579,13 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
             dx = torch.empty(B, _blocks(L.cin), IH, IW, 8, dtype=torch.bfloat16, device=dev)
             pk = _packed_bf16(eng, i, 2 if (L.s == 2 and L.k == 3) else 1)
             nbytes = B * 2 * 8 * (_blocks(L.cout) * OH * OW + _blocks(L.cin) * IH * IW * (2 if act_ref is not None else 1))
+            if ref_act == ACT_LEAKY and Sp.signs is not None:   # one byte per 16-byte unit in place of the reference
+                nbytes = B * (16 * _blocks(L.cout) * OH * OW + 17 * _blocks(L.cin) * IH * IW)
             eng._tick("dgrad", i, 2.0 * B * L.cout * L.cin * L.k * L.k * OH * OW, mw=34 if (L.cin > 64 and L.s == 1 and act_ref is None) else 30, nbytes=nbytes)
-            _hip.call("yogo_conv2d_dgrad_bf16", g, pk, dx, act_ref, ref_act, Sp.mask, B, L.cin, L.cout, IH, IW, L.k, L.s, st)
+            if ref_act == ACT_LEAKY and Sp.signs is not None:
+                _hip.call("yogo_conv2d_dgrad_bf16_signs", g, pk, dx, Sp.signs, Sp.mask, B, L.cin, L.cout, IH, IW, L.k, L.s, st)
+            else:
+                _hip.call("yogo_conv2d_dgrad_bf16", g, pk, dx, act_ref, ref_act, Sp.mask, B, L.cin, L.cout, IH, IW, L.k, L.s, st)
             eng._tock()
             g = dx
     if _WGRAD_SIDE_STREAM:
