@@ -23,7 +23,7 @@ stats = one("stats/*kernel_stats.csv")
 lines = []
 if stats:
     rows = list(csv.DictReader(open(stats)))
-    lines.append(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-inference   ({tag}; bf16, per-GPU batch 128)")
+    lines.append(f"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-inference   ({tag}; bf16, per-GPU batch 128)")
     lines.append(f"{'kernel':70s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>6s}")
     for r in rows[:36]:
         name = r["Name"].split("(")[0][:70]
@@ -52,7 +52,7 @@ for k, v in traffic.items():
 json.dump(out, open("profiles/traffic.json", "w"), indent=1, sort_keys=True)
 top = sorted(out.items(), key=lambda kv: -kv[1].get("hbm_bytes_per_launch", 0))[:12]
 with open(f"profiles/{tag}_hbm_traffic.txt", "w") as f:
-    f.write(f"# rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-inference  ({tag})\n")
+    f.write(f"# rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-inference  ({tag})\n")
     f.write("# bytes per launch; FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md HBM section)\n")
     for k, v in top:
         f.write(f"{k:60s} fetch {v.get('fetch_bytes_per_launch',0)/1e6:10.1f} MB  write {v.get('write_bytes_per_launch',0)/1e6:10.1f} MB  n={v.get('launches_fetch')}\n")

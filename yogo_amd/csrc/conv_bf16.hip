@@ -457,7 +457,11 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
   // requested before the LDS hand-over so that the barriers hide its latency
   constexpr int SW = MW == 4 ? 2 : 1;  // dwords holding the 2 * MW sign bytes of a pixel
   const int sq = p.Mpad >> 4;          // sign bytes per (pixel, half-wave)
-  unsigned sg[(REF == 2 || REF == 3) ? NC : 1][NW][SW];
+  // 8-wavefront tiles take the request to write a sign map at run time (their registers do not decide the occupancy), so the
+  // forward kernels of the 128-channel layers stay ONE kernel; the 4-wavefront tiles have a variant (REF = 3) for it
+  constexpr bool SIGN_OUT = REF == 3 || (REF == 0 && NWV == 8 && !OUT_F32);
+  const bool write_signs = REF == 3 || (SIGN_OUT && p.signs != nullptr);  // uniform
+  unsigned sg[(REF == 2 || SIGN_OUT) ? NC : 1][NW][SW];
   if constexpr (REF == 2) {
     const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)(p.signs + (size_t)b * plane * 2 * sq), (short)0, (int)plane * 2 * sq, 0x00020000);
 #pragma unroll
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
           sg[c][n][0] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs_s, vs, 0, 0);
         }
       }
-  } else if constexpr (REF == 3) {
+  } else if constexpr (SIGN_OUT) {
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -666,7 +670,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
                 for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], LEAKY_SLOPE * v[i]);
               }
             }
-            if constexpr (REF == 3) {  // forward of a LeakyReLU block: the sign map the data gradient will read
+            if constexpr (SIGN_OUT) if (write_signs) {  // forward of a LeakyReLU block: the sign map the data gradient will read
               unsigned mA = 0, mB = 0;
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
@@ -716,7 +720,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
         }
       }
     }
-    if constexpr (REF == 3 && MW > 1) {  // the sign bytes of a pixel go out together
+    if constexpr (SIGN_OUT && MW > 1) if (write_signs) {  // the sign bytes of a pixel go out together
       const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)(p.signs + (size_t)b * plane * 2 * sq), (short)0, (int)plane * 2 * sq, 0x00020000);
 #pragma unroll
       for (int c = 0; c < NC; ++c)
@@ -1022,7 +1026,7 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
   do {                                                                         \
     if (act_ref != nullptr) BFLAUNCH__(MW_, NW_, NWV_, S2D_, PF_, false, 1);   \
     else if (signs_read) BFLAUNCH__(MW_, NW_, NWV_, S2D_, PF_, false, 2);      \
-    else if (signs != nullptr) BFLAUNCH__(MW_, NW_, NWV_, S2D_, PF_, false, 3); \
+    else if (signs != nullptr && NWV_ != 8) BFLAUNCH__(MW_, NW_, NWV_, S2D_, PF_, false, 3); \
     else BFLAUNCH__(MW_, NW_, NWV_, S2D_, PF_, F32_, 0);                       \
   } while (0)
 #define BFLAUNCH(MW_, NW_, NWV_, S2D_, PF_)                                    \
