@@ -181,6 +181,20 @@ int yogo_bn_bwd_bf16(const void* g, const void* z, void* dz, const float* mean, 
 int yogo_nchw_f32_to_bf16_8c(const float* in, void* out, int B, int C, int HW, yogo_stream_t stream);
 int yogo_bf16_8c_to_nchw_f32(const void* in, float* out, int B, int C, int HW, yogo_stream_t stream);
 
+/* ---- the step in front of the path: label rasteriser and batch flips ----------------------------- */
+/* format_labels_tensor, yogo/data/yogo_dataset.py:24-46, for a whole batch.  labels: [N][5] fp32 rows (class, x1, y1, x2, y2),
+ * or (class, xc, yc, w, h) with box_format = 1 (converted as label_file_to_tensor does, :132), all images back to back;
+ * offsets: [B + 1] int32 row ranges; out: [B][6][Sy][Sx] fp32 = (mask, x1, y1, x2, y2, class), written completely; a later
+ * label of a cell overwrites an earlier one, negative cell indices wrap once (Python indexing).  status: one device int32 the
+ * caller zeroes; set to 1 + the row index of a label whose cell is outside the grid (IndexError in the reference). */
+int yogo_labels_rasterize(const float* labels, const int* offsets, float* out, int* status, int B, int Sx, int Sy,
+                          int box_format, yogo_stream_t stream);
+/* RandomHorizontalFlipWithBBs + RandomVerticalFlipWithBBs, yogo/data/data_transforms.py:51-98, applied to a batch in one pass
+ * (the caller draws the decisions).  img: [B][C][H][W], elem_bytes 1 (uint8) or 4 (float32); lab: [B][6][Sy][Sx] fp32; out of
+ * place; either pair may be NULL.  Box coordinates become 1 - x in EVERY cell, as in the reference. */
+int yogo_flip_batch(const void* img_in, void* img_out, int elem_bytes, const float* lab_in, float* lab_out, int B, int C, int H,
+                    int W, int Sy, int Sx, int hflip, int vflip, yogo_stream_t stream);
+
 /* ---- optimiser: torch.optim.AdamW over one flat buffer, yogo/train.py:213-217,324 ---------------------------------------- */
 int yogo_adamw_step(float* p, const float* g, float* m, float* v, long long n, int step, double lr, double beta1,
                     double beta2, double eps, double weight_decay, double grad_scale, yogo_stream_t stream);

@@ -530,6 +530,40 @@ def format_labels_tensor(labels: torch.Tensor, Sx: int, Sy: int) -> torch.Tensor
     return out
 
 
+def label_rows_to_tensor(rows: torch.Tensor, Sx: int, Sy: int) -> torch.Tensor:
+    """yogo/data/yogo_dataset.py:113-133 (label_file_to_tensor after parsing): rows (class, xc, yc, w, h) -> label tensor."""
+    rows = rows.clone().float().reshape(-1, 5)
+    if rows.nelement() == 0:
+        return torch.zeros(6, Sy, Sx)
+    rows[:, 1:] = box_convert(rows[:, 1:], "cxcywh", "xyxy")
+    return format_labels_tensor(rows, Sx, Sy)
+
+
+def hflip_with_bbs(img: torch.Tensor, lab: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """yogo/data/data_transforms.py:51-74, the flipped branch: x1, x2 <- 1 - x2, 1 - x1 in every cell, then mirror along W."""
+    lab = lab.clone()
+    a, b = 1 - lab[:, 3, :, :], 1 - lab[:, 1, :, :]
+    lab[:, 1, :, :], lab[:, 3, :, :] = a, b
+    return torch.flip(img, dims=(3,)), torch.flip(lab, dims=(3,))
+
+
+def vflip_with_bbs(img: torch.Tensor, lab: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """yogo/data/data_transforms.py:77-98, the flipped branch."""
+    lab = lab.clone()
+    a, b = 1 - lab[:, 4, :, :], 1 - lab[:, 2, :, :]
+    lab[:, 2, :, :], lab[:, 4, :, :] = a, b
+    return torch.flip(img, dims=(2,)), torch.flip(lab, dims=(2,))
+
+
+def random_flips_with_bbs(img: torch.Tensor, lab: torch.Tensor, p_h: float = 0.5, p_v: float = 0.5) -> Tuple[torch.Tensor, torch.Tensor]:
+    """the training augmentation of yogo/data/yogo_dataloader.py:203-210: one torch.rand(1) draw per transform and batch."""
+    if torch.rand(1) < p_h:
+        img, lab = hflip_with_bbs(img, lab)
+    if torch.rand(1) < p_v:
+        img, lab = vflip_with_bbs(img, lab)
+    return img, lab
+
+
 def synthetic_images(B: int, H: int = 772, W: int = 1032, seed: int = 0) -> torch.Tensor:
     g = torch.Generator().manual_seed(seed)
     return torch.randint(0, 256, (B, 1, H, W), dtype=torch.uint8, generator=g)
