@@ -76,7 +76,9 @@ __device__ __forceinline__ bf16x8 lds_tr8(const unsigned char* base, int off0, i
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int MBW, int NBW, int NPW, int KS, int T, int S, int R>
+// MPW: co-blocks per wavefront (the wavefront grid is MBW x NBW x KS x kernel rows; a workgroup covers MBW * MPW co-blocks and
+// NBW * NPW ci-blocks).  MPW = 2, NPW = 1 reads 4 + 6 transposed operand halves per 6 MFMAs where MPW = 1, NPW = 2 reads 2 + 12.
+template <int MBW, int NBW, int NPW, int KS, int T, int S, int R, int MPW = 1, bool ROT = false>
 __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_bf16_kernel(const WgradBf16Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
   constexpr int TG = (T == 1) ? 1 : 3;
@@ -92,16 +94,20 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
   const int mb = wave / (TG * KS * NBW);
   const int split = blockIdx.x;
   const int n0b = blockIdx.y * (NBW * NPW * 4);  // first channel BLOCK (of 8) of this workgroup's ci range
-  const int m0b = blockIdx.z * (MBW * 4);
+  const int m0b = blockIdx.z * (MBW * MPW * 4);
 
-  f32x16 acc[NPW][TT];
+  f32x16 acc[MPW][NPW][TT];
 #pragma unroll
-  for (int q = 0; q < NPW; ++q)
+  for (int m = 0; m < MPW; ++m)
 #pragma unroll
-    for (int t = 0; t < TT; ++t)
+    for (int q = 0; q < NPW; ++q)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[q][t][r] = 0.f;
-  float bsum = 0.f;
+      for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][q][t][r] = 0.f;
+  float bsum[MPW];
+#pragma unroll
+  for (int m = 0; m < MPW; ++m) bsum[m] = 0.f;
   const bool do_bias = p.bias_part != nullptr && blockIdx.y == 0 && tg == 0 && nb == 0;
 
   const int u_begin = split * p.units_per_split;
@@ -109,12 +115,12 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
   const int gplane = p.OH * p.OW, xplane = p.IH * p.IW;
 
   // ---- this lane's elements of the tile image: slot i covers LDS unit i*NT + tid -------------------------------------------
-  // g image [MBW][R][wce][4 channel blocks], x image [NBW*NPW][XR][xw][4 channel blocks]; element -> (cb, r, c).
+  // g image [MBW * MPW][R][wce][4 channel blocks], x image [NBW*NPW][XR][xw][4 channel blocks]; element -> (cb, r, c).
   // lc = byte offset inside the image for unit origin (0, 0), rc = r << 16 | c (all ones: never valid)
   int glc[WGB_GSLOTS], xlc[WGB_XSLOTS];
   unsigned grc[WGB_GSLOTS], xrc[WGB_XSLOTS];
   {
-    const int gtot = MBW * 4 * R * p.wce, xtot = NBW * NPW * p.xcb * XR * p.xw;
+    const int gtot = MBW * MPW * 4 * R * p.wce, xtot = NBW * NPW * p.xcb * XR * p.xw;
 #pragma unroll
     for (int i = 0; i < WGB_GSLOTS; ++i) {
       const int e = tid + i * NT;
@@ -182,7 +188,7 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
   const int cnt = (nsteps - ks + KS - 1) / KS;
   const int xpb = p.xcb * 16;                             // bytes per pixel of the x image (64, or 32 for 16-channel inputs)
   const int xblk = XR * p.xw * xpb;                       // bytes of one channel-block group of the x image
-  const int gbase = mb * (R * p.wce * 64) + lane_ch_off;
+  const int gbase = mb * MPW * (R * p.wce * 64) + lane_ch_off;
   // 16-channel image: the lanes of channels 16-31 re-read channels 0-15 (those output columns lie beyond N and are dropped)
   const int xbase = p.ngs * NT * 16 + nb * NPW * xblk + (lane_ch_off & (xpb - 1));
 
@@ -192,7 +198,8 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
     const int r_ = st_ / ksteps_row;                                                                            \
     const int px_ = (st_ - r_ * ksteps_row) * 16 + lane_px;                                                     \
     const int ga_ = gbase + (r_ * p.wce + px_) * 64;                                                            \
-    AV = lds_tr8(buf, ga_, ga_ + 4 * 64);                                                                       \
+    _Pragma("unroll") for (int m = 0; m < MPW; ++m)                                                             \
+      AV[m] = lds_tr8(buf, ga_ + m * (R * p.wce * 64), ga_ + m * (R * p.wce * 64) + 4 * 64);                    \
     _Pragma("unroll") for (int q = 0; q < NPW; ++q)                                                             \
     _Pragma("unroll") for (int t = 0; t < TT; ++t) {                                                            \
       const int xa_ = xbase + q * xblk + (((r_ * S + (T == 1 ? 0 : tg)) * p.xw) + px_ * S + t) * xpb;           \
@@ -200,14 +207,16 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
     }                                                                                                           \
   }
 // bias gradient: the A operand already holds 8 pixels of "this lane's" output channel (padding pixels are zeros)
-#define WB_BIAS(AV)                                                             \
-  if (do_bias) {                                                                \
-    _Pragma("unroll") for (int j = 0; j < 8; ++j) bsum += (float)AV[j];         \
+#define WB_BIAS(AV)                                                                  \
+  if (do_bias) {                                                                     \
+    _Pragma("unroll") for (int m = 0; m < MPW; ++m)                                  \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) bsum[m] += (float)AV[m][j];        \
   }
 #define WB_MFMA(AV, BV)                                           \
+  _Pragma("unroll") for (int m = 0; m < MPW; ++m)                 \
   _Pragma("unroll") for (int q = 0; q < NPW; ++q)                 \
   _Pragma("unroll") for (int t = 0; t < TT; ++t)                  \
-    acc[q][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AV, BV[q][t], acc[q][t], 0, 0, 0);
+    acc[m][q][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AV[m], BV[q][t], acc[m][q][t], 0, 0, 0);
 
   // ring of p.depth LDS buffers: unit u + depth - 1 streams in while unit u is multiplied.  Ordering (LDS-DMA is invisible to
   // the barrier): every wave waits for ITS loads of unit u with a counted vmcnt, then the barrier makes all of them visible and
@@ -229,8 +238,8 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
     const unsigned char* buf = smem_b + ib * p.bufu * 16;
     ib = ib + 1 == p.depth ? 0 : ib + 1;
     if (cnt > 0) {
-      if constexpr (NPW == 1) {  // operands of step i+1 are fetched before the MFMAs of step i
-        bf16x8 a0, a1, b0[NPW][TT], b1[NPW][TT];
+      if constexpr (NPW == 1 && MPW == 1) {  // operands of step i+1 are fetched before the MFMAs of step i
+        bf16x8 a0[MPW], a1[MPW], b0[NPW][TT], b1[NPW][TT];
         WB_LOAD(a0, b0, 0);
         int i = 0;
         for (; i + 1 < cnt; i += 2) {
@@ -249,9 +258,41 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
           WB_MFMA(a0, b0);
           WB_BIAS(a0)
         }
+      } else if constexpr (MPW == 2 && NPW == 1 && ROT) {
+        // 6 accumulator tiles, no room for a second operand set: the A pair alternates between two register sets, and each
+        // B operand is re-fetched for the next step right after the two MFMAs that consumed it
+        bf16x8 a0[MPW], a1[MPW], b0[NPW][TT];
+        WB_LOAD(a0, b0, 0);
+#define WB_STEP(AC, AN, I)                                                                                        \
+  {                                                                                                               \
+    const int st_ = ks + min((I), cnt - 1) * KS;                                                                  \
+    const int r_ = st_ / ksteps_row;                                                                              \
+    const int px_ = (st_ - r_ * ksteps_row) * 16 + lane_px;                                                       \
+    const int ga_ = gbase + (r_ * p.wce + px_) * 64;                                                              \
+    const int xa0_ = xbase + (((r_ * S + tg) * p.xw) + px_ * S) * xpb;                                            \
+    _Pragma("unroll") for (int m = 0; m < MPW; ++m)                                                               \
+      AN[m] = lds_tr8(buf, ga_ + m * (R * p.wce * 64), ga_ + m * (R * p.wce * 64) + 4 * 64);                      \
+    _Pragma("unroll") for (int t = 0; t < TT; ++t) {                                                              \
+      __builtin_amdgcn_sched_barrier(0);                                                                          \
+      _Pragma("unroll") for (int m = 0; m < MPW; ++m)                                                             \
+        acc[m][0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AC[m], b0[0][t], acc[m][0][t], 0, 0, 0);           \
+      __builtin_amdgcn_sched_barrier(0);                                                                          \
+      b0[0][t] = lds_tr8(buf, xa0_ + t * xpb, xa0_ + t * xpb + 4 * S * xpb);                                      \
+    }                                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+  }
+        for (int i = 0; i < cnt; i += 2) {
+          WB_STEP(a0, a1, i + 1)
+          WB_BIAS(a0)
+          if (i + 1 < cnt) {
+            WB_STEP(a1, a0, i + 2)
+            WB_BIAS(a1)
+          }
+        }
+#undef WB_STEP
       } else {  // 6 accumulator tiles: one operand set (the three wavefronts of a SIMD hide each other's LDS latency)
         for (int i = 0; i < cnt; ++i) {
-          bf16x8 a0, b0[NPW][TT];
+          bf16x8 a0[MPW], b0[NPW][TT];
           WB_LOAD(a0, b0, i);
           WB_MFMA(a0, b0);
           WB_BIAS(a0)
@@ -268,19 +309,24 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
   float* sl = p.slab + (size_t)(split * KS + ks) * T * p.Mpad * p.Npad;
   const int m0 = m0b * 8, n0 = n0b * 8;
 #pragma unroll
-  for (int q = 0; q < NPW; ++q)
+  for (int mi = 0; mi < MPW; ++mi)
 #pragma unroll
-    for (int t = 0; t < TT; ++t) {
+    for (int q = 0; q < NPW; ++q)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int n = n0 + (nb * NPW + q) * 32 + l31;
-        sl[((size_t)(tg * TT + t) * p.Mpad + m) * p.Npad + n] = acc[q][t][r];
+      for (int t = 0; t < TT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + (mb * MPW + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const int n = n0 + (nb * NPW + q) * 32 + l31;
+          sl[((size_t)(tg * TT + t) * p.Mpad + m) * p.Npad + n] = acc[mi][q][t][r];
+        }
       }
+  if (do_bias) {  // lane l31 and lane l31 + 32 hold the two pixel halves of channel (mb*MPW + mi)*32 + l31
+#pragma unroll
+    for (int mi = 0; mi < MPW; ++mi) {
+      const float tot = bsum[mi] + __shfl_xor(bsum[mi], 32, 64);
+      if (half == 0) p.bias_part[(size_t)(split * KS + ks) * p.Mpad + m0 + (mb * MPW + mi) * 32 + l31] = tot;
     }
-  if (do_bias) {  // lane l31 and lane l31 + 32 hold the two pixel halves of channel mb*32 + l31
-    const float tot = bsum + __shfl_xor(bsum, 32, 64);
-    if (half == 0) p.bias_part[(size_t)(split * KS + ks) * p.Mpad + m0 + mb * 32 + l31] = tot;
   }
 }
 
@@ -291,7 +337,7 @@ extern "C" int yogo_internal_wgrad_reduce(const float* slab, int nslab, int T, i
 namespace {
 
 struct WbPlan {
-  int MBW, NBW, NPW, KS, R, Mpad, Npad, nchunk_w, base_w, rem_w, wce, nrowg, xw, units, nsplit, units_per_split, ngs, nxs, bufu,
+  int MBW, NBW, NPW, MPW, KS, R, Mpad, Npad, nchunk_w, base_w, rem_w, wce, nrowg, xw, units, nsplit, units_per_split, ngs, nxs, bufu,
       depth, lds_bytes, xcb;
   dim3 grid;
 };
@@ -306,13 +352,19 @@ bool wb_plan(int B, int N, int M, int IH, int IW, int ks, int stride, WbPlan* pl
   if (NBW == 3) NBW = 2;
   // 128 output channels x >= 64 input channels: two ci-blocks per wavefront, so the gradient tile is staged once per 64 (not
   // 32) input channels
-  const int NPW = (MBW == 4 && NBW == 1 && nblocks >= 2 && ks == 3) ? 2 : 1;
+  int NPW = (MBW == 4 && NBW == 1 && nblocks >= 2 && ks == 3) ? 2 : 1;
+  // ... or, the same 128 x 64 workgroup tile as 2 x 2 wavefronts of two co-blocks x one ci-block each: a third less LDS read
+  // traffic per MFMA (YOGO_WGRAD_MPW=0 keeps the ci-pair layout)
+  static int mpw_env = -1;
+  if (mpw_env < 0) mpw_env = getenv("YOGO_WGRAD_MPW") ? atoi(getenv("YOGO_WGRAD_MPW")) : 1;
+  int MPW = 1;
+  if (NPW == 2 && mpw_env) { MBW = 2; NBW = 2; NPW = 1; MPW = 2; }
   const int KS = 4 / (MBW * NBW);
   // rows per unit: few channels -> little MFMA work per row, so take more rows per barrier
   const bool tall = MBW == 1 && NBW == 1 && ks == 3 && stride == 1 && OH >= 64;
-  const int R = NPW == 2 ? (stride == 1 ? 3 : 2) : (stride == 1 ? (tall ? 8 : 4) : 2);
-  pl->MBW = MBW; pl->NBW = NBW; pl->NPW = NPW; pl->KS = KS; pl->R = R;
-  pl->Mpad = round_up(M, 32 * MBW);
+  const int R = (NPW == 2 || MPW == 2) ? (stride == 1 ? 3 : 2) : (stride == 1 ? (tall ? 8 : 4) : 2);
+  pl->MBW = MBW; pl->NBW = NBW; pl->NPW = NPW; pl->MPW = MPW; pl->KS = KS; pl->R = R;
+  pl->Mpad = round_up(M, 32 * MBW * MPW);
   pl->Npad = round_up(N, 32 * NBW * NPW);
   const int TG = ks == 3 ? 3 : 1;
   const int NT = 64 * MBW * NBW * KS * TG;
@@ -328,7 +380,7 @@ bool wb_plan(int B, int N, int M, int IH, int IW, int ks, int stride, WbPlan* pl
       const int w = round_up(cdiv(OW, nc), 16);
       if (w > wmax) continue;
       const int xw = (w - 1) * stride + (ks == 3 ? 3 : 1);
-      const int ngs = cdiv(MBW * 4 * R * w, NT), nxs = cdiv(NBW * NPW * xcb * XR * xw, NT);
+      const int ngs = cdiv(MBW * MPW * 4 * R * w, NT), nxs = cdiv(NBW * NPW * xcb * XR * xw, NT);
       const int bufu = (ngs + nxs) * NT;
       if (ngs > WGB_GSLOTS || nxs > WGB_XSLOTS || 2 * bufu * 16 > WGB_LDS_MAX) continue;
       const int waste = nc * w - OW;
@@ -346,7 +398,7 @@ bool wb_plan(int B, int N, int M, int IH, int IW, int ks, int stride, WbPlan* pl
   pl->lds_bytes = pl->depth * pl->bufu * 16;
   pl->nrowg = cdiv(OH, R);
   pl->units = B * pl->nrowg * pl->nchunk_w;
-  const int gy = pl->Npad / (32 * NBW * NPW), gz = pl->Mpad / (32 * MBW);
+  const int gy = pl->Npad / (32 * NBW * NPW), gz = pl->Mpad / (32 * MBW * MPW);
   int nsplit = max(1, min(pl->units, 256 / max(1, gy * gz)));
   pl->units_per_split = cdiv(pl->units, nsplit);
   pl->nsplit = cdiv(pl->units, pl->units_per_split);
@@ -354,15 +406,15 @@ bool wb_plan(int B, int N, int M, int IH, int IW, int ks, int stride, WbPlan* pl
   return true;
 }
 
-template <int MBW, int NBW, int NPW, int KS, int T, int S, int R>
+template <int MBW, int NBW, int NPW, int KS, int T, int S, int R, int MPW = 1, bool ROT = false>
 void wb_launch_one(const WgradBf16Params& p, const WbPlan& pl, hipStream_t stream) {
   static bool s = false;
   if (!s) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<MBW, NBW, NPW, KS, T, S, R>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<MBW, NBW, NPW, KS, T, S, R, MPW, ROT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, WGB_LDS_MAX);
     s = true;
   }
-  hipLaunchKernelGGL((wgrad_bf16_kernel<MBW, NBW, NPW, KS, T, S, R>), pl.grid, dim3(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)),
+  hipLaunchKernelGGL((wgrad_bf16_kernel<MBW, NBW, NPW, KS, T, S, R, MPW, ROT>), pl.grid, dim3(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)),
                      pl.lds_bytes, stream, p);
 }
 
@@ -410,7 +462,15 @@ extern "C" int yogo_conv2d_wgrad_bf16(const void* x, const void* g, float* dw, f
               Cin, Cout, IH, IW, stride, T, pl.MBW, pl.NBW, pl.NPW, pl.KS, pl.R, pl.wce, pl.nchunk_w, pl.xw, pl.ngs, pl.nxs, pl.depth, pl.lds_bytes,
               pl.units, pl.grid.x, pl.grid.y, pl.grid.z);
   }
-  if (pl.NPW == 2) {
+  static int rot_env = -1;
+  if (rot_env < 0) rot_env = getenv("YOGO_WGRAD_ROTATE") ? atoi(getenv("YOGO_WGRAD_ROTATE")) : 0;
+  if (pl.MPW == 2 && rot_env) {  // experiment: B operands re-fetched right behind their MFMAs, A pair double-buffered
+    if (stride == 1) wb_launch_one<2, 2, 1, 1, 9, 1, 3, 2, true>(p, pl, stream);
+    else wb_launch_one<2, 2, 1, 1, 9, 2, 2, 2, true>(p, pl, stream);
+  } else if (pl.MPW == 2) {
+    if (stride == 1) wb_launch_one<2, 2, 1, 1, 9, 1, 3, 2>(p, pl, stream);
+    else wb_launch_one<2, 2, 1, 1, 9, 2, 2, 2>(p, pl, stream);
+  } else if (pl.NPW == 2) {
     if (stride == 1) wb_launch_one<4, 1, 2, 1, 9, 1, 3>(p, pl, stream);
     else wb_launch_one<4, 1, 2, 1, 9, 2, 2>(p, pl, stream);
   } else {
