@@ -181,6 +181,19 @@ int yogo_bn_bwd_bf16(const void* g, const void* z, void* dz, const float* mean, 
 int yogo_nchw_f32_to_bf16_8c(const float* in, void* out, int B, int C, int HW, yogo_stream_t stream);
 int yogo_bf16_8c_to_nchw_f32(const void* in, float* out, int B, int C, int HW, yogo_stream_t stream);
 
+/* ---- layer 0 of the bf16 training path on the matrix cores (uint8 image, Cin = 1, Cout <= 16, stride 2, even H and W):
+ * Conv2d + the uint8 -> float cast (yogo/model_defns.py:34, yogo/model.py:272) and the BatchNorm2d + activation behind it
+ * (model_defns.py:35).  Weights are rounded to bf16 inside (autocast, yogo/train.py:315-318).  Outputs, each optional:
+ * stats_part = partial (sum, sumsq) of conv + bias in fp32, [rows][16][2] with rows from yogo_conv_first_mfma_stats_rows ->
+ * yogo_bn_finalize(part, rows, 16, ...); z = conv + bias, bf16 NCHW8c; y = act((z - mean) * invstd * gamma + beta), bf16
+ * NCHW8c.  Training runs it twice (statistics, then z + y): two sweeps over the images instead of conv + a separate BatchNorm
+ * pass over the activations. */
+int yogo_conv_first_mfma_supported(int in_dtype, int Cin, int Cout, int IH, int IW, int stride);
+int yogo_conv_first_mfma_stats_rows(int B, int IH, int IW, int* rows);
+int yogo_conv_first_mfma(const void* in, const float* w, const float* bias, void* z, void* y, const float* mean,
+                         const float* invstd, const float* gamma, const float* beta, float* stats_part, int B, int Cout, int IH,
+                         int IW, int act, yogo_stream_t stream);
+
 /* ---- the step in front of the path: label rasteriser and batch flips ----------------------------- */
 /* format_labels_tensor, yogo/data/yogo_dataset.py:24-46, for a whole batch.  labels: [N][5] fp32 rows (class, x1, y1, x2, y2),
  * or (class, xc, yc, w, h) with box_format = 1 (converted as label_file_to_tensor does, :132), all images back to back;

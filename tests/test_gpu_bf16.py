@@ -155,6 +155,48 @@ def test_conv_bf16_fwd_dgrad_wgrad(case):
         assert float((db2.cpu() - bg).abs().max()) < 1e-4 * float(b.grad.abs().max()), (case, clip)
 
 
+@pytest.mark.parametrize("B,IH,IW,Cout,use_bias", [(3, 20, 24, 16, False), (2, 36, 70, 7, True), (2, 772, 1032, 16, False)])
+def test_layer0_on_matrix_cores(B, IH, IW, Cout, use_bias):
+    """yogo_conv_first_mfma: uint8 image -> conv (bf16-rounded weights, exact bf16 inputs, fp32 accumulation) + BatchNorm sums,
+    and z / y = act(BN(z)) of the second sweep."""
+    h = H()
+    assert h.lib().yogo_conv_first_mfma_supported(0, 1, Cout, IH, IW, 2) == 1
+    assert h.lib().yogo_conv_first_mfma_supported(0, 1, Cout, IH + 1, IW, 2) == 0      # odd sizes, other strides, RGB: old kernels
+    assert h.lib().yogo_conv_first_mfma_supported(0, 3, Cout, IH, IW, 2) == 0
+    g = torch.Generator().manual_seed(IH)
+    x = torch.randint(0, 256, (B, 1, IH, IW), generator=g, dtype=torch.uint8)
+    w = torch.randn(Cout, 1, 3, 3, generator=g) * 0.02
+    b = torch.randn(Cout, generator=g) if use_bias else None
+    ref = F.conv2d(x.float(), bf(w), b, stride=2, padding=1)
+    OH, OW = ref.shape[2:]
+    st = h.stream_ptr()
+    rows = h.query_ints("yogo_conv_first_mfma_stats_rows", 1, B, IH, IW)[0]
+    stats = torch.full((rows, 16, 2), float("nan"), device="cuda")
+    xc, wc, bc = x.cuda(), w.cuda(), (b.cuda() if use_bias else None)
+    h.call("yogo_conv_first_mfma", xc, wc, bc, None, None, None, None, None, None, stats, B, Cout, IH, IW, 1, st)
+    ssum = stats.cpu().double().sum(0)
+    torch.testing.assert_close(ssum[:Cout, 0], ref.double().sum((0, 2, 3)), rtol=1e-5, atol=1e-2)
+    torch.testing.assert_close(ssum[:Cout, 1], (ref.double() ** 2).sum((0, 2, 3)), rtol=1e-5, atol=1e-2)
+    assert float(ssum[Cout:].abs().max()) == 0.0 if Cout < 16 else True
+    mean = ref.mean((0, 2, 3))
+    invstd = 1.0 / torch.sqrt(ref.var((0, 2, 3), unbiased=False) + 1e-5)
+    gamma, beta = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    z = torch.full((B, 2, OH, OW, 8), float("nan"), dtype=torch.bfloat16, device="cuda")
+    y = torch.full_like(z, float("nan"))
+    h.call("yogo_conv_first_mfma", xc, wc, bc, z, y, mean.cuda(), invstd.cuda(), gamma.cuda(), beta.cuda(), None, B, Cout, IH, IW, 1, st)
+    assert rel_err(from8c(z, Cout), ref) < 4e-3          # one bf16 rounding of the output
+    padc = z.cpu().float().permute(0, 1, 4, 2, 3).reshape(B, 16, OH, OW)[:, Cout:]
+    assert padc.numel() == 0 or float(padc.abs().max()) == 0.0
+    # y is BatchNorm + LeakyReLU of the stored (rounded) z: bit-identical to the stand-alone kernel on that tensor
+    y2 = torch.full_like(z, float("nan"))
+    h.call("yogo_bn_apply_act_bf16", z, y2, mean.cuda(), invstd.cuda(), 0, 1e-5, gamma.cuda(), beta.cuda(), B, Cout, OH * OW, 1, st)
+    assert torch.equal(y.view(torch.int16), y2.view(torch.int16))
+    # and the direct kernel with the same (rounded) weights agrees to the output rounding
+    z_old = torch.full_like(z, float("nan"))
+    h.call("yogo_conv_first_fwd_train_bf16", xc, 0, bf(w).cuda(), bc, z_old, None, None, B, 1, Cout, IH, IW, 2, 0, st)
+    assert rel_err(z.float().cpu(), z_old.float().cpu()) < 4e-3
+
+
 def test_batchnorm_bf16():
     h = H()
     B, C, Hh, W = 3, 20, 11, 13

@@ -35,9 +35,9 @@ def bench(name, B, Cin, Cout, IH, IW, k, s, kind, reps=10):
         sg = torch.empty(H.query_size("yogo_bf16_signs_bytes", B, Cout, OH, OW), dtype=torch.uint8, device="cuda")
         f = lambda: H.call("yogo_conv2d_fwd_bf16_signs", x8, packed, bias, y8, sg, msk, B, Cin, Cout, IH, IW, k, s, 1, st)
         nbytes = B * (16 * blocks(Cin) * IH * IW + 17 * blocks(Cout) * OH * OW)
-    elif kind == "m":
+    elif kind in "mn":   # n: sign map without the channel mask
         sg = torch.randint(0, 256, (H.query_size("yogo_bf16_signs_bytes", B, Cin, IH, IW),), dtype=torch.uint8, device="cuda")
-        msk = (torch.rand(B, Cin, device="cuda") > 0.1).float()
+        msk = (torch.rand(B, Cin, device="cuda") > 0.1).float() if kind == "m" else None
         f = lambda: H.call("yogo_conv2d_dgrad_bf16_signs", y8, packed, x8, sg, msk, B, Cin, Cout, IH, IW, k, s, st)
         nbytes = B * (17 * blocks(Cin) * IH * IW + 16 * blocks(Cout) * OH * OW)
     elif kind in "fa":
@@ -50,7 +50,7 @@ def bench(name, B, Cin, Cout, IH, IW, k, s, kind, reps=10):
         nbytes = B * 16 * (blocks(Cin) * IH * IW + blocks(Cout) * OH * OW)
     else:
         ref = torch.randn(B, blocks(Cin), IH, IW, 8, device="cuda").to(torch.bfloat16) if kind == "r" else None
-        msk = (torch.rand(B, Cin, device="cuda") > 0.1).float() if kind == "r" else None
+        msk = (torch.rand(B, Cin, device="cuda") > 0.1).float() if kind in "rc" else None   # c: channel mask only
         f = lambda: H.call("yogo_conv2d_dgrad_bf16", y8, packed, x8, ref, 1 if kind == "r" else 0, msk, B, Cin, Cout, IH, IW, k, s, st)
         nbytes = B * 16 * (blocks(Cin) * IH * IW * (2 if kind == "r" else 1) + blocks(Cout) * OH * OW)
     for _ in range(2):

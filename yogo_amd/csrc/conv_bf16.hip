@@ -647,12 +647,15 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
               }
 #pragma unroll
               for (int i = 0; i < 8; ++i) v[i] *= sa[i];
-            } else if constexpr (sign_ref) {  // LeakyReLU backward from the sign map
+            } else if constexpr (sign_ref) {  // LeakyReLU backward from the sign map (a data gradient: there is no bias)
               const unsigned m = sg[sign_ref ? c : 0][n][(mb * 2 + gp) >> 2] >> (8 * ((mb * 2 + gp) & 3));
 #pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                v[i] = (acc[c][mb][n][8 * gp + i] + ba[i]) * ((m >> i) & 1u ? sa[i] : sl[i]);
-                v[4 + i] = (acc[c][mb][n][8 * gp + 4 + i] + ba[4 + i]) * ((m >> (4 + i)) & 1u ? sa[4 + i] : sl[4 + i]);
+              for (int i = 0; i < 8; ++i) {
+                // bit i spread over a word (v_bfe_i32) selects scale or 0.01 * scale bitwise (v_bfi_b32): three instructions
+                // per value with the multiply
+                const int t = (int)(m << (31 - i)) >> 31;
+                const unsigned f = (__builtin_bit_cast(unsigned, sa[i]) & (unsigned)t) | (__builtin_bit_cast(unsigned, sl[i]) & ~(unsigned)t);
+                v[i] = acc[c][mb][n][8 * gp + i] * __builtin_bit_cast(float, f);
               }
             } else if (has_ref) {  // LeakyReLU backward: factor = ref > 0 ? scale : 0.01 * scale
               const bf16x4 r0 = __builtin_bit_cast(bf16x4, rf[REF == 1 ? mb : 0][RF_PER_GP ? 0 : gp][c][n][0]);
@@ -1001,6 +1004,10 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
       const size_t nwg = (size_t)grid.x * grid.y * grid.z;
       if (nwg * 32 <= ((size_t)1 << 24)) { (void)hipMemsetAsync(stamps, 0, nwg * 32, stream); p.stamps = stamps; }
     }
+  }
+  if ((act_ref != nullptr || signs_read) && bias != nullptr) {
+    yogo_set_error("conv_bf16: an activation reference goes with a data gradient (no bias)");
+    return YOGO_ERR_ARG;
   }
   if (B == 0) return YOGO_OK;
   const int lds_bytes = max(p.dma ? tl.lds_bytes : (tl.lds_dummy + 1) * 16, (2 + 2 * NWV) * 32 * MW * 4);

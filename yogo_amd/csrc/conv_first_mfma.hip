@@ -1,0 +1,237 @@
+// Layer 0 of the bf16 training path on the matrix cores: Conv2d(1 -> <=16, 3x3, stride 2, pad 1) on uint8 images
+// (yogo/model_defns.py:34 + the uint8 -> float cast of yogo/model.py:272), with the BatchNorm that follows it
+// (model_defns.py:35) either as partial sums (pass A) or applied together with the activation (pass B).
+//
+// K = 9 taps is short, but the direct VALU kernel (conv_first.hip) spends ~330 lane-instructions per output pixel on 144
+// FMAs, nine bounds-checked byte loads and the BatchNorm sums; here a wavefront turns 32 output pixels into ONE
+// v_mfma_f32_32x32x16_bf16: K = 16 slots = (row ky, column kx | pad) x 4 rows (the 4th is padding), M = 32 rows of which the
+// Cout <= 16 real channels are used, N = 32 pixels.  uint8 inputs are exact in bf16; the weights are rounded to bf16 (what
+// autocast does to the reference's conv, yogo/train.py:315-318).  Per pixel the lane work is the operand build (two 16-bit
+// loads + three byte->float conversions + two packs per image row) and the epilogue -- about 100 lane-instructions -- so
+// the kernel runs at the rate of its stores.
+//
+// Training forward of a BatchNorm block = two sweeps over the IMAGES instead of one over the images and two over the
+// activations: pass A forms the batch statistics without writing anything, pass B recomputes the convolution and writes
+// z (saved for backward) and y = act(BN(z)) (the next layer's input) -- 0.1 + 0.1 GB read and 1.6 GB written per 128 images
+// where conv + separate BatchNorm apply read 0.9 GB and wrote 1.6 GB.
+#include "common.h"
+
+typedef float cfm_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 cfm_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int cfm_u32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvFirstMfmaParams {
+  const unsigned char* in;  // [B][IH][IW] uint8
+  const float* w;           // [Cout][3][3] fp32 (rounded to bf16 here)
+  const float* bias;        // optional [Cout]
+  cfm_u32x4* z;             // optional: conv output, bf16 NCHW8c [B][2][OH*OW] units
+  cfm_u32x4* y;             // optional: act(BatchNorm(z)), same layout
+  const float* mean;        // for y: [Cout] each
+  const float* invstd;
+  const float* gamma;
+  const float* beta;
+  float* stats_part;        // optional: [wavefronts of the grid][16][2] partial (sum, sum of squares) of conv + bias in fp32
+  int B, Cout, IH, IW, OH, OW, act;
+  int gpi;                  // 32-pixel groups per image
+  int total;                // B * gpi
+  unsigned m_ow;            // ceil(2^32 / OW)
+};
+
+namespace {
+
+// sum over the 32 lanes of each half-wave with DPP adds; the result is valid in lanes 16-31 / 48-63
+__device__ __forceinline__ float cfm_half_wave_sum(float v) {
+#define CFM_DPP_ADD(CTRL, ROWMASK) \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, false));
+  CFM_DPP_ADD(0xB1, 0xf)   // quad_perm [1,0,3,2]
+  CFM_DPP_ADD(0x4E, 0xf)   // quad_perm [2,3,0,1]
+  CFM_DPP_ADD(0x141, 0xf)  // row_half_mirror
+  CFM_DPP_ADD(0x140, 0xf)  // row_mirror
+  CFM_DPP_ADD(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
+#undef CFM_DPP_ADD
+  return v;
+}
+
+// three bytes (1, 2, 3) of a word as bf16 values: x = [b1 | b2 << 16], y = [b3 | 0]; small integers are exact in bf16, so
+// the bf16 pattern is the upper half of the float's
+__device__ __forceinline__ void cfm_bytes_to_bf16(unsigned word, unsigned& x, unsigned& y) {
+  const unsigned f1 = __builtin_bit_cast(unsigned, (float)((word >> 8) & 0xFFu));
+  const unsigned f2 = __builtin_bit_cast(unsigned, (float)((word >> 16) & 0xFFu));
+  const unsigned f3 = __builtin_bit_cast(unsigned, (float)(word >> 24));
+  x = (f1 >> 16) | (f2 & 0xFFFF0000u);
+  y = f3 >> 16;
+}
+
+__global__ __launch_bounds__(256) void conv_first_mfma_kernel(const ConvFirstMfmaParams p) {
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  const int wave_g = blockIdx.x * 4 + (tid >> 6), nwaves = gridDim.x * 4;
+  const int npix = p.OH * p.OW;
+  constexpr unsigned OOB = 0x80000000u;
+
+  // A operand: row m = l31 (output channel), K slots 8 * half + j = (ky = slot / 4, kx = slot % 4); kx = 3 and ky = 3 are padding
+  cfm_bf16x8 wa;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int slot = 8 * half + j, ky = slot >> 2, kx = slot & 3;
+    const bool ok = ky < 3 && kx < 3 && l31 < p.Cout;
+    wa[j] = (__bf16)(ok ? p.w[l31 * 9 + min(ky, 2) * 3 + min(kx, 2)] : 0.f);
+  }
+  // this lane's output channels: 4 * half + i (i < 4) and 8 + 4 * half + i -- the accumulator rows of a 32x32 tile
+  float bs[8], mu[8], sc[8], sh[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int ch = (i < 4 ? 0 : 8) + 4 * half + (i & 3);
+    const bool ok = ch < p.Cout;
+    bs[i] = (ok && p.bias != nullptr) ? p.bias[ch] : 0.f;
+    mu[i] = sc[i] = sh[i] = 0.f;  // padding channels: y = act(0) = 0
+    if (ok && p.y != nullptr) {
+      mu[i] = p.mean[ch];
+      sc[i] = p.invstd[ch] * p.gamma[ch];
+      sh[i] = p.beta[ch];
+    }
+  }
+  float s8[8], q8[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s8[i] = q8[i] = 0.f;
+
+  // (image, group in the image) of this wavefront's next group, stepped without divisions; the raw image bytes of group
+  // i + 1 are requested before group i is multiplied
+  int nb = wave_g / p.gpi, ngi = wave_g - nb * p.gpi;
+  unsigned n_lo0 = 0, n_hi0 = 0, n_lo1 = 0, n_hi1 = 0;
+  int n_pix = 0;
+#define CFM_FETCH()                                                                                                    \
+  {                                                                                                                    \
+    n_pix = ngi * 32 + l31;                                                                                            \
+    const bool valid_ = n_pix < npix && nb < p.B;                                                                      \
+    const int pc_ = valid_ ? n_pix : npix - 1;                                                                         \
+    const int oy_ = (int)__umulhi((unsigned)pc_, p.m_ow), ox_ = pc_ - oy_ * p.OW;                                      \
+    /* image rows of this lane's K slots: half 0 -> ky = 0, 1; half 1 -> ky = 2 (and the padding row) */              \
+    const int r0_ = 2 * oy_ - 1 + 2 * half;                                                                            \
+    const auto rs_ = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (size_t)min(nb, p.B - 1) * p.IH * p.IW), (short)0, \
+                                                       p.IH * p.IW, 0x00020000);                                       \
+    const int o0_ = r0_ * p.IW + 2 * ox_ - 2; /* bytes (2ox - 2 .. 2ox + 1) of the row: two aligned 16-bit loads */    \
+    const bool ok0_ = valid_ && r0_ >= 0, ok1_ = valid_ && half == 0; /* rows <= IH - 1: even sizes only */            \
+    n_lo0 = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs_, (ok0_ && ox_ > 0) ? o0_ : (int)OOB, 0, 0);             \
+    n_hi0 = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs_, ok0_ ? o0_ + 2 : (int)OOB, 0, 0);                      \
+    n_lo1 = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs_, (ok1_ && ox_ > 0) ? o0_ + p.IW : (int)OOB, 0, 0);      \
+    n_hi1 = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs_, ok1_ ? o0_ + p.IW + 2 : (int)OOB, 0, 0);               \
+  }
+  CFM_FETCH()
+  for (int g = wave_g; g < p.total; g += nwaves) {  // g is uniform over the wavefront
+    const int b = nb, pix = n_pix;
+    const bool valid = pix < npix;
+    const unsigned lo0 = n_lo0, hi0 = n_hi0, lo1 = n_lo1, hi1 = n_hi1;
+    ngi += nwaves;
+    while (ngi >= p.gpi) {
+      ngi -= p.gpi;
+      ++nb;
+    }
+    CFM_FETCH()
+    unsigned bx, by, bz, bw_;
+    cfm_bytes_to_bf16((lo0 & 0xFFFFu) | (hi0 << 16), bx, by);
+    cfm_bytes_to_bf16((lo1 & 0xFFFFu) | (hi1 << 16), bz, bw_);
+    const cfm_u32x4 bw = {bx, by, bz, bw_};
+    cfm_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, __builtin_bit_cast(cfm_bf16x8, bw), acc, 0, 0, 0);
+
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = acc[i] + bs[i];
+    if (p.stats_part != nullptr) {
+      const float m = valid ? 1.f : 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float vm = v[i] * m;
+        s8[i] += vm;
+        q8[i] = fmaf(vm, v[i], q8[i]);
+      }
+    }
+    if (p.z != nullptr || p.y != nullptr) {
+      cfm_bf16x8 o;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = (__bf16)v[i];
+      // lanes 0-31 end up with channel block 0 (channels 0-7) of their pixel, lanes 32-63 with block 1: one 16-byte unit each
+      const int vo = valid ? (half * npix + pix) * 16 : (int)OOB;
+      if (p.z != nullptr) {
+        const cfm_u32x4 w4 = __builtin_bit_cast(cfm_u32x4, o);
+        const auto r0s = __builtin_amdgcn_permlane32_swap(w4.x, w4.z, false, false);
+        const auto r1s = __builtin_amdgcn_permlane32_swap(w4.y, w4.w, false, false);
+        const cfm_u32x4 st = {r0s[0], r1s[0], r0s[1], r1s[1]};
+        const auto rs_z = __builtin_amdgcn_make_buffer_rsrc((void*)(p.z + (size_t)b * 2 * npix), (short)0, 2 * npix * 16, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(st, rs_z, vo, 0, 0);
+      }
+      if (p.y != nullptr) {  // BatchNorm + activation of the ROUNDED z, as yogo_bn_apply_act_bf16 computes it from the stored tensor
+        cfm_bf16x8 yo;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float r = fmaf((float)o[i] - mu[i], sc[i], sh[i]);
+          if (p.act == ACT_LEAKY) r = fmaxf(r, LEAKY_SLOPE * r);
+          else if (p.act == ACT_SILU) r = act_fwd(r, ACT_SILU);
+          yo[i] = (__bf16)r;
+        }
+        const cfm_u32x4 w4 = __builtin_bit_cast(cfm_u32x4, yo);
+        const auto r0s = __builtin_amdgcn_permlane32_swap(w4.x, w4.z, false, false);
+        const auto r1s = __builtin_amdgcn_permlane32_swap(w4.y, w4.w, false, false);
+        const cfm_u32x4 st = {r0s[0], r1s[0], r0s[1], r1s[1]};
+        const auto rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (size_t)b * 2 * npix), (short)0, 2 * npix * 16, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(st, rs_y, vo, 0, 0);
+      }
+    }
+  }
+#undef CFM_FETCH
+  if (p.stats_part != nullptr) {  // one row of partial sums per wavefront
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float s = cfm_half_wave_sum(s8[i]), q = cfm_half_wave_sum(q8[i]);
+      if (l31 == 31) {
+        const int ch = (i < 4 ? 0 : 8) + 4 * half + (i & 3);
+        float* dst = p.stats_part + ((size_t)wave_g * 16 + ch) * 2;
+        dst[0] = s;
+        dst[1] = q;
+      }
+    }
+  }
+}
+
+int cfm_grid(int total) { return max(1, min(1024, cdiv(total, 4 * 8))); }  // >= 8 groups per wavefront when there is work
+unsigned cfm_magic(int d) { return d <= 1 ? 0xFFFFFFFFu : (unsigned)(((1ull << 32) + (unsigned)d - 1ull) / (unsigned)d); }
+
+}  // namespace
+
+// 1 when the matrix-core kernel takes the shape (else use yogo_conv_first_fwd_train_bf16 + yogo_bn_apply_act_bf16)
+extern "C" int yogo_conv_first_mfma_supported(int in_dtype, int Cin, int Cout, int IH, int IW, int stride) {
+  return in_dtype == 0 && Cin == 1 && Cout >= 1 && Cout <= 16 && stride == 2 && IH >= 4 && IW >= 4 && IH % 2 == 0 && IW % 2 == 0 &&
+         (long long)IH * IW < (1ll << 30) && (IH / 2) * (IW / 2) > 1;
+}
+
+// rows of the BatchNorm partial-sum buffer ([rows][16][2]) a launch with stats_part fills; row stride (mpad) is 16
+extern "C" int yogo_conv_first_mfma_stats_rows(int B, int IH, int IW, int* rows) {
+  YOGO_CHECK_ARG(rows && B >= 0 && IH > 0 && IW > 0, "conv_first_mfma_stats_rows: bad arguments");
+  *rows = cfm_grid(B * cdiv((IH / 2) * (IW / 2), 32)) * 4;
+  return YOGO_OK;
+}
+
+// in: uint8 [B][1][IH][IW]; w: fp32 [Cout][1][3][3] (rounded to bf16 inside); any of the outputs may be NULL:
+//   stats_part: partial (sum, sumsq) of conv + bias (fp32, before rounding) -> yogo_bn_finalize(part, rows, 16, ...)
+//   z: conv + bias in bf16 NCHW8c;  y: act((z - mean) * invstd * gamma + beta) in bf16 NCHW8c (needs mean/invstd/gamma/beta)
+extern "C" int yogo_conv_first_mfma(const void* in, const float* w, const float* bias, void* z, void* y, const float* mean,
+                                    const float* invstd, const float* gamma, const float* beta, float* stats_part, int B, int Cout,
+                                    int IH, int IW, int act, hipStream_t stream) {
+  YOGO_CHECK_ARG(in && w && (z || y || stats_part), "conv_first_mfma: null pointer");
+  YOGO_CHECK_ARG(yogo_conv_first_mfma_supported(0, 1, Cout, IH, IW, 2) && B >= 0, "conv_first_mfma: unsupported shape %dx%d Cout=%d", IH, IW, Cout);
+  YOGO_CHECK_ARG(y == nullptr || (mean && invstd && gamma && beta), "conv_first_mfma: y needs mean / invstd / gamma / beta");
+  if (B == 0) return YOGO_OK;
+  ConvFirstMfmaParams p{};
+  p.in = reinterpret_cast<const unsigned char*>(in); p.w = w; p.bias = bias;
+  p.z = reinterpret_cast<cfm_u32x4*>(z); p.y = reinterpret_cast<cfm_u32x4*>(y);
+  p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta; p.stats_part = stats_part;
+  p.B = B; p.Cout = Cout; p.IH = IH; p.IW = IW; p.OH = IH / 2; p.OW = IW / 2; p.act = act;
+  p.gpi = cdiv(p.OH * p.OW, 32); p.total = B * p.gpi;
+  p.m_ow = cfm_magic(p.OW);
+  YOGO_CHECK_ARG((long long)p.total * 32 < (1ll << 31) && (long long)p.OH * p.OW * p.OW < (1ll << 32), "conv_first_mfma: batch / image too large");
+  hipLaunchKernelGGL(conv_first_mfma_kernel, dim3(cfm_grid(p.total)), dim3(256), 0, stream, p);
+  YOGO_CHECK_LAUNCH("conv_first_mfma");
+  return YOGO_OK;
+}

@@ -60,6 +60,7 @@ class Saved:
     z: Optional[torch.Tensor] = None       # conv output of a BN block
     pre: Optional[torch.Tensor] = None     # pre-activation (SiLU blocks)
     signs: Optional[torch.Tensor] = None   # sign map of y (LeakyReLU blocks without BatchNorm, bf16 path)
+    w_used: Optional[torch.Tensor] = None  # layer 0 on the matrix cores: the bf16-rounded weights the forward multiplied with
     mask: Optional[torch.Tensor] = None    # Dropout2d channel mask, already scaled
     mean: Optional[torch.Tensor] = None
     invstd: Optional[torch.Tensor] = None
@@ -349,6 +350,8 @@ _FUSE_LAYER0_BWD = _os.environ.get("YOGO_FUSE_LAYER0_BWD", "1") != "0"
 # layer) instead of the convolution's epilogue, which sits on the critical path of a one-workgroup-per-CU kernel (0.14-0.2 ms)
 # LeakyReLU blocks without BatchNorm hand the next layer's data gradient a 1-bit-per-value sign map instead of the bf16 output
 _LEAKY_SIGNS = _os.environ.get("YOGO_BF16_SIGNS", "1") != "0"
+# layer 0 (uint8 image, 1 -> <=16 channels, stride 2, BatchNorm) on the matrix cores: statistics sweep + (z, y) sweep over the images
+_L0_MFMA = _os.environ.get("YOGO_L0_MFMA", "1") != "0"
 _BN_STATS_PASS = _os.environ.get("YOGO_BN_STATS_PASS", "1") != "0"   # 0: separate BatchNorm-backward + weight-gradient passes
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
@@ -400,6 +403,37 @@ def forward_bf16_train(eng: Engine, x: torch.Tensor) -> Tuple[torch.Tensor, List
             mask = (torch.rand(B, L.cout, device=dev) >= pdrop).to(torch.float32) / (1.0 - pdrop)
             S.mask = mask
         bn_train = has_bn and (L.bn.training or L.bn.running_mean is None)
+        if (i == 0 and _L0_MFMA and has_bn and mask is None and not last and cur.dtype == torch.uint8
+                and _hip.lib().yogo_conv_first_mfma_supported(0, L.cin, L.cout, H, W, L.s)):
+            bn = L.bn
+            gamma = _f32(bn.weight.detach()) if bn.weight is not None else torch.ones(L.cout, device=dev)
+            beta = _f32(bn.bias.detach()) if bn.bias is not None else torch.zeros(L.cout, device=dev)
+            w32 = _f32(L.conv.weight.detach())
+            out8 = torch.empty(B, _blocks(L.cout), OH, OW, 8, dtype=torch.bfloat16, device=dev)
+            y = torch.empty_like(out8)
+            if bn_train:   # sweep 1: batch statistics, nothing written
+                rows = _hip.query_ints("yogo_conv_first_mfma_stats_rows", 1, B, H, W)[0]
+                stats = torch.empty(rows * 16 * 2, dtype=torch.float32, device=dev)
+                _hip.call("yogo_conv_first_mfma", cur, w32, bias, None, None, None, None, None, None, stats, B, L.cout, H, W, L.act, st)
+                mean = torch.empty(L.cout, dtype=torch.float32, device=dev)
+                invstd = torch.empty(L.cout, dtype=torch.float32, device=dev)
+                track = bn.track_running_stats and bn.running_mean is not None
+                _hip.call("yogo_bn_finalize", stats, rows, 16, L.cout, B * OH * OW, float(bn.eps),
+                          float(bn.momentum if bn.momentum is not None else 0.0), mean, invstd,
+                          bn.running_mean if track else None, bn.running_var if track else None,
+                          bn.num_batches_tracked if track else None, st)
+            else:
+                invstd = torch.empty(L.cout, dtype=torch.float32, device=dev)
+                _hip.call("yogo_bn_invstd", bn.running_var, float(bn.eps), invstd, L.cout, st)
+                mean = bn.running_mean
+            # sweep 2: the convolution again, z (saved for backward) and y = act(BatchNorm(z)) written together
+            _hip.call("yogo_conv_first_mfma", cur, w32, bias, out8, y, mean, invstd, gamma, beta, None, B, L.cout, H, W, L.act, st)
+            S.mean, S.invstd, S.bn_train, S.z, S.y = mean, invstd, bn_train, out8, y
+            S.w_used = w32.to(torch.bfloat16).to(torch.float32)
+            cur = y
+            saved.append(S)
+            H, W = OH, OW
+            continue
         fused_act = ACT_NONE if has_bn else L.act
         stats = None
         rows = mpad = 0
@@ -545,7 +579,8 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
                 _hip.call("yogo_conv_first_bn_wgrad_bf16", S.x_in, xdt, g, S.z, S.mean, S.invstd, gamma, beta, part, B, L.cin, L.cout,
                           IH, IW, L.s, L.act, wst)
                 _hip.call("yogo_partials_reduce", part, rows, cols, 0.0, sums, wst)
-                _hip.call("yogo_conv_first_bn_wgrad_finalize", sums, S.mean, S.invstd, gamma, _f32(L.conv.weight.detach()), dw, dgamma,
+                _hip.call("yogo_conv_first_bn_wgrad_finalize", sums, S.mean, S.invstd, gamma,
+                          S.w_used if S.w_used is not None else _f32(L.conv.weight.detach()), dw, dgamma,
                           dbeta, B, L.cin, L.cout, IH, IW, L.s, 1 if S.bn_train else 0, clip, wst)
                 if bn.weight is not None:
                     grads[id(bn.weight)] = dgamma
