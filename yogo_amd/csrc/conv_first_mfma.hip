@@ -64,7 +64,7 @@ __device__ __forceinline__ void cfm_bytes_to_bf16(unsigned word, unsigned& x, un
 
 __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const ConvFirstMfmaParams p) {
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
-  const int wave_g = blockIdx.x * 4 + (tid >> 6), nwaves = gridDim.x * 4;
+  const int wave_g = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = gridDim.x * 4;  // (scalar: descriptors stay in SGPRs)
   const int npix = p.OH * p.OW;
   constexpr unsigned OOB = 0x80000000u;
 
@@ -163,14 +163,19 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const ConvFirstMfm
         __builtin_amdgcn_raw_buffer_store_b128(st, rs_z, vo, 0, 0);
       }
       if (p.y != nullptr) {  // BatchNorm + activation of the ROUNDED z, as yogo_bn_apply_act_bf16 computes it from the stored tensor
+        float r[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = fmaf((float)o[i] - mu[i], sc[i], sh[i]);
+        if (p.act == ACT_LEAKY) {  // (uniform branches around whole blocks)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) r[i] = fmaxf(r[i], LEAKY_SLOPE * r[i]);
+        } else if (p.act == ACT_SILU) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) r[i] = act_fwd(r[i], ACT_SILU);
+        }
         cfm_bf16x8 yo;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          float r = fmaf((float)o[i] - mu[i], sc[i], sh[i]);
-          if (p.act == ACT_LEAKY) r = fmaxf(r, LEAKY_SLOPE * r);
-          else if (p.act == ACT_SILU) r = act_fwd(r, ACT_SILU);
-          yo[i] = (__bf16)r;
-        }
+        for (int i = 0; i < 8; ++i) yo[i] = (__bf16)r[i];
         const cfm_u32x4 w4 = __builtin_bit_cast(cfm_u32x4, yo);
         const auto r0s = __builtin_amdgcn_permlane32_swap(w4.x, w4.z, false, false);
         const auto r1s = __builtin_amdgcn_permlane32_swap(w4.y, w4.w, false, false);
