@@ -128,6 +128,11 @@ int yogo_conv2d_fwd_bf16(const void* in, const void* packed, const float* bias, 
 int yogo_conv2d_fwd_bf16_pre(const void* in, const void* packed, const float* bias, void* out, void* out_pre,
                              const float* chan_scale, int B, int Cin, int Cout, int IH, int IW, int ksize, int stride, int act,
                              yogo_stream_t stream);
+/* yogo_conv_bf16_pack for a list of tensors in one launch (a training step repacks every layer twice).  table: device int64
+ * [n][8] = {w pointer, scale pointer or 0, packed pointer, Cin, Cout, ksize, mode, first block}; entry k owns
+ * yogo_conv_bf16_pack_blocks blocks starting at its first block; total_blocks = their sum */
+int yogo_conv_bf16_pack_blocks(int Cin, int Cout, int ksize, int mode, int* blocks);
+int yogo_conv_bf16_pack_multi(const void* table, int n, int total_blocks, yogo_stream_t stream);
 /* LeakyReLU sign map of a bf16 NCHW8c tensor: [B][2][H][W][Cpad/16] bytes (Cpad = C rounded up to 32 / 64 / a multiple of 128
  * for C <= 32 / <= 64 / more); byte (h, pixel, q), bit i + 4e = (channel 4h + i of channel block 2q + e > 0), h, e in {0, 1},
  * i < 4; bytes of channel blocks beyond kb(C) are unspecified -- all the data gradient needs of a LeakyReLU block's output (torch's

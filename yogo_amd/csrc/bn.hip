@@ -9,30 +9,34 @@
 #include "common.h"
 
 // ---- finalize: partial rows -> mean, invstd, running stats ---------------------------------------------------
+// One workgroup per 8 channels: lane t sums the rows t / 8, t / 8 + 32, ... of channel 8 * blockIdx.x + t % 8 (8 adjacent
+// channels = 64 contiguous bytes of a row), then the 32 row slices are folded in a fixed order through LDS.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int rows, int row_stride, int C,
                                                           double count, float eps, float momentum,
                                                           float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
                                                           long long* __restrict__ num_batches_tracked) {
-  __shared__ double sh[2][4];
-  const int c = blockIdx.x;
+  __shared__ double sh[2][32][8];
+  const int cl = threadIdx.x & 7, slice = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
   double s = 0.0, q = 0.0;
-  for (int r = threadIdx.x; r < rows; r += 256) {
-    const float* src = part + ((size_t)r * row_stride + c) * 2;
-    s += (double)src[0];
-    q += (double)src[1];
+  if (c < C) {
+    for (int r = slice; r < rows; r += 32) {
+      const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)r * row_stride + c) * 2);
+      s += (double)v.x;
+      q += (double)v.y;
+    }
   }
-  s = wave_sum_d(s);
-  q = wave_sum_d(q);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) {
-    sh[0][wave] = s;
-    sh[1][wave] = q;
-  }
+  sh[0][slice][cl] = s;
+  sh[1][slice][cl] = q;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    s = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
-    q = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+  if (threadIdx.x < 8 && c < C) {
+    s = 0.0;
+    q = 0.0;
+    for (int k = 0; k < 32; ++k) {
+      s += sh[0][k][cl];
+      q += sh[1][k][cl];
+    }
     const double mean = s / count;
     double var = q / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -222,7 +226,7 @@ extern "C" int yogo_bn_finalize(const float* part, int rows, int row_stride, int
                                 float* running_var, long long* num_batches_tracked, hipStream_t stream) {
   YOGO_CHECK_ARG(part && mean_out && invstd_out && C > 0 && rows > 0 && row_stride >= C && count > 0,
                  "bn_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, stream, part, rows, row_stride, C, (double)count, eps,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 8)), dim3(256), 0, stream, part, rows, row_stride, C, (double)count, eps,
                      momentum, mean_out, invstd_out, running_mean, running_var, num_batches_tracked);
   YOGO_CHECK_LAUNCH("bn_finalize");
   return YOGO_OK;

@@ -838,6 +838,40 @@ __global__ __launch_bounds__(256) void conv_first_bf16_kernel(const ConvFirstBf1
   }
 }
 
+// all the packings of a training step in ONE launch: table[n][8] int64 = {w, scale, packed, Cin, Cout, ks, mode, first
+// block}; a workgroup finds its entry by its block index and packs 256 units of it (the body of conv_bf16_pack_kernel)
+__global__ void conv_bf16_pack_multi_kernel(const long long* __restrict__ table, int n) {
+  int e = 0;
+  for (int k = 1; k < n; ++k)
+    if ((int)table[k * 8 + 7] <= (int)blockIdx.x) e = k;
+  const long long* t = table + e * 8;
+  const float* w = reinterpret_cast<const float*>(t[0]);
+  const float* scale = reinterpret_cast<const float*>(t[1]);
+  u32x4* wp = reinterpret_cast<u32x4*>(t[2]);
+  const int Cin = (int)t[3], Cout = (int)t[4], ks = (int)t[5], dgrad = (int)t[6];
+  const int Kc = dgrad ? Cout : Cin, Mc = dgrad ? Cin : Cout;
+  const int Kb = ((Kc + 15) / 16) * 2, mw = Mc <= 32 ? 1 : (Mc <= 64 ? 2 : 4), Mpad = ((Mc + 32 * mw - 1) / (32 * mw)) * (32 * mw);
+  const int T = ks * ks, total = T * Kb * Mpad;
+  const int el = ((int)blockIdx.x - (int)t[7]) * 256 + (int)threadIdx.x;
+  if (el >= total) return;
+  const int m = el % Mpad, kb = (el / Mpad) % Kb, tp = el / (Mpad * Kb);
+  const int ts = dgrad == 2 ? (int)((0x862071534ull >> (4 * tp)) & 15ull) : tp;
+  const int tt = dgrad ? (T - 1 - ts) : ts;
+  bf16x8 o;
+  const float sc = (!dgrad && m < Cout && scale != nullptr) ? scale[m] : 1.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = kb * 8 + j;
+    float v = 0.f;
+    if (m < Mc && k < Kc) {
+      const int co = dgrad ? k : m, ci = dgrad ? m : k;
+      v = w[((size_t)(co * Cin + ci) * ks + tt / ks) * ks + tt % ks] * sc;
+    }
+    o[j] = (__bf16)v;
+  }
+  wp[el] = __builtin_bit_cast(u32x4, o);
+}
+
 namespace {
 
 int bf_pick_mw(int M) { return M <= 32 ? 1 : (M <= 64 ? 2 : 4); }
@@ -913,6 +947,22 @@ extern "C" int yogo_conv_bf16_pack(const float* w_oihw, const float* scale, void
   hipLaunchKernelGGL(conv_bf16_pack_kernel, dim3(min(1024, cdiv(total, 256))), dim3(256), 0, stream, w_oihw, scale,
                      reinterpret_cast<u32x4*>(packed), Cin, Cout, ks, Kb, Mpad, mode);
   YOGO_CHECK_LAUNCH("conv_bf16_pack");
+  return YOGO_OK;
+}
+
+// yogo_conv_bf16_pack for a list of tensors in one launch.  table: device int64 [n][8] = {w pointer, scale pointer or 0,
+// packed pointer, Cin, Cout, ks, mode, first block}; entry k owns blocks [first block k, first block k + 1) with
+// yogo_conv_bf16_pack_blocks blocks each; total_blocks = the sum.
+extern "C" int yogo_conv_bf16_pack_blocks(int Cin, int Cout, int ks, int mode, int* blocks) {
+  YOGO_CHECK_ARG(blocks && Cin > 0 && Cout > 0 && (ks == 1 || ks == 3) && mode >= 0 && mode <= 2, "conv_bf16_pack_blocks: bad arguments");
+  const int K = mode ? Cout : Cin, M = mode ? Cin : Cout;
+  *blocks = cdiv(ks * ks * bf_kb_of(K) * bf_mpad_of(M), 256);
+  return YOGO_OK;
+}
+extern "C" int yogo_conv_bf16_pack_multi(const void* table, int n, int total_blocks, hipStream_t stream) {
+  YOGO_CHECK_ARG(table && n > 0 && total_blocks > 0, "conv_bf16_pack_multi: bad arguments");
+  hipLaunchKernelGGL(conv_bf16_pack_multi_kernel, dim3(total_blocks), dim3(256), 0, stream, reinterpret_cast<const long long*>(table), n);
+  YOGO_CHECK_LAUNCH("conv_bf16_pack_multi");
   return YOGO_OK;
 }
 

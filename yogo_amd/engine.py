@@ -352,6 +352,7 @@ _FUSE_LAYER0_BWD = _os.environ.get("YOGO_FUSE_LAYER0_BWD", "1") != "0"
 _LEAKY_SIGNS = _os.environ.get("YOGO_BF16_SIGNS", "1") != "0"
 # layer 0 (uint8 image, 1 -> <=16 channels, stride 2, BatchNorm) on the matrix cores: statistics sweep + (z, y) sweep over the images
 _L0_MFMA = _os.environ.get("YOGO_L0_MFMA", "1") != "0"
+_PACK_MULTI = _os.environ.get("YOGO_PACK_MULTI", "1") != "0"   # 0: one packing launch per layer and direction
 _BN_STATS_PASS = _os.environ.get("YOGO_BN_STATS_PASS", "1") != "0"   # 0: separate BatchNorm-backward + weight-gradient passes
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
@@ -377,11 +378,61 @@ def _packed_bf16(eng: Engine, i: int, mode: int) -> torch.Tensor:
     return buf
 
 
+def _pack_all_bf16(eng: Engine) -> None:
+    """Forward and data-gradient packings of every matrix-core layer in ONE launch (the weights change every step)."""
+    jobs = [(i, mode) for i in range(1, len(eng.layers)) for mode in (0, 2 if (eng.layers[i].s == 2 and eng.layers[i].k == 3) else 1)]
+    ws = [eng.layers[i].conv.weight for i, _ in jobs]
+    if any(w.dtype != torch.float32 or not w.is_contiguous() for w in ws) or not jobs or not _PACK_MULTI:
+        return   # (the per-layer path converts)
+    if all((h := eng._pack.get((i, 10 + m))) is not None and h[0] == w._version and h[1] == w.data_ptr() for (i, m), w in zip(jobs, ws)):
+        return
+    dev = ws[0].device
+    key = tuple(w.data_ptr() for w in ws)
+    st = getattr(eng, "_pack_multi", None)
+    if st is None or st[0] != key:
+        bufs, rows, blk = [], [], 0
+        for (i, mode), w in zip(jobs, ws):
+            L = eng.layers[i]
+            buf = torch.empty(_hip.query_size("yogo_conv_bf16_packed_bytes", L.cin, L.cout, L.k, mode), dtype=torch.uint8, device=dev)
+            bufs.append(buf)
+            rows.append([w.data_ptr(), 0, buf.data_ptr(), L.cin, L.cout, L.k, mode, blk])
+            blk += _hip.query_ints("yogo_conv_bf16_pack_blocks", 1, L.cin, L.cout, L.k, mode)[0]
+        st = (key, bufs, torch.tensor(rows, dtype=torch.int64, device=dev), blk)
+        eng._pack_multi = st
+    _, bufs, table, blk = st
+    _hip.call("yogo_conv_bf16_pack_multi", table, len(jobs), blk, _hip.stream_ptr())
+    for (i, mode), w, buf in zip(jobs, ws, bufs):
+        eng._pack[(i, 10 + mode)] = (w._version, w.data_ptr(), buf)
+
+
+def _dropout_masks(eng: Engine, B: int, dev) -> Dict[int, torch.Tensor]:
+    """Dropout2d channel masks (already scaled by 1 / (1 - p)) of all layers from ONE torch.rand call."""
+    act = [(i, float(L.drop.p)) for i, L in enumerate(eng.layers) if L.drop is not None and L.drop.training and L.drop.p > 0]
+    if not act:
+        return {}
+    key = (B, tuple(act), str(dev))
+    cached = getattr(eng, "_drop_consts", None)
+    if cached is None or cached[0] != key:
+        sizes = [B * eng.layers[i].cout for i, _ in act]
+        pvec = torch.cat([torch.full((n,), p, dtype=torch.float32) for n, (_, p) in zip(sizes, act)]).to(dev)
+        cached = (key, sizes, pvec, 1.0 / (1.0 - pvec))
+        eng._drop_consts = cached
+    _, sizes, pvec, inv_keep = cached
+    m = (torch.rand(pvec.numel(), device=dev) >= pvec).to(torch.float32) * inv_keep
+    out, off = {}, 0
+    for n, (i, _) in zip(sizes, act):
+        out[i] = m[off:off + n].view(B, eng.layers[i].cout)
+        off += n
+    return out
+
+
 def forward_bf16_train(eng: Engine, x: torch.Tensor) -> Tuple[torch.Tensor, List[Saved]]:
     _hip.require_cuda(x, "the input batch")
     dev, st, B = x.device, _hip.stream_ptr(), x.shape[0]
     if not eng._first_direct(0):
         raise RuntimeError("yogo_amd: bf16 training needs a 1- or 3-channel 3x3 first convolution")
+    _pack_all_bf16(eng)
+    masks = _dropout_masks(eng, B, dev)
     cur = x.contiguous() if x.dtype == torch.uint8 else _f32(x)
     H, W = int(cur.shape[2]), int(cur.shape[3])
     saved: List[Saved] = []
@@ -398,9 +449,8 @@ def forward_bf16_train(eng: Engine, x: torch.Tensor) -> Tuple[torch.Tensor, List
         bias = _f32(L.conv.bias.detach()) if L.conv.bias is not None else None
         S = Saved(x_in=cur)
         mask = None
-        if L.drop is not None and L.drop.training and L.drop.p > 0:
-            pdrop = float(L.drop.p)
-            mask = (torch.rand(B, L.cout, device=dev) >= pdrop).to(torch.float32) / (1.0 - pdrop)
+        if i in masks:
+            mask = masks[i]
             S.mask = mask
         bn_train = has_bn and (L.bn.training or L.bn.running_mean is None)
         if (i == 0 and _L0_MFMA and has_bn and mask is None and not last and cur.dtype == torch.uint8
