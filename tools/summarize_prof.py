@@ -26,7 +26,7 @@ if stats:
     lines.append(f"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-inference   ({tag}; bf16, per-GPU batch 128)")
     lines.append(f"{'kernel':70s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>6s}")
     for r in rows[:36]:
-        name = r["Name"].split("(")[0][:70]
+        name = r["Name"].replace("(anonymous namespace)::", "").split("(")[0][:70]
         lines.append(f"{name:70s} {r['Calls']:>6s} {float(r['TotalDurationNs'])/1e6:10.3f} {float(r['AverageNs'])/1e3:10.1f} {float(r['Percentage']):6.2f}")
     open(f"profiles/{tag}_kernel_stats.txt", "w").write("\n".join(lines) + "\n")
 
@@ -37,7 +37,7 @@ for kind, pat, mult in (("fetch", "fetch/*counter_collection.csv", 2.0), ("write
         continue
     agg = defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0]
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
         agg[k][0] += float(r["Counter_Value"]) * 1024.0 * mult
         agg[k][1] += 1
     for k, (tot, n) in agg.items():
