@@ -255,7 +255,8 @@ struct ConvFirstWgradParams {
   int B, Cin, Cout, IH, IW, OH, OW, stride;
 };
 
-#define CFW_PPT 16  // pixels per thread of the weight-gradient kernel (accumulators live in registers across them)
+#define CFW_PPT 32  // pixels per thread of the weight-gradient kernels (accumulators live in registers across them; the
+                    // cross-lane reductions at the end cost ~1800 instructions per wavefront, so fewer, longer workgroups)
 
 // Per pass of COC output channels every lane keeps COC x (9*CIN + 1) accumulators over its CFW_PPT pixels, so the cross-lane
 // reduction (DPP adds) is paid once per 4096 pixels and pass instead of once per pixel group.
@@ -366,7 +367,9 @@ struct ConvFirstBnWgradParams {
 // GRAM (Cin = 1): z is the bias-free convolution of the patches, so A2[c][j] = invstd_c * (sum_j' W[c][j'] G[j'][j] - mean_c P[j])
 // with the 9x9 Gram matrix G = sum patch_j' patch_j of the input -- channel independent: 45 accumulators replace 16 x 9, the
 // A2 columns of the partial rows stay unwritten and the finalize kernel forms A2 from G (appended after P).
-template <typename TIn, int CIN, int COC, bool GRAM>
+// FAST (uint8, one channel, stride 2, even image sizes): the three bytes of a patch row come from two aligned 16-bit loads
+// and only the top row / left column can fall outside the image -- a third of the per-byte bounds arithmetic.
+template <typename TIn, int CIN, int COC, bool GRAM, bool FAST = false>
 __global__ __launch_bounds__(CF_THREADS, GRAM ? 3 : 2) void conv_first_bn_wgrad_kernel(const ConvFirstBnWgradParams p) {
   constexpr int NJ = CIN * 9;
   constexpr int PER = 2 * NJ + 2;  // per channel: A1[NJ], A2[NJ], S1, S2
@@ -386,6 +389,19 @@ __global__ __launch_bounds__(CF_THREADS, GRAM ? 3 : 2) void conv_first_bn_wgrad_
   const int pc = ok ? pix : 0;                                                                             \
   const int oy = pc / p.OW, ox = pc - oy * p.OW;                                                           \
   float x[NJ];                                                                                             \
+  if constexpr (FAST) {                                                                                    \
+    const unsigned char* ib_ = reinterpret_cast<const unsigned char*>(inb);                                \
+    _Pragma("unroll") for (int kh = 0; kh < 3; ++kh) {                                                     \
+      const int iy = 2 * oy + kh - 1; /* <= IH - 1 */                                                      \
+      const bool rok = ok && iy >= 0;                                                                      \
+      const int o_ = rok ? iy * p.IW + 2 * ox : 0; /* bytes o_ - 2 .. o_ + 1 */                            \
+      const unsigned hi_ = *reinterpret_cast<const unsigned short*>(ib_ + o_);                             \
+      const unsigned lo_ = *reinterpret_cast<const unsigned short*>(ib_ + ((rok && ox > 0) ? o_ - 2 : o_)); \
+      x[kh * 3 + 0] = (rok && ox > 0) ? (float)(lo_ >> 8) : 0.f;                                           \
+      x[kh * 3 + 1] = rok ? (float)(hi_ & 0xFFu) : 0.f;                                                    \
+      x[kh * 3 + 2] = rok ? (float)(hi_ >> 8) : 0.f;                                                       \
+    }                                                                                                      \
+  } else                                                                                                   \
   _Pragma("unroll") for (int ci = 0; ci < CIN; ++ci)                                                       \
   _Pragma("unroll") for (int kh = 0; kh < 3; ++kh)                                                         \
   _Pragma("unroll") for (int kw = 0; kw < 3; ++kw) {                                                       \
@@ -715,7 +731,9 @@ extern "C" int yogo_conv_first_bn_wgrad_bf16(const void* in, int in_dtype, const
   p.OH = (IH - 1) / stride + 1; p.OW = (IW - 1) / stride + 1;
   if (B == 0) return YOGO_OK;
   dim3 grid(first_wgrad_tiles(p.OH, p.OW), B);
-  if (in_dtype == 0 && Cin == 1) hipLaunchKernelGGL((conv_first_bn_wgrad_kernel<uint8_t, 1, 8, true>), grid, dim3(CF_THREADS), 0, stream, p);
+  if (in_dtype == 0 && Cin == 1 && stride == 2 && IH % 2 == 0 && IW % 2 == 0 && (long long)IH * IW < (1ll << 31))
+    hipLaunchKernelGGL((conv_first_bn_wgrad_kernel<uint8_t, 1, 8, true, true>), grid, dim3(CF_THREADS), 0, stream, p);
+  else if (in_dtype == 0 && Cin == 1) hipLaunchKernelGGL((conv_first_bn_wgrad_kernel<uint8_t, 1, 8, true>), grid, dim3(CF_THREADS), 0, stream, p);
   else if (in_dtype == 0) hipLaunchKernelGGL((conv_first_bn_wgrad_kernel<uint8_t, 3, 2, false>), grid, dim3(CF_THREADS), 0, stream, p);
   else if (Cin == 1) hipLaunchKernelGGL((conv_first_bn_wgrad_kernel<float, 1, 8, true>), grid, dim3(CF_THREADS), 0, stream, p);
   else hipLaunchKernelGGL((conv_first_bn_wgrad_kernel<float, 3, 2, false>), grid, dim3(CF_THREADS), 0, stream, p);

@@ -30,7 +30,7 @@ struct ConvFirstMfmaParams {
   const float* invstd;
   const float* gamma;
   const float* beta;
-  float* stats_part;        // optional: [wavefronts of the grid][16][2] partial (sum, sum of squares) of conv + bias in fp32
+  float* stats_part;        // optional: [workgroups of the grid][16][2] partial (sum, sum of squares) of conv + bias in fp32
   int B, Cout, IH, IW, OH, OW, act;
   int gpi;                  // 32-pixel groups per image
   int total;                // B * gpi
@@ -186,16 +186,21 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const ConvFirstMfm
     }
   }
 #undef CFM_FETCH
-  if (p.stats_part != nullptr) {  // one row of partial sums per wavefront
+  if (p.stats_part != nullptr) {  // one row of partial sums per workgroup (the four wavefronts meet in LDS)
+    __shared__ float red[4][16][2];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const float s = cfm_half_wave_sum(s8[i]), q = cfm_half_wave_sum(q8[i]);
       if (l31 == 31) {
         const int ch = (i < 4 ? 0 : 8) + 4 * half + (i & 3);
-        float* dst = p.stats_part + ((size_t)wave_g * 16 + ch) * 2;
-        dst[0] = s;
-        dst[1] = q;
+        red[tid >> 6][ch][0] = s;
+        red[tid >> 6][ch][1] = q;
       }
+    }
+    __syncthreads();
+    if (tid < 32) {
+      const int ch = tid >> 1, k = tid & 1;
+      p.stats_part[((size_t)blockIdx.x * 16 + ch) * 2 + k] = (red[0][ch][k] + red[1][ch][k]) + (red[2][ch][k] + red[3][ch][k]);
     }
   }
 }
@@ -214,7 +219,7 @@ extern "C" int yogo_conv_first_mfma_supported(int in_dtype, int Cin, int Cout, i
 // rows of the BatchNorm partial-sum buffer ([rows][16][2]) a launch with stats_part fills; row stride (mpad) is 16
 extern "C" int yogo_conv_first_mfma_stats_rows(int B, int IH, int IW, int* rows) {
   YOGO_CHECK_ARG(rows && B >= 0 && IH > 0 && IW > 0, "conv_first_mfma_stats_rows: bad arguments");
-  *rows = cfm_grid(B * cdiv((IH / 2) * (IW / 2), 32)) * 4;
+  *rows = cfm_grid(B * cdiv((IH / 2) * (IW / 2), 32));
   return YOGO_OK;
 }
 
