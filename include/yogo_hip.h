@@ -199,6 +199,24 @@ int yogo_conv_first_mfma(const void* in, const float* w, const float* bias, void
                          const float* invstd, const float* gamma, const float* beta, float* stats_part, int B, int Cout, int IH,
                          int IW, int act, yogo_stream_t stream);
 
+/* Batch statistics of that layer WITHOUT the convolution: z = w . patch + b is linear in the 3x3 patch, so the statistics of all
+ * channels follow from P = sum patch (9) and G = sum patch (x) patch (9 x 9) over the batch -- accumulated exactly in integers.
+ * part: scratch, yogo_conv_first_gram_rows x 54 uint32; gram: double[90], gram_f32: float[90] (P[9], then G[9][9]).
+ * yogo_bn_stats_from_gram = yogo_bn_finalize on those sums (w rounded to bf16 as the convolution does); the backward pass
+ * reuses gram_f32 (yogo_conv_first_bn_wgrad_bf16_xg / _finalize_xg) instead of sweeping the image again. */
+int yogo_conv_first_gram_rows(int B, int IH, int IW, int* rows);
+int yogo_conv_first_gram(const void* in, void* part, double* gram, float* gram_f32, int B, int IH, int IW, yogo_stream_t stream);
+int yogo_bn_stats_from_gram(const double* gram, const float* w, const float* bias, int Cout, long long count, float eps,
+                            float momentum, float* mean_out, float* invstd_out, float* running_mean, float* running_var,
+                            long long* num_batches_tracked, yogo_stream_t stream);
+int yogo_conv_first_bn_wgrad_bf16_xg(const void* in, int in_dtype, const void* g, const void* z, const float* mean,
+                                     const float* invstd, const float* gamma, const float* beta, float* part, int B, int Cin,
+                                     int Cout, int IH, int IW, int stride, int act, yogo_stream_t stream);
+int yogo_conv_first_bn_wgrad_finalize_xg(const float* sums, const float* gram, const float* mean, const float* invstd,
+                                         const float* gamma, const float* w_oihw, float* dw, float* dgamma, float* dbeta, int B,
+                                         int Cin, int Cout, int IH, int IW, int stride, int training, float clip,
+                                         yogo_stream_t stream);
+
 /* ---- the step in front of the path: label rasteriser and batch flips ----------------------------- */
 /* format_labels_tensor, yogo/data/yogo_dataset.py:24-46, for a whole batch.  labels: [N][5] fp32 rows (class, x1, y1, x2, y2),
  * or (class, xc, yc, w, h) with box_format = 1 (converted as label_file_to_tensor does, :132), all images back to back;

@@ -197,6 +197,44 @@ def test_layer0_on_matrix_cores(B, IH, IW, Cout, use_bias):
     assert rel_err(z.float().cpu(), z_old.float().cpu()) < 4e-3
 
 
+@pytest.mark.parametrize("B,IH,IW", [(3, 20, 24), (2, 772, 1032)])
+def test_layer0_statistics_from_gram(B, IH, IW):
+    """yogo_conv_first_gram + yogo_bn_stats_from_gram: patch sums are exact integers; mean / invstd / running statistics equal
+    those of the convolution output (float64 reference)."""
+    h = H()
+    g = torch.Generator().manual_seed(IW)
+    x = torch.randint(0, 256, (B, 1, IH, IW), generator=g, dtype=torch.uint8)
+    x[0, 0, : IH // 2] = 200                        # a flat region: the statistics must survive the cancellation
+    Cout = 16
+    w = torch.randn(Cout, 1, 3, 3, generator=g) * 0.1
+    w[3] -= w[3].mean()                              # a zero-mean filter
+    b = torch.randn(Cout, generator=g)
+    st = h.stream_ptr()
+    rows = h.query_ints("yogo_conv_first_gram_rows", 1, B, IH, IW)[0]
+    part = torch.empty(rows * 54, dtype=torch.int32, device="cuda")
+    gram, gram32 = torch.empty(90, dtype=torch.float64, device="cuda"), torch.empty(90, device="cuda")
+    xc = x.cuda()
+    h.call("yogo_conv_first_gram", xc, part, gram, gram32, B, IH, IW, st)
+    patches = F.unfold(x.double(), 3, padding=1, stride=2)            # [B, 9, L]
+    P = patches.sum((0, 2))
+    G = torch.einsum("bjl,bkl->jk", patches, patches)
+    assert torch.equal(gram.cpu(), torch.cat((P, G.reshape(-1))))    # exact
+    assert torch.equal(gram32.cpu(), torch.cat((P, G.reshape(-1))).float())
+    OH, OW = IH // 2, IW // 2
+    mean, invstd = torch.empty(Cout, device="cuda"), torch.empty(Cout, device="cuda")
+    rm, rv = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
+    nbt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    h.call("yogo_bn_stats_from_gram", gram, w.cuda(), b.cuda(), Cout, B * OH * OW, 1e-5, 0.1, mean, invstd, rm, rv, nbt, st)
+    z = F.conv2d(x.double(), bf(w).double(), b.double(), stride=2, padding=1)
+    m_ref, v_ref = z.mean((0, 2, 3)), z.var((0, 2, 3), unbiased=False)
+    n = B * OH * OW
+    torch.testing.assert_close(mean.cpu().double(), m_ref, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(invstd.cpu().double(), 1.0 / torch.sqrt(v_ref + 1e-5), rtol=1e-6, atol=0)
+    torch.testing.assert_close(rm.cpu().double(), 0.1 * m_ref, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(rv.cpu().double(), 0.9 + 0.1 * v_ref * n / (n - 1), rtol=1e-6, atol=0)
+    assert int(nbt.item()) == 1
+
+
 def test_batchnorm_bf16():
     h = H()
     B, C, Hh, W = 3, 20, 11, 13

@@ -362,6 +362,7 @@ struct ConvFirstBnWgradParams {
   const float *mean, *invstd, *gamma, *beta;
   float* part;
   int B, Cin, Cout, Mb, IH, IW, OH, OW, stride, act;
+  int ext_gram;  // GRAM kernels: the caller already has P and G of this batch (yogo_conv_first_gram) -- skip that pass
 };
 
 // GRAM (Cin = 1): z is the bias-free convolution of the patches, so A2[c][j] = invstd_c * (sum_j' W[c][j'] G[j'][j] - mean_c P[j])
@@ -411,7 +412,10 @@ __global__ __launch_bounds__(CF_THREADS, GRAM ? 3 : 2) void conv_first_bn_wgrad_
     x[(ci * 3 + kh) * 3 + kw] = in ? v : 0.f;                                                              \
   }
 
-  if constexpr (GRAM) {
+  if constexpr (GRAM) if (p.ext_gram) {  // (uniform) the P / G columns of the row are zero-filled, the finalize reads the caller's
+    for (int e = tid; e < NJ + NJ * NJ; e += CF_THREADS) prow[p.Cout * PER + e] = 0.f;
+  }
+  if constexpr (GRAM) if (!p.ext_gram) {
     // ---- pass over the image alone: P[j] = sum patch_j, G[j][j2] = sum patch_j * patch_j2 (upper triangle) -------------
     float ps[NJ], gm[NG];
 #pragma unroll
@@ -564,8 +568,10 @@ __global__ void conv_first_bn_wgrad_finalize_kernel(const float* __restrict__ su
                                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                     const float* __restrict__ w, float* __restrict__ dw,
                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int Cout, int NJ,
-                                                    float inv_count, int training, int gram, float clip) {
+                                                    float inv_count, int training, int gram, float clip,
+                                                    const float* __restrict__ ext_pg) {
   const int PER = 2 * NJ + 2;
+  const float* pg = ext_pg != nullptr ? ext_pg : sums + Cout * PER;  // P[NJ] then G[NJ][NJ]
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= Cout * (NJ + 2)) return;
   const int c = e / (NJ + 2), j = e - c * (NJ + 2);
@@ -575,10 +581,10 @@ __global__ void conv_first_bn_wgrad_finalize_kernel(const float* __restrict__ su
   if (j < NJ) {
     const float c1 = gamma[c] * invstd[c];
     if (training) {
-      const float Pj = sums[Cout * PER + j];
+      const float Pj = pg[j];
       float a2;
       if (gram) {  // sum xh * patch_j = invstd * (sum_j' W[c][j'] G[j'][j] - mean * P[j])
-        const float* G = sums + Cout * PER + NJ;
+        const float* G = pg + NJ;
         float t = 0.f;
         for (int k = 0; k < NJ; ++k) t = fmaf(w[c * NJ + k], G[k * NJ + j], t);
         a2 = invstd[c] * (t - mean[c] * Pj);
@@ -718,9 +724,25 @@ extern "C" int yogo_conv_first_bn_wgrad_cols(int Cin, int Cout, int* cols) {
 
 // part: rows (yogo_conv_first_wgrad_rows) x cols floats.  Follow with yogo_partials_reduce(part, rows, cols, 0, sums) and
 // yogo_conv_first_bn_wgrad_finalize.
+static int conv_first_bn_wgrad_impl(const void* in, int in_dtype, const void* g, const void* z, const float* mean,
+                                    const float* invstd, const float* gamma, const float* beta, float* part, int B, int Cin, int Cout,
+                                    int IH, int IW, int stride, int act, int ext_gram, hipStream_t stream);
 extern "C" int yogo_conv_first_bn_wgrad_bf16(const void* in, int in_dtype, const void* g, const void* z, const float* mean,
                                              const float* invstd, const float* gamma, const float* beta, float* part, int B,
                                              int Cin, int Cout, int IH, int IW, int stride, int act, hipStream_t stream) {
+  return conv_first_bn_wgrad_impl(in, in_dtype, g, z, mean, invstd, gamma, beta, part, B, Cin, Cout, IH, IW, stride, act, 0, stream);
+}
+// the same when the caller holds P and G of this batch already (yogo_conv_first_gram in the forward pass): no Gram pass;
+// finish with yogo_conv_first_bn_wgrad_finalize_xg
+extern "C" int yogo_conv_first_bn_wgrad_bf16_xg(const void* in, int in_dtype, const void* g, const void* z, const float* mean,
+                                                const float* invstd, const float* gamma, const float* beta, float* part, int B,
+                                                int Cin, int Cout, int IH, int IW, int stride, int act, hipStream_t stream) {
+  YOGO_CHECK_ARG(Cin == 1, "conv_first_bn_wgrad_bf16_xg: one input channel only");
+  return conv_first_bn_wgrad_impl(in, in_dtype, g, z, mean, invstd, gamma, beta, part, B, Cin, Cout, IH, IW, stride, act, 1, stream);
+}
+static int conv_first_bn_wgrad_impl(const void* in, int in_dtype, const void* g, const void* z, const float* mean,
+                                    const float* invstd, const float* gamma, const float* beta, float* part, int B, int Cin, int Cout,
+                                    int IH, int IW, int stride, int act, int ext_gram, hipStream_t stream) {
   YOGO_CHECK_ARG(in && g && z && mean && invstd && gamma && beta && part, "conv_first_bn_wgrad_bf16: null pointer");
   YOGO_CHECK_ARG((Cin == 1 || Cin == 3) && Cout > 0 && (stride == 1 || stride == 2) && (in_dtype == 0 || in_dtype == 1),
                  "conv_first_bn_wgrad_bf16: unsupported shape");
@@ -728,7 +750,7 @@ extern "C" int yogo_conv_first_bn_wgrad_bf16(const void* in, int in_dtype, const
   p.in = in; p.g = reinterpret_cast<const cf_u32x4*>(g); p.z = reinterpret_cast<const cf_u32x4*>(z);
   p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta; p.part = part;
   p.B = B; p.Cin = Cin; p.Cout = Cout; p.Mb = ((Cout + 15) / 16) * 2; p.IH = IH; p.IW = IW; p.stride = stride; p.act = act;
-  p.OH = (IH - 1) / stride + 1; p.OW = (IW - 1) / stride + 1;
+  p.OH = (IH - 1) / stride + 1; p.OW = (IW - 1) / stride + 1; p.ext_gram = ext_gram;
   if (B == 0) return YOGO_OK;
   dim3 grid(first_wgrad_tiles(p.OH, p.OW), B);
   if (in_dtype == 0 && Cin == 1 && stride == 2 && IH % 2 == 0 && IW % 2 == 0 && (long long)IH * IW < (1ll << 31))
@@ -741,15 +763,33 @@ extern "C" int yogo_conv_first_bn_wgrad_bf16(const void* in, int in_dtype, const
   return YOGO_OK;
 }
 
+static int conv_first_bn_wgrad_finalize_impl(const float* sums, const float* ext_pg, const float* mean, const float* invstd,
+                                             const float* gamma, const float* w_oihw, float* dw, float* dgamma, float* dbeta, int B,
+                                             int Cin, int Cout, int IH, int IW, int stride, int training, float clip, hipStream_t stream);
 extern "C" int yogo_conv_first_bn_wgrad_finalize(const float* sums, const float* mean, const float* invstd, const float* gamma,
                                                  const float* w_oihw, float* dw, float* dgamma, float* dbeta, int B, int Cin,
                                                  int Cout, int IH, int IW, int stride, int training, float clip,
                                                  hipStream_t stream) {
+  return conv_first_bn_wgrad_finalize_impl(sums, nullptr, mean, invstd, gamma, w_oihw, dw, dgamma, dbeta, B, Cin, Cout, IH, IW, stride,
+                                           training, clip, stream);
+}
+// gram: float[90] = P[9] then G[9][9] of the batch (yogo_conv_first_gram)
+extern "C" int yogo_conv_first_bn_wgrad_finalize_xg(const float* sums, const float* gram, const float* mean, const float* invstd,
+                                                    const float* gamma, const float* w_oihw, float* dw, float* dgamma, float* dbeta,
+                                                    int B, int Cin, int Cout, int IH, int IW, int stride, int training, float clip,
+                                                    hipStream_t stream) {
+  YOGO_CHECK_ARG(gram != nullptr && Cin == 1, "conv_first_bn_wgrad_finalize_xg: bad arguments");
+  return conv_first_bn_wgrad_finalize_impl(sums, gram, mean, invstd, gamma, w_oihw, dw, dgamma, dbeta, B, Cin, Cout, IH, IW, stride,
+                                           training, clip, stream);
+}
+static int conv_first_bn_wgrad_finalize_impl(const float* sums, const float* ext_pg, const float* mean, const float* invstd,
+                                             const float* gamma, const float* w_oihw, float* dw, float* dgamma, float* dbeta, int B,
+                                             int Cin, int Cout, int IH, int IW, int stride, int training, float clip, hipStream_t stream) {
   YOGO_CHECK_ARG(sums && mean && invstd && gamma && w_oihw && dw && dgamma && dbeta, "conv_first_bn_wgrad_finalize: null pointer");
   const int OH = (IH - 1) / stride + 1, OW = (IW - 1) / stride + 1, NJ = Cin * 9;
   const int n = Cout * (NJ + 2);
   hipLaunchKernelGGL(conv_first_bn_wgrad_finalize_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, sums, mean, invstd, gamma,
-                     w_oihw, dw, dgamma, dbeta, Cout, NJ, 1.0f / ((float)B * (float)OH * (float)OW), training, Cin == 1 ? 1 : 0, clip);
+                     w_oihw, dw, dgamma, dbeta, Cout, NJ, 1.0f / ((float)B * (float)OH * (float)OW), training, Cin == 1 ? 1 : 0, clip, ext_pg);
   YOGO_CHECK_LAUNCH("conv_first_bn_wgrad_finalize");
   return YOGO_OK;
 }

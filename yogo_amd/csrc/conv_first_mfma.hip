@@ -205,6 +205,134 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const ConvFirstMfm
   }
 }
 
+// ---- batch statistics without the convolution: P = sum patch (9), G = sum patch (x) patch (9 x 9) --------------------------
+// z_c = w_c . patch + b_c is linear in the patch, so  sum z_c = w_c . P + N b_c  and  sum (z_c - b_c)^2 = w_c^T G w_c:  the
+// statistics of ALL channels follow from 54 channel-independent sums over the uint8 image.  They are accumulated as INTEGERS
+// (32 pixels per lane: <= 2.1e6 per accumulator; a workgroup: <= 5.4e8), so G and P are exact and the variance comes out of
+// a double-precision quadratic form -- more accurate than summing rounded fp32 outputs.  The layer-0 backward pass needs the
+// same G (conv_first_bn_wgrad_kernel) and takes it from here instead of sweeping the image again.
+#define CFG_PPT 32
+__device__ __forceinline__ unsigned cfm_wave_sum_u32(unsigned v) {
+#define CFM_DPP_ADDU(CTRL, ROWMASK) v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, false);
+  CFM_DPP_ADDU(0xB1, 0xf)
+  CFM_DPP_ADDU(0x4E, 0xf)
+  CFM_DPP_ADDU(0x141, 0xf)
+  CFM_DPP_ADDU(0x140, 0xf)
+  CFM_DPP_ADDU(0x142, 0xa)
+  CFM_DPP_ADDU(0x143, 0xc)
+#undef CFM_DPP_ADDU
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// part: [gridDim.y * gridDim.x][54] uint32 = P[9], then the upper triangle of G row by row
+__global__ __launch_bounds__(256) void conv_first_gram_kernel(const unsigned char* __restrict__ in, unsigned* __restrict__ part, int IH,
+                                                              int IW, int OH, int OW) {
+  __shared__ unsigned red[4][54];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y, npix = OH * OW;
+  const unsigned char* ib = in + (size_t)b * IH * IW;
+  unsigned acc[54];
+#pragma unroll
+  for (int q = 0; q < 54; ++q) acc[q] = 0u;
+  const int pbase = blockIdx.x * (256 * CFG_PPT);
+  for (int k = 0; k < CFG_PPT; ++k) {
+    const int pix = pbase + k * 256 + tid;
+    const bool ok = pix < npix;
+    const int pc = ok ? pix : 0;
+    const int oy = pc / OW, ox = pc - oy * OW;
+    unsigned x[9];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int iy = 2 * oy + kh - 1;  // <= IH - 1 (even sizes)
+      const bool rok = ok && iy >= 0;
+      const int o = rok ? iy * IW + 2 * ox : 0;  // bytes o - 2 .. o + 1
+      const unsigned hi = *reinterpret_cast<const unsigned short*>(ib + o);
+      const unsigned lo = *reinterpret_cast<const unsigned short*>(ib + ((rok && ox > 0) ? o - 2 : o));
+      x[kh * 3 + 0] = (rok && ox > 0) ? (lo >> 8) : 0u;
+      x[kh * 3 + 1] = rok ? (hi & 0xFFu) : 0u;
+      x[kh * 3 + 2] = rok ? (hi >> 8) : 0u;
+    }
+    int q = 9;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      acc[j] += x[j];
+#pragma unroll
+      for (int j2 = j; j2 < 9; ++j2) {
+        acc[q] = __umul24(x[j], x[j2]) + acc[q];
+        ++q;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 54; ++q) {
+    const unsigned v = cfm_wave_sum_u32(acc[q]);
+    if (lane == 0) red[wave][q] = v;
+  }
+  __syncthreads();
+  if (tid < 54) part[((size_t)b * gridDim.x + blockIdx.x) * 54 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+// one workgroup per partial column: exact 64-bit sum over the rows -> gram (double) and gram_f32, both [90] = P[9], G[9][9]
+__global__ __launch_bounds__(256) void conv_first_gram_fold_kernel(const unsigned* __restrict__ part, int rows, double* __restrict__ gram,
+                                                                   float* __restrict__ gram_f32) {
+  __shared__ unsigned long long sh[256];
+  const int q = blockIdx.x;
+  unsigned long long s = 0ull;
+  for (int r = threadIdx.x; r < rows; r += 256) s += part[(size_t)r * 54 + q];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double v = (double)sh[0];
+    if (q < 9) {
+      gram[q] = v;
+      gram_f32[q] = (float)v;
+    } else {  // packed upper triangle -> both halves of the full matrix
+      int t = q - 9, j = 0;
+      while (t >= 9 - j) {
+        t -= 9 - j;
+        ++j;
+      }
+      const int j2 = j + t;
+      gram[9 + j * 9 + j2] = v; gram[9 + j2 * 9 + j] = v;
+      gram_f32[9 + j * 9 + j2] = (float)v; gram_f32[9 + j2 * 9 + j] = (float)v;
+    }
+  }
+}
+
+// mean / invstd / running statistics of conv(x, bf16(w)) + bias from P and G (the semantics of bn_finalize_kernel)
+__global__ void bn_stats_from_gram_kernel(const double* __restrict__ gram, const float* __restrict__ w, const float* __restrict__ bias,
+                                          int Cout, double count, float eps, float momentum, float* __restrict__ mean_out,
+                                          float* __restrict__ invstd_out, float* __restrict__ running_mean,
+                                          float* __restrict__ running_var, long long* __restrict__ num_batches_tracked) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cout) return;
+  double wv[9];
+  for (int j = 0; j < 9; ++j) wv[j] = (double)(float)(__bf16)w[c * 9 + j];
+  double sp = 0.0, quad = 0.0;
+  for (int j = 0; j < 9; ++j) {
+    sp += wv[j] * gram[j];
+    double row = 0.0;
+    for (int k = 0; k < 9; ++k) row += wv[k] * gram[9 + j * 9 + k];
+    quad += wv[j] * row;
+  }
+  const double m0 = sp / count;                      // mean of the bias-free convolution
+  double var = quad / count - m0 * m0;
+  if (var < 0.0) var = 0.0;
+  const double mean = m0 + (bias != nullptr ? (double)bias[c] : 0.0);
+  mean_out[c] = (float)mean;
+  invstd_out[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean != nullptr) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+    running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+  }
+  if (c == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;
+}
+
 int cfm_grid(int total) { return max(1, min(1024, cdiv(total, 4 * 8))); }  // >= 8 groups per wavefront when there is work
 unsigned cfm_magic(int d) { return d <= 1 ? 0xFFFFFFFFu : (unsigned)(((1ull << 32) + (unsigned)d - 1ull) / (unsigned)d); }
 
@@ -243,5 +371,35 @@ extern "C" int yogo_conv_first_mfma(const void* in, const float* w, const float*
   YOGO_CHECK_ARG((long long)p.total * 32 < (1ll << 31) && (long long)p.OH * p.OW * p.OW < (1ll << 32), "conv_first_mfma: batch / image too large");
   hipLaunchKernelGGL(conv_first_mfma_kernel, dim3(cfm_grid(p.total)), dim3(256), 0, stream, p);
   YOGO_CHECK_LAUNCH("conv_first_mfma");
+  return YOGO_OK;
+}
+
+// P = sum of the 3x3 stride-2 patches, G = sum of their outer products over a uint8 batch [B][1][IH][IW] (even sizes), exact:
+// part = scratch of yogo_conv_first_gram_rows x 54 uint32; gram = double[90], gram_f32 = float[90] (P[9], then G[9][9])
+extern "C" int yogo_conv_first_gram_rows(int B, int IH, int IW, int* rows) {
+  YOGO_CHECK_ARG(rows && B >= 0 && IH > 0 && IW > 0, "conv_first_gram_rows: bad arguments");
+  *rows = B * cdiv((IH / 2) * (IW / 2), 256 * CFG_PPT);
+  return YOGO_OK;
+}
+extern "C" int yogo_conv_first_gram(const void* in, void* part, double* gram, float* gram_f32, int B, int IH, int IW, hipStream_t stream) {
+  YOGO_CHECK_ARG(in && part && gram && gram_f32 && B > 0, "conv_first_gram: bad arguments");
+  YOGO_CHECK_ARG(yogo_conv_first_mfma_supported(0, 1, 1, IH, IW, 2) && B <= 65535, "conv_first_gram: unsupported shape %dx%d", IH, IW);
+  const int OH = IH / 2, OW = IW / 2, tiles = cdiv(OH * OW, 256 * CFG_PPT);
+  hipLaunchKernelGGL(conv_first_gram_kernel, dim3(tiles, B), dim3(256), 0, stream, reinterpret_cast<const unsigned char*>(in),
+                     reinterpret_cast<unsigned*>(part), IH, IW, OH, OW);
+  hipLaunchKernelGGL(conv_first_gram_fold_kernel, dim3(54), dim3(256), 0, stream, reinterpret_cast<const unsigned*>(part), tiles * B, gram,
+                     gram_f32);
+  YOGO_CHECK_LAUNCH("conv_first_gram");
+  return YOGO_OK;
+}
+// BatchNorm batch statistics of conv(x, bf16(w)) + bias for all Cout channels from the Gram sums (count = B * OH * OW);
+// running statistics and num_batches_tracked are updated like yogo_bn_finalize does
+extern "C" int yogo_bn_stats_from_gram(const double* gram, const float* w, const float* bias, int Cout, long long count, float eps,
+                                       float momentum, float* mean_out, float* invstd_out, float* running_mean, float* running_var,
+                                       long long* num_batches_tracked, hipStream_t stream) {
+  YOGO_CHECK_ARG(gram && w && mean_out && invstd_out && Cout > 0 && count > 0, "bn_stats_from_gram: bad arguments");
+  hipLaunchKernelGGL(bn_stats_from_gram_kernel, dim3(cdiv(Cout, 64)), dim3(64), 0, stream, gram, w, bias, Cout, (double)count, eps, momentum,
+                     mean_out, invstd_out, running_mean, running_var, num_batches_tracked);
+  YOGO_CHECK_LAUNCH("bn_stats_from_gram");
   return YOGO_OK;
 }

@@ -61,6 +61,7 @@ class Saved:
     pre: Optional[torch.Tensor] = None     # pre-activation (SiLU blocks)
     signs: Optional[torch.Tensor] = None   # sign map of y (LeakyReLU blocks without BatchNorm, bf16 path)
     w_used: Optional[torch.Tensor] = None  # layer 0 on the matrix cores: the bf16-rounded weights the forward multiplied with
+    gram: Optional[torch.Tensor] = None    # layer 0: float[90] patch sums P and Gram matrix G of the batch (reused by backward)
     mask: Optional[torch.Tensor] = None    # Dropout2d channel mask, already scaled
     mean: Optional[torch.Tensor] = None
     invstd: Optional[torch.Tensor] = None
@@ -352,6 +353,8 @@ _FUSE_LAYER0_BWD = _os.environ.get("YOGO_FUSE_LAYER0_BWD", "1") != "0"
 _LEAKY_SIGNS = _os.environ.get("YOGO_BF16_SIGNS", "1") != "0"
 # layer 0 (uint8 image, 1 -> <=16 channels, stride 2, BatchNorm) on the matrix cores: statistics sweep + (z, y) sweep over the images
 _L0_MFMA = _os.environ.get("YOGO_L0_MFMA", "1") != "0"
+# ... with the batch statistics from the patch Gram matrix of the images (no convolution in the statistics sweep; backward reuses it)
+_L0_GRAM = _os.environ.get("YOGO_L0_GRAM", "1") != "0"
 _PACK_MULTI = _os.environ.get("YOGO_PACK_MULTI", "1") != "0"   # 0: one packing launch per layer and direction
 _BN_STATS_PASS = _os.environ.get("YOGO_BN_STATS_PASS", "1") != "0"   # 0: separate BatchNorm-backward + weight-gradient passes
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
@@ -461,7 +464,20 @@ def forward_bf16_train(eng: Engine, x: torch.Tensor) -> Tuple[torch.Tensor, List
             w32 = _f32(L.conv.weight.detach())
             out8 = torch.empty(B, _blocks(L.cout), OH, OW, 8, dtype=torch.bfloat16, device=dev)
             y = torch.empty_like(out8)
-            if bn_train:   # sweep 1: batch statistics, nothing written
+            if bn_train and _L0_GRAM:   # sweep 1: exact integer patch sums -> statistics of all channels (and backward's G)
+                rows = _hip.query_ints("yogo_conv_first_gram_rows", 1, B, H, W)[0]
+                gpart = torch.empty(rows * 54, dtype=torch.int32, device=dev)
+                gram64 = torch.empty(90, dtype=torch.float64, device=dev)
+                S.gram = torch.empty(90, dtype=torch.float32, device=dev)
+                _hip.call("yogo_conv_first_gram", cur, gpart, gram64, S.gram, B, H, W, st)
+                mean = torch.empty(L.cout, dtype=torch.float32, device=dev)
+                invstd = torch.empty(L.cout, dtype=torch.float32, device=dev)
+                track = bn.track_running_stats and bn.running_mean is not None
+                _hip.call("yogo_bn_stats_from_gram", gram64, w32, bias, L.cout, B * OH * OW, float(bn.eps),
+                          float(bn.momentum if bn.momentum is not None else 0.0), mean, invstd,
+                          bn.running_mean if track else None, bn.running_var if track else None,
+                          bn.num_batches_tracked if track else None, st)
+            elif bn_train:   # sweep 1: batch statistics, nothing written
                 rows = _hip.query_ints("yogo_conv_first_mfma_stats_rows", 1, B, H, W)[0]
                 stats = torch.empty(rows * 16 * 2, dtype=torch.float32, device=dev)
                 _hip.call("yogo_conv_first_mfma", cur, w32, bias, None, None, None, None, None, None, stats, B, L.cout, H, W, L.act, st)
@@ -626,10 +642,11 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
             xdt = 0 if S.x_in.dtype == torch.uint8 else 1
             if fuse0:
                 keep.append(S.z)
-                _hip.call("yogo_conv_first_bn_wgrad_bf16", S.x_in, xdt, g, S.z, S.mean, S.invstd, gamma, beta, part, B, L.cin, L.cout,
+                xg = "_xg" if S.gram is not None else ""
+                _hip.call("yogo_conv_first_bn_wgrad_bf16" + xg, S.x_in, xdt, g, S.z, S.mean, S.invstd, gamma, beta, part, B, L.cin, L.cout,
                           IH, IW, L.s, L.act, wst)
                 _hip.call("yogo_partials_reduce", part, rows, cols, 0.0, sums, wst)
-                _hip.call("yogo_conv_first_bn_wgrad_finalize", sums, S.mean, S.invstd, gamma,
+                _hip.call("yogo_conv_first_bn_wgrad_finalize" + xg, sums, *((S.gram,) if S.gram is not None else ()), S.mean, S.invstd, gamma,
                           S.w_used if S.w_used is not None else _f32(L.conv.weight.detach()), dw, dgamma,
                           dbeta, B, L.cin, L.cout, IH, IW, L.s, 1 if S.bn_train else 0, clip, wst)
                 if bn.weight is not None:
