@@ -69,7 +69,7 @@ def test_layout_round_trip():
 
 
 CASES = [(2, 16, 32, 20, 37, 3, 1), (1, 32, 64, 21, 40, 3, 2), (2, 64, 128, 13, 19, 3, 1), (1, 128, 128, 25, 33, 3, 2),
-         (2, 128, 128, 9, 129, 3, 1), (1, 128, 12, 7, 11, 1, 1), (1, 24, 40, 11, 9, 3, 1), (1, 16, 32, 3, 600, 3, 1)]
+         (2, 128, 128, 9, 129, 3, 1), (1, 128, 12, 7, 11, 1, 1), (1, 24, 40, 11, 9, 3, 1), (1, 16, 32, 3, 600, 3, 1), (1, 16, 32, 70, 45, 3, 1)]
 
 
 @pytest.mark.parametrize("case", CASES)

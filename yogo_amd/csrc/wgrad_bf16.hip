@@ -78,11 +78,14 @@ __device__ __forceinline__ bf16x8 lds_tr8(const unsigned char* base, int off0, i
 
 // MPW: co-blocks per wavefront (the wavefront grid is MBW x NBW x KS x kernel rows; a workgroup covers MBW * MPW co-blocks and
 // NBW * NPW ci-blocks).  MPW = 2, NPW = 1 reads 4 + 6 transposed operand halves per 6 MFMAs where MPW = 1, NPW = 2 reads 2 + 12.
-template <int MBW, int NBW, int NPW, int KS, int T, int S, int R, int MPW = 1, bool ROT = false>
+// PACK2 (16 input channels): the 32 output columns of an MFMA hold TWO taps -- lanes of columns 16-31 read the input one pixel
+// further instead of re-reading channels that do not exist -- so a kernel row costs 2 MFMAs and 4 B reads instead of 3 and 6.
+template <int MBW, int NBW, int NPW, int KS, int T, int S, int R, int MPW = 1, bool ROT = false, bool PACK2 = false>
 __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_bf16_kernel(const WgradBf16Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
   constexpr int TG = (T == 1) ? 1 : 3;
   constexpr int TT = T / TG;
+  constexpr int TM = PACK2 ? (TT + 1) / 2 : TT;  // MFMAs (B operands, accumulator tiles) per k-step and (co, ci) block pair
   constexpr int NT = 64 * MBW * NBW * KS * TG;
   constexpr int XR = (T == 1) ? R : (R - 1) * S + 3;
   constexpr unsigned OOB = 0x80000000u;
@@ -96,13 +99,13 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
   const int n0b = blockIdx.y * (NBW * NPW * 4);  // first channel BLOCK (of 8) of this workgroup's ci range
   const int m0b = blockIdx.z * (MBW * MPW * 4);
 
-  f32x16 acc[MPW][NPW][TT];
+  f32x16 acc[MPW][NPW][TM];
 #pragma unroll
   for (int m = 0; m < MPW; ++m)
 #pragma unroll
     for (int q = 0; q < NPW; ++q)
 #pragma unroll
-      for (int t = 0; t < TT; ++t)
+      for (int t = 0; t < TM; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][q][t][r] = 0.f;
   float bsum[MPW];
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
   const int xblk = XR * p.xw * xpb;                       // bytes of one channel-block group of the x image
   const int gbase = mb * MPW * (R * p.wce * 64) + lane_ch_off;
   // 16-channel image: the lanes of channels 16-31 re-read channels 0-15 (those output columns lie beyond N and are dropped)
-  const int xbase = p.ngs * NT * 16 + nb * NPW * xblk + (lane_ch_off & (xpb - 1));
+  const int xbase = p.ngs * NT * 16 + nb * NPW * xblk + (lane_ch_off & (xpb - 1)) + (PACK2 ? (gi & 1) * xpb : 0);
 
 #define WB_LOAD(AV, BV, I)                                                                                      \
   {                                                                                                             \
@@ -201,8 +204,8 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
     _Pragma("unroll") for (int m = 0; m < MPW; ++m)                                                             \
       AV[m] = lds_tr8(buf, ga_ + m * (R * p.wce * 64), ga_ + m * (R * p.wce * 64) + 4 * 64);                    \
     _Pragma("unroll") for (int q = 0; q < NPW; ++q)                                                             \
-    _Pragma("unroll") for (int t = 0; t < TT; ++t) {                                                            \
-      const int xa_ = xbase + q * xblk + (((r_ * S + (T == 1 ? 0 : tg)) * p.xw) + px_ * S + t) * xpb;           \
+    _Pragma("unroll") for (int t = 0; t < TM; ++t) {                                                            \
+      const int xa_ = xbase + q * xblk + (((r_ * S + (T == 1 ? 0 : tg)) * p.xw) + px_ * S + (PACK2 ? 2 * t : t)) * xpb; \
       BV[q][t] = lds_tr8(buf, xa_, xa_ + 4 * S * xpb);                                                          \
     }                                                                                                           \
   }
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
 #define WB_MFMA(AV, BV)                                           \
   _Pragma("unroll") for (int m = 0; m < MPW; ++m)                 \
   _Pragma("unroll") for (int q = 0; q < NPW; ++q)                 \
-  _Pragma("unroll") for (int t = 0; t < TT; ++t)                  \
+  _Pragma("unroll") for (int t = 0; t < TM; ++t)                  \
     acc[m][q][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AV[m], BV[q][t], acc[m][q][t], 0, 0, 0);
 
   // ring of p.depth LDS buffers: unit u + depth - 1 streams in while unit u is multiplied.  Ordering (LDS-DMA is invisible to
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
     ib = ib + 1 == p.depth ? 0 : ib + 1;
     if (cnt > 0) {
       if constexpr (NPW == 1 && MPW == 1) {  // operands of step i+1 are fetched before the MFMAs of step i
-        bf16x8 a0[MPW], a1[MPW], b0[NPW][TT], b1[NPW][TT];
+        bf16x8 a0[MPW], a1[MPW], b0[NPW][TM], b1[NPW][TM];
         WB_LOAD(a0, b0, 0);
         int i = 0;
         for (; i + 1 < cnt; i += 2) {
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
 #undef WB_STEP
       } else {  // 6 accumulator tiles: one operand set (the three wavefronts of a SIMD hide each other's LDS latency)
         for (int i = 0; i < cnt; ++i) {
-          bf16x8 a0[MPW], b0[NPW][TT];
+          bf16x8 a0[MPW], b0[NPW][TM];
           WB_LOAD(a0, b0, i);
           WB_MFMA(a0, b0);
           WB_BIAS(a0)
@@ -313,12 +316,16 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
 #pragma unroll
     for (int q = 0; q < NPW; ++q)
 #pragma unroll
-      for (int t = 0; t < TT; ++t) {
+      for (int t = 0; t < TM; ++t) {
+        // PACK2: column l31 of tile t = input channel l31 & 15 of tap 2t + (l31 >> 4)
+        const int tap = PACK2 ? 2 * t + (l31 >> 4) : t;
+        const int n = n0 + (nb * NPW + q) * 32 + (PACK2 ? (l31 & 15) : l31);
+        if (tap < TT) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + (mb * MPW + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          const int n = n0 + (nb * NPW + q) * 32 + l31;
-          sl[((size_t)(tg * TT + t) * p.Mpad + m) * p.Npad + n] = acc[mi][q][t][r];
+          for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (mb * MPW + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            sl[((size_t)(tg * TT + tap) * p.Mpad + m) * p.Npad + n] = acc[mi][q][t][r];
+          }
         }
       }
   if (do_bias) {  // lane l31 and lane l31 + 32 hold the two pixel halves of channel (mb*MPW + mi)*32 + l31
@@ -406,15 +413,15 @@ bool wb_plan(int B, int N, int M, int IH, int IW, int ks, int stride, WbPlan* pl
   return true;
 }
 
-template <int MBW, int NBW, int NPW, int KS, int T, int S, int R, int MPW = 1, bool ROT = false>
+template <int MBW, int NBW, int NPW, int KS, int T, int S, int R, int MPW = 1, bool ROT = false, bool PACK2 = false>
 void wb_launch_one(const WgradBf16Params& p, const WbPlan& pl, hipStream_t stream) {
   static bool s = false;
   if (!s) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<MBW, NBW, NPW, KS, T, S, R, MPW, ROT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<MBW, NBW, NPW, KS, T, S, R, MPW, ROT, PACK2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, WGB_LDS_MAX);
     s = true;
   }
-  hipLaunchKernelGGL((wgrad_bf16_kernel<MBW, NBW, NPW, KS, T, S, R, MPW, ROT>), pl.grid, dim3(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)),
+  hipLaunchKernelGGL((wgrad_bf16_kernel<MBW, NBW, NPW, KS, T, S, R, MPW, ROT, PACK2>), pl.grid, dim3(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)),
                      pl.lds_bytes, stream, p);
 }
 
@@ -475,7 +482,11 @@ extern "C" int yogo_conv2d_wgrad_bf16(const void* x, const void* g, float* dw, f
     else wb_launch_one<4, 1, 2, 1, 9, 2, 2>(p, pl, stream);
   } else {
     const int cfg = pl.MBW * 100 + pl.NBW * 10 + pl.KS;
-    if (pl.R == 8) {
+    static int pack2_env = -1;
+    if (pack2_env < 0) pack2_env = getenv("YOGO_WGRAD_PACK2") ? atoi(getenv("YOGO_WGRAD_PACK2")) : 1;
+    if (pl.R == 8 && pl.xcb == 2 && pack2_env) {
+      wb_launch_one<1, 1, 1, 4, 9, 1, 8, 1, false, true>(p, pl, stream);
+    } else if (pl.R == 8) {
       wb_launch_one<1, 1, 1, 4, 9, 1, 8>(p, pl, stream);
     } else
     switch (cfg) {
