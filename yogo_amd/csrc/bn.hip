@@ -345,12 +345,15 @@ __global__ __launch_bounds__(256) void bn_apply_act_8c_kernel(const u32x4_t* __r
   bn8c_load(q, cb, C, mean, invstd_or_var, stat_is_var, eps, gamma, beta);
   const u32x4_t* zp = z + (size_t)plane * HW;
   u32x4_t* yp = y + (size_t)plane * HW;
+  float sh2[8];  // y = z * sc + (beta - mean * sc): one FMA per value (conv_first_mfma_kernel applies the same form)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) sh2[j] = fmaf(-q.mu[j], q.sc[j], q.sh[j]);
   for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
     const bf16x8_t v = __builtin_bit_cast(bf16x8_t, zp[i]);
     bf16x8_t o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float r = act_fwd(fmaf((float)v[j] - q.mu[j], q.sc[j], q.sh[j]), act);
+      const float r = act_fwd(fmaf((float)v[j], q.sc[j], sh2[j]), act);
       o[j] = (cb * 8 + j < C) ? (__bf16)r : (__bf16)0.f;
     }
     yp[i] = __builtin_bit_cast(u32x4_t, o);

@@ -77,17 +77,16 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const ConvFirstMfm
     wa[j] = (__bf16)(ok ? p.w[l31 * 9 + min(ky, 2) * 3 + min(kx, 2)] : 0.f);
   }
   // this lane's output channels: 4 * half + i (i < 4) and 8 + 4 * half + i -- the accumulator rows of a 32x32 tile
-  float bs[8], mu[8], sc[8], sh[8];
+  float bs[8], sc[8], sh[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int ch = (i < 4 ? 0 : 8) + 4 * half + (i & 3);
     const bool ok = ch < p.Cout;
     bs[i] = (ok && p.bias != nullptr) ? p.bias[ch] : 0.f;
-    mu[i] = sc[i] = sh[i] = 0.f;  // padding channels: y = act(0) = 0
-    if (ok && p.y != nullptr) {
-      mu[i] = p.mean[ch];
+    sc[i] = sh[i] = 0.f;  // padding channels: y = act(0) = 0
+    if (ok && p.y != nullptr) {  // y = z * sc + sh with sh = beta - mean * sc (the form of bn_apply_act_8c_kernel)
       sc[i] = p.invstd[ch] * p.gamma[ch];
-      sh[i] = p.beta[ch];
+      sh[i] = fmaf(-p.mean[ch], sc[i], p.beta[ch]);
     }
   }
   float s8[8], q8[8];
@@ -138,7 +137,11 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const ConvFirstMfm
 
     float v[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = acc[i] + bs[i];
+    for (int i = 0; i < 8; ++i) v[i] = acc[i];
+    if (p.bias != nullptr) {  // (uniform)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += bs[i];
+    }
     if (p.stats_part != nullptr) {
       const float m = valid ? 1.f : 0.f;
 #pragma unroll
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const ConvFirstMfm
       if (p.y != nullptr) {  // BatchNorm + activation of the ROUNDED z, as yogo_bn_apply_act_bf16 computes it from the stored tensor
         float r[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) r[i] = fmaf((float)o[i] - mu[i], sc[i], sh[i]);
+        for (int i = 0; i < 8; ++i) r[i] = fmaf((float)o[i], sc[i], sh[i]);
         if (p.act == ACT_LEAKY) {  // (uniform branches around whole blocks)
 #pragma unroll
           for (int i = 0; i < 8; ++i) r[i] = fmaxf(r[i], LEAKY_SLOPE * r[i]);
