@@ -191,8 +191,8 @@ int yogo_bf16_8c_to_nchw_f32(const void* in, float* out, int B, int C, int HW, y
  * (model_defns.py:35).  Weights are rounded to bf16 inside (autocast, yogo/train.py:315-318).  Outputs, each optional:
  * stats_part = partial (sum, sumsq) of conv + bias in fp32, [rows][16][2] with rows from yogo_conv_first_mfma_stats_rows ->
  * yogo_bn_finalize(part, rows, 16, ...); z = conv + bias, bf16 NCHW8c; y = act((z - mean) * invstd * gamma + beta), bf16
- * NCHW8c.  Training runs it twice (statistics, then z + y): two sweeps over the images instead of conv + a separate BatchNorm
- * pass over the activations. */
+ * NCHW8c; without y the activation is applied to z (inference, BatchNorm folded into w / bias).  Training: statistics (this
+ * kernel or yogo_conv_first_gram), then z + y in one sweep instead of conv + a separate BatchNorm pass over the activations. */
 int yogo_conv_first_mfma_supported(int in_dtype, int Cin, int Cout, int IH, int IW, int stride);
 int yogo_conv_first_mfma_stats_rows(int B, int IH, int IW, int* rows);
 int yogo_conv_first_mfma(const void* in, const float* w, const float* bias, void* z, void* y, const float* mean,

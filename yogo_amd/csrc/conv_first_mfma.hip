@@ -151,6 +151,15 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const ConvFirstMfm
         q8[i] = fmaf(vm, v[i], q8[i]);
       }
     }
+    if (p.y == nullptr && p.act != ACT_NONE) {  // inference (BatchNorm folded into w / bias): z = act(conv + bias)
+      if (p.act == ACT_LEAKY) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], LEAKY_SLOPE * v[i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = act_fwd(v[i], ACT_SILU);
+      }
+    }
     if (p.z != nullptr || p.y != nullptr) {
       cfm_bf16x8 o;
 #pragma unroll
@@ -356,7 +365,8 @@ extern "C" int yogo_conv_first_mfma_stats_rows(int B, int IH, int IW, int* rows)
 
 // in: uint8 [B][1][IH][IW]; w: fp32 [Cout][1][3][3] (rounded to bf16 inside); any of the outputs may be NULL:
 //   stats_part: partial (sum, sumsq) of conv + bias (fp32, before rounding) -> yogo_bn_finalize(part, rows, 16, ...)
-//   z: conv + bias in bf16 NCHW8c;  y: act((z - mean) * invstd * gamma + beta) in bf16 NCHW8c (needs mean/invstd/gamma/beta)
+//   z: conv + bias in bf16 NCHW8c;  y: act((z - mean) * invstd * gamma + beta) in bf16 NCHW8c (needs mean/invstd/gamma/beta);
+//   without y the activation goes onto z (inference with BatchNorm folded into w and bias): z = act(conv + bias)
 extern "C" int yogo_conv_first_mfma(const void* in, const float* w, const float* bias, void* z, void* y, const float* mean,
                                     const float* invstd, const float* gamma, const float* beta, float* stats_part, int B, int Cout,
                                     int IH, int IW, int act, hipStream_t stream) {

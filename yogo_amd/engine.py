@@ -820,8 +820,11 @@ class InferEngineBF16:
                     raise RuntimeError(f"yogo_amd: layer 0 expects {L.cin} channels, got {cur.shape[1]}")
                 mb = _hip.lib().yogo_bf16_channel_blocks(L.cout)
                 out = torch.empty(B, mb, OH, OW, 8, dtype=torch.bfloat16, device=dev)
-                _hip.call("yogo_conv_first_fwd_bf16", cur, 0 if cur.dtype == torch.uint8 else 1, wq, bias, out, B, L.cin, L.cout, H, W,
-                          L.s, L.act, st)
+                if _L0_MFMA and cur.dtype == torch.uint8 and _hip.lib().yogo_conv_first_mfma_supported(0, L.cin, L.cout, H, W, L.s):
+                    _hip.call("yogo_conv_first_mfma", cur, wq, bias, out, None, None, None, None, None, None, B, L.cout, H, W, L.act, st)
+                else:
+                    _hip.call("yogo_conv_first_fwd_bf16", cur, 0 if cur.dtype == torch.uint8 else 1, wq, bias, out, B, L.cin, L.cout, H, W,
+                              L.s, L.act, st)
                 if last:
                     raise RuntimeError("yogo_amd: a one-layer network is not supported by the bf16 inference path")
             elif last:
