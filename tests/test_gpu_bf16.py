@@ -347,8 +347,47 @@ def test_fused_layer0_backward_matches_separate_passes():
             assert torch.equal(a, b_), n
 
 
+def test_bf16_dropout_masks():
+    """Dropout2d in the bf16 training path: all layers' channel masks come from one rand call; every layer keeps its own p,
+    the survivors are scaled by 1 / (1 - p), dropped channels are zero in the block output."""
+    from yogo_amd import engine as E
+    from yogo_amd.model import YOGO
+
+    torch.manual_seed(3)
+    m = YOGO((96, 128), 0.0425, 0.0555, 7).cuda()
+    m.train()
+    eng = E.get_engine(m.model)
+    x = torch.randint(0, 256, (64, 1, 96, 128), dtype=torch.uint8).cuda()
+    with torch.no_grad():
+        raw, saved = E.forward_bf16_train(eng, x)
+    assert torch.isfinite(raw).all()
+    ps = [float(L.drop.p) for L in eng.layers if L.drop is not None]
+    assert len(set(ps)) > 1                      # the reference uses different rates (model_defns.py:38-52)
+    seen = 0
+    for L, S in zip(eng.layers, saved):
+        if L.drop is None:
+            assert S.mask is None
+            continue
+        p = float(L.drop.p)
+        mask = S.mask.cpu()
+        assert mask.shape == (64, L.cout) and S.mask.is_contiguous()
+        vals = mask.unique().tolist()
+        assert all(v == 0.0 or abs(v - 1 / (1 - p)) < 1e-6 for v in vals) and len(vals) == 2
+        frac = float((mask == 0).float().mean())
+        assert abs(frac - p) < 4 * (p * (1 - p) / mask.numel()) ** 0.5 + 1e-3
+        y = from8c(S.y, L.cout)
+        assert torch.all(y[mask == 0] == 0)
+        seen += 1
+    assert seen == len(ps) == 3
+    m.eval()
+    with torch.no_grad():
+        _, saved = E.forward_bf16_train(eng, x[:2])
+    assert all(S.mask is None for S in saved)
+
+
 @pytest.mark.parametrize("name,hw,rgb", [("silu_model", (96, 128), False), ("quarter_filters", (130, 70), True),
-                                         ("depth_ver_3", (96, 128), False), ("triple_filters", (64, 96), False)])
+                                         ("depth_ver_3", (96, 128), False), ("triple_filters", (64, 96), False),
+                                         ("base_model", (97, 131), False)])   # odd sizes: the direct layer-0 kernels
 def test_bf16_training_other_architectures(name, hw, rgb):
     """two optimisation steps in bf16 against the same two steps in fp32 for other registered ModelDefns (SiLU blocks keep
     their pre-activation for the backward pass; widths 4..384; rgb input): loss within 2 %"""
