@@ -1,3 +1,6 @@
+"""usage: prof_kernels.py <dir with stats/*kernel_stats.csv> <comma list of name fragments>
+per-step launch count and average duration of the matching kernels of a rocprofv3 --kernel-trace --stats --output-format csv run of
+bench.py (steps are counted by the adamw_kernel launches)."""
 import csv,glob,sys
 f=glob.glob(sys.argv[1]+"/stats/*kernel_stats.csv")[0]
 rows=list(csv.DictReader(open(f)))
