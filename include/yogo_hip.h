@@ -90,6 +90,10 @@ int yogo_decode_fwd(const float* raw, float* out, const float* cxs, const float*
 int yogo_decode_bwd(const float* raw, const float* out, const float* gout, float* graw, int B, int P, int Sy, int Sx,
                     int inference, yogo_stream_t stream);
 
+/* the same, gradient written as bf16 NCHW8c [B][2 * ceil(P / 16)][Sy][Sx][8] for the bf16 backward pass of the head convolution */
+int yogo_decode_bwd_bf16(const float* raw, const float* out, const float* gout, void* graw8c, int B, int P, int Sy, int Sx,
+                         int inference, yogo_stream_t stream);
+
 /* ---- loss: YOGOLoss.forward, yogo/yogo_loss.py:38-129 (+ its autograd) ------------------------------------------------- */
 int yogo_loss_workspace_bytes(int B, int Sy, int Sx, size_t* bytes);
 /* loss_out: 4 device floats {total, iou_loss, objectness_loss, classification_loss}; grad = d total / d pred */

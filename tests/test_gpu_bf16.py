@@ -235,6 +235,28 @@ def test_layer0_statistics_from_gram(B, IH, IW):
     assert int(nbt.item()) == 1
 
 
+@pytest.mark.parametrize("inference", [0, 1])
+def test_decode_backward_straight_to_bf16(inference):
+    """yogo_decode_bwd_bf16 == yogo_decode_bwd followed by the fp32 -> bf16 NCHW8c conversion, bit for bit"""
+    h = H()
+    B, P, Sy, Sx = 3, 12, 13, 17
+    g = torch.Generator().manual_seed(9 + inference)
+    raw = torch.randn(B, P, Sy, Sx, generator=g).cuda()
+    raw[0, 2, 0, 0] = 90.0                         # beyond the exp clamp: zero gradient
+    gout = torch.randn(B, P, Sy, Sx, generator=g).cuda()
+    st = h.stream_ptr()
+    cx, cy = torch.linspace(0, 1 - 1 / Sx, Sx).cuda(), torch.linspace(0, 1 - 1 / Sy, Sy).cuda()
+    out = torch.empty_like(raw)
+    h.call("yogo_decode_fwd", raw, out, cx, cy, B, P, Sy, Sx, 0.05, 0.06, 1.0, 1.0, inference, st)
+    g32 = torch.empty_like(raw)
+    h.call("yogo_decode_bwd", raw, out, gout, g32, B, P, Sy, Sx, inference, st)
+    want = torch.empty(B, 2, Sy, Sx, 8, dtype=torch.bfloat16, device="cuda")
+    h.call("yogo_nchw_f32_to_bf16_8c", g32, want, B, P, Sy * Sx, st)
+    got = torch.full_like(want, float("nan"))
+    h.call("yogo_decode_bwd_bf16", raw, out, gout, got, B, P, Sy, Sx, inference, st)
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+
+
 def test_batchnorm_bf16():
     h = H()
     B, C, Hh, W = 3, 20, 11, 13

@@ -67,6 +67,45 @@ __global__ __launch_bounds__(256) void decode_bwd_kernel(const float* __restrict
   }
 }
 
+// the same with the gradient written as bf16 NCHW8c [B][kb(P)][cells][8] (padding channels zero): what the bf16 backward pass of
+// the head convolution reads -- saves the fp32 tensor and the conversion pass
+typedef __bf16 dl_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int dl_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void decode_bwd_bf16_kernel(const float* __restrict__ raw, const float* __restrict__ out,
+                                                              const float* __restrict__ gout, dl_u32x4* __restrict__ g8, float inv_sx,
+                                                              float inv_sy, int P, int Pb, int cells, int inference) {
+  const int b = blockIdx.y;
+  const int cell = blockIdx.x * 256 + threadIdx.x;
+  if (cell >= cells) return;
+  const size_t base = (size_t)b * P * cells + cell;
+  const float* r = raw + base;
+  const float* o = out + base;
+  const float* g = gout + base;
+  const int C = P - 5;
+  float dot = 0.f;
+  if (inference)
+    for (int c = 0; c < C; ++c) dot += g[(size_t)(5 + c) * cells] * o[(size_t)(5 + c) * cells];
+  const float s0 = sigmoidf_(r[0]), s1 = sigmoidf_(r[(size_t)cells]), s4 = o[(size_t)4 * cells];
+  for (int kb = 0; kb < Pb; ++kb) {
+    dl_bf16x8 u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ch = kb * 8 + j;
+      float v = 0.f;
+      if (ch < P) {
+        const float gv = g[(size_t)ch * cells];
+        if (ch == 0) v = gv * (inv_sx * (s0 * (1.f - s0)));
+        else if (ch == 1) v = gv * (inv_sy * (s1 * (1.f - s1)));
+        else if (ch == 2 || ch == 3) v = r[(size_t)ch * cells] <= 80.f ? gv * o[(size_t)ch * cells] : 0.f;
+        else if (ch == 4) v = gv * (s4 * (1.f - s4));
+        else v = inference ? o[(size_t)ch * cells] * (gv - dot) : gv;
+      }
+      u[j] = (__bf16)v;
+    }
+    g8[((size_t)b * Pb + kb) * cells + cell] = __builtin_bit_cast(dl_u32x4, u);
+  }
+}
+
 // ---- loss forward + backward -------------------------------------------------------------------------------------
 // d max(a,b)/da as torch's `maximum` backward: 1 if a > b, 0.5 on ties, 0 otherwise (min likewise)
 __device__ __forceinline__ float dmax_a(float a, float b) { return a > b ? 1.f : (a == b ? 0.5f : 0.f); }
@@ -255,6 +294,19 @@ extern "C" int yogo_decode_bwd(const float* raw, const float* out, const float* 
   hipLaunchKernelGGL(decode_bwd_kernel, dim3(cdiv(cells, 256), B), dim3(256), 0, stream, raw, out, gout, graw,
                      (float)(1.0 / Sx), (float)(1.0 / Sy), P, cells, inference);
   YOGO_CHECK_LAUNCH("decode_bwd");
+  return YOGO_OK;
+}
+
+// graw8c: bf16 NCHW8c [B][2 * ceil(P / 16)][Sy][Sx][8]
+extern "C" int yogo_decode_bwd_bf16(const float* raw, const float* out, const float* gout, void* graw8c, int B, int P, int Sy, int Sx,
+                                    int inference, hipStream_t stream) {
+  YOGO_CHECK_ARG(raw && out && gout && graw8c, "decode_bwd_bf16: null pointer");
+  YOGO_CHECK_ARG(B >= 0 && P > 5 && Sy > 0 && Sx > 0 && B <= 65535, "decode_bwd_bf16: bad shape");
+  if (B == 0) return YOGO_OK;
+  const int cells = Sy * Sx;
+  hipLaunchKernelGGL(decode_bwd_bf16_kernel, dim3(cdiv(cells, 256), B), dim3(256), 0, stream, raw, out, gout,
+                     reinterpret_cast<dl_u32x4*>(graw8c), (float)(1.0 / Sx), (float)(1.0 / Sy), P, ((P + 15) / 16) * 2, cells, inference);
+  YOGO_CHECK_LAUNCH("decode_bwd_bf16");
   return YOGO_OK;
 }
 

@@ -575,11 +575,15 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
             return grad_out[id(param)]
         return torch.empty(param.shape, dtype=torch.float32, device=dev)
 
-    graw = _f32(graw)
-    B, P, Sy, Sx = graw.shape
     keep: list = []   # tensors in use on the weight-gradient stream
-    g = torch.empty(B, _blocks(P), Sy, Sx, 8, dtype=torch.bfloat16, device=dev)
-    _hip.call("yogo_nchw_f32_to_bf16_8c", graw, g, B, P, Sy * Sx, st)
+    if graw.dtype == torch.bfloat16 and graw.ndim == 5:   # already NCHW8c (yogo_decode_bwd_bf16)
+        g = graw
+        B = g.shape[0]
+    else:
+        graw = _f32(graw)
+        B, P, Sy, Sx = graw.shape
+        g = torch.empty(B, _blocks(P), Sy, Sx, 8, dtype=torch.bfloat16, device=dev)
+        _hip.call("yogo_nchw_f32_to_bf16_8c", graw, g, B, P, Sy * Sx, st)
     n = len(eng.layers)
     for i in range(n - 1, -1, -1):
         L, S = eng.layers[i], saved[i]

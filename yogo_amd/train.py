@@ -134,11 +134,13 @@ class HipTrainer:
             _hip.call("yogo_loss_fwd_bwd", pred, lab, gpred, out, ws, B, P, Sy, Sx, float(L.no_obj_weight), float(L.iou_weight),
                       float(L.classify_weight), float(L.label_smoothing), st)
             # ---- backward: decode, then the backbone (clamp fused into the gradient kernels) -------------------------
-            graw = torch.empty_like(raw)
-            _hip.call("yogo_decode_bwd", raw, pred, gpred, graw, B, P, Sy, Sx, int(bool(m.inference)), st)
-            if self.half:
-                backward_bf16_train(eng, saved, graw, grad_out=self.flat.grad_views)
+            if self.half:   # the head's gradient goes straight to bf16 NCHW8c
+                g8 = torch.empty(B, ((P + 15) // 16) * 2, Sy, Sx, 8, dtype=torch.bfloat16, device=raw.device)
+                _hip.call("yogo_decode_bwd_bf16", raw, pred, gpred, g8, B, P, Sy, Sx, int(bool(m.inference)), st)
+                backward_bf16_train(eng, saved, g8, grad_out=self.flat.grad_views)
             else:
+                graw = torch.empty_like(raw)
+                _hip.call("yogo_decode_bwd", raw, pred, gpred, graw, B, P, Sy, Sx, int(bool(m.inference)), st)
                 eng.backward(saved, graw, grad_out=self.flat.grad_views)
             # ---- data-parallel exchange: one RCCL all-reduce of the flat gradient --------------------------------------
             scale = 1.0
