@@ -25,6 +25,12 @@ typedef void* yogo_stream_t; /* hipStream_t */
 
 const char* yogo_hip_last_error(void);
 int yogo_hip_abi_version(void);
+/* Launch log (test / profiling aid, no counterpart in the reference): while enabled, every entry point that launches a
+ * convolution / weight-gradient kernel appends one line "<kernel instantiation as rocprofv3 names it> | <planner parameters>".
+ * enable = 1 clears and starts recording, 0 stops.  yogo_hip_launch_log_read copies the text into a HOST buffer (NUL
+ * terminated, truncated to cap) and reports the bytes needed. */
+int yogo_hip_launch_log(int enable);
+int yogo_hip_launch_log_read(char* buf, size_t cap, size_t* needed);
 
 /* ---- convolution, fp32 matrix cores ---------------------------------------------------------------------------
  * nn.Conv2d(cin, cout, 3, stride=1|2, padding=1) and nn.Conv2d(cin, cout, 1): yogo/model_defns.py:34-67,

@@ -1,11 +1,18 @@
 #!/usr/bin/env bash
 # Build libyogo_hip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
+#   bash build.sh        -> yogo_amd/lib/libyogo_hip.so       (the product: no diagnostic code is compiled in)
+#   bash build.sh diag   -> yogo_amd/lib/libyogo_hip_diag.so  (-DYOGO_DIAG: ablation bits + s_memtime phase stamps in
+#                           conv_bf16_kernel, driven by yogo_diag_conv_bf16(); tools/ only, never loaded by the package)
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="$HERE/../lib"
-mkdir -p "$OUT" "$HERE/obj"
+OBJ="$HERE/obj"
+LIBNAME="libyogo_hip.so"
+DEFS=()
+if [[ "${1:-}" == "diag" ]]; then OBJ="$HERE/obj_diag"; LIBNAME="libyogo_hip_diag.so"; DEFS=(-DYOGO_DIAG); fi
+mkdir -p "$OUT" "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-COMMON=(-O3 --offload-arch=gfx950 -fPIC -std=c++17 -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -I"$HERE" -I"$HERE/../../include")
+COMMON=(-O3 --offload-arch=gfx950 -fPIC -std=c++17 -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -I"$HERE" -I"$HERE/../../include" "${DEFS[@]}")
 pids=()
 for f in "$HERE"/*.hip; do
   base="$(basename "$f" .hip)"
@@ -13,11 +20,11 @@ for f in "$HERE"/*.hip; do
   case "$base" in
     nms|decode_loss) extra=(-ffp-contract=off) ;;
   esac
-  if [[ ! -f "$HERE/obj/$base.o" || "$f" -nt "$HERE/obj/$base.o" || "$HERE/common.h" -nt "$HERE/obj/$base.o" ]]; then
-    "$HIPCC" "${COMMON[@]}" "${extra[@]}" -c "$f" -o "$HERE/obj/$base.o" &
+  if [[ ! -f "$OBJ/$base.o" || "$f" -nt "$OBJ/$base.o" || "$HERE/common.h" -nt "$OBJ/$base.o" ]]; then
+    "$HIPCC" "${COMMON[@]}" "${extra[@]}" -c "$f" -o "$OBJ/$base.o" &
     pids+=($!)
   fi
 done
 for p in "${pids[@]:-}"; do [[ -n "$p" ]] && wait "$p"; done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$HERE"/obj/*.o -o "$OUT/libyogo_hip.so"
-echo "built $OUT/libyogo_hip.so"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$OBJ"/*.o -o "$OUT/$LIBNAME"
+echo "built $OUT/$LIBNAME"

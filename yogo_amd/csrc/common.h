@@ -13,6 +13,9 @@
 // defined in api_common.hip
 extern "C" const char* yogo_hip_last_error(void);
 void yogo_set_error(const char* fmt, ...);
+// launch log (api_common.hip): one line per kernel launch while yogo_hip_launch_log(1) is in effect
+bool yogo_launch_log_enabled();
+void yogo_launch_log(const char* fmt, ...);
 
 #define YOGO_CHECK_ARG(cond, ...)                 \
   do {                                            \

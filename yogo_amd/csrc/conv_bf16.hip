@@ -57,9 +57,21 @@ struct ConvBf16Params {
   // while the matrix cores work on chunk c.  ni_slots / n_slots: input / all slots of a chunk; bufu: units per buffer.
   int dma, ni_slots, n_slots, bufu;
   int bufs;  // LDS units between the buffers of consecutive chunks: bufu (two buffers) or 0 (dma = 2: one buffer, see below)
-  int dbg;  // experiments (YOGO_BF16_DBG): 1 = no output stores, 2 = no MFMA loop, 4 = no DMA, 8 / 16 = no input / weight DMA
-  unsigned long long* stamps;  // experiments (YOGO_BF16_STAMPS): [workgroup][4] s_memtime at start / loop / epilogue / end
+#ifdef YOGO_DIAG
+  // diagnostic build only (bash build.sh diag -> libyogo_hip_diag.so; tools/bench_conv_bf16.py): ablation bits and phase stamps.
+  // The production library contains none of this code.
+  int dbg;  // 1 = no output stores, 2 = no MFMA loop, 4 = no DMA, 8 / 16 = no input / weight DMA
+  unsigned long long* stamps;  // [workgroup][4] s_memtime at start / loop / epilogue / end
+#endif
 };
+
+#ifdef YOGO_DIAG
+#define BF_DBG(BIT) (p.dbg & (BIT))
+#define BF_STAMP() (p.stamps ? __builtin_amdgcn_s_memtime() : 0ull)
+#else
+#define BF_DBG(BIT) 0
+#define BF_STAMP() 0ull
+#endif
 
 // sum over the 32 lanes of each half-wave with DPP adds (no LDS traffic); the result is valid in lanes 16-31 / 48-63
 __device__ __forceinline__ float half_wave_sum(float v) {
@@ -99,7 +111,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
   constexpr int NC = S2D ? 2 : 1;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const unsigned long long t_start = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+  [[maybe_unused]] const unsigned long long t_start = BF_STAMP();
   // XCD-aware bijective remap: contiguous runs of (image, tile) per XCD so halo rows hit the same L2
   const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
   const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
@@ -303,7 +315,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
     if constexpr (S2D) BF_RUN(NC - 1, n0tap * hk, ntap * hk)                                      \
   }
 
-  const unsigned long long t_loop = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+  [[maybe_unused]] const unsigned long long t_loop = BF_STAMP();
   if (p.dma) {
     // Every lane owns PF fixed elements of a chunk: slots [0, ni) cover the input tile, [ni, ns) the weight slices.  The
     // source byte offset of each is decoded ONCE; image borders, tile tails and unused slices become out-of-range offsets,
@@ -356,8 +368,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
   {                                                                                                                    \
     u32x4* lb_ = smem4 + ((C) & 1) * p.bufs + wave * 64;                                                               \
     _Pragma("unroll") for (int i = 0; i < PF; ++i) {                                                                   \
-      if (i < ni) { if (!(p.dbg & 8)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_i, (lds_ptr_t)(lb_ + i * NT), 16, voffv[i], (C) * so_i, 0, 0); } \
-      else if (i < ns) { if (!(p.dbg & 16)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(lb_ + i * NT), 16, voffv[i], (C) * so_w, 0, 0); } \
+      if (i < ni) { if (!BF_DBG(8)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_i, (lds_ptr_t)(lb_ + i * NT), 16, voffv[i], (C) * so_i, 0, 0); } \
+      else if (i < ns) { if (!BF_DBG(16)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(lb_ + i * NT), 16, voffv[i], (C) * so_w, 0, 0); } \
     }                                                                                                                  \
   }
 // one slot of chunk C, chosen at run time: issued between the MFMA clusters of the previous chunk, so the DMA instructions
@@ -399,11 +411,11 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
       // two buffers: chunk c + 1 is requested slot by slot between the MFMA clusters of chunk c
       dnext = 0;
       dchunk = c + 1;
-      dend = (p.dma == 1 && c + 1 < p.nchunk && !(p.dbg & 4)) ? ns : 0;
+      dend = (p.dma == 1 && c + 1 < p.nchunk && !BF_DBG(4)) ? ns : 0;
       const u32x4* ldsI = smem4 + (c & 1) * p.bufs;
       const u32x4* ldsW = ldsI + p.ldsw_off;
       __builtin_amdgcn_sched_barrier(0);
-      if (!(p.dbg & 2)) BF_COMPUTE()
+      if (!BF_DBG(2)) BF_COMPUTE()
       while (dnext < dend) {  // fewer MFMA clusters than slots: the rest goes out now
         DMA_ONE(dnext, dchunk)
         ++dnext;
@@ -442,7 +454,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
 #undef ACC_ZERO
 #undef BF_HOOK
 
-  const unsigned long long t_epi = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+  [[maybe_unused]] const unsigned long long t_epi = BF_STAMP();
   // ---- epilogue: bias (+ BatchNorm partial sums of the fp32 pre-activation) + activation [or act'(ref)] + channel mask,
   //      then bf16 NCHW8c or fp32 NCHW.  The per-channel bias / scale of the BM channels go through LDS (fetched before the
   //      main loop); bf16 output: the two half-waves exchange one 8-byte group (v_permlane32_swap) so that every lane stores
@@ -507,7 +519,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
         for (int c = 0; c < NC; ++c)
 #pragma unroll
           for (int n = 0; n < NW; ++n) {
-            const bool valid = (c == 0 ? pvalid[n] : pvalid1[n]) && !(p.dbg & 1);
+            const bool valid = (c == 0 ? pvalid[n] : pvalid1[n]) && !BF_DBG(1);
             if (valid) {
 #pragma unroll
               for (int i = 0; i < 4; ++i)
@@ -528,7 +540,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
     for (int c = 0; c < NC; ++c)
 #pragma unroll
       for (int n = 0; n < NW; ++n) {
-        const bool valid = (c == 0 ? pvalid[n] : pvalid1[n]) && !(p.dbg & 1);
+        const bool valid = (c == 0 ? pvalid[n] : pvalid1[n]) && !BF_DBG(1);
         vo[c][n] = valid ? (opix[n] + c) * 16 + half * plane16 : (int)0x80000000u;
       }
     // training dgrad into a block without BatchNorm: act'(ref).  All of this lane's reference values (8 bytes per group) are
@@ -595,7 +607,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
             if (do_stats || p.act == ACT_SILU || p.out_pre != nullptr || (has_ref && p.ref_act != ACT_LEAKY)) {  // general order of operations
 #pragma unroll
               for (int i = 0; i < 8; ++i) v[i] = acc[c][mb][n][8 * gp + i] + ba[i];
-              if (do_stats && !(p.dbg & 256)) {
+              if (do_stats) {
                 if (full_tile) {  // every pixel of the workgroup's tile exists: no masking
 #pragma unroll
                   for (int i = 0; i < 8; ++i) {
@@ -709,8 +721,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
           float sr[8], qr[8];
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            sr[i] = (p.dbg & 128) ? s8[i] : half_wave_sum(s8[i]);
-            qr[i] = (p.dbg & 128) ? q8[i] : half_wave_sum(q8[i]);
+            sr[i] = half_wave_sum(s8[i]);
+            qr[i] = half_wave_sum(q8[i]);
           }
           if (l31 == 31) {
 #pragma unroll
@@ -753,10 +765,12 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
       dst[1] = q;
     }
   }
+#ifdef YOGO_DIAG
   if (p.stamps && tid == 0) {
     unsigned long long* d = p.stamps + (size_t)widx * 4;
     d[0] = t_start; d[1] = t_loop; d[2] = t_epi; d[3] = __builtin_amdgcn_s_memtime();
   }
+#endif
 }
 
 // ---- weight packing: OIHW fp32 (x optional per-output-channel scale = folded BatchNorm) -> [T][Kb][Mpad] units ----------
@@ -969,6 +983,18 @@ extern "C" int yogo_conv_bf16_pack_multi(const void* table, int n, int total_blo
 // channel blocks of a bf16 NCHW8c tensor with C channels AS THE NEXT LAYER READS IT (padded to 16 channels = 2 blocks)
 extern "C" int yogo_bf16_channel_blocks(int C) { return bf_kb_of(C); }
 
+#ifdef YOGO_DIAG
+// diagnostic build only: ablation bits, synchronous staging, and a caller-owned stamp buffer ([workgroups][4] u64)
+static int g_diag_dbg = 0, g_diag_nodma = 0;
+static unsigned long long* g_diag_stamps = nullptr;
+static size_t g_diag_stamps_bytes = 0;
+extern "C" int yogo_diag_conv_bf16(int dbg_bits, int no_dma, void* stamps, size_t stamps_bytes) {
+  g_diag_dbg = dbg_bits; g_diag_nodma = no_dma;
+  g_diag_stamps = reinterpret_cast<unsigned long long*>(stamps); g_diag_stamps_bytes = stamps_bytes;
+  return YOGO_OK;
+}
+#endif
+
 namespace {
 
 // One launcher for forward and data-gradient.  (K, M) are the GEMM contraction / output channel counts, (IH, IW) the
@@ -982,29 +1008,19 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
   const bool small_n = s2d || a == 2;  // two accumulator sets / four-fold input tile: half the pixel groups per wavefront
   // 64 GEMM rows at stride 1 with a long contraction: 8 wavefronts x 4 pixel groups (64 rows x 1024 px), the same staged
   // bytes per MFMA as the 128-row tile; everything else with <= 64 rows stays on 4-wavefront workgroups
-  static int wide64_env = -1;
-  if (wide64_env < 0) wide64_env = getenv("YOGO_BF16_WIDE64") ? atoi(getenv("YOGO_BF16_WIDE64")) : 1;
-  const bool wide64 = wide64_env && MW == 2 && !small_n && K >= 64 && OH * OW >= 4096;
+  const bool wide64 = MW == 2 && !small_n && K >= 64 && OH * OW >= 4096;
   const int NW = MW == 1 ? (small_n ? 2 : 4) : (small_n ? 1 : (wide64 ? 4 : 2));
-  // experiment (YOGO_BF16_HALFWG=1): 128-row tiles on two 4-wavefront workgroups per CU with ONE LDS buffer each, so that one
-  // workgroup's staging / epilogue overlaps the other's MFMAs
-  static int halfwg_env = -1;
-  if (halfwg_env < 0) halfwg_env = getenv("YOGO_BF16_HALFWG") ? atoi(getenv("YOGO_BF16_HALFWG")) : 0;
-  const bool halfwg = halfwg_env && MW == 4 && !small_n;
-  const int NWV = ((MW == 4 && !halfwg) || wide64) ? 8 : 4;  // 128-channel tiles: 8 wavefronts share the staged weight slice
+  const int NWV = (MW == 4 || wide64) ? 8 : 4;  // 128-channel tiles: 8 wavefronts share the staged weight slice
   const int PF = NWV == 8 ? 10 : 16;  // = 160 KB / 128 KB of LDS for the two buffers at most
   const int Kb = bf_kb_of(K), Mpad = bf_mpad_of(M);
   // the grid the workgroups tile: output pixels, or 2x2 output quads of one row parity
   const int OHt = s2d ? (OH + 1) / 2 : OH, OWt = s2d ? (OW + 1) / 2 : OW;
   BfTiling tl;
-  // 4-wavefront workgroups: two per CU when the pipelined tiling fits half the LDS
+  // 4-wavefront workgroups: as many per CU as a pipelined tiling allows (4, 3, 2)
   bool planned = false;
-  if (halfwg) planned = bf_plan(OHt, OWt, a, T, ks, Kb, MW, NW, NWV, PF, BF_LDS_BUDGET, &tl, true) && tl.dma;
-  if (NWV == 4 && !planned) {  // as many workgroups per CU as a pipelined tiling allows: 4, 3, 2
-    static int ladder_env = -1;
-    if (ladder_env < 0) ladder_env = getenv("YOGO_BF16_LDS_LADDER") ? atoi(getenv("YOGO_BF16_LDS_LADDER")) : 0;
+  if (NWV == 4) {
     const int ladder[3] = {40 * 1024, 53 * 1024, BF_LDS_BUDGET};
-    for (int i = ladder_env; i < 3 && !planned; ++i)
+    for (int i = 0; i < 3 && !planned; ++i)
       planned = bf_plan(OHt, OWt, s2d ? 1 : a, s2d ? 6 : T, s2d ? 2 : ks, Kb, MW, NW, NWV, PF, ladder[i], &tl) && tl.dma;
   }
   if (!planned) planned = bf_plan(OHt, OWt, s2d ? 1 : a, s2d ? 6 : T, s2d ? 2 : ks, Kb, MW, NW, NWV, PF, BF_LDS_MAX, &tl);
@@ -1039,36 +1055,28 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
   p.CKb = tl.CKb; p.ckb_shift = tl.CKb == 8 ? 3 : (tl.CKb == 4 ? 2 : 1); p.nchunk = Kb / tl.CKb;
   p.ldsw_off = tl.ldsw_off; p.lds_dummy = tl.lds_dummy; p.act = act;
   p.dma = tl.dma; p.ni_slots = tl.ni_slots; p.n_slots = tl.n_slots; p.bufu = tl.bufu; p.bufs = tl.dma == 1 ? tl.bufu : 0;
+#ifdef YOGO_DIAG
+  p.dbg = g_diag_dbg;
+  if (g_diag_nodma && (tl.lds_dummy + 1) * 16 <= BF_LDS_MAX) p.dma = 0;  // synchronous staging through registers
   {
-    static int nopf = -1;
-    if (nopf < 0) nopf = getenv("YOGO_BF16_NO_DMA") ? 1 : 0;  // experiments: synchronous staging through registers
-    if (nopf && (tl.lds_dummy + 1) * 16 <= BF_LDS_MAX) p.dma = 0;
-    static int dbg = -1;
-    if (dbg < 0) dbg = getenv("YOGO_BF16_DBG") ? atoi(getenv("YOGO_BF16_DBG")) : 0;
-    p.dbg = dbg;
-    static unsigned long long* stamps = nullptr;
-    static int want_stamps = -1;
-    if (want_stamps < 0) want_stamps = getenv("YOGO_BF16_STAMPS") ? 1 : 0;
-    if (want_stamps) {
-      if (!stamps) (void)hipMalloc(&stamps, (size_t)1 << 24);
-      const size_t nwg = (size_t)grid.x * grid.y * grid.z;
-      if (nwg * 32 <= ((size_t)1 << 24)) { (void)hipMemsetAsync(stamps, 0, nwg * 32, stream); p.stamps = stamps; }
+    const size_t nwg = (size_t)grid.x * grid.y * grid.z;
+    if (g_diag_stamps != nullptr && nwg * 32 <= g_diag_stamps_bytes) {
+      (void)hipMemsetAsync(g_diag_stamps, 0, nwg * 32, stream);
+      p.stamps = g_diag_stamps;
     }
   }
+#endif
   if ((act_ref != nullptr || signs_read) && bias != nullptr) {
     yogo_set_error("conv_bf16: an activation reference goes with a data gradient (no bias)");
     return YOGO_ERR_ARG;
   }
   if (B == 0) return YOGO_OK;
   const int lds_bytes = max(p.dma ? tl.lds_bytes : (tl.lds_dummy + 1) * 16, (2 + 2 * NWV) * 32 * MW * 4);
-  {
-    static int verbose = -1;
-    if (verbose < 0) verbose = getenv("YOGO_IGEMM_VERBOSE") ? 1 : 0;
-    if (verbose)
-      fprintf(stderr, "[bf16] K=%d M=%d in=%dx%d a=%d s2d=%d T=%d | MW=%d NW=%d NWV=%d ncb=%d TW=%d CKb=%d rows=%d LW=%d lds=%d dma=%d slots=%d+%d grid=%ux%ux%u\n",
-              K, M, IH, IW, a, s2d, T, MW, NW, NWV, tl.ncb, tl.TW, tl.CKb, tl.rows_max, tl.LW, lds_bytes, p.dma, tl.ni_slots,
-              tl.n_slots - tl.ni_slots, grid.x, grid.y, grid.z);
-  }
+  char plan_txt[256] = "";
+  if (yogo_launch_log_enabled())
+    snprintf(plan_txt, sizeof(plan_txt), "K=%d M=%d in=%dx%d out=%dx%d a=%d s2d=%d T=%d ncb=%d TW=%d tiles_per_band=%d CKb=%d nchunk=%d rows=%d LW=%d lds=%d dma=%d slots=%d+%d grid=%ux%ux%u",
+             K, M, IH, IW, OH, OW, a, s2d, T, tl.ncb, tl.TW, tl.tiles_per_band, tl.CKb, Kb / tl.CKb, tl.rows_max, tl.LW, lds_bytes, p.dma, tl.ni_slots,
+             tl.n_slots - tl.ni_slots, grid.x, grid.y, grid.z);
 #define BFLAUNCH__(MW_, NW_, NWV_, S2D_, PF_, F32_, REF_)                                                                          \
   do {                                                                                                                 \
     static bool attr_set = false;                                                                                      \
@@ -1078,6 +1086,7 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
       attr_set = true;                                                                                                 \
     }                                                                                                                  \
     hipLaunchKernelGGL((conv_bf16_kernel<MW_, NW_, NWV_, S2D_, PF_, F32_, REF_>), grid, dim3(64 * NWV_), lds_bytes, stream, p); \
+    yogo_launch_log("conv_bf16_kernel<" #MW_ ", " #NW_ ", " #NWV_ ", " #S2D_ ", " #PF_ ", " #F32_ ", " #REF_ "> | %s", plan_txt);   \
   } while (0)
 #define BFLAUNCH_(MW_, NW_, NWV_, S2D_, PF_, F32_)                             \
   do {                                                                         \
@@ -1100,8 +1109,7 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
     else if (MW == 2) BFLAUNCH(2, 1, 4, false, 16);
     else BFLAUNCH(1, 2, 4, false, 16);
   } else {
-    if (MW == 4 && halfwg) BFLAUNCH(4, 2, 4, false, 16);
-    else if (MW == 4) BFLAUNCH(4, 2, 8, false, 10);
+    if (MW == 4) BFLAUNCH(4, 2, 8, false, 10);
     else if (MW == 2 && wide64) BFLAUNCH(2, 4, 8, false, 10);
     else if (MW == 2) BFLAUNCH(2, 2, 4, false, 16);
     else BFLAUNCH(1, 4, 4, false, 16);
@@ -1110,20 +1118,6 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
 #undef BFLAUNCH_
 #undef BFLAUNCH__
   YOGO_CHECK_LAUNCH("conv_bf16");
-  if (p.stamps) {  // experiments: mean cycles per phase over the workgroups
-    const size_t nwg = (size_t)grid.x * grid.y * grid.z;
-    std::vector<unsigned long long> h(nwg * 4);
-    (void)hipStreamSynchronize(stream);
-    (void)hipMemcpy(h.data(), p.stamps, nwg * 32, hipMemcpyDeviceToHost);
-    double a = 0, b = 0, c = 0; size_t n = 0;
-    for (size_t i = 0; i < nwg; ++i) {
-      if (h[i * 4 + 3] == 0) continue;
-      a += (double)(h[i * 4 + 1] - h[i * 4]); b += (double)(h[i * 4 + 2] - h[i * 4 + 1]); c += (double)(h[i * 4 + 3] - h[i * 4 + 2]); ++n;
-    }
-    unsigned long long lo = ~0ull, hi = 0;
-    for (size_t i = 0; i < nwg; ++i) if (h[i * 4 + 3]) { lo = h[i * 4] < lo ? h[i * 4] : lo; hi = h[i * 4 + 3] > hi ? h[i * 4 + 3] : hi; }
-    fprintf(stderr, "[bf16 stamps] wgs=%zu prologue=%.0f loop=%.0f epilogue=%.0f shader cycles per workgroup, kernel span=%llu cycles\n", n, a / n, b / n, c / n, hi - lo);
-  }
   return YOGO_OK;
 }
 

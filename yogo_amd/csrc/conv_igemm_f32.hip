@@ -43,7 +43,6 @@ struct IgemmParams {
   int act;                  // forward activation fused in epilogue
   int ref_act;              // dgrad: activation whose derivative multiplies the result
   int pf;                   // 1: register-prefetch pipeline (shape fits its capacity), 0: direct staging
-  int dbg;                  // experiments only (YOGO_IGEMM_DBG): 1 = stage only chunk 0, 2 = skip MFMA
 };
 
 // FUSED_S2: stride-2 dgrad with the four output parity classes computed from ONE staged dy tile.  The wavefront's
@@ -264,10 +263,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const IgemmParam
     __syncthreads();
     for (int c = 0; c < p.nchunk; ++c) {
       const bool more = c + 1 < p.nchunk;
-      if (more && !(p.dbg & 1)) PF_ISSUE((c + 1) * p.CK);
-      if (!(p.dbg & 2)) IGEMM_COMPUTE();
+      if (more) PF_ISSUE((c + 1) * p.CK);
+      IGEMM_COMPUTE();
       __syncthreads();
-      if (more && !(p.dbg & 1)) {
+      if (more) {
         PF_COMMIT((c + 1) * p.CK);
         __syncthreads();
       }
@@ -276,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const IgemmParam
   for (int c = 0; c < p.nchunk; ++c) {
     const int k0 = c * p.CK;
     __syncthreads();
-    if (!((p.dbg & 1) && c > 0)) {
+    {
     // ---- stage the input tile: CK channels x rows_in rows x lw columns, zero padded.  Each wavefront takes four
     //      (channel,row) lines per pass; loads are unconditional (clamped address + select) and issued together,
     //      stores of out-of-range lines go to a dummy LDS word: no branches, four loads in flight per lane. ---------
@@ -335,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const IgemmParam
     __syncthreads();
     // ---- MFMA over k-steps (tap x channel pair), software pipelined with two operand sets: the LDS reads of step
     //      s+1 are issued before the MW*NW MFMAs (>= 256 cycles) of step s, so LDS latency never stalls the pipe. ----
-    if (!(p.dbg & 2)) IGEMM_COMPUTE();
+    IGEMM_COMPUTE();
   }
 #undef PF_ISSUE
 #undef PF_W_LOAD
@@ -459,12 +458,7 @@ struct Geom {
   int dy[MAX_TAPS], dx[MAX_TAPS];
 };
 
-int igemm_cfg() {  // experiments: YOGO_IGEMM_CFG=1 -> 64x(2x32)-pixel tiles for wide layers (3 workgroups per CU)
-  static int cfg = -1;
-  if (cfg < 0) { const char* e = getenv("YOGO_IGEMM_CFG"); cfg = e ? atoi(e) : 0; }
-  return cfg;
-}
-int pick_mw(int M) { return M <= 32 ? 1 : ((M <= 64 || igemm_cfg() == 1) ? 2 : 4); }
+int pick_mw(int M) { return M <= 32 ? 1 : (M <= 64 ? 2 : 4); }
 int pick_nw(int mw, int M) { (void)M; return mw == 1 ? 4 : 2; }
 int kpad_of(int K) { return K >= 16 ? round_up(K, 16) : round_up(K, 2); }
 int mpad_of(int M) { return round_up(M, 32 * pick_mw(M)); }
@@ -546,17 +540,12 @@ int launch_igemm(const Geom& g, const float* in, const float* wp, const float* b
   p.lds_dummy = tl.ldsw_off + g.T * tl.CK * 32 * MW;
   for (int t = 0; t < g.T; ++t) p.toff[t] = (g.dy[t] - dy_min) * tl.LWp + (g.dx[t] - dx_min);
   p.act = act; p.ref_act = ref_act; p.pf = tl.pf;
-  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("YOGO_IGEMM_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
 
   dim3 grid(tl.ncb * tl.tiles_per_band, Mpad / (32 * MW), g.B);
-  {
-    static int verbose = -1;
-    if (verbose < 0) verbose = getenv("YOGO_IGEMM_VERBOSE") ? 1 : 0;
-    if (verbose)
-      fprintf(stderr, "[igemm] K=%d M=%d in=%dx%d lat=%dx%d a=%d T=%d | MW=%d NW=%d ncb=%d TW=%d CK=%d rows=%d LW=%d lds=%d pf=%d grid=%ux%ux%u\n",
-              g.K, g.M, g.IH, g.IW, g.OHt, g.OWt, g.a, g.T, MW, NW, tl.ncb, tl.TW, tl.CK, tl.rows_max, tl.LWp, tl.lds_bytes,
-              tl.pf, grid.x, grid.y, grid.z);
-  }
+  char plan_txt[224] = "";
+  if (yogo_launch_log_enabled())
+    snprintf(plan_txt, sizeof(plan_txt), "K=%d M=%d in=%dx%d lat=%dx%d a=%d T=%d ncb=%d TW=%d CK=%d rows=%d LW=%d lds=%d pf=%d grid=%ux%ux%u",
+             g.K, g.M, g.IH, g.IW, g.OHt, g.OWt, g.a, g.T, tl.ncb, tl.TW, tl.CK, tl.rows_max, tl.LWp, tl.lds_bytes, tl.pf, grid.x, grid.y, grid.z);
   if (stats_rows_out) *stats_rows_out = g.B * (int)grid.x;
   if (g.B == 0 || g.OHt <= 0 || g.OWt <= 0) return YOGO_OK;
 #define LAUNCH(MW_, NW_, FU_)                                                                               \
@@ -567,7 +556,8 @@ int launch_igemm(const Geom& g, const float* in, const float* wp, const float* b
                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);                          \
       attr_set = true;                                                                                      \
     }                                                                                                       \
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<MW_, NW_, FU_>), grid, dim3(256), (p.dbg & 1024) ? 100 * 1024 : tl.lds_bytes, stream, p); \
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<MW_, NW_, FU_>), grid, dim3(256), tl.lds_bytes, stream, p);   \
+    yogo_launch_log("conv_igemm_f32_kernel<" #MW_ ", " #NW_ ", " #FU_ "> | %s", plan_txt);                  \
   } while (0)
   if (fused_s2) {
     if (MW == 2) LAUNCH(2, 4, true);

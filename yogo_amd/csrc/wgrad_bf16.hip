@@ -343,6 +343,8 @@ extern "C" int yogo_internal_wgrad_reduce(const float* slab, int nslab, int T, i
 
 namespace {
 
+thread_local char g_wb_plan_txt[256] = "";  // planner parameters of the launch in flight (launch log)
+
 struct WbPlan {
   int MBW, NBW, NPW, MPW, KS, R, Mpad, Npad, nchunk_w, base_w, rem_w, wce, nrowg, xw, units, nsplit, units_per_split, ngs, nxs, bufu,
       depth, lds_bytes, xcb;
@@ -361,11 +363,9 @@ bool wb_plan(int B, int N, int M, int IH, int IW, int ks, int stride, WbPlan* pl
   // 32) input channels
   int NPW = (MBW == 4 && NBW == 1 && nblocks >= 2 && ks == 3) ? 2 : 1;
   // ... or, the same 128 x 64 workgroup tile as 2 x 2 wavefronts of two co-blocks x one ci-block each: a third less LDS read
-  // traffic per MFMA (YOGO_WGRAD_MPW=0 keeps the ci-pair layout)
-  static int mpw_env = -1;
-  if (mpw_env < 0) mpw_env = getenv("YOGO_WGRAD_MPW") ? atoi(getenv("YOGO_WGRAD_MPW")) : 1;
+  // traffic per MFMA
   int MPW = 1;
-  if (NPW == 2 && mpw_env) { MBW = 2; NBW = 2; NPW = 1; MPW = 2; }
+  if (NPW == 2) { MBW = 2; NBW = 2; NPW = 1; MPW = 2; }
   const int KS = 4 / (MBW * NBW);
   // rows per unit: few channels -> little MFMA work per row, so take more rows per barrier
   const bool tall = MBW == 1 && NBW == 1 && ks == 3 && stride == 1 && OH >= 64;
@@ -423,6 +423,8 @@ void wb_launch_one(const WgradBf16Params& p, const WbPlan& pl, hipStream_t strea
   }
   hipLaunchKernelGGL((wgrad_bf16_kernel<MBW, NBW, NPW, KS, T, S, R, MPW, ROT, PACK2>), pl.grid, dim3(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)),
                      pl.lds_bytes, stream, p);
+  yogo_launch_log("wgrad_bf16_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %s, %s> | %s", MBW, NBW, NPW, KS, T, S, R, MPW, ROT ? "true" : "false",
+                  PACK2 ? "true" : "false", g_wb_plan_txt);
 }
 
 template <int MBW, int NBW, int KS>
@@ -461,20 +463,11 @@ extern "C" int yogo_conv2d_wgrad_bf16(const void* x, const void* g, float* dw, f
   p.nchunk_w = pl.nchunk_w; p.base_w = pl.base_w; p.rem_w = pl.rem_w; p.wce = pl.wce; p.nrowg = pl.nrowg;
   p.xw = pl.xw;
   p.units = pl.units; p.units_per_split = pl.units_per_split; p.ngs = pl.ngs; p.nxs = pl.nxs; p.bufu = pl.bufu; p.depth = pl.depth; p.xcb = pl.xcb;
-  {
-    static int verbose = -1;
-    if (verbose < 0) verbose = getenv("YOGO_IGEMM_VERBOSE") ? 1 : 0;
-    if (verbose)
-      fprintf(stderr, "[wgrad bf16] N=%d M=%d in=%dx%d s=%d T=%d | MBW=%d NBW=%d NPW=%d KS=%d R=%d wce=%d x%d chunks xw=%d slots=%d+%d depth=%d lds=%d units=%d grid=%ux%ux%u\n",
-              Cin, Cout, IH, IW, stride, T, pl.MBW, pl.NBW, pl.NPW, pl.KS, pl.R, pl.wce, pl.nchunk_w, pl.xw, pl.ngs, pl.nxs, pl.depth, pl.lds_bytes,
-              pl.units, pl.grid.x, pl.grid.y, pl.grid.z);
-  }
-  static int rot_env = -1;
-  if (rot_env < 0) rot_env = getenv("YOGO_WGRAD_ROTATE") ? atoi(getenv("YOGO_WGRAD_ROTATE")) : 0;
-  if (pl.MPW == 2 && rot_env) {  // experiment: B operands re-fetched right behind their MFMAs, A pair double-buffered
-    if (stride == 1) wb_launch_one<2, 2, 1, 1, 9, 1, 3, 2, true>(p, pl, stream);
-    else wb_launch_one<2, 2, 1, 1, 9, 2, 2, 2, true>(p, pl, stream);
-  } else if (pl.MPW == 2) {
+  if (yogo_launch_log_enabled())
+    snprintf(g_wb_plan_txt, sizeof(g_wb_plan_txt), "N=%d M=%d in=%dx%d s=%d T=%d B=%d R=%d wce=%d nchunk_w=%d xw=%d slots=%d+%d depth=%d lds=%d units=%d units_per_split=%d grid=%ux%ux%u",
+             Cin, Cout, IH, IW, stride, T, B, pl.R, pl.wce, pl.nchunk_w, pl.xw, pl.ngs, pl.nxs, pl.depth, pl.lds_bytes, pl.units, pl.units_per_split,
+             pl.grid.x, pl.grid.y, pl.grid.z);
+  if (pl.MPW == 2) {
     if (stride == 1) wb_launch_one<2, 2, 1, 1, 9, 1, 3, 2>(p, pl, stream);
     else wb_launch_one<2, 2, 1, 1, 9, 2, 2, 2>(p, pl, stream);
   } else if (pl.NPW == 2) {
@@ -482,9 +475,7 @@ extern "C" int yogo_conv2d_wgrad_bf16(const void* x, const void* g, float* dw, f
     else wb_launch_one<4, 1, 2, 1, 9, 2, 2>(p, pl, stream);
   } else {
     const int cfg = pl.MBW * 100 + pl.NBW * 10 + pl.KS;
-    static int pack2_env = -1;
-    if (pack2_env < 0) pack2_env = getenv("YOGO_WGRAD_PACK2") ? atoi(getenv("YOGO_WGRAD_PACK2")) : 1;
-    if (pl.R == 8 && pl.xcb == 2 && pack2_env) {
+    if (pl.R == 8 && pl.xcb == 2) {
       wb_launch_one<1, 1, 1, 4, 9, 1, 8, 1, false, true>(p, pl, stream);
     } else if (pl.R == 8) {
       wb_launch_one<1, 1, 1, 4, 9, 1, 8>(p, pl, stream);

@@ -113,6 +113,10 @@ class Engine:
         # optional per-launch HIP-event timing (bench.py): list of (kind, layer, mw, flops, start_event, end_event)
         self.prof: Optional[list] = None
         self._open = None
+        # bumped whenever a kernel writes parameters or BatchNorm buffers through raw pointers (AdamW on the flat buffer,
+        # bn_finalize / bn_stats_from_gram on the running statistics): torch's _version does not see those writes, so every
+        # cache of derived tensors (packed weights, folded inference weights) keys on this counter as well
+        self.generation: int = 0
 
     def _tick(self, kind: str, layer: int, flops: float, mw: int = 0, nbytes: float = 0.0) -> None:
         """open a HIP-event bracket around one kernel call (bench.py): algorithmic FLOPs and bytes of that call"""
@@ -129,7 +133,9 @@ class Engine:
 
     # ------------------------------------------------------------------------------------------------------
     def invalidate_packed(self) -> None:
+        """parameters / BatchNorm buffers were rewritten behind torch's back: drop every derived tensor"""
         self._pack.clear()
+        self.generation += 1
 
     def _packed(self, i: int, mode: int) -> torch.Tensor:
         L = self.layers[i]
@@ -221,6 +227,8 @@ class Engine:
                               float(bn.momentum if bn.momentum is not None else 0.0), mean, invstd,
                               bn.running_mean if track else None, bn.running_var if track else None,
                               bn.num_batches_tracked if track else None, st)
+                    if track:
+                        self.generation += 1   # running statistics rewritten by raw pointer
                     _hip.call("yogo_bn_apply_act", out, y, mean, invstd, 0, float(bn.eps), gamma, beta, B, L.cout, OH * OW,
                               L.act, st)
                     S.mean, S.invstd = mean, invstd
@@ -258,6 +266,8 @@ class Engine:
             return torch.empty(param.shape, dtype=torch.float32, device=dev)
         g = _f32(graw)
         n = len(self.layers)
+        if g is graw and self.layers[-1].bn is not None:
+            g = g.clone()   # yogo_bn_bwd writes dz in place: never into the gradient autograd handed us
         for i in range(n - 1, -1, -1):
             L, S = self.layers[i], saved[i]
             B, _, OH, OW = g.shape
@@ -339,24 +349,20 @@ def _blocks(c: int) -> int:
     return ((c + 15) // 16) * 2
 
 
-import os as _os
-
-_WGRAD_BF16_MFMA = _os.environ.get("YOGO_WGRAD_BF16", "1") != "0"   # 0: fp32-MFMA weight gradients on the widened inputs
-# 1: weight gradients run on a second HIP stream, beside the data-gradient / BatchNorm-backward chain they do not feed
-# (measured: -2 % step time).  Off by default: with two kernels sharing the chip the per-kernel HIP-event / rocprofv3 durations
-# that bench.py's roofline is built from stop being attributable to one kernel.
-_WGRAD_SIDE_STREAM = _os.environ.get("YOGO_WGRAD_STREAM", "0") != "0"
-_FUSE_LAYER0_BWD = _os.environ.get("YOGO_FUSE_LAYER0_BWD", "1") != "0"
-# 1: BatchNorm batch statistics of layers > 0 come from a separate sweep over the stored bf16 output (0.08 ms per 128-channel
-# layer) instead of the convolution's epilogue, which sits on the critical path of a one-workgroup-per-CU kernel (0.14-0.2 ms)
-# LeakyReLU blocks without BatchNorm hand the next layer's data gradient a 1-bit-per-value sign map instead of the bf16 output
-_LEAKY_SIGNS = _os.environ.get("YOGO_BF16_SIGNS", "1") != "0"
-# layer 0 (uint8 image, 1 -> <=16 channels, stride 2, BatchNorm) on the matrix cores: statistics sweep + (z, y) sweep over the images
-_L0_MFMA = _os.environ.get("YOGO_L0_MFMA", "1") != "0"
-# ... with the batch statistics from the patch Gram matrix of the images (no convolution in the statistics sweep; backward reuses it)
-_L0_GRAM = _os.environ.get("YOGO_L0_GRAM", "1") != "0"
-_PACK_MULTI = _os.environ.get("YOGO_PACK_MULTI", "1") != "0"   # 0: one packing launch per layer and direction
-_BN_STATS_PASS = _os.environ.get("YOGO_BN_STATS_PASS", "1") != "0"   # 0: separate BatchNorm-backward + weight-gradient passes
+# Execution plan of the bf16 training path.  Plain module constants (no environment switches): the alternatives they once
+# selected were measured in round 1 ("measured and dropped") and only the winners stayed; the tests flip
+# _FUSE_LAYER0_BWD / _L0_GRAM to compare the fused kernels with the separate passes they replace.
+_WGRAD_BF16_MFMA = True     # weight gradients on the bf16 matrix cores (False: exact fp32 MFMA on the widened inputs)
+# weight gradients on a second HIP stream, beside the data-gradient / BatchNorm-backward chain they do not feed (-2 % step
+# time).  bench.py switches it off while it times single kernels with HIP events (two kernels sharing the chip are not
+# attributable).
+_WGRAD_SIDE_STREAM = False
+_FUSE_LAYER0_BWD = True     # BatchNorm backward + activation derivative + first-conv weight gradient in one sweep
+_LEAKY_SIGNS = True         # LeakyReLU blocks without BatchNorm hand the next data gradient a 1-bit sign map, not the bf16 output
+_L0_MFMA = True             # layer 0 (uint8 image, 1 -> <=16 channels, stride 2, BatchNorm) on the matrix cores
+_L0_GRAM = True             # ... with the batch statistics from the exact integer patch Gram matrix (backward reuses it)
+_PACK_MULTI = True          # all weight packings of a step in one launch
+_BN_STATS_PASS = True       # BatchNorm statistics of layers > 0 by a sweep over the stored bf16 output (not the conv epilogue)
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
 
@@ -431,6 +437,18 @@ def _dropout_masks(eng: Engine, B: int, dev) -> Dict[int, torch.Tensor]:
 
 def forward_bf16_train(eng: Engine, x: torch.Tensor) -> Tuple[torch.Tensor, List[Saved]]:
     _hip.require_cuda(x, "the input batch")
+    if x.ndim != 4:
+        raise RuntimeError(f"yogo_amd: expected a [B,C,H,W] batch, got {tuple(x.shape)}")
+    if x.shape[1] != eng.layers[0].cin:
+        raise RuntimeError(f"yogo_amd: layer 0 expects {eng.layers[0].cin} channels, got {x.shape[1]}")
+    for j in range(1, len(eng.layers)):
+        if eng.layers[j].cin != eng.layers[j - 1].cout:
+            raise RuntimeError(f"yogo_amd: layer {j} expects {eng.layers[j].cin} channels, layer {j - 1} produces {eng.layers[j - 1].cout}")
+    for j, Lj in enumerate(eng.layers):
+        bnj = Lj.bn
+        if (bnj is not None and (bnj.training or bnj.running_mean is None) and bnj.track_running_stats
+                and bnj.running_mean is not None and bnj.momentum is None):
+            raise RuntimeError("yogo_amd: BatchNorm2d(momentum=None) is not supported")
     dev, st, B = x.device, _hip.stream_ptr(), x.shape[0]
     if not eng._first_direct(0):
         raise RuntimeError("yogo_amd: bf16 training needs a 1- or 3-channel 3x3 first convolution")
@@ -477,6 +495,8 @@ def forward_bf16_train(eng: Engine, x: torch.Tensor) -> Tuple[torch.Tensor, List
                           float(bn.momentum if bn.momentum is not None else 0.0), mean, invstd,
                           bn.running_mean if track else None, bn.running_var if track else None,
                           bn.num_batches_tracked if track else None, st)
+                if track:
+                    eng.generation += 1
             elif bn_train:   # sweep 1: batch statistics, nothing written
                 rows = _hip.query_ints("yogo_conv_first_mfma_stats_rows", 1, B, H, W)[0]
                 stats = torch.empty(rows * 16 * 2, dtype=torch.float32, device=dev)
@@ -488,6 +508,8 @@ def forward_bf16_train(eng: Engine, x: torch.Tensor) -> Tuple[torch.Tensor, List
                           float(bn.momentum if bn.momentum is not None else 0.0), mean, invstd,
                           bn.running_mean if track else None, bn.running_var if track else None,
                           bn.num_batches_tracked if track else None, st)
+                if track:
+                    eng.generation += 1
             else:
                 invstd = torch.empty(L.cout, dtype=torch.float32, device=dev)
                 _hip.call("yogo_bn_invstd", bn.running_var, float(bn.eps), invstd, L.cout, st)
@@ -549,6 +571,8 @@ def forward_bf16_train(eng: Engine, x: torch.Tensor) -> Tuple[torch.Tensor, List
                           float(bn.momentum if bn.momentum is not None else 0.0), mean, invstd,
                           bn.running_mean if track else None, bn.running_var if track else None,
                           bn.num_batches_tracked if track else None, st)
+                if track:
+                    eng.generation += 1
                 _hip.call("yogo_bn_apply_act_bf16", out8, y, mean, invstd, 0, float(bn.eps), gamma, beta, B, L.cout, OH * OW, L.act, st)
             else:
                 invstd = torch.empty(L.cout, dtype=torch.float32, device=dev)
@@ -757,7 +781,7 @@ class InferEngineBF16:
         self._prep: List[Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]] = []
 
     def _state_key(self):
-        k = []
+        k = [self.engine.generation]
         for L in self.engine.layers:
             ts = [L.conv.weight, L.conv.bias]
             if L.bn is not None:

@@ -57,6 +57,17 @@ class FlatParams:
         for p in self.params:
             p.grad = self.grad_views[id(p)]
 
+    def check_homed(self) -> None:
+        """every parameter must still be a view of the flat buffer: ``model.to(...)``, ``.half()`` or ``.float()`` after the
+        trainer was built re-allocate ``param.data`` and the fused AdamW kernel would then update memory the model no longer reads"""
+        lo = self.flat.data_ptr()
+        off = 0
+        for p in self.params:
+            if p.data_ptr() != lo + 4 * off or p.dtype != torch.float32:
+                raise RuntimeError("yogo_amd: a model parameter no longer lives in the trainer's flat buffer (was the model moved or "
+                                   "cast after HipTrainer was built?) -- build a new HipTrainer")
+            off += p.numel()
+
 
 class HipTrainer:
     def __init__(
@@ -92,6 +103,55 @@ class HipTrainer:
     def current_lr(self) -> float:
         return cosine_lr(self.global_step, self.lr, self.t_max, self.eta_min)
 
+    # ---- checkpointing: the layout of torch.optim.AdamW.state_dict() (what the reference's Trainer.checkpoint stores under
+    #      "optimizer_state_dict", yogo/train.py:280-293), so reference checkpoints resume here and vice versa ----------------
+    def state_dict(self) -> Dict:
+        state = {}
+        off = 0
+        step = torch.tensor(float(self.global_step))
+        for i, p in enumerate(self.flat.params):
+            n = p.numel()
+            if self.global_step > 0:   # torch creates the per-parameter state lazily at the first step
+                state[i] = {"step": step.clone(),
+                            "exp_avg": self.flat.exp_avg[off:off + n].view(p.shape).clone(),
+                            "exp_avg_sq": self.flat.exp_avg_sq[off:off + n].view(p.shape).clone()}
+            off += n
+        group = {"lr": self.current_lr(), "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "initial_lr": self.lr, "params": list(range(len(self.flat.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd: Dict) -> None:
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self.flat.params):
+            raise ValueError("yogo_amd: optimizer state does not match the model (one parameter group over all parameters expected)")
+        g = groups[0]
+        self.betas = tuple(g.get("betas", self.betas))
+        self.eps = float(g.get("eps", self.eps))
+        self.wd = float(g.get("weight_decay", self.wd))
+        # the cosine schedule (base lr, eta_min, T_max) stays what this trainer was built with: the schedule is a closed form of
+        # global_step here, and the reference restarts its scheduler on --from-pretrained as well (yogo/train.py:136-148)
+        off, steps = 0, []
+        for i, p in zip(g["params"], self.flat.params):
+            n = p.numel()
+            st = sd["state"].get(i)
+            if st is None:
+                self.flat.exp_avg[off:off + n].zero_()
+                self.flat.exp_avg_sq[off:off + n].zero_()
+            else:
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"yogo_amd: optimizer state of parameter {i} has shape {tuple(st['exp_avg'].shape)}, expected {tuple(p.shape)}")
+                self.flat.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                self.flat.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.append(int(float(st["step"])))
+            off += n
+        if steps:
+            if len(set(steps)) != 1:
+                raise ValueError("yogo_amd: per-parameter step counts differ; the fused AdamW kernel keeps one step count")
+            self.global_step = steps[0]
+        else:
+            self.global_step = 0
+
     def broadcast_parameters(self, src: int = 0) -> None:
         """rank-0 weights and BatchNorm buffers to every rank (what DDP does at construction)"""
         if self.world > 1:
@@ -110,6 +170,7 @@ class HipTrainer:
             st = _hip.stream_ptr()
             eng = self.engine
             eng.clip = m._clip
+            self.flat.check_homed()
             if imgs.ndim == 3:
                 imgs = imgs[None]
             if not imgs.is_floating_point() and imgs.dtype != torch.uint8:
