@@ -1,0 +1,296 @@
+"""Parity at PRODUCTION shapes (BASELINE configs[2]: base_model, 772x1032x1, per-GPU batch 128, bf16).
+
+The small-shape tests of test_gpu_bf16.py never reach the kernel instantiations and tilings a 772x1032 batch selects (e.g.
+conv_bf16_kernel<2,4,8,...> needs OH*OW >= 4096; the planner picks other band widths / chunk depths / slot counts).  Here
+  (A) every layer of base_model runs every direction (forward, data gradient, weight gradient -- with the sign-map / bias /
+      fp32-head variants the training step uses) at 772x1032 against F.conv2d + autograd in fp32 ON THE CPU on bf16-rounded
+      inputs, with the per-kernel bf16 tolerances of test_gpu_bf16.py (8e-3 of the output range for one bf16 rounding, 1e-4
+      of max|g| for fp32-accumulated weight gradients); weight gradients also at B = 128 (the split-K plan depends on B);
+  (B) one full bf16 HipTrainer.step at 772x1032 is compared with the CPU oracle's fp32 step (loss, every gradient tensor,
+      running statistics);
+  (C) the production batch 128 -- exactly bench.py's step -- with the launch log proving which instantiations / planner
+      parameters ran: they must include every conv_bf16_kernel<...> and wgrad_bf16_kernel<...> row of the committed
+      rocprofv3 summary (profiles/r*_kernel_stats.txt) and nothing the per-layer tests did not launch too.  Numerics through
+      a size-independent property: a batch of 64 copies of (B)'s two images has the same batch statistics, loss and
+      (mean) gradients as the two images, so the B = 128 step must reproduce the oracle's B = 2 step.
+(torch's own GPU convolutions are deliberately not used as a reference: MIOpen has no precompiled gfx950 kernels in this
+image and would spend minutes compiling.)
+Reference rows: yogo/model_defns.py:30-77 (blocks), yogo/train.py:309-325 (step)."""
+import glob
+import os
+import re
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import yogo_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HI, WI, C = 772, 1032, 7
+# (cin, cout, k, stride, IH, IW, bias, fwd variant, dgrad variant) of layers 1..7 as HipTrainer(half=True) calls them:
+#   fwd "signs" = LeakyReLU block without BatchNorm (writes the sign map), "plain" = conv only (BatchNorm follows), "head" = fp32 out
+#   dgrad "signs" = previous block is LeakyReLU without BatchNorm (reads its sign map), "plain" = previous block has BatchNorm
+LAYERS = {
+    1: (16, 32, 3, 1, 386, 516, True, "signs", "plain"),
+    2: (32, 64, 3, 2, 386, 516, True, "signs", "signs"),
+    3: (64, 128, 3, 1, 193, 258, True, "signs", "signs"),
+    4: (128, 128, 3, 2, 193, 258, False, "plain", "signs"),
+    5: (128, 128, 3, 1, 97, 129, True, "plain", "plain"),
+    6: (128, 128, 3, 1, 97, 129, True, "signs", "plain"),
+    7: (128, 5 + C, 1, 1, 97, 129, True, "head", "signs"),
+}
+SEEN = set()   # kernel instantiations launched by the per-layer tests (A)
+
+
+def H():
+    from yogo_amd import _hip
+
+    return _hip
+
+
+def bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+def to8c(t):
+    h = H()
+    B, Cc, Hh, W = t.shape
+    out = torch.empty(B, h.lib().yogo_bf16_channel_blocks(Cc), Hh, W, 8, dtype=torch.bfloat16, device="cuda")
+    h.call("yogo_nchw_f32_to_bf16_8c", t.contiguous().float(), out, B, Cc, Hh * W, h.stream_ptr())
+    return out
+
+
+def from8c(t, Cc):
+    h = H()
+    B, cb, Hh, W, _ = t.shape
+    out = torch.empty(B, Cc, Hh, W, device="cuda")
+    h.call("yogo_bf16_8c_to_nchw_f32", t, out, B, Cc, Hh * W, h.stream_ptr())
+    return out
+
+
+def rel(a, b):
+    """max |a - b| / max |b| on the device"""
+    return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+
+
+def kernels_of(lines):
+    return {re.sub(r"\s+", "", ln.split("|")[0]) for ln in lines}
+
+
+def sign_map_gpu(y, Cc):
+    """include/yogo_hip.h, yogo_bf16_signs_bytes: [B][2][H][W][Cpad/16] bytes; byte (h, pixel, q), bit i + 4e = (channel 4h + i of
+    channel block 2q + e > 0).  y: fp32 NCHW on the device."""
+    B, _, Hh, W = y.shape
+    cpad = 32 if Cc <= 32 else (64 if Cc <= 64 else (Cc + 127) // 128 * 128)
+    pos = torch.zeros(B, cpad, Hh, W, dtype=torch.int32, device="cuda")
+    pos[:, :Cc] = (y > 0)
+    # channel = 16 q + 8 e + 4 h + i
+    pos = pos.view(B, cpad // 16, 2, 2, 4, Hh, W).permute(0, 3, 5, 6, 1, 2, 4)   # [B][h][H][W][q][e][i]
+    wts = torch.tensor([[1, 2, 4, 8], [16, 32, 64, 128]], dtype=torch.int32, device="cuda")
+    return (pos * wts).sum((-1, -2)).to(torch.uint8).reshape(-1)
+
+
+@pytest.mark.parametrize("layer", sorted(LAYERS))
+def test_layer_every_direction_at_772x1032(layer):
+    h = H()
+    cin, cout, k, s, IH, IW, has_bias, fvar, dvar = LAYERS[layer]
+    B = 2
+    pad = 1 if k == 3 else 0
+    g = torch.Generator(device="cuda").manual_seed(100 + layer)
+    xd = bf(torch.randn(B, cin, IH, IW, generator=g, device="cuda"))          # device copies feed the kernels,
+    w = torch.randn(cout, cin, k, k, generator=g, device="cuda") / (cin * k * k) ** 0.5
+    bdev = torch.randn(cout, generator=g, device="cuda") if has_bias else None
+    x = xd.cpu().requires_grad_(True)                                         # CPU copies feed the fp32 reference
+    wb = bf(w).cpu().requires_grad_(True)
+    b = bdev.cpu().requires_grad_(True) if has_bias else None
+    ref_pre = F.conv2d(x, wb, b, stride=s, padding=pad)
+    OH, OW = ref_pre.shape[2:]
+    st = h.stream_ptr()
+    mask = ((torch.rand(B, cout, generator=g, device="cuda") > 0.1).float() / 0.9) if fvar == "signs" else None
+    x8 = to8c(xd)
+    h.launch_log(True)
+    # ---- forward ---------------------------------------------------------------------------------------------------------
+    packed = torch.empty(h.query_size("yogo_conv_bf16_packed_bytes", cin, cout, k, 0), dtype=torch.uint8, device="cuda")
+    h.call("yogo_conv_bf16_pack", w, None, packed, cin, cout, k, 0, st)
+    bd = bdev
+    if fvar == "head":
+        o32 = torch.full((B, cout, OH, OW), float("nan"), device="cuda")
+        h.call("yogo_conv2d_fwd_bf16", x8, packed, bd, None, o32, None, None, B, cin, cout, IH, IW, k, s, 0, st)
+        assert rel(o32.cpu(), ref_pre.detach()) < 2e-5 * max(1.0, (cin * k * k) ** 0.5 / 8), layer
+    else:
+        out = torch.full((B, h.lib().yogo_bf16_channel_blocks(cout), OH, OW, 8), float("nan"), dtype=torch.bfloat16, device="cuda")
+        if fvar == "signs":
+            sg = torch.full((h.query_size("yogo_bf16_signs_bytes", B, cout, OH, OW),), 0xA5, dtype=torch.uint8, device="cuda")
+            h.call("yogo_conv2d_fwd_bf16_signs", x8, packed, bd, out, sg, mask, B, cin, cout, IH, IW, k, s, 1, st)
+            want = F.leaky_relu(ref_pre.detach(), 0.01) * mask.cpu()[:, :, None, None]
+            got = from8c(out, cout)
+            assert rel(got.cpu(), want) < 8e-3, layer
+            # the sign map is the map of the STORED output (bit-exact), channel blocks that exist only
+            cpad = 32 if cout <= 32 else (64 if cout <= 64 else (cout + 127) // 128 * 128)
+            used = (cout + 15) // 16
+            assert torch.equal(sg.view(-1, cpad // 16)[:, :used], sign_map_gpu(got, cout).view(-1, cpad // 16)[:, :used]), layer
+        else:
+            h.call("yogo_conv2d_fwd_bf16", x8, packed, bd, out, None, None, None, B, cin, cout, IH, IW, k, s, 0, st)
+            assert rel(from8c(out, cout).cpu(), ref_pre.detach()) < 8e-3, layer
+    # ---- backward ----------------------------------------------------------------------------------------------------------
+    gy = bf(torch.randn(B, cout, OH, OW, generator=g, device="cuda"))
+    ref_pre.backward(gy.cpu())
+    gy8 = to8c(gy)
+    dmode = 2 if (s == 2 and k == 3) else 1
+    pd = torch.empty(h.query_size("yogo_conv_bf16_packed_bytes", cin, cout, k, dmode), dtype=torch.uint8, device="cuda")
+    h.call("yogo_conv_bf16_pack", w, None, pd, cin, cout, k, dmode, st)
+    dx = torch.full((B, h.lib().yogo_bf16_channel_blocks(cin), IH, IW, 8), float("nan"), dtype=torch.bfloat16, device="cuda")
+    if dvar == "signs":
+        refy = torch.randn(B, cin, IH, IW, generator=g, device="cuda")
+        cmask = (torch.rand(B, cin, generator=g, device="cuda") > 0.1).float() / 0.9
+        h.call("yogo_conv2d_dgrad_bf16_signs", gy8, pd, dx, sign_map_gpu(refy, cin), cmask, B, cin, cout, IH, IW, k, s, st)
+        want = x.grad * torch.where(refy.cpu() > 0, 1.0, 0.01) * cmask.cpu()[:, :, None, None]
+    else:
+        h.call("yogo_conv2d_dgrad_bf16", gy8, pd, dx, None, 0, None, B, cin, cout, IH, IW, k, s, st)
+        want = x.grad
+    assert rel(from8c(dx, cin).cpu(), want) < 8e-3, layer
+    # ---- weight gradient: B = 2 and the production batch 128 (split-K plan) -----------------------------------------------------
+    for Bw in (B, 128):
+        if Bw == B:
+            xw, gw, wg, bg = x8, gy8, wb.grad, (b.grad if b is not None else None)
+        else:
+            del ref_pre, want
+            xs = bf(torch.randn(Bw, cin, IH, IW, generator=g, device="cuda"))
+            gs = bf(torch.randn(Bw, cout, OH, OW, generator=g, device="cuda"))
+            xw, gw = to8c(xs), to8c(gs)
+            xs, gs = xs.cpu(), gs.cpu()
+            wg = torch.zeros(w.shape, dtype=torch.float64)
+            for i0 in range(0, Bw, 16):   # chunked fp32 reference on the CPU, summed in fp64
+                wg += torch.nn.grad.conv2d_weight(xs[i0:i0 + 16], w.shape, gs[i0:i0 + 16], stride=s, padding=pad).double()
+            wg = wg.float()
+            bg = gs.double().sum((0, 2, 3)).float() if b is not None else None
+            del xs, gs
+        ws = torch.empty(h.query_size("yogo_conv2d_wgrad_bf16_workspace_bytes", Bw, cin, cout, IH, IW, k, s) // 4, device="cuda")
+        dw = torch.full((cout, cin, k, k), float("nan"), device="cuda")
+        db = torch.full((cout,), float("nan"), device="cuda") if b is not None else None
+        h.call("yogo_conv2d_wgrad_bf16", xw, gw, dw, db, ws, Bw, cin, cout, IH, IW, k, s, 0.0, st)
+        assert float((dw.cpu() - wg).abs().max()) < 1e-4 * float(wg.abs().max()), (layer, Bw)
+        if b is not None:
+            assert float((db.cpu() - bg).abs().max()) < 1e-4 * float(bg.abs().max()), (layer, Bw)
+    h.launch_log(False)
+    SEEN.update(kernels_of(h.read_launch_log()))
+
+
+def _model(B, seed=0):
+    from yogo_amd.model import YOGO
+
+    torch.manual_seed(seed)
+    m = YOGO((HI, WI), 0.0425, 0.0555, C, clip_value=1e9).cuda()   # unclamped: the raw gradients are compared
+    m.train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout2d):
+            mod.p = 0.0
+    return m
+
+
+def _oracle_step(sd, x, lab, device):
+    spec = O.arch("base_model", C)
+    names = [k for k, v in sd.items() if k.startswith("model.") and v.is_floating_point() and "running" not in k]
+    sdd = {k: v.to(device) for k, v in sd.items()}
+    leaf = {k: sdd[k].clone().requires_grad_(True) for k in names}
+    sdl = dict(sdd)
+    sdl.update(leaf)
+    ns = {}
+    pred = O.yogo_forward(x.to(device), sdl, spec, 0.0425, 0.0555, train=True, new_stats=ns)
+    loss, _ = O.yogo_loss(pred, lab.to(device))
+    loss.backward()
+    return float(loss.detach()), {k: v.grad.detach() for k, v in leaf.items()}, ns
+
+
+def _compare_step(tr, model, loss_ref, grads_ref, stats_ref, cos_min, ratio_tol, what):
+    got = tr.loss_components()
+    assert abs(got["loss"] - loss_ref) < 2e-2 * abs(loss_ref), (what, got, loss_ref)
+    off = 0
+    flat = tr.flat.grad
+    worst = (1.0, None)
+    for name, p in model.named_parameters():
+        n = p.numel()
+        a = flat[off:off + n].double()
+        b_ = grads_ref[name].reshape(-1).to(a.device).double()
+        off += n
+        blk = model.model[int(name.split(".")[1])] if name.split(".")[1].isdigit() else None
+        if name.endswith(".0.bias") and isinstance(blk, torch.nn.Sequential) and any(isinstance(q, torch.nn.BatchNorm2d) for q in blk):
+            # a conv bias in front of BatchNorm: the gradient is mathematically zero (BatchNorm removes the mean); both sides hold
+            # rounding noise only -- bounded against the scale of the same block's weight gradient instead of compared
+            wmax = float(grads_ref[name.replace(".bias", ".weight")].abs().max())
+            assert float(a.abs().max()) < 1e-2 * wmax and float(b_.abs().max()) < 1e-2 * wmax, (what, name)
+            continue
+        cos = float((a * b_).sum() / (a.norm() * b_.norm() + 1e-30))
+        ratio = float(a.norm() / (b_.norm() + 1e-30))
+        print(f"[{what}] {name:24s} cos {cos:.5f} norm ratio {ratio:.4f}")
+        if cos < worst[0]:
+            worst = (cos, name)
+        # bf16 activations and activation gradients through 8 layers: direction and scale of every gradient tensor are kept
+        assert cos > cos_min and abs(ratio - 1) < ratio_tol, (what, name, cos, ratio)
+    sd = model.state_dict()
+    for k, v in stats_ref.items():
+        if "num_batches" in k:
+            assert int(sd[k]) == int(v)
+        else:
+            torch.testing.assert_close(sd[k].cpu(), v.cpu(), rtol=2e-2, atol=2e-2)
+    return worst
+
+
+def test_bf16_training_step_at_772x1032_vs_cpu_oracle():
+    """(B): one bf16 step at the production image size, B = 2, against the oracle's fp32 step on the CPU"""
+    from yogo_amd.train import HipTrainer
+    from yogo_amd.yogo_loss import YOGOLoss
+
+    B = 2
+    m = _model(B, seed=21)
+    sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    x = O.synthetic_images(B, HI, WI, seed=22)
+    lab = O.synthetic_labels(B, m.Sx, m.Sy, K=64, num_classes=C, seed=23)
+    tr = HipTrainer(m, YOGOLoss().cuda(), total_steps=10, half=True)
+    tr.step(x.cuda(), lab.cuda())
+    loss_ref, grads_ref, ns = _oracle_step(sd0, x, lab, "cpu")
+    _compare_step(tr, m, loss_ref, grads_ref, ns, 0.95, 0.1, "B=2 vs CPU oracle")
+
+
+def test_production_batch_step_and_kernel_set():
+    """(C): bench.py's step (B = 128, bf16) on 64 copies of (B)'s two images: the launch log must contain every
+    conv_bf16_kernel / wgrad_bf16_kernel instantiation of the committed rocprofv3 summary and -- when the per-layer tests (A)
+    ran in this session -- nothing the per-layer tests did not launch too; loss, gradients and batch statistics must
+    reproduce the oracle's fp32 step on the two images (same batch statistics, mean-reduced loss)"""
+    from yogo_amd.train import HipTrainer
+    from yogo_amd.yogo_loss import YOGOLoss
+
+    h = H()
+    B, rep = 128, 64
+    m = _model(B, seed=21)
+    sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    x2 = O.synthetic_images(2, HI, WI, seed=22)
+    lab2 = O.synthetic_labels(2, m.Sx, m.Sy, K=64, num_classes=C, seed=23)
+    x = x2.cuda().repeat(rep, 1, 1, 1)
+    lab = lab2.cuda().repeat(rep, 1, 1, 1)
+    tr = HipTrainer(m, YOGOLoss().cuda(), total_steps=10, half=True)
+    h.launch_log(True)
+    tr.step(x, lab)
+    torch.cuda.synchronize()
+    h.launch_log(False)
+    lines = h.read_launch_log()
+    launched = kernels_of(lines)
+    print("\n".join(sorted(set(lines))))
+    profs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats.txt")))
+    assert profs, "no committed rocprofv3 summary"
+    want = set()
+    for ln in open(profs[-1]):
+        mm = re.search(r"((?:conv_bf16_kernel|wgrad_bf16_kernel)<[^>]*>)", ln)
+        if mm:
+            want.add(re.sub(r"\s+", "", mm.group(1)))
+    assert want, profs[-1]
+    missing = want - launched
+    assert not missing, f"instantiations of {os.path.basename(profs[-1])} that this step did not launch: {sorted(missing)}"
+    if SEEN:
+        conv = {k for k in launched if k.startswith(("conv_bf16_kernel", "wgrad_bf16_kernel"))}
+        assert conv <= SEEN, f"launched at B=128 but not covered by the per-layer parity tests: {sorted(conv - SEEN)}"
+    loss_ref, grads_ref, ns = _oracle_step(sd0, x2, lab2, "cpu")
+    _compare_step(tr, m, loss_ref, grads_ref, ns, 0.95, 0.1, "B=128 (64 x 2 images) vs CPU oracle on the 2 images")

@@ -114,3 +114,17 @@ def require_cuda(t: torch.Tensor, what: str) -> None:
         raise RuntimeError(
             f"yogo_amd: {what} must live on an MI355X device (got {t.device}); the hot path is HIP-only, there is no CPU fallback"
         )
+
+
+def launch_log(enable: bool) -> None:
+    """start (and clear) / stop the library's launch log (include/yogo_hip.h: yogo_hip_launch_log)"""
+    call("yogo_hip_launch_log", 1 if enable else 0)
+
+
+def read_launch_log() -> List[str]:
+    """the recorded lines "<kernel instantiation> | <planner parameters>", one per kernel launch"""
+    need = ctypes.c_size_t(0)
+    call("yogo_hip_launch_log_read", None, 0, ctypes.addressof(need))
+    buf = ctypes.create_string_buffer(int(need.value) + 1)
+    call("yogo_hip_launch_log_read", ctypes.addressof(buf), len(buf), ctypes.addressof(need))
+    return [ln for ln in buf.value.decode().split("\n") if ln]
