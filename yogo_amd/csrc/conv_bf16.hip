@@ -61,7 +61,7 @@ struct ConvBf16Params {
   // diagnostic build only (bash build.sh diag -> libyogo_hip_diag.so; tools/bench_conv_bf16.py): ablation bits and phase stamps.
   // The production library contains none of this code.
   int dbg;  // 1 = no output stores, 2 = no MFMA loop, 4 = no DMA, 8 / 16 = no input / weight DMA
-  unsigned long long* stamps;  // [workgroup][4] s_memtime at start / loop / epilogue / end
+  unsigned long long* stamps;  // [workgroup][16]: s_memtime at start / loop / epilogue / end; [4..7] / [8..11]: ping-pong phase sums of wave 0 / 4 (fetch, barrier, MFMA, barrier)
 #endif
 };
 
@@ -89,6 +89,52 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 // n / d through the precomputed magic number m = ceil(2^32 / d) (d = 1: m does not fit, n is returned)
 __device__ __forceinline__ int udivm(int n, int d, unsigned m) { return d == 1 ? n : (int)__umulhi((unsigned)n, m); }
 
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+// raw buffer descriptor of `bytes` bytes at `ptr`
+__device__ __forceinline__ i32x4 bf_make_rsrc(const void* ptr, int bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
+  return i32x4{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xFFFFu), bytes, 0x00020000};
+}
+// One LDS-DMA piece from inline asm (invisible to hipcc's waitcnt bookkeeping; retired by explicit s_waitcnt vmcnt): 64 lanes x
+// 16 bytes from (descriptor, per-lane byte offset + scalar offset) to LDS bytes [lds_addr, lds_addr + 1024).  The dynamic LDS
+// block of this kernel starts at LDS address 0 (no static __shared__ objects).
+__device__ __forceinline__ void bf_dma16(i32x4 rsrc, unsigned lds_addr, int voff, int soff) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(lds_addr), "s"(rsrc), "s"(soff)
+               : "memory");
+}
+
+// Five LDS-DMA pieces of one descriptor in ONE statement (ping-pong fetch phase: a wavefront beside an MFMA-saturating partner
+// issues an instruction only every ~10 cycles, so the request sequence is kept to 3 instructions per piece): LDS destinations
+// lds_addr + k * STRIDE (M0 is stepped in place), per-lane source offsets v0..v4, common scalar offset.
+template <int STRIDE>
+__device__ __forceinline__ void bf_dma16x5(i32x4 rsrc, unsigned lds_addr, int soff, int v0, int v1, int v2, int v3, int v4) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %7\n\t"
+      "s_nop 4\n\t"
+      "buffer_load_dwordx4 %1, %6, %8 offen lds\n\t"
+      "s_add_u32 m0, m0, %9\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %2, %6, %8 offen lds\n\t"
+      "s_add_u32 m0, m0, %9\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %3, %6, %8 offen lds\n\t"
+      "s_add_u32 m0, m0, %9\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %4, %6, %8 offen lds\n\t"
+      "s_add_u32 m0, m0, %9\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %5, %6, %8 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "s"(rsrc), "s"(lds_addr), "s"(soff), "i"(STRIDE)
+      : "memory", "scc");
+}
+
 // NWV wavefronts per workgroup, each owning NW 32-pixel groups x all MW channel blocks: NWV = 8 shares one staged weight
 // slice between 512 output pixels (the weight slice is the larger part of the LDS traffic at 128 channels).
 //
@@ -101,7 +147,16 @@ __device__ __forceinline__ int udivm(int n, int d, unsigned m) { return d == 1 ?
 // PF: slots (16-byte elements per lane and chunk) of the LDS-DMA pipeline.  When a chunk fits (p.dma) the kernel runs
 //   barrier -> issue DMA(c+1 -> buffer (c+1)&1) -> MFMA(c from buffer c&1): one barrier per chunk, no staging registers, no
 //   ds_write, no vector-ALU address work inside the loop (every lane's source offsets are decoded once per workgroup).
-template <int MW, int NW, int NWV, bool S2D, int PF, bool OUT_F32, int REF>
+//
+// PP ("ping-pong", 8-wavefront workgroups = two wavefronts per SIMD, stride-1 / stride-2 forward-type 3x3 tiles): the two
+//   wavefronts of a SIMD alternate roles phase by phase -- one issues a cluster of 3 * MW * NW back-to-back MFMAs from
+//   operands it already holds while the other fetches its next 3 steps' operands from LDS and issues its share of the next
+//   chunk's LDS-DMA -- separated by raw s_barriers (waves 4-7 run one phase behind waves 0-3).  The matrix pipe of every SIMD
+//   then always has one wavefront whose MFMAs need nothing but registers; in the interleaved loop (PP = false) both
+//   wavefronts wait for LDS / issue DMA at the same moments and the pipe idles (47 % busy measured, profiles/r02_*).
+//   The LDS-DMA is issued from inline asm with a counted / explicit vmcnt: hipcc would otherwise drain it (vmcnt(0)) in front
+//   of every later LDS read.
+template <int MW, int NW, int NWV, bool S2D, int PF, bool OUT_F32, int REF, bool PP = false>
 __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Params p) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem4[];
   constexpr int BM = 32 * MW;
@@ -257,8 +312,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
     const int k2_ = 2 * (s_ & (hk - 1));                                                          \
     const u32x4* wI_ = ldsI + (k2_ * per_kb + __builtin_amdgcn_readlane(toff_lane, t_));          \
     const u32x4* wW_ = ldsW + ((t_ << p.ckb_shift) + k2_) * BM;                                   \
-    _Pragma("unroll") for (int mb = 0; mb < MW; ++mb) AV[mb] = wW_[a_vu + mb * 32];               \
-    _Pragma("unroll") for (int n = 0; n < NW; ++n) BV[n] = wI_[b_vu[n]];                          \
+    if (!BF_DBG(64)) { _Pragma("unroll") for (int mb = 0; mb < MW; ++mb) AV[mb] = wW_[a_vu + mb * 32]; } \
+    if (!BF_DBG(32)) { _Pragma("unroll") for (int n = 0; n < NW; ++n) BV[n] = wI_[b_vu[n]]; }     \
   }
 #define BF_MFMA(CI, AV, BV)                                                                       \
   _Pragma("unroll") for (int mb = 0; mb < MW; ++mb)                                               \
@@ -340,7 +395,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
 #pragma unroll
       for (int i = 0; i < PF; ++i) {
         const int e = tid + i * NT;
-        if (i < ni) {  // uniform
+        if (i < ni) {  // uniform (ping-pong layout: ni = PF / 2 slots are reserved for the input tile, unused ones fetch nothing)
           const int iy_ = iy0 + r_, ix_ = ix0 + x_;
           const bool iok = (e < itotal) && (iy_ >= 0) && (iy_ < p.IH) && (ix_ >= 0) && (ix_ < p.IW);
           voffv[i] = iok ? kc_ * kcb + iy_ * rowb + ix_ * 16 : (int)OOB;
@@ -387,6 +442,112 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
 #define DMA_ISSUE(C) (void)ns, (void)so_i, (void)so_w, (void)rs_i, (void)rs_w, (void)voffv;
 #define DMA_ONE(I, C) (void)(I), (void)voffv;
 #endif
+    if constexpr (PP) {
+      // ---- ping-pong pipeline (see the kernel comment).  The launcher selects it only for 3x3 taps with 16-channel chunks
+      //      (CKb = 2: one step per tap, 9 steps = 3 phases of 3 steps per chunk) through the double-buffered DMA pipeline.
+      //      A wavefront issues one instruction every ~4-5 cycles whatever its kind, so the fetch phase has to be SHORT in
+      //      instructions to fit beside the partner's 24 MFMAs (768 cycles): every step-dependent part of an operand address is a
+      //      compile-time immediate of the ds_read (weights: tap * 4 KB + channel block * 512 B; input: kernel column * 16 B off
+      //      a per-kernel-row base), the bases move once per chunk, and the DMA slots of a phase are fixed (first half of the
+      //      slots in phase 0, second half in phase 1, none in phase 2 -- their data is needed one phase later).
+      static_assert(NWV == 8 && !S2D, "ping-pong needs two wavefronts per SIMD");
+      constexpr int PS = 3;
+      const int grp = wave >> 2;                 // 0: waves 0-3 (lead), 1: waves 4-7 (one phase behind) -- scalar
+      const i32x4 rsi = bf_make_rsrc(inb, ibytes), rsw = bf_make_rsrc(p.wp, wbytes);
+      const unsigned bufbytes = (unsigned)p.bufs * 16u;
+      const unsigned a_b0 = (unsigned)(p.ldsw_off + a_vu) * 16u;
+      unsigned b_b0[NW][3];
+#pragma unroll
+      for (int n = 0; n < NW; ++n)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) b_b0[n][ky] = (unsigned)(b_vu[n] + ky * lw) * 16u;
+      static_assert(PF == 10, "the ping-pong slot layout is 5 input + 5 weight slots");
+      const unsigned la0 = (unsigned)(wave * 64 * 16);
+      const unsigned char* lds_b = reinterpret_cast<const unsigned char*>(smem4);
+// slots 0-4: input tile (descriptor of this image), slots 5-9: weight slices; slots that hold nothing carry out-of-range offsets
+#define PP_DMA_IN(LA, SOI) if (!BF_DBG(4)) bf_dma16x5<NT * 16>(rsi, (LA), (SOI), voffv[0], voffv[1], voffv[2], voffv[3], voffv[4]);
+#define PP_DMA_W(LA, SOW) if (!BF_DBG(4)) bf_dma16x5<NT * 16>(rsw, (LA) + (unsigned)(5 * NT * 16), (SOW), voffv[5], voffv[6], voffv[7], voffv[8], voffv[9]);
+#define PP_BARRIER()                              \
+  __builtin_amdgcn_sched_barrier(0);              \
+  __builtin_amdgcn_s_barrier();                   \
+  __builtin_amdgcn_sched_barrier(0);
+      PP_DMA_IN(la0, 0)
+      PP_DMA_W(la0, 0)
+      ACC_ZERO()
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PP_BARRIER()                 // chunk 0 has landed for everybody
+      if (grp) { PP_BARRIER() }    // the trailing half starts one phase later
+      u32x4 av[PS][MW], bv[PS][NW];
+#ifdef YOGO_DIAG
+      unsigned long long ph_sum[4] = {0ull, 0ull, 0ull, 0ull}, ph_t = __builtin_amdgcn_s_memtime();
+#define PP_STAMP(K)                                                         \
+  if (p.stamps) {                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                      \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();             \
+    ph_sum[K] += t_ - ph_t;                                                 \
+    ph_t = t_;                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                      \
+  }
+#else
+#define PP_STAMP(K)
+#endif
+      for (int c = 0; c < p.nchunk; ++c) {
+        const unsigned par = (c & 1) ? bufbytes : 0u;
+        const unsigned char* pa = lds_b + (a_b0 + par);
+        const unsigned char* pb[NW][3];
+#pragma unroll
+        for (int n = 0; n < NW; ++n)
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) pb[n][ky] = lds_b + (b_b0[n][ky] + par);
+        const bool more = c + 1 < p.nchunk;                           // (nothing is fetched behind the last chunk)
+        const unsigned lan = la0 + ((c & 1) ? 0u : bufbytes);         // this wavefront's LDS base in the OTHER buffer
+        const int soi = (c + 1) * so_i, sow = (c + 1) * so_w;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {   // phase q = kernel row q: steps (q, 0..2)
+          // ---- fetch phase.  Buffer (c + 1) & 1 is free: its last reader (the trailing half's fetch of chunk c - 1) finished
+          //      before the barrier that opened this chunk.
+#pragma unroll
+          for (int j = 0; j < PS; ++j) {
+            if (!BF_DBG(64)) {
+#pragma unroll
+              for (int mb = 0; mb < MW; ++mb)
+                av[j][mb] = *reinterpret_cast<const u32x4*>(pa + ((q * 3 + j) * 2 * BM + mb * 32) * 16);
+            }
+            if (!BF_DBG(32)) {
+#pragma unroll
+              for (int n = 0; n < NW; ++n) bv[j][n] = *reinterpret_cast<const u32x4*>(pb[n][q] + j * 16);
+            }
+          }
+          if (q < 2 && more) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (q == 0) { PP_DMA_IN(lan, soi) } else { PP_DMA_W(lan, sow) }
+          }
+          if (q == 2 && grp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (trailing half) my part of chunk c + 1 has landed
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          PP_STAMP(0)
+          PP_BARRIER()
+          PP_STAMP(1)
+          // ---- MFMA phase: registers only
+#pragma unroll
+          for (int j = 0; j < PS; ++j) BF_MFMA(0, av[j], bv[j])
+          if (q == 2 && !grp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (leading half) ... before the barrier in front of its first fetch of chunk c + 1
+          PP_STAMP(2)
+          PP_BARRIER()
+          PP_STAMP(3)
+        }
+      }
+      if (!grp) { PP_BARRIER() }   // same number of barriers for both halves
+#ifdef YOGO_DIAG
+      if (p.stamps && (tid == 0 || tid == 256)) {
+        unsigned long long* d = p.stamps + (size_t)widx * 16 + 4 + (tid >> 8) * 4;
+        d[0] = ph_sum[0]; d[1] = ph_sum[1]; d[2] = ph_sum[2]; d[3] = ph_sum[3];
+      }
+#endif
+#undef PP_STAMP
+#undef PP_DMA_IN
+#undef PP_DMA_W
+#undef PP_BARRIER
+    } else {
     int dnext = 0, dend = 0, dchunk = 0;
 #undef BF_HOOK
 #define BF_HOOK()                   \
@@ -421,6 +582,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
         ++dnext;
       }
     }
+    }  // !PP
 #undef DMA_ISSUE
 #undef DMA_ONE
 #undef BF_HOOK
@@ -767,7 +929,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
   }
 #ifdef YOGO_DIAG
   if (p.stamps && tid == 0) {
-    unsigned long long* d = p.stamps + (size_t)widx * 4;
+    unsigned long long* d = p.stamps + (size_t)widx * 16;
     d[0] = t_start; d[1] = t_loop; d[2] = t_epi; d[3] = __builtin_amdgcn_s_memtime();
   }
 #endif
@@ -983,11 +1145,14 @@ extern "C" int yogo_conv_bf16_pack_multi(const void* table, int n, int total_blo
 // channel blocks of a bf16 NCHW8c tensor with C channels AS THE NEXT LAYER READS IT (padded to 16 channels = 2 blocks)
 extern "C" int yogo_bf16_channel_blocks(int C) { return bf_kb_of(C); }
 
+static bool g_bf_pp = true;   // (diagnostic build: yogo_diag_conv_bf16_pp(0) selects the interleaved main loop for A/B runs)
 #ifdef YOGO_DIAG
+extern "C" int yogo_diag_conv_bf16_pp(int on) { g_bf_pp = on != 0; return YOGO_OK; }
 // diagnostic build only: ablation bits, synchronous staging, and a caller-owned stamp buffer ([workgroups][4] u64)
 static int g_diag_dbg = 0, g_diag_nodma = 0;
 static unsigned long long* g_diag_stamps = nullptr;
 static size_t g_diag_stamps_bytes = 0;
+// stamps: [workgroups][16] u64 (see ConvBf16Params::stamps)
 extern "C" int yogo_diag_conv_bf16(int dbg_bits, int no_dma, void* stamps, size_t stamps_bytes) {
   g_diag_dbg = dbg_bits; g_diag_nodma = no_dma;
   g_diag_stamps = reinterpret_cast<unsigned long long*>(stamps); g_diag_stamps_bytes = stamps_bytes;
@@ -996,6 +1161,30 @@ extern "C" int yogo_diag_conv_bf16(int dbg_bits, int no_dma, void* stamps, size_
 #endif
 
 namespace {
+
+template <int MW, int NW, int NWV, bool S2D, int PF, bool F32, int REF, bool PP>
+void bf_launch_one(dim3 grid, int lds_bytes, hipStream_t stream, const ConvBf16Params& p, const char* plan_txt) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<MW, NW, NWV, S2D, PF, F32, REF, PP>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, BF_LDS_MAX);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_bf16_kernel<MW, NW, NWV, S2D, PF, F32, REF, PP>), grid, dim3(64 * NWV), lds_bytes, stream, p);
+  yogo_launch_log("conv_bf16_kernel<%d, %d, %d, %s, %d, %s, %d, %s> | %s", MW, NW, NWV, S2D ? "true" : "false", PF, F32 ? "true" : "false", REF,
+                  PP ? "true" : "false", plan_txt);
+}
+// the ping-pong main loop exists for the 8-wavefront tiles with bf16 output (two wavefronts per SIMD)
+template <int MW, int NW, int NWV, bool S2D, int PF, bool F32, int REF>
+void bf_launch_t(dim3 grid, int lds_bytes, hipStream_t stream, const ConvBf16Params& p, bool use_pp, const char* plan_txt) {
+  if constexpr (NWV == 8 && !S2D && !F32) {
+    if (use_pp) {
+      bf_launch_one<MW, NW, NWV, S2D, PF, F32, REF, true>(grid, lds_bytes, stream, p, plan_txt);
+      return;
+    }
+  }
+  bf_launch_one<MW, NW, NWV, S2D, PF, F32, REF, false>(grid, lds_bytes, stream, p, plan_txt);
+}
 
 // One launcher for forward and data-gradient.  (K, M) are the GEMM contraction / output channel counts, (IH, IW) the
 // physical input dims, (OH, OW) the output dims, `a` the input step per output pixel; s2d = 1: parity-decomposed data
@@ -1060,8 +1249,8 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
   if (g_diag_nodma && (tl.lds_dummy + 1) * 16 <= BF_LDS_MAX) p.dma = 0;  // synchronous staging through registers
   {
     const size_t nwg = (size_t)grid.x * grid.y * grid.z;
-    if (g_diag_stamps != nullptr && nwg * 32 <= g_diag_stamps_bytes) {
-      (void)hipMemsetAsync(g_diag_stamps, 0, nwg * 32, stream);
+    if (g_diag_stamps != nullptr && nwg * 128 <= g_diag_stamps_bytes) {
+      (void)hipMemsetAsync(g_diag_stamps, 0, nwg * 128, stream);
       p.stamps = g_diag_stamps;
     }
   }
@@ -1071,23 +1260,21 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
     return YOGO_ERR_ARG;
   }
   if (B == 0) return YOGO_OK;
-  const int lds_bytes = max(p.dma ? tl.lds_bytes : (tl.lds_dummy + 1) * 16, (2 + 2 * NWV) * 32 * MW * 4);
+  int lds_bytes = max(p.dma ? tl.lds_bytes : (tl.lds_dummy + 1) * 16, (2 + 2 * NWV) * 32 * MW * 4);
+  // ping-pong main loop: 3x3 taps, 16-channel chunks (one step per tap) through the double-buffered LDS-DMA pipeline, with its
+  // fixed slot layout: 5 slots for the input tile, 5 for the weight slices, two buffers of 10 slots = all of the LDS
+  const bool use_pp = NWV == 8 && !s2d && T == 9 && p.dma == 1 && tl.CKb == 2 && tl.ni_slots <= 5 && tl.n_slots - tl.ni_slots <= 5 && g_bf_pp;
+  if (use_pp) {
+    p.ni_slots = 5; p.n_slots = 10; p.ldsw_off = 5 * 64 * NWV; p.bufu = 10 * 64 * NWV; p.bufs = p.bufu;
+    lds_bytes = 2 * p.bufu * 16;
+  }
   char plan_txt[256] = "";
   if (yogo_launch_log_enabled())
     snprintf(plan_txt, sizeof(plan_txt), "K=%d M=%d in=%dx%d out=%dx%d a=%d s2d=%d T=%d ncb=%d TW=%d tiles_per_band=%d CKb=%d nchunk=%d rows=%d LW=%d lds=%d dma=%d slots=%d+%d grid=%ux%ux%u",
              K, M, IH, IW, OH, OW, a, s2d, T, tl.ncb, tl.TW, tl.tiles_per_band, tl.CKb, Kb / tl.CKb, tl.rows_max, tl.LW, lds_bytes, p.dma, tl.ni_slots,
              tl.n_slots - tl.ni_slots, grid.x, grid.y, grid.z);
-#define BFLAUNCH__(MW_, NW_, NWV_, S2D_, PF_, F32_, REF_)                                                                          \
-  do {                                                                                                                 \
-    static bool attr_set = false;                                                                                      \
-    if (!attr_set) {                                                                                                   \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<MW_, NW_, NWV_, S2D_, PF_, F32_, REF_>), \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, BF_LDS_MAX);                               \
-      attr_set = true;                                                                                                 \
-    }                                                                                                                  \
-    hipLaunchKernelGGL((conv_bf16_kernel<MW_, NW_, NWV_, S2D_, PF_, F32_, REF_>), grid, dim3(64 * NWV_), lds_bytes, stream, p); \
-    yogo_launch_log("conv_bf16_kernel<" #MW_ ", " #NW_ ", " #NWV_ ", " #S2D_ ", " #PF_ ", " #F32_ ", " #REF_ "> | %s", plan_txt);   \
-  } while (0)
+#define BFLAUNCH__(MW_, NW_, NWV_, S2D_, PF_, F32_, REF_)                                                               \
+  bf_launch_t<MW_, NW_, NWV_, S2D_, PF_, F32_, REF_>(grid, lds_bytes, stream, p, use_pp, plan_txt)
 #define BFLAUNCH_(MW_, NW_, NWV_, S2D_, PF_, F32_)                             \
   do {                                                                         \
     if (act_ref != nullptr) BFLAUNCH__(MW_, NW_, NWV_, S2D_, PF_, false, 1);   \
