@@ -124,6 +124,9 @@ def main():
                     help="bf16 (default, BASELINE configs[2]): bf16 activations/gradients + bf16 MFMA, fp32 master weights and "
                          "statistics; f32: fp32 storage + exact fp32 MFMA")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; default) or gloo (rehearsal of the N>1 path on one GPU)")
+    ap.add_argument("--comm", default="torch", choices=["torch", "rccl"],
+                    help="gradient exchange transport: torch.distributed (backend above) or librccl called directly through the C ABI")
+    ap.add_argument("--no-overlap", action="store_true", help="one all-reduce after backward instead of the overlapped two-part exchange")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -154,7 +157,8 @@ def main():
     model = YOGO((H, W), ANCHOR_W, ANCHOR_H, NUM_CLASSES).to(dev)
     model.train()
     B = args.batch
-    trainer = HipTrainer(model, YOGOLoss().to(dev), total_steps=args.steps + args.warmup + 41, half=(args.dtype == "bf16"))
+    trainer = HipTrainer(model, YOGOLoss().to(dev), total_steps=args.steps + args.warmup + 41, half=(args.dtype == "bf16"),
+                         comm=args.comm, overlap=not args.no_overlap)
     trainer.broadcast_parameters()
     imgs = synthetic_images(B, H, W, device=dev, seed=100 + rank)
     labels = synthetic_labels(B, model.Sx, model.Sy, K=64, num_classes=NUM_CLASSES, device=dev, seed=200 + rank)

@@ -227,6 +227,18 @@ int yogo_conv_first_bn_wgrad_finalize_xg(const float* sums, const float* gram, c
                                          int Cin, int Cout, int IH, int IW, int stride, int training, float clip,
                                          yogo_stream_t stream);
 
+/* ---- data-parallel exchange over RCCL / xGMI (replaces torch DDP: init_process_group("nccl") + DistributedDataParallel,
+ * yogo/train.py:155-159; gradient all-reduce overlapped with backward, buffers broadcast from rank 0).  One process per GPU.
+ * librccl.so is opened lazily.  yogo_comm_unique_id fills a HOST buffer of yogo_comm_unique_id_bytes() bytes on rank 0; the host
+ * hands it to every rank (any rendez-vous) and each rank calls yogo_comm_init (collective).  The all-reduce is an in-place SUM
+ * of fp32 values enqueued on `stream`; the mean's 1 / world is folded into yogo_adamw_step (grad_scale). */
+int yogo_comm_unique_id_bytes(void);
+int yogo_comm_unique_id(void* id_out_host);
+int yogo_comm_init(int rank, int world, const void* unique_id_host, void** comm_out);
+int yogo_comm_allreduce_flat(void* comm, float* buf, size_t count, yogo_stream_t stream);
+int yogo_comm_broadcast_flat(void* comm, void* buf, size_t bytes, int root, yogo_stream_t stream);
+int yogo_comm_destroy(void* comm);
+
 /* ---- the step in front of the path: label rasteriser and batch flips ----------------------------- */
 /* format_labels_tensor, yogo/data/yogo_dataset.py:24-46, for a whole batch.  labels: [N][5] fp32 rows (class, x1, y1, x2, y2),
  * or (class, xc, yc, w, h) with box_format = 1 (converted as label_file_to_tensor does, :132), all images back to back;

@@ -1,6 +1,8 @@
-"""World-size-2 data-parallel exchange on CPU (gloo): the flat-buffer logic of yogo_amd.train -- per-rank clamp BEFORE the
-exchange, one sum all-reduce, 1/world scale -- reproduces the single-process gradient of the concatenated batch, and the
-flat parameter buffer really backs the module's parameters.  Compute is done by the CPU oracle (test infrastructure)."""
+"""World-size-2 data-parallel exchange on CPU (gloo) THROUGH HipTrainer's own methods (broadcast_parameters, the backward hook
+that starts the head-side part of the all-reduce, exchange_begin / exchange_end): per-rank clamp BEFORE the exchange, SUM
+all-reduce in two parts, 1/world scale -- reproduces the mean of the ranks' clamped gradients (DDP semantics), and the flat
+parameter buffer really backs the module's parameters.  The per-rank gradients come from the CPU oracle (test
+infrastructure); the kernels themselves are covered by the GPU tests (tests/test_gpu_dp.py runs HipTrainer.step on two ranks)."""
 import os
 import socket
 
@@ -25,7 +27,7 @@ def _worker(rank, world, port, tmp):
     sys.path[:0] = [root, os.path.join(root, "oracle")]
     import yogo_oracle as O
     from yogo_amd.model import YOGO
-    from yogo_amd.train import FlatParams, cosine_lr
+    from yogo_amd.train import HipTrainer, cosine_lr
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -33,9 +35,17 @@ def _worker(rank, world, port, tmp):
     torch.manual_seed(0)
     Himg, Wimg, C, Bper = 48, 64, 3, 2
     model = YOGO((Himg, Wimg), 0.0425, 0.0555, C, model_func=__import__("yogo_amd.model_defns", fromlist=["x"]).get_model_func("quarter_filters"))
-    flat = FlatParams(model)
-    # rank-0 weights everywhere (what HipTrainer.broadcast_parameters does)
-    dist.broadcast(flat.flat, src=0)
+    if rank == 1:   # different weights on rank 1 until the broadcast
+        with torch.no_grad():
+            for p_ in model.parameters():
+                p_.add_(1.0)
+    tr = HipTrainer(model, total_steps=10)          # no kernels run here: construction + the exchange methods are host logic
+    flat = tr.flat
+    assert tr.world == world and 0 < tr.split_off < flat.total
+    tr.broadcast_parameters()                        # rank-0 weights and buffers everywhere (what DDP does at construction)
+    w0 = flat.flat.clone()
+    dist.broadcast(w0, src=0)
+    assert torch.equal(w0, flat.flat)
     assert all(p.data_ptr() >= flat.flat.data_ptr() and p.data_ptr() < flat.flat.data_ptr() + 4 * flat.total for p in model.parameters())
     sd = {k: v.clone() for k, v in model.state_dict().items()}
     spec = O.arch("quarter_filters", C)
@@ -55,9 +65,15 @@ def _worker(rank, world, port, tmp):
     mine = grads_for(xs[rank * Bper:(rank + 1) * Bper], labs[rank * Bper:(rank + 1) * Bper])
     for n, p in zip(names, model.parameters()):
         flat.grad_views[id(p)].copy_(mine[n])
-    # the exchange exactly as HipTrainer.step does it
-    dist.all_reduce(flat.grad, op=dist.ReduceOp.SUM)
-    scale = 1.0 / world
+    # the exchange exactly as HipTrainer.step drives it: the backward hook fires when the middle layer's gradients are done
+    # (head-side part starts travelling), the rest follows after backward, exchange_end joins and returns the mean's scale
+    for i in range(len(tr.engine.layers) - 1, -1, -1):
+        tr._on_layer_done(i)
+        if i == tr.split_layer:
+            assert len(tr._pending) == 1
+    tr.exchange_begin(0, tr.split_off)
+    scale = tr.exchange_end()
+    assert scale == 1.0 / world and not tr._pending
     got = flat.grad * scale
     # reference: every rank's clamped gradient averaged (DDP semantics: hooks clamp per rank, then mean)
     all_g = [grads_for(xs[r * Bper:(r + 1) * Bper], labs[r * Bper:(r + 1) * Bper]) for r in range(world)]

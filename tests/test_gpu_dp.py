@@ -1,0 +1,111 @@
+"""The N > 1 path for real on one card: two fresh processes (ranks) share cuda:0, gloo carries the exchange, each runs
+HipTrainer.step on its shard -- broadcast_parameters, per-rank BatchNorm statistics, per-rank clamp, the two-part overlapped
+all-reduce started from the backward hook, the 1 / world scale folded into the AdamW kernel.  Checked against the oracle:
+every rank's clamped gradient (its own batch statistics) averaged, then one AdamW step.  Mirrors the reference's DDP set-up
+(yogo/train.py:155-159) -- which the reference itself never tests.  Also: the direct-RCCL transport (yogo_comm_*) at world 1."""
+import ctypes
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+import yogo_oracle as O
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("half", [False, True])
+def test_two_ranks_on_one_card(tmp_path, half):
+    world, port = 2, str(_free_port())
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), str(r), str(world), port, str(tmp_path), "1" if half else "0", "torch"],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    res = [torch.load(tmp_path / f"rank{r}.pt", weights_only=False) for r in range(world)]
+    # rank-0 weights everywhere before the step, identical parameters and summed gradients after it
+    for k in res[0]["sd0"]:
+        assert torch.equal(res[0]["sd0"][k], res[1]["sd0"][k]), k
+    assert torch.equal(res[0]["flat"], res[1]["flat"]) and torch.equal(res[0]["grad_sum"], res[1]["grad_sum"])
+    assert 0 < res[0]["split_off"] < res[0]["flat"].numel()
+    # BatchNorm statistics stay per rank (the reference has no SyncBN): different shards -> different running means
+    assert not torch.equal(res[0]["sd1"]["model.0.1.running_mean"], res[1]["sd1"]["model.0.1.running_mean"])
+    # oracle: per-rank gradients (own batch statistics), clamped per rank, averaged, one AdamW step
+    sd0 = res[0]["sd0"]
+    Himg, Wimg, C, Bper = 96, 128, 5, 2
+    spec = O.arch("base_model", C)
+    names = [k for k, v in sd0.items() if k.startswith("model.") and v.is_floating_point() and "running" not in k]
+    Sx, Sy = O.grid_size(spec, Himg, Wimg)
+    xs = O.synthetic_images(world * Bper, Himg, Wimg, seed=5)
+    labs = O.synthetic_labels(world * Bper, Sx, Sy, K=5, num_classes=C, seed=6)
+    gsum = {k: torch.zeros_like(sd0[k]) for k in names}
+    for r in range(world):
+        leaf = {k: sd0[k].clone().requires_grad_(True) for k in names}
+        sdl = dict(sd0)
+        sdl.update(leaf)
+        pred = O.yogo_forward(xs[r * Bper:(r + 1) * Bper], sdl, spec, 0.0425, 0.0555, train=True)
+        loss, _ = O.yogo_loss(pred, labs[r * Bper:(r + 1) * Bper])
+        loss.backward()
+        g = O.clamp_grads({k: v.grad for k, v in leaf.items()})
+        for k in names:
+            gsum[k] += g[k]
+        assert abs(res[r]["loss"]["loss"] - float(loss.detach())) < (2e-2 if half else 1e-3) * abs(float(loss.detach())), (r, res[r]["loss"])
+    off = 0
+    for k in names:
+        n = sd0[k].numel()
+        got_g = res[0]["grad_sum"][off:off + n].view(sd0[k].shape)
+        gmax = float(gsum[k].abs().max())
+        if k != "model.5.0.bias":       # (a conv bias in front of BatchNorm: mathematically zero, rounding noise on both sides)
+            if half:
+                cos = float((got_g * gsum[k]).sum() / (got_g.norm() * gsum[k].norm() + 1e-30))
+                # bf16 activations through 8 layers on TWO images per rank against the fp32 oracle: the direction is kept (0.95 at
+                # 4 images, test_gpu_bf16.py; measured here: 0.946 for layer 0, 0.90 for the layer-1 bias).  The exchange logic
+                # is the same code on both paths -- the fp32 variant of this test checks it tightly.
+                assert cos > 0.85, (k, cos)
+            else:
+                assert float((got_g - gsum[k]).abs().max()) < 2e-3 * gmax + 1e-6, (k, float((got_g - gsum[k]).abs().max()), gmax)
+        if not half:
+            p, _, _ = O.adamw_step(sd0[k], gsum[k] / world, torch.zeros_like(sd0[k]), torch.zeros_like(sd0[k]), 1, 3e-4)
+            d = (res[0]["flat"][off:off + n].view(sd0[k].shape) - p).abs()
+            solid = (gsum[k].abs() > 1e-3 * gmax) if k != "model.5.0.bias" else torch.zeros_like(d, dtype=torch.bool)
+            assert float(d.max()) < 7e-4, (k, float(d.max()))              # Adam's first step: at most 2 lr where the sign is noise
+            assert not bool(solid.any()) or float(d[solid].max()) < 2e-5, (k, float(d[solid].max()))
+        off += n
+
+
+def test_direct_rccl_transport_world1():
+    """yogo_comm_*: librccl through the C ABI.  One rank is all a one-GPU box offers (RCCL refuses two ranks on one device),
+    so this checks the plumbing -- dlopen, unique id, communicator, in-place all-reduce / broadcast on a side stream, destroy --
+    and that a one-rank SUM is the identity."""
+    from yogo_amd import _hip as h
+
+    n = h.lib().yogo_comm_unique_id_bytes()
+    assert n == 128
+    idb = ctypes.create_string_buffer(n)
+    h.call("yogo_comm_unique_id", ctypes.addressof(idb))
+    assert any(idb.raw)
+    comm = ctypes.c_void_p(0)
+    h.call("yogo_comm_init", 0, 1, ctypes.addressof(idb), ctypes.addressof(comm))
+    assert comm.value
+    x = torch.randn(541852, device="cuda")
+    want = x.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    h.call("yogo_comm_allreduce_flat", comm.value, x, x.numel(), side.cuda_stream)
+    h.call("yogo_comm_broadcast_flat", comm.value, x, x.numel() * 4, 0, side.cuda_stream)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert torch.equal(x, want)
+    h.call("yogo_comm_destroy", comm.value)

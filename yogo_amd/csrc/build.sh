@@ -26,5 +26,5 @@ for f in "$HERE"/*.hip; do
   fi
 done
 for p in "${pids[@]:-}"; do [[ -n "$p" ]] && wait "$p"; done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$OBJ"/*.o -o "$OUT/$LIBNAME"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$OBJ"/*.o -ldl -o "$OUT/$LIBNAME"
 echo "built $OUT/$LIBNAME"

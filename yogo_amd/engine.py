@@ -252,9 +252,10 @@ class Engine:
 
     # ------------------------------------------------------------------------------------------------------
     def backward(self, saved: List[Saved], graw: torch.Tensor,
-                 grad_out: Optional[Dict[int, torch.Tensor]] = None) -> List[Optional[torch.Tensor]]:
+                 grad_out: Optional[Dict[int, torch.Tensor]] = None, on_layer=None) -> List[Optional[torch.Tensor]]:
         """returns gradients in the order of ``backbone.parameters()``.  ``grad_out`` maps id(param) to a preallocated
-        contiguous destination (views of one flat gradient buffer in the trainer)."""
+        contiguous destination (views of one flat gradient buffer in the trainer).  ``on_layer(i)`` is called once every
+        gradient kernel of layers >= i has been enqueued (the trainer starts the all-reduce of that part there)."""
         st = _hip.stream_ptr()
         dev = graw.device
         clip = float(self.clip)
@@ -314,6 +315,8 @@ class Engine:
                 if has_bias:
                     grads[id(L.conv.bias)] = db
             grads[id(L.conv.weight)] = dw
+            if on_layer is not None:
+                on_layer(i)
             # ---- data gradient, with the previous block's activation derivative and dropout mask fused -------------
             if i > 0:
                 Lp, Sp = self.layers[i - 1], saved[i - 1]
@@ -590,7 +593,7 @@ def forward_bf16_train(eng: Engine, x: torch.Tensor) -> Tuple[torch.Tensor, List
 
 
 def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
-                        grad_out: Optional[Dict[int, torch.Tensor]] = None) -> List[Optional[torch.Tensor]]:
+                        grad_out: Optional[Dict[int, torch.Tensor]] = None, on_layer=None) -> List[Optional[torch.Tensor]]:
     st, dev, clip = _hip.stream_ptr(), graw.device, float(eng.clip)
     grads: Dict[int, torch.Tensor] = {}
 
@@ -697,6 +700,10 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
         if has_bias:
             grads[id(L.conv.bias)] = db
         grads[id(L.conv.weight)] = dw
+        if on_layer is not None:
+            if wstream is not main:
+                main.wait_stream(wstream)   # the weight gradient of this layer is part of what the hook hands over
+            on_layer(i)
         if i > 0:
             Lp, Sp = eng.layers[i - 1], saved[i - 1]
             ref_act = Lp.act

@@ -10,10 +10,17 @@ per-parameter clamp, DDP gradient averaging, ``optimizer.step()``, ``scheduler.s
   2.17 MB (``torch.distributed`` backend "nccl" is RCCL on ROCm; over xGMI the message is latency-bound, so a single
   bucket is the right granularity -- SURVEY.md section 8e);
 * gradients are clamped per rank BEFORE the all-reduce (the reference's hooks fire before DDP averages);
+* the exchange is OVERLAPPED with backward like DDP's buckets (yogo/train.py:155-159; torch fills buckets from the head side):
+  the flat gradient is cut once, in front of the middle layer -- the head-side part (82 % of the bytes in base_model) is
+  all-reduced on the communication stream as soon as its last gradient kernel is enqueued and travels under the backward
+  pass of the input-side layers; the small remainder follows at the end of backward;
+* two transports: ``comm="torch"`` (``torch.distributed``; backend "nccl" = RCCL on ROCm, gloo in the CPU tests) and
+  ``comm="rccl"`` (librccl called directly through the C ABI, ``yogo_comm_*`` in include/yogo_hip.h, on a side HIP stream);
 * BatchNorm statistics stay per GPU (the reference has no SyncBN).
 """
 from __future__ import annotations
 
+import ctypes
 import math
 from typing import Dict, List, Optional, Tuple
 
@@ -82,6 +89,8 @@ class HipTrainer:
         decay_factor: float = 10.0,
         process_group=None,
         half: bool = False,
+        comm: str = "torch",
+        overlap: bool = True,
     ):
         self.model = model
         self.loss = loss if loss is not None else YOGOLoss()
@@ -95,10 +104,86 @@ class HipTrainer:
         self.half = bool(half)   # bf16 activations / activation gradients (the reference's --half is fp16 autocast)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.rank = dist.get_rank(process_group) if self.world > 1 else 0
         self.flat = FlatParams(model)
         self.engine = get_engine(model.model)
         self.engine.invalidate_packed()
         self.last_loss: Optional[torch.Tensor] = None   # 4 device floats: total, iou, objectness, classification
+        # ---- data-parallel exchange -----------------------------------------------------------------------------------
+        if comm not in ("torch", "rccl"):
+            raise ValueError("comm must be 'torch' (torch.distributed) or 'rccl' (librccl through the C ABI)")
+        self.comm = comm
+        self.overlap = bool(overlap)
+        nl = len(self.engine.layers)
+        self.split_layer = nl // 2      # gradients of layers >= split_layer travel while layers < split_layer are still in backward
+        first = {}                      # layer index -> offset of its first parameter in the flat buffer
+        off = 0
+        for name, p in model.named_parameters():
+            parts = name.split(".")
+            if len(parts) > 1 and parts[0] == "model" and parts[1].isdigit():
+                first.setdefault(int(parts[1]), off)
+            off += p.numel()
+        self.split_off = first.get(self.split_layer, 0)
+        self._pending: list = []
+        self._rccl = None
+        self._comm_stream = None
+        if self.world > 1 and comm == "rccl":
+            self._init_rccl()
+
+    # ---- exchange: one (overlapped: two-part) all-reduce of the flat gradient ------------------------------------------------
+    def _init_rccl(self) -> None:
+        """create the RCCL communicator through the C ABI; the 128-byte unique id travels through torch.distributed"""
+        dev = self.flat.flat.device
+        n = _hip.lib().yogo_comm_unique_id_bytes()
+        buf = ctypes.create_string_buffer(n)
+        if self.rank == 0:
+            _hip.call("yogo_comm_unique_id", ctypes.addressof(buf))
+        box = [bytes(buf.raw)]
+        dist.broadcast_object_list(box, src=0, group=self.pg)
+        idb = ctypes.create_string_buffer(box[0], n)
+        handle = ctypes.c_void_p(0)
+        with torch.cuda.device(dev):
+            _hip.call("yogo_comm_init", self.rank, self.world, ctypes.addressof(idb), ctypes.addressof(handle))
+            self._comm_stream = torch.cuda.Stream(device=dev)
+        self._rccl = handle.value
+
+    def close(self) -> None:
+        if self._rccl is not None:
+            torch.cuda.synchronize()
+            _hip.call("yogo_comm_destroy", self._rccl)
+            self._rccl = None
+
+    def exchange_begin(self, lo: int, hi: int) -> None:
+        """start the SUM all-reduce of flat.grad[lo:hi] over the ranks; everything enqueued on the current stream so far is
+        ordered before it, later kernels of the current stream run beside it"""
+        if self.world <= 1 or hi <= lo:
+            return
+        view = self.flat.grad[lo:hi]
+        if self._rccl is not None:
+            main = torch.cuda.current_stream()
+            self._comm_stream.wait_stream(main)
+            _hip.call("yogo_comm_allreduce_flat", self._rccl, view, hi - lo, self._comm_stream.cuda_stream)
+            self._pending.append(None)
+        else:
+            self._pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def exchange_end(self) -> float:
+        """make the current stream wait for the outstanding all-reduces; returns the factor that turns the SUM into the
+        mean (folded into the AdamW kernel: yogo_adamw_step's grad_scale)"""
+        if self.world <= 1:
+            return 1.0
+        for w in self._pending:
+            if w is not None:
+                w.wait()
+        if self._rccl is not None and self._pending:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+        self._pending.clear()
+        return 1.0 / self.world
+
+    def _on_layer_done(self, i: int) -> None:
+        """backward hook: every gradient kernel of layers >= i has been enqueued"""
+        if self.overlap and i == self.split_layer and self.split_off > 0:
+            self.exchange_begin(self.split_off, self.flat.total)
 
     def current_lr(self) -> float:
         return cosine_lr(self.global_step, self.lr, self.t_max, self.eta_min)
@@ -154,11 +239,19 @@ class HipTrainer:
 
     def broadcast_parameters(self, src: int = 0) -> None:
         """rank-0 weights and BatchNorm buffers to every rank (what DDP does at construction)"""
-        if self.world > 1:
+        if self.world <= 1:
+            return
+        bufs = [b for b in self.model.buffers() if b.is_floating_point() or b.dtype == torch.long]
+        if self._rccl is not None:
+            st = torch.cuda.current_stream().cuda_stream
+            _hip.call("yogo_comm_broadcast_flat", self._rccl, self.flat.flat, self.flat.total * 4, src, st)
+            for b in bufs:
+                if b.is_cuda and b.numel() > 0:
+                    _hip.call("yogo_comm_broadcast_flat", self._rccl, b, b.numel() * b.element_size(), src, st)
+        else:
             dist.broadcast(self.flat.flat, src=src, group=self.pg)
-            for b in self.model.buffers():
-                if b.is_floating_point() or b.dtype == torch.long:
-                    dist.broadcast(b, src=src, group=self.pg)
+            for b in bufs:
+                dist.broadcast(b, src=src, group=self.pg)
 
     @torch.no_grad()
     def step(self, imgs: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
@@ -195,19 +288,19 @@ class HipTrainer:
             _hip.call("yogo_loss_fwd_bwd", pred, lab, gpred, out, ws, B, P, Sy, Sx, float(L.no_obj_weight), float(L.iou_weight),
                       float(L.classify_weight), float(L.label_smoothing), st)
             # ---- backward: decode, then the backbone (clamp fused into the gradient kernels) -------------------------
+            hook = self._on_layer_done if self.world > 1 else None
             if self.half:   # the head's gradient goes straight to bf16 NCHW8c
                 g8 = torch.empty(B, ((P + 15) // 16) * 2, Sy, Sx, 8, dtype=torch.bfloat16, device=raw.device)
                 _hip.call("yogo_decode_bwd_bf16", raw, pred, gpred, g8, B, P, Sy, Sx, int(bool(m.inference)), st)
-                backward_bf16_train(eng, saved, g8, grad_out=self.flat.grad_views)
+                backward_bf16_train(eng, saved, g8, grad_out=self.flat.grad_views, on_layer=hook)
             else:
                 graw = torch.empty_like(raw)
                 _hip.call("yogo_decode_bwd", raw, pred, gpred, graw, B, P, Sy, Sx, int(bool(m.inference)), st)
-                eng.backward(saved, graw, grad_out=self.flat.grad_views)
-            # ---- data-parallel exchange: one RCCL all-reduce of the flat gradient --------------------------------------
-            scale = 1.0
-            if self.world > 1:
-                dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.pg)
-                scale = 1.0 / self.world
+                eng.backward(saved, graw, grad_out=self.flat.grad_views, on_layer=hook)
+            # ---- data-parallel exchange: the rest of the flat gradient (all of it without overlap), then the join ---------------
+            started = self.split_off if (self.overlap and self._pending) else self.flat.total
+            self.exchange_begin(0, started)
+            scale = self.exchange_end()
             # ---- AdamW + cosine LR (scheduler stepped every iteration) ----------------------------------------------------
             lr = self.current_lr()
             self.global_step += 1
