@@ -256,3 +256,22 @@ def test_layer0_partial_buffers_exact_size(B, IH, IW):
     part2 = Guarded(rows * cols)
     h.call("yogo_conv_first_bn_wgrad_bf16_xg", x_end, 0, gy, z, mean.view, invstd.view, gamma, beta, part2.view, B, 1, Cout, IH, IW, 2, 1, st)
     part2.check("conv_first_bn_wgrad on the last image of an allocation")
+
+
+def test_host_tensor_at_the_boundary_is_an_error_not_a_fault():
+    """a host tensor handed to an entry point would make a kernel read host memory (a GPU memory fault that aborts the process --
+    how a `.cuda()`-moved model whose resize_model rebuilt its grids on the stale `self.device` died in round 2): refused in _hip.call"""
+    from yogo_amd.model import YOGO
+
+    h = H()
+    var, out = torch.ones(4), torch.empty(4, device="cuda")
+    with pytest.raises(RuntimeError, match="host tensor"):
+        h.call("yogo_bn_invstd", var, 1e-5, out, 4, h.stream_ptr())
+    # the regression itself: .cuda() does not update YOGO.device (only .to() does, as in the reference); resize_model must
+    # rebuild the grids where the old ones live
+    net = YOGO((128, 160), 0.0425, 0.0555, 3, inference=True).cuda().eval()
+    net.resize_model(64)
+    assert net._Cxs.is_cuda and net._Cys.is_cuda and net.height_multiplier.is_cuda and (net.Sx, net.Sy) == (20, 8)
+    with torch.no_grad():
+        y = net(torch.zeros(1, 1, 64, 160, dtype=torch.uint8, device="cuda"))
+    assert tuple(y.shape) == (1, 8, 8, 20) and bool(torch.isfinite(y).all())

@@ -1,0 +1,81 @@
+"""Own statistics behind ``Metrics`` (yogo_amd/metrics.py; torchmetrics is not installable here): hand-computed cases for the
+COCO mAP protocol, the confusion matrix / per-class accuracy, precision, recall, the binned ROC and the calibration error."""
+import numpy as np
+import torch
+
+from yogo_amd.metrics import MeanAveragePrecision, _ClassStats
+
+
+def _img(boxes, scores, labels):
+    return {"boxes": torch.tensor(boxes, dtype=torch.float32).reshape(-1, 4), "scores": torch.tensor(scores, dtype=torch.float32),
+            "labels": torch.tensor(labels, dtype=torch.long)}
+
+
+def _gt(boxes, labels):
+    return {"boxes": torch.tensor(boxes, dtype=torch.float32).reshape(-1, 4), "labels": torch.tensor(labels, dtype=torch.long)}
+
+
+def test_map_perfect_and_empty():
+    m = MeanAveragePrecision()
+    m.update([_img([[0, 0, 10, 10]], [0.9], [1]), _img([[5, 5, 20, 30]], [0.8], [2])], [_gt([[0, 0, 10, 10]], [1]), _gt([[5, 5, 20, 30]], [2])])
+    r = m.compute()
+    assert float(r["map"]) == 1.0 and float(r["map_50"]) == 1.0 and float(r["map_75"]) == 1.0 and float(r["mar_100"]) == 1.0
+    assert r["classes"].tolist() == [1, 2]
+    m.reset()
+    assert float(m.compute()["map"]) == -1.0
+
+
+def test_map_iou_thresholds_and_ranking():
+    # one class, two images.  Image A: detection with IoU 0.6 (TP up to threshold 0.6: thresholds .5, .55, .6 -> 3 of 10).
+    # Image B: a confident false positive (no overlap) and no second detection for its ground truth.
+    m = MeanAveragePrecision()
+    det_a = [0, 0, 10, 6]          # vs gt [0,0,10,10]: inter 60, union 100 -> IoU 0.6
+    m.update([_img([det_a], [0.7], [0]), _img([[50, 50, 60, 60]], [0.9], [0])],
+             [_gt([[0, 0, 10, 10]], [0]), _gt([[0, 0, 10, 10]], [0])])
+    r = m.compute()
+    # ranked: FP (0.9), then TP (0.7).  2 ground truths.  At a threshold where A is a TP: recall reaches 0.5 with precision 1/2;
+    # the 101-point interpolation gives precision 0.5 for recall thresholds 0 .. 0.5 (51 points) and 0 beyond: AP = 51 * 0.5 / 101
+    ap = 51 * 0.5 / 101
+    np.testing.assert_allclose(float(r["map_50"]), ap, rtol=1e-6)
+    np.testing.assert_allclose(float(r["map"]), 3 * ap / 10, rtol=1e-6)
+    np.testing.assert_allclose(float(r["map_75"]), 0.0, atol=1e-12)
+    np.testing.assert_allclose(float(r["mar_100"]), 3 * 0.5 / 10, rtol=1e-6)
+    # a class without ground truth does not enter the mean
+    m.update([_img([[0, 0, 1, 1]], [0.99], [7])], [_gt(np.zeros((0, 4)), [])])
+    np.testing.assert_allclose(float(m.compute()["map_50"]), ap, rtol=1e-6)
+
+
+def test_map_greedy_matching_one_gt_two_detections():
+    # two detections on one ground truth: the higher-scored one takes it, the other is a false positive
+    m = MeanAveragePrecision()
+    m.update([_img([[0, 0, 10, 10], [0, 0, 10, 9]], [0.6, 0.9], [3, 3])], [_gt([[0, 0, 10, 10]], [3])])
+    r = m.compute()
+    # ranked: (0.9, IoU 0.9 -> TP for thresholds <= 0.9), (0.6, IoU 1.0 but the gt is taken -> FP; at 0.95 the first misses and
+    # the second matches: FP then TP -> AP 0.5)
+    np.testing.assert_allclose(float(r["map_50"]), 1.0, rtol=1e-6)
+    np.testing.assert_allclose(float(r["map"]), (9 * 1.0 + 0.5) / 10, rtol=1e-6)
+
+
+def test_class_statistics():
+    st = _ClassStats(num_classes=3, roc_thresholds=5, n_bins=4)
+    probs = torch.tensor([[0.7, 0.2, 0.1], [0.1, 0.8, 0.1], [0.6, 0.3, 0.1], [0.2, 0.2, 0.6], [0.3, 0.6, 0.1]])
+    target = torch.tensor([0, 1, 1, 2, 1])
+    st.update(probs[:3], target[:3])
+    st.update(probs[3:], target[3:])
+    out = st.compute()
+    assert st.confmat.tolist() == [[1, 0, 0], [1, 2, 0], [0, 0, 1]]          # rows = true class, columns = predicted
+    np.testing.assert_allclose(out["MulticlassRecall"].numpy(), [1.0, 2 / 3, 1.0], rtol=1e-6)
+    np.testing.assert_allclose(out["MulticlassAccuracy"].numpy(), [1.0, 2 / 3, 1.0], rtol=1e-6)
+    np.testing.assert_allclose(out["MulticlassPrecision"].numpy(), [0.5, 1.0, 1.0], rtol=1e-6)
+    fpr, tpr, thr = out["MulticlassROC"]
+    assert thr.tolist() == [1.0, 0.75, 0.5, 0.25, 0.0] and fpr.shape == (3, 5) and tpr.shape == (3, 5)
+    # class 1 one-vs-rest: positives have p1 = .8, .3, .6; negatives .2, .2
+    np.testing.assert_allclose(tpr[1].numpy(), [0, 1 / 3, 2 / 3, 1.0, 1.0], rtol=1e-6)
+    np.testing.assert_allclose(fpr[1].numpy(), [0, 0, 0, 0, 1.0], rtol=1e-6)
+    # calibration: confidences .7 .8 .6 .6 .6, correct 1 1 0 1 1; bins (0,.25] (.25,.5] (.5,.75] (.75,1]
+    # bin 3: conf .7 .6 .6 .6 (mean .625), acc 3/4 -> |.75 - .625| * 4/5 ; bin 4: conf .8, acc 1 -> .2 * 1/5
+    np.testing.assert_allclose(float(out["MulticlassCalibrationError"]), 0.125 * 0.8 + 0.2 * 0.2, rtol=1e-6)
+    # raw logits are soft-maxed first (torchmetrics' normalisation), argmax statistics are unchanged
+    st2 = _ClassStats(3, 5, 4)
+    st2.update(torch.log(probs) * 3 + 5, target)
+    assert st2.confmat.tolist() == st.confmat.tolist()

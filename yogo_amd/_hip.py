@@ -79,6 +79,11 @@ def _ptr(t):
     if t is None:
         return None
     if isinstance(t, torch.Tensor):
+        # every tensor argument of the C ABI is a DEVICE pointer (host buffers travel as ctypes addresses): a host tensor here
+        # would make a kernel dereference host memory -- a GPU memory fault that takes the process down instead of an error
+        if not t.is_cuda:
+            raise RuntimeError(f"yogo_amd: a host tensor {tuple(t.shape)} {t.dtype} was handed to a HIP entry point; the hot path "
+                               "takes device tensors only (was a buffer left on the CPU?)")
         return t.data_ptr()
     return t
 

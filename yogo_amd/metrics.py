@@ -1,0 +1,338 @@
+"""``Metrics`` -- the evaluation half behind ``yogo test`` and the end-of-training test (yogo/metrics.py:22-234, called from
+yogo/train.py:446-528): prediction <-> label matching (``format_preds_and_labels_v2`` on top of the batched HIP threshold +
+NMS kernel), then mAP, confusion matrix, per-class accuracy / precision / recall, ROC curves and calibration error.
+
+The reference delegates the statistics to ``torchmetrics`` (MeanAveragePrecision, MulticlassConfusionMatrix, MulticlassAccuracy,
+MulticlassROC(thresholds=500), MulticlassPrecision, MulticlassRecall, MulticlassCalibrationError(n_bins=30)), which is not
+installable here; they are restated below from their published definitions (COCO evaluation protocol for mAP) with plain
+torch / numpy on the host -- these are a few thousand matched rows per test set, not a hot path.  PARITY UNPINNED against a
+real torchmetrics (none available); pinned by hand-computed cases in tests/test_metrics.py.
+
+Quirks of the reference that are kept on purpose:
+* ``min_class_confidence_threshold`` defaults to 0.9 (yogo/metrics.py:30) and ``Trainer.test`` / ``yogo test`` run the network
+  with ``inference=False``, so the "class confidences" that enter NMS scoring and that threshold are raw logits;
+* every matched (prediction, label) pair is handed to mAP as its own one-box "image" (yogo/metrics.py:204-234);
+* ``num_classes = len(classes)`` is taken BEFORE the background class is appended (yogo/metrics.py:35-36), while
+  ``convert_background_errors(num_classes)`` reuses the LAST real class index for background -- reproduced as is.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from yogo_amd.utils.prediction_formatting import PredictionLabelMatch, format_preds_and_labels_v2_batched
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# COCO mean average precision (the protocol torchmetrics.detection.MeanAveragePrecision implements)
+# ---------------------------------------------------------------------------------------------------------------------
+_IOU_THRS = np.linspace(0.5, 0.95, 10)
+_REC_THRS = np.linspace(0.0, 1.0, 101)
+_MAX_DETS = (1, 10, 100)
+_AREAS = {"all": (0.0, 1e10), "small": (0.0, 32.0 ** 2), "medium": (32.0 ** 2, 96.0 ** 2), "large": (96.0 ** 2, 1e10)}
+
+
+def _box_iou_np(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    lt = np.maximum(a[:, None, :2], b[None, :, :2])
+    rb = np.minimum(a[:, None, 2:], b[None, :, 2:])
+    wh = np.clip(rb - lt, 0, None)
+    inter = wh[..., 0] * wh[..., 1]
+    union = area_a[:, None] + area_b[None, :] - inter
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.where(union > 0, inter / union, 0.0)
+
+
+class MeanAveragePrecision:
+    """COCO mAP over lists of per-image dicts: preds {boxes [n,4] xyxy, scores [n], labels [n]}, targets {boxes, labels}."""
+
+    def __init__(self, box_format: str = "xyxy") -> None:
+        if box_format != "xyxy":
+            raise ValueError("only box_format='xyxy' is supported")
+        self.reset()
+
+    def reset(self) -> None:
+        self._images: List[Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray, np.ndarray]] = []
+
+    def update(self, preds: List[Dict[str, torch.Tensor]], targets: List[Dict[str, torch.Tensor]]) -> None:
+        if len(preds) != len(targets):
+            raise ValueError("preds and targets must have the same length")
+        for p, t in zip(preds, targets):
+            self._images.append((
+                p["boxes"].detach().cpu().double().numpy().reshape(-1, 4), p["scores"].detach().cpu().double().numpy().reshape(-1),
+                p["labels"].detach().cpu().long().numpy().reshape(-1),
+                t["boxes"].detach().cpu().double().numpy().reshape(-1, 4), t["labels"].detach().cpu().long().numpy().reshape(-1)))
+
+    def _evaluate_image(self, img, cls: int, area: Tuple[float, float], max_det: int):
+        db, ds, dl, gb, gl = img
+        dsel, gsel = dl == cls, gl == cls
+        if not dsel.any() and not gsel.any():
+            return None
+        db, ds, gb = db[dsel], ds[dsel], gb[gsel]
+        order = np.argsort(-ds, kind="mergesort")[:max_det]
+        db, ds = db[order], ds[order]
+        g_area = (gb[:, 2] - gb[:, 0]) * (gb[:, 3] - gb[:, 1])
+        g_ign = (g_area < area[0]) | (g_area > area[1])
+        gorder = np.argsort(g_ign, kind="mergesort")          # non-ignored ground truth first
+        gb, g_ign = gb[gorder], g_ign[gorder]
+        ious = _box_iou_np(db, gb) if len(db) and len(gb) else np.zeros((len(db), len(gb)))
+        T, D, G = len(_IOU_THRS), len(db), len(gb)
+        dm = np.zeros((T, D), dtype=bool)
+        d_ign = np.zeros((T, D), dtype=bool)
+        gm = np.zeros((T, G), dtype=bool)
+        for ti, thr in enumerate(_IOU_THRS):
+            for d in range(D):
+                best, m = min(thr, 1 - 1e-10), -1
+                for g in range(G):
+                    if gm[ti, g]:
+                        continue
+                    if m > -1 and not g_ign[m] and g_ign[g]:
+                        break                                  # a non-ignored match beats every ignored one
+                    if ious[d, g] < best:
+                        continue
+                    best, m = ious[d, g], g
+                if m > -1:
+                    dm[ti, d], d_ign[ti, d], gm[ti, m] = True, g_ign[m], True
+        d_area = (db[:, 2] - db[:, 0]) * (db[:, 3] - db[:, 1])
+        out_of_range = (d_area < area[0]) | (d_area > area[1])
+        d_ign = d_ign | (~dm & out_of_range[None, :])
+        return ds, dm, d_ign, int((~g_ign).sum())
+
+    def compute(self) -> Dict[str, torch.Tensor]:
+        classes = sorted({int(c) for im in self._images for c in np.concatenate((im[2], im[4]))})
+        T, R, K, A, M = len(_IOU_THRS), len(_REC_THRS), len(classes), len(_AREAS), len(_MAX_DETS)
+        precision = -np.ones((T, R, K, A, M))
+        recall = -np.ones((T, K, A, M))
+        for ki, cls in enumerate(classes):
+            imgs = [im for im in self._images if (im[2] == cls).any() or (im[4] == cls).any()]
+            for ai, area in enumerate(_AREAS.values()):
+                for mi, max_det in enumerate(_MAX_DETS):
+                    ev = [e for e in (self._evaluate_image(im, cls, area, max_det) for im in imgs) if e is not None]
+                    if not ev:
+                        continue
+                    npig = sum(e[3] for e in ev)
+                    if npig == 0:
+                        continue
+                    scores = np.concatenate([e[0] for e in ev])
+                    order = np.argsort(-scores, kind="mergesort")
+                    dm = np.concatenate([e[1] for e in ev], axis=1)[:, order]
+                    dig = np.concatenate([e[2] for e in ev], axis=1)[:, order]
+                    tps = np.cumsum(dm & ~dig, axis=1, dtype=np.float64)
+                    fps = np.cumsum(~dm & ~dig, axis=1, dtype=np.float64)
+                    for ti in range(T):
+                        tp, fp = tps[ti], fps[ti]
+                        nd = len(tp)
+                        rc = tp / npig
+                        pr = tp / (tp + fp + np.spacing(1))
+                        recall[ti, ki, ai, mi] = rc[-1] if nd else 0
+                        for i in range(nd - 1, 0, -1):          # precision envelope
+                            if pr[i] > pr[i - 1]:
+                                pr[i - 1] = pr[i]
+                        inds = np.searchsorted(rc, _REC_THRS, side="left")
+                        q = np.zeros(R)
+                        ok = inds < nd
+                        q[ok] = pr[inds[ok]]
+                        precision[ti, :, ki, ai, mi] = q
+
+        def mean_valid(x):
+            x = x[x > -1]
+            return torch.tensor(float(x.mean()) if x.size else -1.0)
+
+        areas = list(_AREAS)
+        out = {
+            "map": mean_valid(precision[:, :, :, 0, 2]),
+            "map_50": mean_valid(precision[0, :, :, 0, 2]),
+            "map_75": mean_valid(precision[5, :, :, 0, 2]),
+            "map_small": mean_valid(precision[:, :, :, areas.index("small"), 2]),
+            "map_medium": mean_valid(precision[:, :, :, areas.index("medium"), 2]),
+            "map_large": mean_valid(precision[:, :, :, areas.index("large"), 2]),
+            "mar_1": mean_valid(recall[:, :, 0, 0]),
+            "mar_10": mean_valid(recall[:, :, 0, 1]),
+            "mar_100": mean_valid(recall[:, :, 0, 2]),
+            "mar_small": mean_valid(recall[:, :, areas.index("small"), 2]),
+            "mar_medium": mean_valid(recall[:, :, areas.index("medium"), 2]),
+            "mar_large": mean_valid(recall[:, :, areas.index("large"), 2]),
+            "map_per_class": torch.tensor(-1.0),
+            "mar_100_per_class": torch.tensor(-1.0),
+            "classes": torch.tensor(classes, dtype=torch.int32),
+        }
+        return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# classification statistics over the matched rows
+# ---------------------------------------------------------------------------------------------------------------------
+def _as_probabilities(scores: torch.Tensor) -> torch.Tensor:
+    """torchmetrics' normalisation for curve / calibration metrics: softmax unless the scores already lie in [0, 1]"""
+    if scores.numel() and not bool(((scores >= 0) & (scores <= 1)).all()):
+        return scores.softmax(1)
+    return scores
+
+
+def _safe_div(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    return torch.where(b != 0, a / torch.where(b != 0, b, torch.ones_like(b)), torch.zeros_like(a))
+
+
+class _ClassStats:
+    """confusion matrix (rows = true class, columns = predicted class), binned one-vs-rest ROC states, calibration bins"""
+
+    def __init__(self, num_classes: int, roc_thresholds: int = 500, n_bins: int = 30) -> None:
+        self.C = num_classes
+        self.thresholds = torch.linspace(0, 1, roc_thresholds, dtype=torch.float64)
+        self.n_bins = n_bins
+        self.reset()
+
+    def reset(self) -> None:
+        self.confmat = torch.zeros(self.C, self.C, dtype=torch.long)
+        self.roc_tp = torch.zeros(len(self.thresholds), self.C, dtype=torch.long)   # predicted positive & is class
+        self.roc_fp = torch.zeros(len(self.thresholds), self.C, dtype=torch.long)
+        self.pos = torch.zeros(self.C, dtype=torch.long)
+        self.n = 0
+        self.bin_count = torch.zeros(self.n_bins, dtype=torch.float64)
+        self.bin_conf = torch.zeros(self.n_bins, dtype=torch.float64)
+        self.bin_acc = torch.zeros(self.n_bins, dtype=torch.float64)
+
+    def update(self, scores: torch.Tensor, target: torch.Tensor) -> None:
+        scores = scores.detach().cpu().double().reshape(-1, scores.shape[-1])
+        target = target.detach().cpu().long().reshape(-1)
+        if scores.shape[0] == 0:
+            return
+        pred = scores.argmax(1)
+        valid = (target >= 0) & (target < self.C) & (pred < self.C)
+        idx = target[valid] * self.C + pred[valid]
+        self.confmat += torch.bincount(idx, minlength=self.C * self.C).view(self.C, self.C)
+        prob = _as_probabilities(scores)[:, : self.C]
+        onehot = torch.nn.functional.one_hot(target.clamp(0, self.C - 1), self.C).bool() & ((target >= 0) & (target < self.C))[:, None]
+        above = prob[None, :, :] >= self.thresholds[:, None, None]                  # [T, N, C]
+        self.roc_tp += (above & onehot[None]).sum(1)
+        self.roc_fp += (above & ~onehot[None]).sum(1)
+        self.pos += onehot.sum(0)
+        self.n += scores.shape[0]
+        conf, arg = prob.max(1)
+        acc = (arg == target).double()
+        edges = torch.linspace(0, 1, self.n_bins + 1, dtype=torch.float64)
+        b = (torch.bucketize(conf, edges, right=True) - 1).clamp(0, self.n_bins - 1)
+        self.bin_count += torch.bincount(b, minlength=self.n_bins).double()
+        self.bin_conf += torch.bincount(b, weights=conf, minlength=self.n_bins)
+        self.bin_acc += torch.bincount(b, weights=acc, minlength=self.n_bins)
+
+    def compute(self) -> Dict[str, Any]:
+        cm = self.confmat.double()
+        tp = cm.diag()
+        support, predicted = cm.sum(1), cm.sum(0)
+        recall = _safe_div(tp, support)
+        precision = _safe_div(tp, predicted)
+        neg = (self.n - self.pos).double()
+        tpr = _safe_div(self.roc_tp.double(), self.pos.double()[None, :].expand_as(self.roc_tp)).flip(0).T   # [C, T], thresholds descending
+        fpr = _safe_div(self.roc_fp.double(), neg[None, :].expand_as(self.roc_fp)).flip(0).T
+        cnt = self.bin_count
+        prop = cnt / cnt.sum() if float(cnt.sum()) > 0 else cnt
+        ece = float((_safe_div(self.bin_acc, cnt) - _safe_div(self.bin_conf, cnt)).abs().mul(prop).sum())
+        return {
+            "MulticlassAccuracy": recall.float(),          # torchmetrics' per-class accuracy (average=None) = per-class recall
+            "MulticlassPrecision": precision.float(),
+            "MulticlassRecall": recall.float(),
+            "MulticlassROC": (fpr.float(), tpr.float(), self.thresholds.flip(0).float()),
+            "MulticlassCalibrationError": torch.tensor(ece),
+        }
+
+
+class Metrics:
+    """yogo/metrics.py:22-234 -- same constructor, ``update`` / ``compute`` / ``reset`` / ``forward`` and return tuple."""
+
+    @torch.no_grad()
+    def __init__(
+        self,
+        classes: List[str],
+        device: str = "cpu",
+        sync_on_compute: bool = False,
+        min_class_confidence_threshold: float = 0.9,
+        include_mAP: bool = True,
+        include_background: bool = True,
+    ):
+        self.device = device
+        self.classes = classes + (["background"] if include_background else [])
+        self.num_classes = len(classes)
+        self.min_class_confidence_threshold = min_class_confidence_threshold
+        self.include_mAP = include_mAP
+        self.include_background = include_background
+        self.sync_on_compute = sync_on_compute          # (the reference never synchronises either: train.py:465-471)
+        if include_mAP:
+            self.mAP = MeanAveragePrecision(box_format="xyxy")
+        self._stats = _ClassStats(self.num_classes)
+        self.num_obj_missed_by_class = torch.zeros(self.num_classes, dtype=torch.long)
+        self.num_obj_extra_by_class = torch.zeros(self.num_classes, dtype=torch.long)
+        self.total_num_true_objects = torch.zeros(1, dtype=torch.long)
+
+    @torch.no_grad()
+    def update(self, preds: torch.Tensor, labels: torch.Tensor, use_IoU: bool = True) -> None:
+        # one batched threshold + NMS launch for the whole batch, then the per-image Hungarian matching on the host
+        matches = format_preds_and_labels_v2_batched(preds.detach(), labels.detach(),
+                                                     min_class_confidence_threshold=self.min_class_confidence_threshold)
+        plm = PredictionLabelMatch.concat(matches)
+
+        def count_classes(cls: torch.Tensor) -> torch.Tensor:
+            values, counts = cls.unique(return_counts=True)
+            out = torch.zeros(self.num_classes, dtype=torch.long)
+            out[values.long()] = counts
+            return out
+
+        if plm.missed_labels is not None:
+            self.num_obj_missed_by_class += count_classes(plm.missed_labels[:, 5].cpu())
+        if plm.extra_predictions is not None:
+            self.num_obj_extra_by_class += count_classes(plm.extra_predictions[:, 5:].argmax(dim=1).cpu())
+        self.total_num_true_objects += plm.labels.shape[0]
+        if self.include_background:
+            plm = plm.convert_background_errors(self.num_classes)
+        fps, fls = plm.preds, plm.labels
+        if self.include_mAP:
+            self.mAP.update(*self._format_for_mAP(fps, fls))
+        self._stats.update(fps[:, 5:], fls[:, 5:].squeeze(-1))
+
+    @torch.no_grad()
+    def compute(self) -> Tuple[Any, ...]:
+        pr = self._stats.compute()
+        mAP_metrics = self.mAP.compute() if self.include_mAP else {"map": torch.tensor(0.0)}
+        return (
+            mAP_metrics,
+            self._stats.confmat.clone(),
+            pr["MulticlassAccuracy"],
+            pr["MulticlassROC"],
+            pr["MulticlassPrecision"],
+            pr["MulticlassRecall"],
+            pr["MulticlassCalibrationError"].item(),
+            self.num_obj_missed_by_class.cpu(),
+            self.num_obj_extra_by_class.cpu(),
+            self.total_num_true_objects.cpu(),
+        )
+
+    @torch.no_grad()
+    def get_wandb_confusion_matrix(self, confusion_metrics):
+        """the reference turns the matrix into a wandb table (yogo/utils/utils.py:50-129); wandb is optional here, so the
+        rows (true class, predicted class, count) are returned as plain data"""
+        names = self.classes
+        return [[names[i] if i < len(names) else str(i), names[j] if j < len(names) else str(j), int(confusion_metrics[i, j])]
+                for i in range(confusion_metrics.shape[0]) for j in range(confusion_metrics.shape[1])]
+
+    def reset(self) -> None:
+        if self.include_mAP:
+            self.mAP.reset()
+        self._stats.reset()
+
+    @torch.no_grad()
+    def forward(self, preds, labels):
+        self.update(preds, labels)
+        res = self.compute()
+        self.reset()
+        return res
+
+    def _format_for_mAP(self, preds: torch.Tensor, labels: torch.Tensor):
+        """every matched pair becomes its own one-box image (yogo/metrics.py:204-234)"""
+        fp, fl = [], []
+        for p, l in zip(preds, labels):
+            fp.append({"boxes": p[:4].reshape(1, 4), "scores": p[4].reshape(1), "labels": p[5:].argmax().reshape(1)})
+            fl.append({"boxes": l[1:5].reshape(1, 4), "labels": l[5].reshape(1).long()})
+        return fp, fl

@@ -228,11 +228,14 @@ class YOGO(nn.Module):
         crop_size = (img_height or org_img_height, img_width or org_img_width)
         Sx, Sy = self.get_grid_size(crop_size)
         self.Sx, self.Sy = Sx, Sy
-        _Cxs = torch.linspace(0, 1 - 1 / Sx, Sx, device=self.device).expand(Sy, -1)
-        _Cys = torch.linspace(0, 1 - 1 / Sy, Sy, device=self.device).expand(1, -1).transpose(0, 1).expand(Sy, Sx)
-        self.register_buffer("height_multiplier", torch.tensor(org_img_height / crop_size[0]))
-        self.register_buffer("width_multiplier", torch.tensor(org_img_width / crop_size[1]))
-        self.register_buffer("img_size", torch.tensor(crop_size))
+        # the new grids live where the old ones do (``self.device`` goes stale under ``.cuda()`` -- only ``.to()`` updates it,
+        # in the reference too; a host grid handed to the decode kernel would be a GPU memory fault, not an error)
+        dev = self._Cxs.device
+        _Cxs = torch.linspace(0, 1 - 1 / Sx, Sx, device=dev).expand(Sy, -1)
+        _Cys = torch.linspace(0, 1 - 1 / Sy, Sy, device=dev).expand(1, -1).transpose(0, 1).expand(Sy, Sx)
+        self.register_buffer("height_multiplier", torch.tensor(org_img_height / crop_size[0], device=dev))
+        self.register_buffer("width_multiplier", torch.tensor(org_img_width / crop_size[1], device=dev))
+        self.register_buffer("img_size", torch.tensor(crop_size, device=dev))
         self.register_buffer("_Cxs", _Cxs.clone())
         self.register_buffer("_Cys", _Cys.clone())
         self._scalars = None
