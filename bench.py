@@ -9,7 +9,7 @@
 One JSON line on rank 0.  A "step" is one optimisation step over one per-GPU batch resident in HBM (weak scaling:
 per-GPU batch fixed, the images are sharded over ranks, one RCCL all-reduce of the flat gradient per step).
 `roofline` is measured live with HIP events (torch.cuda.Event on the stream the kernels are launched on) around every
-launch of the dominant kernel -- conv_bf16_kernel<4,2,8,false,10,false,0> (the stride-1 bf16 convolutions with 128 GEMM rows) by
+launch of the dominant kernel -- conv_bf16_kernel<4,2,8,false,10,false,0,true> (the stride-1 bf16 convolutions with 128 GEMM rows, ping-pong main loop) by
 default, conv_igemm_f32_kernel<4,2> under --dtype f32;
 `cpu_baseline` times the CPU oracle (oracle/yogo_oracle.py: the reference's algorithm on torch CPU ops) on a bounded
 sample of the same workload -- a reported baseline, never the target.
@@ -36,22 +36,61 @@ HBM_PEAK_GBS = 8000.0           # same table, "HBM3E peak BW" (6.29 TB/s measure
 TRAIN_GFLOP_PER_IMG = 66.48
 
 
-def cpu_baseline(batch: int = 8, steps: int = 2):
-    """oracle training step (fwd + loss + bwd + clamp + AdamW) on the host cores, bounded sample"""
+def _median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
+
+
+def cpu_baseline(batch: int = 8):
+    """the CPU oracle (oracle/yogo_oracle.py = the reference's algorithm on torch CPU ops) on the host cores
+    of this box, bounded samples of the same workload: (i) eval forward + decode, (ii) full train step, (iii) the per-image
+    format_preds loop.  2 warm-up + 5 timed iterations, median; the thread count is the one that maximises the oracle's own
+    throughput (a sweep over a forward pass), reported next to the core count."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import yogo_oracle as O
 
     cores = len(os.sched_getaffinity(0))
-    torch.set_num_threads(cores)
     spec = O.arch("base_model", NUM_CLASSES)
     sd = O.init_state(spec, seed=0)
+    for k in list(sd):   # trained-like running statistics keep the eval-mode activations finite (SURVEY.md 7, hard parts)
+        if k.endswith("running_var"):
+            sd[k] = torch.full_like(sd[k], 5000.0)
     x = O.synthetic_images(batch, H, W, seed=0)
     Sx, Sy = O.grid_size(spec, H, W)
     lab = O.synthetic_labels(batch, Sx, Sy, K=64, num_classes=NUM_CLASSES, seed=1)
+
+    def fwd():
+        with torch.no_grad():
+            return O.yogo_forward(x, sd, spec, ANCHOR_W, ANCHOR_H, inference=True)
+
+    best_t, best_thr = None, cores
+    for thr in sorted({t for t in (4, 8, 16, 32, 64, cores) if t <= cores}):
+        torch.set_num_threads(thr)
+        fwd()
+        t0 = time.perf_counter()
+        fwd()
+        dt = time.perf_counter() - t0
+        if best_t is None or dt < best_t:
+            best_t, best_thr = dt, thr
+    torch.set_num_threads(best_thr)
+
+    def timed(fn, warm=2, reps=5):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return _median(ts)
+
+    t_fwd = timed(fwd)
     names = [k for k, v in sd.items() if v.is_floating_point() and "running" not in k]
     state = {k: (torch.zeros_like(sd[k]), torch.zeros_like(sd[k])) for k in names}
+    step_no = [0]
 
-    def one(step):
+    def one():
+        step_no[0] += 1
         leaf = {k: sd[k].clone().requires_grad_(True) for k in names}
         sdl = dict(sd)
         sdl.update(leaf)
@@ -60,56 +99,117 @@ def cpu_baseline(batch: int = 8, steps: int = 2):
         loss, _ = O.yogo_loss(out, lab)
         loss.backward()
         g = O.clamp_grads({k: v.grad for k, v in leaf.items()})
-        lr = O.cosine_lr(step - 1, 3e-4, 1000, 3e-5)
+        lr = O.cosine_lr(step_no[0] - 1, 3e-4, 1000, 3e-5)
         for k in names:
-            p, m, v = O.adamw_step(sd[k], g[k], state[k][0], state[k][1], step, lr)
+            p, m, v = O.adamw_step(sd[k], g[k], state[k][0], state[k][1], step_no[0], lr)
             sd[k], state[k] = p.detach(), (m, v)
         sd.update(ns)
 
-    one(1)  # warm-up
-    t0 = time.perf_counter()
-    for s in range(steps):
-        one(2 + s)
-    dt = time.perf_counter() - t0
-    return {"value": round(batch * steps / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} oracle train steps (fwd+loss+bwd+AdamW), fp32, batch {batch}, after 1 warm-up step"}
+    t_step = timed(one)
+    # (iii) the reference's per-image post-processing loop (yogo/infer.py:45,73) on realistic predictions (100 objects per image)
+    preds = O.synthetic_predictions(64, Sx, Sy, NUM_CLASSES, K=100, seed=2)
+    t_fmt = timed(lambda: [O.format_preds(p) for p in preds], warm=1, reps=3)
+    return {"value": round(batch / t_step, 3), "unit": "images/s", "cores": best_thr, "cores_available": cores, "kind": "port",
+            "sample": f"oracle train step (fwd+loss+bwd+clamp+AdamW), fp32, batch {batch}: median of 5 after 2 warm-up steps, "
+                      f"{best_thr} torch threads (fastest of a sweep; {cores} cores visible)",
+            "eval_forward_decode_images_per_s": round(batch / t_fwd, 3),
+            "format_preds_loop_realistic_images_per_s": round(64 / t_fmt, 1)}
 
 
-def inference_extras(model, dev, B: int = 64):
-    """secondary numbers (not the headline metric): eval forward + decode at fp32 and under bf16 autocast (how `yogo infer`
-    runs the model), and the batched threshold+NMS kernel on the 'realistic' synthetic prediction tensor"""
-    from yogo_amd.synthetic import synthetic_images, synthetic_predictions
+def _timed_gpu(fn, reps=5):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def inference_extras(model, dev, B: int = 256):
+    """BASELINE configs[4] (secondary to the training metric): `yogo infer` at batch 256 -- eval forward + box decode + batched
+    threshold / NMS (format_preds_batched) end to end on synthetic images (the network of this run, after its training steps),
+    and the NMS kernel alone on 'dense' predictions (93 % of the cells fire, what a random-init network gives: the worst
+    case) and on 'realistic' ones (100 objects per image).  Roofline of decode / NMS: HBM, algorithmic bytes 0.60 MB per image
+    (SURVEY.md 8d)."""
+    from yogo_amd.synthetic import synthetic_dense_predictions, synthetic_images, synthetic_predictions
     from yogo_amd.utils import format_preds_batched
 
     model.eval()
     model.inference = True
     x = synthetic_images(B, H, W, device=dev, seed=7)
-    out = {}
-
-    def timed(fn, reps=5):
-        fn()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps
-
+    out = {"batch": B}
     with torch.no_grad():
-        ms32 = timed(lambda: model(x))
+        ms32 = _timed_gpu(lambda: model(x[:64]))
         with torch.autocast("cuda", dtype=torch.bfloat16):
-            ms16 = timed(lambda: model(x))
-        preds = synthetic_predictions(256, model.Sx, model.Sy, NUM_CLASSES, K=100, device=dev)
-        msn = timed(lambda: format_preds_batched(preds))
-    out["forward_decode_fp32_images_per_s"] = round(B / ms32 * 1e3, 1)
+            ms16 = _timed_gpu(lambda: model(x))
+
+            def e2e():
+                format_preds_batched(model(x))
+            ms_e2e = _timed_gpu(e2e)
+        dense = synthetic_dense_predictions(B, model.Sx, model.Sy, NUM_CLASSES, device=dev)
+        ms_nd = _timed_gpu(lambda: format_preds_batched(dense), reps=2)
+        real = synthetic_predictions(B, model.Sx, model.Sy, NUM_CLASSES, K=100, device=dev)
+        ms_nr = _timed_gpu(lambda: format_preds_batched(real))
+        raw = torch.randn(B, 5 + NUM_CLASSES, model.Sy, model.Sx, device=dev)
+        dec = torch.empty_like(raw)
+        from yogo_amd import _hip
+
+        aw, ah, wm, hm = model._decode_scalars()
+        ms_dec = _timed_gpu(lambda: _hip.call("yogo_decode_fwd", raw, dec, model._Cxs, model._Cys, B, 5 + NUM_CLASSES, model.Sy, model.Sx,
+                                              aw, ah, wm, hm, 1, _hip.stream_ptr()), reps=20)
+    img_bytes = (5 + NUM_CLASSES) * model.Sy * model.Sx * 4
+    out["forward_decode_fp32_images_per_s"] = round(64 / ms32 * 1e3, 1)
     out["forward_decode_bf16_images_per_s"] = round(B / ms16 * 1e3, 1)
-    out["threshold_nms_realistic_images_per_s"] = round(256 / msn * 1e3, 1)
-    out["note"] = "eval-mode base_model, batch 64 (forward) / 256 (NMS, 100 objects per image); secondary to the training metric"
+    out["end_to_end_bf16_forward_decode_nms_images_per_s"] = round(B / ms_e2e * 1e3, 1)
+    out["threshold_nms_dense_images_per_s"] = round(B / ms_nd * 1e3, 1)
+    out["threshold_nms_realistic_images_per_s"] = round(B / ms_nr * 1e3, 1)
+    out["roofline_decode"] = {"bound": "hbm", "achieved": round(2 * B * img_bytes / ms_dec / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(2 * B * img_bytes / ms_dec / 1e6 / HBM_PEAK_GBS, 4), "avg_call_ms": round(ms_dec, 4)}
+    out["roofline_nms_realistic"] = {"bound": "hbm", "achieved": round(B * img_bytes / ms_nr / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": round(B * img_bytes / ms_nr / 1e6 / HBM_PEAK_GBS, 4), "avg_call_ms": round(ms_nr, 4)}
+    out["note"] = ("eval-mode base_model at batch 256 (fp32 forward at 64); dense = 93 % of the 12 513 cells fire with overlapping boxes "
+                   "(NMS worst case, bound by the greedy suppression chain), realistic = 100 objects per image")
     model.train()
     model.inference = False
     return out
+
+
+def fp32_forward_loss(dev, B: int = 64):
+    """BASELINE configs[1]: fp32 forward + loss at batch 64 (train-mode forward with BatchNorm batch statistics, decode, fused loss
+    kernel), with the fp32-MFMA fraction of the 128-channel convolutions (conv_igemm_f32_kernel<4, 2, false>, peak 157.3 TFLOP/s)"""
+    from yogo_amd import _hip
+    from yogo_amd.engine import get_engine
+    from yogo_amd.model import YOGO
+    from yogo_amd.synthetic import synthetic_images, synthetic_labels
+    from yogo_amd.yogo_loss import YOGOLoss
+
+    torch.manual_seed(0)
+    m = YOGO((H, W), ANCHOR_W, ANCHOR_H, NUM_CLASSES).to(dev)
+    m.train()
+    x = synthetic_images(B, H, W, device=dev, seed=300)
+    lab = synthetic_labels(B, m.Sx, m.Sy, K=64, num_classes=NUM_CLASSES, device=dev, seed=301)
+    L = YOGOLoss().to(dev)
+    eng = get_engine(m.model)
+
+    def run():
+        with torch.no_grad():
+            L(m(x), lab)
+
+    ms = _timed_gpu(run, reps=3)
+    eng.prof = []
+    run()
+    torch.cuda.synchronize()
+    sel = [e for e in eng.prof if e[0] == "fwd" and e[2] == 4]
+    t = sum(e[4].elapsed_time(e[5]) for e in sel)
+    fl = sum(e[3] for e in sel)
+    eng.prof = None
+    tf = fl / max(t, 1e-9) / 1e9
+    return {"images_per_s": round(B / ms * 1e3, 1), "ms": round(ms, 3), "batch": B, "dtype": "f32",
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32_kernel<4, 2, false> (forward of the 128-channel 3x3 layers)",
+                         "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)}}
 
 
 def main():
@@ -236,15 +336,15 @@ def main():
             except Exception:
                 tj = {}
         if args.dtype == "bf16":
-            # dominant kernel: conv_bf16_kernel<4,2,8,false,10,false,0> = every stride-1 convolution with 128 GEMM rows (forward of
-            # layers 3/5/6, data gradient of layers 5/6).  Algorithmic FLOPs per launch: 2*B*Cout*Cin*k*k*OH*OW.
+            # dominant kernel: conv_bf16_kernel<4,2,8,false,10,false,0,true> = every stride-1 convolution with 128 GEMM rows (forward
+            # of layers 3/5/6, data gradient of layers 5/6).  Algorithmic FLOPs per launch: 2*B*Cout*Cin*k*k*OH*OW.
             sel = [e for e in prof if e[0] in ("fwd", "dgrad") and e[2] == 34]
             ms = ms_of(sel)
             fl = sum(e[3] for e in sel)
             achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            traffic = tj.get("conv_bf16_kernel<4,2,8,false,10,false,0>", {}).get("hbm_bytes_per_launch")
+            traffic = tj.get("conv_bf16_kernel<4,2,8,false,10,false,0,true>", {}).get("hbm_bytes_per_launch")
             allc = [e for e in prof if e[0] in ("fwd", "dgrad") and e[2] in (30, 34)]
-            roof = {"bound": "mfma", "kernel": "conv_bf16_kernel<4,2,8,false,10,false,0> (stride-1 bf16 convolutions with 128 GEMM rows: "
+            roof = {"bound": "mfma", "kernel": "conv_bf16_kernel<4,2,8,false,10,false,0,true> (stride-1 bf16 convolutions with 128 GEMM rows: "
                                                "forward of layers 3/5/6, data gradient of layers 5/6)",
                     "achieved": round(achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
@@ -278,6 +378,7 @@ def main():
         }
         if world == 1 and not args.no_inference:
             rec["inference"] = inference_extras(model, dev)
+            rec["configs1_fp32_forward_loss"] = fp32_forward_loss(dev)
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline()
         print(json.dumps(rec))

@@ -65,3 +65,21 @@ def synthetic_predictions(B: int, Sx: int, Sy: int, num_classes: int = 7, K: int
         vals = torch.where(use[:, None, :], vals, cur)
         flat.scatter_(2, cell[:, None, :].expand(B, P, K), vals)
     return out
+
+
+def synthetic_dense_predictions(B: int, Sx: int, Sy: int, num_classes: int = 7, frac: float = 0.93, device="cuda", seed: int = 3) -> torch.Tensor:
+    """'dense' post-process input (what a random-init network produces -- ~93 % of the cells pass the
+    objectness threshold, the NMS worst case): every cell predicts a box near its own centre with anchor-sized extents, so each
+    box overlaps dozens of neighbours; objectness U(0.5, 1) on `frac` of the cells, U(0, 0.5) on the rest."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    P = 5 + num_classes
+    out = torch.empty(B, P, Sy, Sx, device=device)
+    out[:, 0] = (torch.arange(Sx, device=device).float()[None, None, :] + torch.rand(B, Sy, Sx, device=device, generator=g)) / Sx
+    out[:, 1] = (torch.arange(Sy, device=device).float()[None, :, None] + torch.rand(B, Sy, Sx, device=device, generator=g)) / Sy
+    out[:, 2] = 0.0425 * torch.exp(torch.randn(B, Sy, Sx, device=device, generator=g) * 0.2)
+    out[:, 3] = 0.0555 * torch.exp(torch.randn(B, Sy, Sx, device=device, generator=g) * 0.2)
+    fire = torch.rand(B, Sy, Sx, device=device, generator=g) < frac
+    u = torch.rand(B, Sy, Sx, device=device, generator=g) * 0.5
+    out[:, 4] = torch.where(fire, 0.5 + u, u)
+    out[:, 5:] = torch.softmax(torch.randn(B, num_classes, Sy, Sx, device=device, generator=g) * 2, dim=1)
+    return out
