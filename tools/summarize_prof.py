@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 output (gpurun_out/<round>/{stats,fetch,write}) into profiles/: kernel-time table and per-launch HBM
-traffic of the dominant kernels (FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE is doubled as the MI355X guide prescribes for
-gfx950 -- it tallies 128-B requests at 64 B)."""
+"""Summarise rocprofv3 output (gpurun_out/<round>/{stats,fetch,write,mfma}, produced by tools/collect_profile.sh) into
+profiles/: kernel-time table, per-launch HBM traffic of the dominant kernels (FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE is
+doubled as the MI355X guide prescribes for gfx950 -- it tallies 128-B requests at 64 B) and the matrix-core utilisation per
+kernel (SQ_VALU_MFMA_BUSY_CYCLES over 1024 SIMDs x the kernel's cycles, GRBM_GUI_ACTIVE / 8 XCDs)."""
 import csv
 import glob
 import json
@@ -19,7 +20,7 @@ def one(pattern):
     return f[0] if f else None
 
 
-stats = one("stats/*kernel_stats.csv")
+stats = one("stats/*kernel_stats.csv") or one("stats/*/*kernel_stats.csv")
 lines = []
 if stats:
     rows = list(csv.DictReader(open(stats)))
@@ -32,7 +33,7 @@ if stats:
 
 traffic = {}
 for kind, pat, mult in (("fetch", "fetch/*counter_collection.csv", 2.0), ("write", "write/*counter_collection.csv", 1.0)):
-    f = one(pat)
+    f = one(pat) or one(pat.replace("/", "/*/", 1))
     if not f:
         continue
     agg = defaultdict(lambda: [0.0, 0])
@@ -56,5 +57,33 @@ with open(f"profiles/{tag}_hbm_traffic.txt", "w") as f:
     f.write("# bytes per launch; FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md HBM section)\n")
     for k, v in top:
         f.write(f"{k:60s} fetch {v.get('fetch_bytes_per_launch',0)/1e6:10.1f} MB  write {v.get('write_bytes_per_launch',0)/1e6:10.1f} MB  n={v.get('launches_fetch')}\n")
-print(open(f"profiles/{tag}_kernel_stats.txt").read()[:2500])
+# ---- matrix-core utilisation ------------------------------------------------------------------------------------------
+mf = one("mfma/*counter_collection.csv") or one("mfma/*/*counter_collection.csv")
+if mf:
+    agg = defaultdict(lambda: defaultdict(float))
+    nl = defaultdict(int)
+    for r in csv.DictReader(open(mf)):
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+            nl[k] += 1
+    rows = []
+    for k, c in agg.items():
+        cyc = c["GRBM_GUI_ACTIVE"] / 8.0
+        if cyc <= 0 or not k:
+            continue
+        wc = max(c["SQ_WAVE_CYCLES"], 1.0)
+        rows.append((c["GRBM_GUI_ACTIVE"], k, nl[k], cyc / nl[k], c["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0), c["SQ_WAIT_ANY"] / wc,
+                     c["SQ_WAIT_INST_ANY"] / wc, c["SQ_ACTIVE_INST_ANY"] / wc))
+    rows.sort(reverse=True)
+    with open(f"profiles/{tag}_mfma_util.txt", "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE "
+                f"--output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-inference  ({tag})\n")
+        f.write("# mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): fraction of the kernel's cycles in which a SIMD's matrix pipe is busy;\n")
+        f.write("# wait_any / wait_inst / active = shares of SQ_WAVE_CYCLES (parked at s_waitcnt or a barrier / issue stall / issuing)\n")
+        f.write(f"{'kernel':66s} {'launches':>8s} {'cycles/launch':>14s} {'mfma_busy':>10s} {'wait_any':>9s} {'wait_inst':>10s} {'active':>7s}\n")
+        for r in rows[:28]:
+            f.write(f"{r[1][:66]:66s} {r[2]:8d} {r[3]:14.0f} {r[4]:10.3f} {r[5]:9.2f} {r[6]:10.2f} {r[7]:7.2f}\n")
+    print(open(f"profiles/{tag}_mfma_util.txt").read())
+print(open(f"profiles/{tag}_kernel_stats.txt").read()[:3200])
 print(open(f"profiles/{tag}_hbm_traffic.txt").read())

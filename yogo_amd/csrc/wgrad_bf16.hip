@@ -39,7 +39,17 @@ struct WgradBf16Params {
   int ngs, nxs, bufu;                 // g / x slots in use, 16-byte units per LDS buffer
   int xcb;                            // channel blocks per pixel of the staged x image: 4, or 2 for 16-channel inputs
   int depth;                          // LDS buffers in the ring (2 or 3): units in flight ahead of the MFMAs = depth - 1
+#ifdef YOGO_DIAG
+  int diag;                           // diagnostic build: experiment bits for in-process A/B runs (tools/ab_wgrad_bf16.py)
+#endif
 };
+#ifdef YOGO_DIAG
+#define WB_DIAG(BIT) (p.diag & (BIT))
+static int g_wb_diag = 0;
+extern "C" int yogo_diag_wgrad_bf16(int bits) { g_wb_diag = bits; return YOGO_OK; }
+#else
+#define WB_DIAG(BIT) 0
+#endif
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
@@ -82,6 +92,9 @@ __device__ __forceinline__ bf16x8 lds_tr8(const unsigned char* base, int off0, i
 // further instead of re-reading channels that do not exist -- so a kernel row costs 2 MFMAs and 4 B reads instead of 3 and 6.
 template <int MBW, int NBW, int NPW, int KS, int T, int S, int R, int MPW = 1, bool ROT = false, bool PACK2 = false>
 __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_bf16_kernel(const WgradBf16Params p) {
+  // LEAN: the instruction-lean step loop below (one pixel split per wavefront grid, 64-byte pixels in the staged x image; the
+  // launcher only instantiates KS = 1 tilings with xcb = 4)
+  constexpr bool LEAN = KS == 1 && !PACK2 && !ROT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
   constexpr int TG = (T == 1) ? 1 : 3;
   constexpr int TT = T / TG;
@@ -111,7 +124,10 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
   float bsum[MPW];
 #pragma unroll
   for (int m = 0; m < MPW; ++m) bsum[m] = 0.f;
-  const bool do_bias = p.bias_part != nullptr && blockIdx.y == 0 && tg == 0 && nb == 0;
+  // bias gradient = row sums of the gradient operand.  LEAN: every wavefront of the first ci-block workgroup takes part (the
+  // NBW * TG wavefronts that hold the same operand sum alternate steps, each writes its own partial row); otherwise one does.
+  const bool do_bias = p.bias_part != nullptr && blockIdx.y == 0 && (LEAN || (tg == 0 && nb == 0));
+  [[maybe_unused]] int bias_turn = nb * TG + tg;   // LEAN: steps until this wavefront's next turn
 
   const int u_begin = split * p.units_per_split;
   const int u_end = min(p.units, u_begin + p.units_per_split);
@@ -162,6 +178,8 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
     const i32x4 rs_x = make_rsrc(p.x + (size_t)b_ * p.Nb * xplane, p.Nb * xplane * 16);                               \
     const unsigned lb_ = (unsigned)(((BUF) * p.bufu + wave * 64) * 16);  /* the dynamic LDS block starts at LDS address 0 */ \
     const int gorg_ = (oy0_ * p.OW + ox0_) * 16, rmax_ = p.OH - oy0_;                                                 \
+    const int iy0_ = oy0_ * S - p.pad, ix0_ = ox0_ * S - p.pad;                                                       \
+    const int xorg_ = (iy0_ * p.IW + ix0_) * 16;                                                                      \
     _Pragma("unroll") for (int i = 0; i < WGB_GSLOTS; ++i) {                                                          \
       if (i < p.ngs) {                                                                                                \
         const int c_ = (int)(grc[i] & 0xFFFFu), r_ = (int)(grc[i] >> 16);                                             \
@@ -169,8 +187,6 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
         dma16(rs_g, lb_ + i * NT * 16, ok_ ? glc[i] + gorg_ : (int)OOB);                                              \
       }                                                                                                               \
     }                                                                                                                 \
-    const int iy0_ = oy0_ * S - p.pad, ix0_ = ox0_ * S - p.pad;                                                       \
-    const int xorg_ = (iy0_ * p.IW + ix0_) * 16;                                                                      \
     _Pragma("unroll") for (int i = 0; i < WGB_XSLOTS; ++i) {                                                          \
       if (i < p.nxs) {                                                                                                \
         const int c_ = (int)(xrc[i] & 0xFFFFu), r_ = (int)(xrc[i] >> 16);                                             \
@@ -194,6 +210,8 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
   const int gbase = mb * MPW * (R * p.wce * 64) + lane_ch_off;
   // 16-channel image: the lanes of channels 16-31 re-read channels 0-15 (those output columns lie beyond N and are dropped)
   const int xbase = p.ngs * NT * 16 + nb * NPW * xblk + (lane_ch_off & (xpb - 1)) + (PACK2 ? (gi & 1) * xpb : 0);
+  [[maybe_unused]] const int lean_a0 = gbase + lane_px * 64;                                     // (xpb = 64 on this path)
+  [[maybe_unused]] const int lean_b0 = xbase + ((T == 1 ? 0 : tg) * p.xw + lane_px * S) * 64;
 
 #define WB_LOAD(AV, BV, I)                                                                                      \
   {                                                                                                             \
@@ -240,6 +258,43 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
     }
     const unsigned char* buf = smem_b + ib * p.bufu * 16;
     ib = ib + 1 == p.depth ? 0 : ib + 1;
+    if constexpr (LEAN) {
+      // ---- lean step loop (KS = 1, 64-byte pixels): a wavefront beside two MFMA-busy partners issues an instruction only every
+      //      5-10 cycles, so the loop is kept to the ds_reads and the MFMAs themselves -- rows and 16-pixel steps are walked by
+      //      (unrolled) loops instead of a division per step, and every step-dependent part of an operand address (step * 1 KB,
+      //      tap * 64 B, second pixel half + 256 B) is an immediate of the ds_read; the per-lane bases move once per row.
+      const unsigned char* pa0 = buf + lean_a0;
+      const unsigned char* pa1 = buf + lean_a0 + R * p.wce * 64;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const unsigned char* pb = buf + lean_b0 + (r * S) * p.xw * 64;
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+          if (kx < ksteps_row) {   // (uniform)
+            bf16x8 av[MPW], bvv[NPW][TM];
+            av[0] = lds_tr8(pa0, kx * 1024, kx * 1024 + 256);
+            if constexpr (MPW == 2) av[1] = lds_tr8(pa1, kx * 1024, kx * 1024 + 256);
+#pragma unroll
+            for (int q = 0; q < NPW; ++q)
+#pragma unroll
+              for (int t = 0; t < TM; ++t)
+                bvv[q][t] = lds_tr8(pb + q * xblk, kx * 1024 * S + t * 64, kx * 1024 * S + t * 64 + 256 * S);
+            WB_MFMA(av, bvv);
+            if (do_bias) {   // the NBW * TG wavefronts that hold the same gradient operand take turns summing it
+              if (--bias_turn < 0) {
+                bias_turn = NBW * TG - 1;
+#pragma unroll
+                for (int m = 0; m < MPW; ++m)
+#pragma unroll
+                  for (int j = 0; j < 8; ++j) bsum[m] += (float)av[m][j];
+              }
+            }
+          }
+        }
+        pa0 += ksteps_row * 1024;
+        pa1 += ksteps_row * 1024;
+      }
+    } else
     if (cnt > 0) {
       if constexpr (NPW == 1 && MPW == 1) {  // operands of step i+1 are fetched before the MFMAs of step i
         bf16x8 a0[MPW], a1[MPW], b0[NPW][TM], b1[NPW][TM];
@@ -261,38 +316,6 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
           WB_MFMA(a0, b0);
           WB_BIAS(a0)
         }
-      } else if constexpr (MPW == 2 && NPW == 1 && ROT) {
-        // 6 accumulator tiles, no room for a second operand set: the A pair alternates between two register sets, and each
-        // B operand is re-fetched for the next step right after the two MFMAs that consumed it
-        bf16x8 a0[MPW], a1[MPW], b0[NPW][TT];
-        WB_LOAD(a0, b0, 0);
-#define WB_STEP(AC, AN, I)                                                                                        \
-  {                                                                                                               \
-    const int st_ = ks + min((I), cnt - 1) * KS;                                                                  \
-    const int r_ = st_ / ksteps_row;                                                                              \
-    const int px_ = (st_ - r_ * ksteps_row) * 16 + lane_px;                                                       \
-    const int ga_ = gbase + (r_ * p.wce + px_) * 64;                                                              \
-    const int xa0_ = xbase + (((r_ * S + tg) * p.xw) + px_ * S) * xpb;                                            \
-    _Pragma("unroll") for (int m = 0; m < MPW; ++m)                                                               \
-      AN[m] = lds_tr8(buf, ga_ + m * (R * p.wce * 64), ga_ + m * (R * p.wce * 64) + 4 * 64);                      \
-    _Pragma("unroll") for (int t = 0; t < TT; ++t) {                                                              \
-      __builtin_amdgcn_sched_barrier(0);                                                                          \
-      _Pragma("unroll") for (int m = 0; m < MPW; ++m)                                                             \
-        acc[m][0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AC[m], b0[0][t], acc[m][0][t], 0, 0, 0);           \
-      __builtin_amdgcn_sched_barrier(0);                                                                          \
-      b0[0][t] = lds_tr8(buf, xa0_ + t * xpb, xa0_ + t * xpb + 4 * S * xpb);                                      \
-    }                                                                                                             \
-    __builtin_amdgcn_sched_barrier(0);                                                                            \
-  }
-        for (int i = 0; i < cnt; i += 2) {
-          WB_STEP(a0, a1, i + 1)
-          WB_BIAS(a0)
-          if (i + 1 < cnt) {
-            WB_STEP(a1, a0, i + 2)
-            WB_BIAS(a1)
-          }
-        }
-#undef WB_STEP
       } else {  // 6 accumulator tiles: one operand set (the three wavefronts of a SIMD hide each other's LDS latency)
         for (int i = 0; i < cnt; ++i) {
           bf16x8 a0[MPW], b0[NPW][TM];
@@ -329,10 +352,11 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
         }
       }
   if (do_bias) {  // lane l31 and lane l31 + 32 hold the two pixel halves of channel (mb*MPW + mi)*32 + l31
+    const int brow = LEAN ? (split * KS + ks) * (NBW * TG) + nb * TG + tg : split * KS + ks;
 #pragma unroll
     for (int mi = 0; mi < MPW; ++mi) {
       const float tot = bsum[mi] + __shfl_xor(bsum[mi], 32, 64);
-      if (half == 0) p.bias_part[(size_t)(split * KS + ks) * p.Mpad + m0 + (mb * MPW + mi) * 32 + l31] = tot;
+      if (half == 0) p.bias_part[(size_t)brow * p.Mpad + m0 + (mb * MPW + mi) * 32 + l31] = tot;
     }
   }
 }
@@ -376,7 +400,7 @@ bool wb_plan(int B, int N, int M, int IH, int IW, int ks, int stride, WbPlan* pl
   const int TG = ks == 3 ? 3 : 1;
   const int NT = 64 * MBW * NBW * KS * TG;
   const int XR = ks == 3 ? (R - 1) * stride + 3 : R;
-  const int xcb = (NBW * NPW == 1 && N <= 16) ? 2 : 4;  // 16-channel inputs: 32-byte pixels in the staged image
+  const int xcb = (NBW * NPW == 1 && N <= 16 && KS != 1) ? 2 : 4;  // 16-channel inputs: 32-byte pixels in the staged image (not on the lean KS = 1 path)
   pl->xcb = xcb;
   // column chunks: staged width a multiple of 16, at most 64; the widest that fits the slots and two LDS buffers, then the
   // count with the least zero padding
@@ -441,7 +465,8 @@ extern "C" int yogo_conv2d_wgrad_bf16_workspace_bytes(int B, int Cin, int Cout, 
                  "wgrad_bf16_workspace_bytes: bad arguments");
   WbPlan pl;
   YOGO_CHECK_ARG(wb_plan(B, Cin, Cout, IH, IW, ks, stride, &pl), "wgrad_bf16: no LDS plan");
-  *bytes = ((size_t)pl.nsplit * pl.KS * ks * ks * pl.Mpad * pl.Npad + (size_t)pl.nsplit * pl.KS * pl.Mpad) * sizeof(float);
+  // slabs + bias partial rows (at most 6 per slab row on the lean path: one per wavefront sharing a gradient operand)
+  *bytes = ((size_t)pl.nsplit * pl.KS * ks * ks * pl.Mpad * pl.Npad + (size_t)pl.nsplit * pl.KS * 6 * pl.Mpad) * sizeof(float);
   return YOGO_OK;
 }
 
@@ -462,6 +487,9 @@ extern "C" int yogo_conv2d_wgrad_bf16(const void* x, const void* g, float* dw, f
   p.IH = IH; p.IW = IW; p.OH = (IH + 2 * pad - ks) / stride + 1; p.OW = (IW + 2 * pad - ks) / stride + 1; p.pad = pad;
   p.nchunk_w = pl.nchunk_w; p.base_w = pl.base_w; p.rem_w = pl.rem_w; p.wce = pl.wce; p.nrowg = pl.nrowg;
   p.xw = pl.xw;
+#ifdef YOGO_DIAG
+  p.diag = g_wb_diag;
+#endif
   p.units = pl.units; p.units_per_split = pl.units_per_split; p.ngs = pl.ngs; p.nxs = pl.nxs; p.bufu = pl.bufu; p.depth = pl.depth; p.xcb = pl.xcb;
   if (yogo_launch_log_enabled())
     snprintf(g_wb_plan_txt, sizeof(g_wb_plan_txt), "N=%d M=%d in=%dx%d s=%d T=%d B=%d R=%d wce=%d nchunk_w=%d xw=%d slots=%d+%d depth=%d lds=%d units=%d units_per_split=%d grid=%ux%ux%u",
@@ -470,9 +498,6 @@ extern "C" int yogo_conv2d_wgrad_bf16(const void* x, const void* g, float* dw, f
   if (pl.MPW == 2) {
     if (stride == 1) wb_launch_one<2, 2, 1, 1, 9, 1, 3, 2>(p, pl, stream);
     else wb_launch_one<2, 2, 1, 1, 9, 2, 2, 2>(p, pl, stream);
-  } else if (pl.NPW == 2) {
-    if (stride == 1) wb_launch_one<4, 1, 2, 1, 9, 1, 3>(p, pl, stream);
-    else wb_launch_one<4, 1, 2, 1, 9, 2, 2>(p, pl, stream);
   } else {
     const int cfg = pl.MBW * 100 + pl.NBW * 10 + pl.KS;
     if (pl.R == 8 && pl.xcb == 2) {
@@ -493,6 +518,7 @@ extern "C" int yogo_conv2d_wgrad_bf16(const void* x, const void* g, float* dw, f
     }
   }
   YOGO_CHECK_LAUNCH("conv2d_wgrad_bf16");
-  return yogo_internal_wgrad_reduce(p.slab, pl.nsplit * pl.KS, T, Cout, Cin, pl.Mpad, pl.Npad, clip, dw, p.bias_part, pl.nsplit * pl.KS, db,
-                                    stream);
+  const bool lean = pl.KS == 1;   // (= the kernel's LEAN: KS = 1 tilings never pack two taps)
+  const int nbias = pl.nsplit * pl.KS * (lean ? pl.NBW * (T == 1 ? 1 : 3) : 1);
+  return yogo_internal_wgrad_reduce(p.slab, pl.nsplit * pl.KS, T, Cout, Cin, pl.Mpad, pl.Npad, clip, dw, p.bias_part, nbias, db, stream);
 }
