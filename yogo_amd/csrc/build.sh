@@ -9,7 +9,9 @@ OUT="$HERE/../lib"
 OBJ="$HERE/obj"
 LIBNAME="libyogo_hip.so"
 DEFS=()
-if [[ "${1:-}" == "diag" ]]; then OBJ="$HERE/obj_diag"; LIBNAME="libyogo_hip_diag.so"; DEFS=(-DYOGO_DIAG); fi
+if [[ "${1:-}" == "diag" ]]; then OBJ="$HERE/obj_diag"; LIBNAME="libyogo_hip_diag.so"; DEFS=(-DYOGO_DIAG -DYOGO_DIAG_PHASES); fi
+# diag-coarse: start / loop / epilogue / end stamps only (the per-phase sums of the ping-pong loop cost it scalar registers)
+if [[ "${1:-}" == "diag-coarse" ]]; then OBJ="$HERE/obj_diagc"; LIBNAME="libyogo_hip_diag.so"; DEFS=(-DYOGO_DIAG); fi
 mkdir -p "$OUT" "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 COMMON=(-O3 --offload-arch=gfx950 -fPIC -std=c++17 -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -I"$HERE" -I"$HERE/../../include" "${DEFS[@]}")
@@ -20,7 +22,11 @@ for f in "$HERE"/*.hip; do
   case "$base" in
     nms|decode_loss) extra=(-ffp-contract=off) ;;
   esac
-  if [[ ! -f "$OBJ/$base.o" || "$f" -nt "$OBJ/$base.o" || "$HERE/common.h" -nt "$OBJ/$base.o" ]]; then
+  stale=0
+  for dep in "$f" "$HERE/common.h" "$HERE"/"$base"_*.inc; do
+    [[ -f "$dep" && ( ! -f "$OBJ/$base.o" || "$dep" -nt "$OBJ/$base.o" ) ]] && stale=1
+  done
+  if [[ "$stale" == 1 ]]; then
     "$HIPCC" "${COMMON[@]}" "${extra[@]}" -c "$f" -o "$OBJ/$base.o" &
     pids+=($!)
   fi

@@ -14,6 +14,7 @@
 // At bf16 every layer of the network is HBM-bound on MI355X (ridge ~312 FLOP/B, the widest layer offers ~230), so the
 // kernel is built around few, wide memory operations rather than around MFMA issue.
 #include "common.h"
+#include <type_traits>
 #include <cstdlib>
 #include <vector>
 
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
       PP_BARRIER()                 // chunk 0 has landed for everybody
       if (grp) { PP_BARRIER() }    // the trailing half starts one phase later
       u32x4 av[PS][MW], bv[PS][NW];
-#ifdef YOGO_DIAG
+#ifdef YOGO_DIAG_PHASES
       unsigned long long ph_sum[4] = {0ull, 0ull, 0ull, 0ull}, ph_t = __builtin_amdgcn_s_memtime();
 #define PP_STAMP(K)                                                         \
   if (p.stamps) {                                                           \
@@ -537,7 +538,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
         }
       }
       if (!grp) { PP_BARRIER() }   // same number of barriers for both halves
-#ifdef YOGO_DIAG
+#ifdef YOGO_DIAG_PHASES
       if (p.stamps && (tid == 0 || tid == 256)) {
         unsigned long long* d = p.stamps + (size_t)widx * 16 + 4 + (tid >> 8) * 4;
         d[0] = ph_sum[0]; d[1] = ph_sum[1]; d[2] = ph_sum[2]; d[3] = ph_sum[3];
@@ -729,173 +730,25 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
             }
         }
     }
-#pragma unroll
-    for (int mb = 0; mb < MW; ++mb) {
-#pragma unroll
-      for (int gp = 0; gp < 2; ++gp) {
-        const int cb = (m0 >> 3) + mb * 4 + 2 * gp;  // channel block the lower half-wave stores (uniform); Mb is even
-        if (cb >= p.Mb) continue;
-        if constexpr (REF == 1 && RF_PER_GP) {
-          const auto rs_r = __builtin_amdgcn_make_buffer_rsrc((void*)(p.act_ref + (size_t)b * p.Mb * plane * 2), (short)0, p.Mb * plane16, 0x00020000);
-#pragma unroll
-          for (int c = 0; c < NC; ++c)
-#pragma unroll
-            for (int n = 0; n < NW; ++n) {
-              const bool valid = c == 0 ? pvalid[n] : pvalid1[n];
-              const int vr = valid ? (opix[n] + c) * 16 + half * 8 + cb * plane16 : (int)0x80000000u;
-              rf[0][0][c][n][0] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_r, vr, 0, 0));
-              rf[0][0][c][n][1] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_r, vr + plane16, 0, 0));
-            }
-        }
-        const int cl = mb * 32 + 16 * gp + 4 * half;  // local channel of group A; group B = cl + 8
-        const float4 bA = *reinterpret_cast<const float4*>(eb + cl), bB = *reinterpret_cast<const float4*>(eb + cl + 8);
-        const float4 sA = *reinterpret_cast<const float4*>(es + cl), sB = *reinterpret_cast<const float4*>(es + cl + 8);
-        const float ba[8] = {bA.x, bA.y, bA.z, bA.w, bB.x, bB.y, bB.z, bB.w};
-        const float sa[8] = {sA.x, sA.y, sA.z, sA.w, sB.x, sB.y, sB.z, sB.w};
-        float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, q8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        float bs[8], sl[8];  // bias * scale, leaky slope * scale
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          bs[i] = ba[i] * sa[i];
-          sl[i] = LEAKY_SLOPE * sa[i];
-        }
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-#pragma unroll
-          for (int n = 0; n < NW; ++n) {
-            // out = act(acc + bias) * scale, or (acc + bias) * act'(ref) * scale.  The channel scale is >= 0 (Dropout2d mask /
-            // zero for padding channels), so LeakyReLU commutes with it: one FMA + mul + max per value.
-            float v[8];
-            if (do_stats || p.act == ACT_SILU || p.out_pre != nullptr || (has_ref && p.ref_act != ACT_LEAKY)) {  // general order of operations
-#pragma unroll
-              for (int i = 0; i < 8; ++i) v[i] = acc[c][mb][n][8 * gp + i] + ba[i];
-              if (do_stats) {
-                if (full_tile) {  // every pixel of the workgroup's tile exists: no masking
-#pragma unroll
-                  for (int i = 0; i < 8; ++i) {
-                    s8[i] += v[i];
-                    q8[i] = fmaf(v[i], v[i], q8[i]);
-                  }
-                } else {
-                  const float m = pvalid[n] ? 1.f : 0.f;
-#pragma unroll
-                  for (int i = 0; i < 8; ++i) {
-                    const float vm = v[i] * m;
-                    s8[i] += vm;
-                    q8[i] = fmaf(vm, v[i], q8[i]);
-                  }
-                }
-              }
-              if (p.out_pre != nullptr) {  // the pre-activation goes out through the same 16-byte-unit exchange
-                bf16x8 po;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) po[i] = (__bf16)v[i];
-                const u32x4 pw = __builtin_bit_cast(u32x4, po);
-                const auto q0 = __builtin_amdgcn_permlane32_swap(pw.x, pw.z, false, false);
-                const auto q1 = __builtin_amdgcn_permlane32_swap(pw.y, pw.w, false, false);
-                const u32x4 pst = {q0[0], q1[0], q0[1], q1[1]};
-                const auto rs_p = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out_pre + (size_t)b * p.Mb * plane * 2), (short)0, p.Mb * plane16, 0x00020000);
-                __builtin_amdgcn_raw_buffer_store_b128(pst, rs_p, vo[c][n] + cb * plane16, 0, 0);
-              }
-              if constexpr (sign_ref) {  // (the launcher only takes the sign map for LeakyReLU)
-                const unsigned m = sg[sign_ref ? c : 0][n][(mb * 2 + gp) >> 2] >> (8 * ((mb * 2 + gp) & 3));
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                  v[i] *= (m >> i) & 1u ? 1.f : LEAKY_SLOPE;
-                  v[4 + i] *= (m >> (4 + i)) & 1u ? 1.f : LEAKY_SLOPE;
-                }
-              } else if (has_ref) {
-                const bf16x4 r0 = __builtin_bit_cast(bf16x4, rf[REF == 1 ? mb : 0][RF_PER_GP ? 0 : gp][c][n][0]);
-                const bf16x4 r1 = __builtin_bit_cast(bf16x4, rf[REF == 1 ? mb : 0][RF_PER_GP ? 0 : gp][c][n][1]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                  v[i] *= act_bwd_factor((float)r0[i], p.ref_act);
-                  v[4 + i] *= act_bwd_factor((float)r1[i], p.ref_act);
-                }
-              } else if (p.act == ACT_LEAKY) {  // (uniform branches: a select over all activations would evaluate SiLU's exp)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], LEAKY_SLOPE * v[i]);
-              } else if (p.act == ACT_SILU) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = act_fwd(v[i], ACT_SILU);
-              }
-#pragma unroll
-              for (int i = 0; i < 8; ++i) v[i] *= sa[i];
-            } else if constexpr (sign_ref) {  // LeakyReLU backward from the sign map (a data gradient: there is no bias)
-              const unsigned m = sg[sign_ref ? c : 0][n][(mb * 2 + gp) >> 2] >> (8 * ((mb * 2 + gp) & 3));
-#pragma unroll
-              for (int i = 0; i < 8; ++i) {
-                // bit i spread over a word (v_bfe_i32) selects scale or 0.01 * scale bitwise (v_bfi_b32): three instructions
-                // per value with the multiply
-                const int t = (int)(m << (31 - i)) >> 31;
-                const unsigned f = (__builtin_bit_cast(unsigned, sa[i]) & (unsigned)t) | (__builtin_bit_cast(unsigned, sl[i]) & ~(unsigned)t);
-                v[i] = acc[c][mb][n][8 * gp + i] * __builtin_bit_cast(float, f);
-              }
-            } else if (has_ref) {  // LeakyReLU backward: factor = ref > 0 ? scale : 0.01 * scale
-              const bf16x4 r0 = __builtin_bit_cast(bf16x4, rf[REF == 1 ? mb : 0][RF_PER_GP ? 0 : gp][c][n][0]);
-              const bf16x4 r1 = __builtin_bit_cast(bf16x4, rf[REF == 1 ? mb : 0][RF_PER_GP ? 0 : gp][c][n][1]);
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                v[i] = (acc[c][mb][n][8 * gp + i] + ba[i]) * ((float)r0[i] > 0.f ? sa[i] : sl[i]);
-                v[4 + i] = (acc[c][mb][n][8 * gp + 4 + i] + ba[4 + i]) * ((float)r1[i] > 0.f ? sa[4 + i] : sl[4 + i]);
-              }
-            } else {
-#pragma unroll
-              for (int i = 0; i < 8; ++i) v[i] = fmaf(acc[c][mb][n][8 * gp + i], sa[i], bs[i]);
-              if (p.act == ACT_LEAKY) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], LEAKY_SLOPE * v[i]);
-              }
-            }
-            if constexpr (SIGN_OUT) if (write_signs) {  // forward of a LeakyReLU block: the sign map the data gradient will read
-              unsigned mA = 0, mB = 0;
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                mA |= (v[i] > 0.f ? 1u : 0u) << i;
-                mB |= (v[4 + i] > 0.f ? 1u : 0u) << i;
-              }
-              // one byte = this lane's 4 + 4 signs BEFORE the half-wave exchange of the data below: the data gradient's lanes
-              // hold the same channels
-              if constexpr (MW == 1) {  // (32-channel tiles: two byte stores instead of NW more live registers)
-                const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)(p.signs + (size_t)b * plane * 2 * sq), (short)0, (int)plane * 2 * sq, 0x00020000);
-                const int vs = vo[c][n] < 0 ? (int)0x80000000u : (vo[c][n] >> 4) * sq + (m0 >> 4) + gp;
-                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(mA | (mB << 4)), rs_s, vs, 0, 0);
-              } else {
-                sg[c][n][(mb * 2 + gp) >> 2] |= (mA | (mB << 4)) << (8 * ((mb * 2 + gp) & 3));
-              }
-            }
-            bf16x8 o;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) o[i] = (__bf16)v[i];
-            u32x4 w = __builtin_bit_cast(u32x4, o);  // (x, y) = group A, (z, w) = group B of this lane's pixel
-            // lanes 32-63 hand their group A down, lanes 0-31 hand their group B up
-            const auto r0 = __builtin_amdgcn_permlane32_swap(w.x, w.z, false, false);
-            const auto r1 = __builtin_amdgcn_permlane32_swap(w.y, w.w, false, false);
-            const u32x4 st = {r0[0], r1[0], r0[1], r1[1]};
-            // the channel-block offset goes into the vector offset: with a scalar offset register hipcc (ROCm 7.2) leaves
-            // out the wait state between a 16-byte buffer store and a VALU write of its data registers, and gfx950 then
-            // stores the overwritten values
-            __builtin_amdgcn_raw_buffer_store_b128(st, rs_o, vo[c][n] + cb * plane16, 0, 0);
-          }
-        }
-        if (do_stats) {
-          // 16 independent DPP chains (the compiler interleaves them), then ONE predicated block of LDS writes
-          float sr[8], qr[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            sr[i] = half_wave_sum(s8[i]);
-            qr[i] = half_wave_sum(q8[i]);
-          }
-          if (l31 == 31) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              const int ch = cl + (i < 4 ? i : 4 + i);  // group B starts 8 channels above group A
-              red[(wave * BM + ch) * 2 + 0] = sr[i];
-              red[(wave * BM + ch) * 2 + 1] = qr[i];
-            }
-          }
-        }
-      }
+    // The group loop exists twice: the GENERAL order of operations (BatchNorm partial sums, SiLU, a second pre-activation output,
+    // a non-LeakyReLU reference) and the lean one every launch of the training step takes.  One uniform test up here instead of
+    // one per unrolled block: merged, the blocks carry each other's live values (16 statistics registers zeroed per group,
+    // moves at every join) and the epilogue -- two wavefronts per SIMD, bound by instruction issue -- is a fifth of a tile's time.
+    [[maybe_unused]] const bool leaky = p.act == ACT_LEAKY;
+    [[maybe_unused]] const bool general = do_stats || p.act == ACT_SILU || p.out_pre != nullptr || (has_ref && p.ref_act != ACT_LEAKY);
+    // (the 4-wavefront tiles and the bf16-reference variant keep ONE merged loop with the test inside: split, they need more
+    //  registers than their occupancy allows)
+    constexpr bool SPLIT = NWV == 8 && REF != 1;
+    if constexpr (SPLIT) {
+      auto epi_groups = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+#include "conv_bf16_epi_groups.inc"
+      };
+      if (general) epi_groups(std::integral_constant<int, 1>{});
+      else epi_groups(std::integral_constant<int, 0>{});
+    } else {
+      constexpr int MODE = 2;
+#include "conv_bf16_epi_groups.inc"
     }
     if constexpr (SIGN_OUT && MW > 1) if (write_signs) {  // the sign bytes of a pixel go out together
       const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)(p.signs + (size_t)b * plane * 2 * sq), (short)0, (int)plane * 2 * sq, 0x00020000);
