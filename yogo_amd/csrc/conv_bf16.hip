@@ -15,6 +15,7 @@
 // kernel is built around few, wide memory operations rather than around MFMA issue.
 #include "common.h"
 #include <type_traits>
+#include <utility>
 #include <cstdlib>
 #include <vector>
 
@@ -58,6 +59,7 @@ struct ConvBf16Params {
   // while the matrix cores work on chunk c.  ni_slots / n_slots: input / all slots of a chunk; bufu: units per buffer.
   int dma, ni_slots, n_slots, bufu;
   int bufs;  // LDS units between the buffers of consecutive chunks: bufu (two buffers) or 0 (dma = 2: one buffer, see below)
+  int ring;  // stride-2 data gradient of the 128-channel tile: 16-channel chunks in a ring of 4 LDS buffers (fixed 2 + 3 slot layout)
 #ifdef YOGO_DIAG
   // diagnostic build only (bash build.sh diag -> libyogo_hip_diag.so; tools/bench_conv_bf16.py): ablation bits and phase stamps.
   // The production library contains none of this code.
@@ -134,6 +136,40 @@ __device__ __forceinline__ void bf_dma16x5(i32x4 rsrc, unsigned lds_addr, int so
       : "=&s"(keep)
       : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "s"(rsrc), "s"(lds_addr), "s"(soff), "i"(STRIDE)
       : "memory", "scc");
+}
+
+// Five LDS-DMA pieces in one statement, the first two through descriptor ra (scalar offset sa), the other three through rb (sb):
+// the 2 + 3 slot layout of the stride-2 data gradient's chunk ring (gradient tile, weight slices).
+template <int STRIDE>
+__device__ __forceinline__ void bf_dma16_2p3(i32x4 ra, i32x4 rb, unsigned lds_addr, int sa, int sb, int v0, int v1, int v2, int v3, int v4) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %8\n\t"
+      "s_nop 4\n\t"
+      "buffer_load_dwordx4 %1, %6, %9 offen lds\n\t"
+      "s_add_u32 m0, m0, %11\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %2, %6, %9 offen lds\n\t"
+      "s_add_u32 m0, m0, %11\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %3, %7, %10 offen lds\n\t"
+      "s_add_u32 m0, m0, %11\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %4, %7, %10 offen lds\n\t"
+      "s_add_u32 m0, m0, %11\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %5, %7, %10 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "s"(ra), "s"(rb), "s"(lds_addr), "s"(sa), "s"(sb), "i"(STRIDE)
+      : "memory", "scc");
+}
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a compile-time unrolled loop whose index can feed constexpr
+template <class F, int... I>
+__device__ __forceinline__ void bf_static_for(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
 }
 
 // NWV wavefronts per workgroup, each owning NW 32-pixel groups x all MW channel blocks: NWV = 8 shares one staged weight
@@ -549,6 +585,96 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
 #undef PP_DMA_W
 #undef PP_BARRIER
     } else {
+    bool ring_done = false;
+    if constexpr (S2D && NWV == 8 && MW == 4 && NW == 1) {
+      // ---- stride-2 data gradient of the 128-channel tile: 16-channel chunks (one step per tap) in a RING of four LDS buffers,
+      //      three chunks in flight.  Measured on the two-buffer loop below: ~55 instructions per step around 4 MFMAs make it
+      //      issue-bound (28 k ticks per tile, the same with the DMA switched off), and once the steps are lean a chunk's
+      //      LDS-DMA round trip (~5 k ticks) is what a chunk costs -- with one chunk in flight.  Here: the step loop is unrolled
+      //      for the 3 (py = 0) or 6 (py = 1) taps of the workgroup's row parity, every step-dependent address part is an
+      //      immediate (weights: tap * 4 KB + channel block * 512 B; gradient tile: column * 16 B off one base per tile row), a
+      //      chunk's five DMA pieces (2 + 3 fixed slots) are one asm statement, and chunk c + 3 is requested when chunk c - 1
+      //      has been consumed: counted waits (vector memory operations retire in order), one barrier per chunk.
+      if (p.ring) {
+        ring_done = true;
+        constexpr int NB = 4, D = 3;  // buffers, chunks in flight (5 DMA pieces per chunk and wavefront: the counted waits below)
+        const i32x4 rsi = bf_make_rsrc(inb, ibytes), rsw = bf_make_rsrc(p.wp, wbytes);
+        const unsigned bufbytes = (unsigned)p.bufs * 16u;
+        const unsigned la0 = (unsigned)(wave * 64 * 16);
+        const unsigned char* lds_b = reinterpret_cast<const unsigned char*>(smem4);
+        const unsigned a_b0 = (unsigned)(p.ldsw_off + a_vu) * 16u;
+        const unsigned b_b0[2] = {(unsigned)b_vu[0] * 16u, (unsigned)(lw + b_vu[0]) * 16u};  // tile row of the tap
+#define RING_DMA(C) if (!BF_DBG(4)) bf_dma16_2p3<NT * 16>(rsi, rsw, la0 + (unsigned)((C) & (NB - 1)) * bufbytes, (C) * so_i, (C) * so_w, \
+                                                         voffv[0], voffv[1], voffv[2], voffv[3], voffv[4]);
+#define RING_BARRIER()                            \
+  __builtin_amdgcn_sched_barrier(0);              \
+  __builtin_amdgcn_s_barrier();                   \
+  __builtin_amdgcn_sched_barrier(0);
+        const int nck = p.nchunk;
+        RING_DMA(0)
+        if (nck > 1) { RING_DMA(1) }
+        if (nck > 2) { RING_DMA(2) }
+        ACC_ZERO()
+        // (one copy of the chunk loop per row parity: a branch inside it would merge 128 accumulator registers per chunk)
+        auto chunks = [&](auto py_tag) {
+          constexpr int PY = decltype(py_tag)::value;
+          constexpr int NTAP = 3 + 3 * PY, N0 = 1 + PY;
+          for (int c = 0; c < nck; ++c) {
+            // chunk c has landed when at most the requests behind it are outstanding: min(D - 1, nck - 1 - c) chunks of 5 pieces
+            const int behind = min(D - 1, nck - 1 - c);
+            if (behind >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else if (behind == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            RING_BARRIER()   // ... for everybody; and everybody has consumed chunk c - 1, whose buffer chunk c + 3 may now take
+            if (c + D < nck) { RING_DMA(c + D) }
+            const unsigned par = (unsigned)(c & (NB - 1)) * bufbytes;
+            const unsigned char* pa = lds_b + (a_b0 + par);
+            const unsigned char* pb[2] = {lds_b + (b_b0[0] + par), lds_b + (b_b0[1] + par)};
+            u32x4 av0[MW], av1[MW], bv0, bv1;
+            auto fetch = [&](auto t_tag, u32x4 (&av)[MW], u32x4& bv) {
+              constexpr int t_ = decltype(t_tag)::value, ti_ = 3 * PY + t_;
+              constexpr int row_ = (0x190 >> ti_) & 1, col_ = (0x144 >> ti_) & 1;
+#pragma unroll
+              for (int mb = 0; mb < MW; ++mb) av[mb] = *reinterpret_cast<const u32x4*>(pa + (t_ * 2 * BM + mb * 32) * 16);
+              bv = *reinterpret_cast<const u32x4*>(pb[row_] + col_ * 16);
+            };
+            fetch(std::integral_constant<int, 0>{}, av0, bv0);
+            auto step = [&](auto t_tag) {
+              constexpr int t_ = decltype(t_tag)::value;
+              constexpr int cls = t_ < N0 ? 0 : 1;
+              if constexpr (t_ + 1 < NTAP) {
+                if constexpr (t_ & 1) fetch(std::integral_constant<int, t_ + 1>{}, av0, bv0);
+                else fetch(std::integral_constant<int, t_ + 1>{}, av1, bv1);
+              }
+              if (!BF_DBG(2)) {
+#pragma unroll
+                for (int mb = 0; mb < MW; ++mb)
+                  acc[cls][mb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (t_ & 1) ? av1[mb] : av0[mb]),
+                                                                           __builtin_bit_cast(bf16x8, (t_ & 1) ? bv1 : bv0), acc[cls][mb][0], 0, 0, 0);
+              }
+              // one operand read of the next step behind each MFMA (two behind the first)
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              __builtin_amdgcn_sched_barrier(0);
+            };
+            __builtin_amdgcn_sched_barrier(0);
+            bf_static_for(step, std::make_integer_sequence<int, NTAP>{});
+          }
+        };
+        if (py) chunks(std::integral_constant<int, 1>{});
+        else chunks(std::integral_constant<int, 0>{});
+        RING_BARRIER()   // (the epilogue's scratch overlays the buffers)
+#undef RING_DMA
+#undef RING_BARRIER
+      }
+    }
+    if (!ring_done) {
     int dnext = 0, dend = 0, dchunk = 0;
 #undef BF_HOOK
 #define BF_HOOK()                   \
@@ -583,6 +709,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
         ++dnext;
       }
     }
+    }  // two-buffer loop
     }  // !PP
 #undef DMA_ISSUE
 #undef DMA_ONE
@@ -915,7 +1042,7 @@ struct BfTiling {
 // (OH, OW): the grid the workgroups tile (output pixels; quads for the stride-2 data gradient), T: weight slices staged at
 // most, PF: DMA slots of the kernel variant.  LDS image of a chunk: input tile from unit 0, weight slices from ldsw_off.
 bool bf_plan(int OH, int OW, int a, int T, int span, int Kb, int MW, int NW, int NWV, int PF, int budget, BfTiling* out,
-             bool force_single = false) {
+             bool force_single = false, int force_ckb = 0, int force_nbuf = 0, int force_ni = 0) {
   const int BM = 32 * MW, PT = 32 * NWV * NW, NT = 64 * NWV;
   BfTiling best{};
   long long best_score = -1;
@@ -928,12 +1055,15 @@ bool bf_plan(int OH, int OW, int a, int T, int span, int Kb, int MW, int NW, int
     const int rows_max = (nrow_lat - 1) * a + span;
     const int chs = rows_max * LW;
     for (int CKb : {8, 4, 2}) {
-      if (Kb % CKb) continue;
-      const int ni = cdiv(CKb * chs, NT), nw = cdiv(T * CKb * BM, NT);
+      if (Kb % CKb || (force_ckb && CKb != force_ckb)) continue;
+      const int ni_need = cdiv(CKb * chs, NT), nw = cdiv(T * CKb * BM, NT);
+      if (force_ni && ni_need > force_ni) continue;
+      const int ni = force_ni ? force_ni : ni_need;  // (a fixed slot layout: unused slots carry out-of-range offsets)
       const int ldsw_off = ni * NT;  // slot-aligned, so a DMA slot is all input or all weights
       const int bufu = (ni + nw) * NT;
-      const int nbuf = (Kb / CKb <= 2 || force_single) ? 1 : 2;  // short contractions: one buffer (more workgroups per CU)
+      const int nbuf = force_nbuf ? force_nbuf : ((Kb / CKb <= 2 || force_single) ? 1 : 2);  // short contractions: one buffer (more workgroups per CU)
       const int dma = (ni + nw <= PF && nbuf * bufu * 16 <= budget) ? (nbuf == 1 ? 2 : 1) : 0;
+      if (force_nbuf && !dma) continue;
       const int dummy = ldsw_off + T * CKb * BM;
       const int bytes = dma ? nbuf * bufu * 16 : (dummy + 1) * 16;
       if (bytes > budget) continue;
@@ -998,9 +1128,11 @@ extern "C" int yogo_conv_bf16_pack_multi(const void* table, int n, int total_blo
 // channel blocks of a bf16 NCHW8c tensor with C channels AS THE NEXT LAYER READS IT (padded to 16 channels = 2 blocks)
 extern "C" int yogo_bf16_channel_blocks(int C) { return bf_kb_of(C); }
 
+static bool g_bf_ring = true; // (diagnostic build: yogo_diag_conv_bf16_ring(0) selects the two-buffer loop of the stride-2 data gradient)
 static bool g_bf_pp = true;   // (diagnostic build: yogo_diag_conv_bf16_pp(0) selects the interleaved main loop for A/B runs)
 #ifdef YOGO_DIAG
 extern "C" int yogo_diag_conv_bf16_pp(int on) { g_bf_pp = on != 0; return YOGO_OK; }
+extern "C" int yogo_diag_conv_bf16_ring(int on) { g_bf_ring = on != 0; return YOGO_OK; }
 // diagnostic build only: ablation bits, synchronous staging, and a caller-owned stamp buffer ([workgroups][4] u64)
 static int g_diag_dbg = 0, g_diag_nodma = 0;
 static unsigned long long* g_diag_stamps = nullptr;
@@ -1065,6 +1197,12 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
     for (int i = 0; i < 3 && !planned; ++i)
       planned = bf_plan(OHt, OWt, s2d ? 1 : a, s2d ? 6 : T, s2d ? 2 : ks, Kb, MW, NW, NWV, PF, ladder[i], &tl) && tl.dma;
   }
+  // stride-2 data gradient of the 128-channel tile: 16-channel chunks in a ring of four buffers with the fixed 2 + 3 slot layout
+  bool ring = false;
+  if (s2d && MW == 4 && Kb >= 8 && g_bf_ring) {
+    ring = bf_plan(OHt, OWt, 1, 6, 2, Kb, MW, NW, NWV, 5, BF_LDS_MAX, &tl, false, 2, 4, 2);
+    planned = ring;
+  }
   if (!planned) planned = bf_plan(OHt, OWt, s2d ? 1 : a, s2d ? 6 : T, s2d ? 2 : ks, Kb, MW, NW, NWV, PF, BF_LDS_MAX, &tl);
   if (!planned) {
     yogo_set_error("conv_bf16: no LDS tiling fits (K=%d M=%d OW=%d a=%d)", K, M, OW, a);
@@ -1097,6 +1235,7 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
   p.CKb = tl.CKb; p.ckb_shift = tl.CKb == 8 ? 3 : (tl.CKb == 4 ? 2 : 1); p.nchunk = Kb / tl.CKb;
   p.ldsw_off = tl.ldsw_off; p.lds_dummy = tl.lds_dummy; p.act = act;
   p.dma = tl.dma; p.ni_slots = tl.ni_slots; p.n_slots = tl.n_slots; p.bufu = tl.bufu; p.bufs = tl.dma == 1 ? tl.bufu : 0;
+  p.ring = ring ? 1 : 0;
 #ifdef YOGO_DIAG
   p.dbg = g_diag_dbg;
   if (g_diag_nodma && (tl.lds_dummy + 1) * 16 <= BF_LDS_MAX) p.dma = 0;  // synchronous staging through registers
