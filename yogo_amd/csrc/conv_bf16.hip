@@ -59,6 +59,7 @@ struct ConvBf16Params {
   // while the matrix cores work on chunk c.  ni_slots / n_slots: input / all slots of a chunk; bufu: units per buffer.
   int dma, ni_slots, n_slots, bufu;
   int bufs;  // LDS units between the buffers of consecutive chunks: bufu (two buffers) or 0 (dma = 2: one buffer, see below)
+  int lean4; // 4-wavefront 3x3 tiles, 16-channel chunks, one LDS buffer: the unrolled step loop
   int ring;  // stride-2 data gradient of the 128-channel tile: 16-channel chunks in a ring of 4 LDS buffers (fixed 2 + 3 slot layout)
 #ifdef YOGO_DIAG
   // diagnostic build only (bash build.sh diag -> libyogo_hip_diag.so; tools/bench_conv_bf16.py): ablation bits and phase stamps.
@@ -185,6 +186,8 @@ __device__ __forceinline__ void bf_static_for(F&& f, std::integer_sequence<int, 
 //   barrier -> issue DMA(c+1 -> buffer (c+1)&1) -> MFMA(c from buffer c&1): one barrier per chunk, no staging registers, no
 //   ds_write, no vector-ALU address work inside the loop (every lane's source offsets are decoded once per workgroup).
 //
+// PP on a 4-wavefront tile selects the UNROLLED single-buffer step loop of the 3x3 / 16-channel-chunk case instead (a separate
+//   instantiation: merged with the generic loop it costs the registers that keep four workgroups on a CU).
 // PP ("ping-pong", 8-wavefront workgroups = two wavefronts per SIMD, stride-1 / stride-2 forward-type 3x3 tiles): the two
 //   wavefronts of a SIMD alternate roles phase by phase -- one issues a cluster of 3 * MW * NW back-to-back MFMAs from
 //   operands it already holds while the other fetches its next 3 steps' operands from LDS and issues its share of the next
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
 #define DMA_ISSUE(C) (void)ns, (void)so_i, (void)so_w, (void)rs_i, (void)rs_w, (void)voffv;
 #define DMA_ONE(I, C) (void)(I), (void)voffv;
 #endif
-    if constexpr (PP) {
+    if constexpr (PP && NWV == 8) {
       // ---- ping-pong pipeline (see the kernel comment).  The launcher selects it only for 3x3 taps with 16-channel chunks
       //      (CKb = 2: one step per tap, 9 steps = 3 phases of 3 steps per chunk) through the double-buffered DMA pipeline.
       //      A wavefront issues one instruction every ~4-5 cycles whatever its kind, so the fetch phase has to be SHORT in
@@ -688,6 +691,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
   }
     DMA_ISSUE(0)
     ACC_ZERO()
+    constexpr bool LEAN4 = PP && NWV == 4;   // (the kernel's PP flag selects the unrolled step loop for the 4-wavefront tiles)
     for (int c = 0; c < p.nchunk; ++c) {
       // dma = 2 (at most two chunks): ONE buffer, the next chunk is fetched after the MFMAs -- half the LDS, so more
       // workgroups per CU cover each other's latencies, which matters more than overlap inside a workgroup that short
@@ -703,7 +707,62 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
       const u32x4* ldsI = smem4 + (c & 1) * p.bufs;
       const u32x4* ldsW = ldsI + p.ldsw_off;
       __builtin_amdgcn_sched_barrier(0);
-      if (!BF_DBG(2)) BF_COMPUTE()
+      if constexpr (LEAN4) {
+        // ---- single-buffer 3x3 tiles with 16-channel chunks (the 16/32-channel layers: one or two chunks, four workgroups per
+        //      CU): the 9 steps UNROLLED, operand addresses = one base per kernel row + immediates.  The generic step loop
+        //      spends ~55 instructions per step (tap / channel arithmetic, v_readlane tap offsets, DMA slot hooks); with 16
+        //      wavefronts per CU these kernels issue more than one instruction per SIMD cycle (profiles/r02_mfma_util.txt:
+        //      "active" 0.29-0.36 per wavefront x 4) -- they are bound by instruction issue, not by HBM.
+        {
+          if (!BF_DBG(2)) {
+            const unsigned char* pa_ = reinterpret_cast<const unsigned char*>(ldsW + a_vu);
+            const unsigned char* pi_ = reinterpret_cast<const unsigned char*>(ldsI);
+            // (the row pitch is laundered per chunk: as a loop invariant the 3 x NW per-row bases would be hoisted into registers
+            //  that the occupancy of these tiles does not have; a scalar add per base at its use is free)
+            int lw_ = lw;
+            asm volatile("" : "+s"(lw_));
+            if constexpr (MW == 1) {  // (one operand set; the other workgroups of the CU cover the LDS latency)
+#pragma unroll
+              for (int ky = 0; ky < 3; ++ky) {
+                const unsigned char* pb_[NW];
+#pragma unroll
+                for (int n = 0; n < NW; ++n) pb_[n] = pi_ + ky * lw_ * 16 + b_vu[n] * 16;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                  u32x4 a1_[MW], b1_[NW];
+#pragma unroll
+                  for (int mb = 0; mb < MW; ++mb) a1_[mb] = *reinterpret_cast<const u32x4*>(pa_ + (((ky * 3 + kx) * 2) * BM + mb * 32) * 16);
+#pragma unroll
+                  for (int n = 0; n < NW; ++n) b1_[n] = *reinterpret_cast<const u32x4*>(pb_[n] + kx * 16);
+                  BF_MFMA(0, a1_, b1_)
+                  __builtin_amdgcn_sched_barrier(0);  // (or every step's reads are hoisted to the top: 180 registers)
+                }
+              }
+            } else {  // two operand sets: the reads of step s + 1 go out before the MFMAs of step s
+              u32x4 a2_[2][MW], b2_[2][NW];
+#pragma unroll
+              for (int mb = 0; mb < MW; ++mb) a2_[0][mb] = *reinterpret_cast<const u32x4*>(pa_ + (mb * 32) * 16);
+#pragma unroll
+              for (int n = 0; n < NW; ++n) b2_[0][n] = *reinterpret_cast<const u32x4*>(pi_ + b_vu[n] * 16);
+#pragma unroll
+              for (int s9 = 0; s9 < 9; ++s9) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (s9 + 1 < 9) {
+                  const int ky = (s9 + 1) / 3, kx = (s9 + 1) % 3;
+#pragma unroll
+                  for (int mb = 0; mb < MW; ++mb) a2_[(s9 + 1) & 1][mb] = *reinterpret_cast<const u32x4*>(pa_ + (((s9 + 1) * 2) * BM + mb * 32) * 16);
+#pragma unroll
+                  for (int n = 0; n < NW; ++n) b2_[(s9 + 1) & 1][n] = *reinterpret_cast<const u32x4*>(pi_ + ky * lw_ * 16 + b_vu[n] * 16 + kx * 16);
+                }
+                BF_MFMA(0, a2_[s9 & 1], b2_[s9 & 1])
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+          }
+        }
+      } else {
+        if (!BF_DBG(2)) BF_COMPUTE()
+      }
       while (dnext < dend) {  // fewer MFMA clusters than slots: the rest goes out now
         DMA_ONE(dnext, dchunk)
         ++dnext;
@@ -1128,11 +1187,13 @@ extern "C" int yogo_conv_bf16_pack_multi(const void* table, int n, int total_blo
 // channel blocks of a bf16 NCHW8c tensor with C channels AS THE NEXT LAYER READS IT (padded to 16 channels = 2 blocks)
 extern "C" int yogo_bf16_channel_blocks(int C) { return bf_kb_of(C); }
 
+static bool g_bf_lean4 = true; // (diagnostic build: yogo_diag_conv_bf16_lean4(0) selects the generic step loop of the 4-wavefront tiles)
 static bool g_bf_ring = true; // (diagnostic build: yogo_diag_conv_bf16_ring(0) selects the two-buffer loop of the stride-2 data gradient)
 static bool g_bf_pp = true;   // (diagnostic build: yogo_diag_conv_bf16_pp(0) selects the interleaved main loop for A/B runs)
 #ifdef YOGO_DIAG
 extern "C" int yogo_diag_conv_bf16_pp(int on) { g_bf_pp = on != 0; return YOGO_OK; }
 extern "C" int yogo_diag_conv_bf16_ring(int on) { g_bf_ring = on != 0; return YOGO_OK; }
+extern "C" int yogo_diag_conv_bf16_lean4(int on) { g_bf_lean4 = on != 0; return YOGO_OK; }
 // diagnostic build only: ablation bits, synchronous staging, and a caller-owned stamp buffer ([workgroups][4] u64)
 static int g_diag_dbg = 0, g_diag_nodma = 0;
 static unsigned long long* g_diag_stamps = nullptr;
@@ -1164,6 +1225,12 @@ template <int MW, int NW, int NWV, bool S2D, int PF, bool F32, int REF>
 void bf_launch_t(dim3 grid, int lds_bytes, hipStream_t stream, const ConvBf16Params& p, bool use_pp, const char* plan_txt) {
   if constexpr (NWV == 8 && !S2D && !F32) {
     if (use_pp) {
+      bf_launch_one<MW, NW, NWV, S2D, PF, F32, REF, true>(grid, lds_bytes, stream, p, plan_txt);
+      return;
+    }
+  }
+  if constexpr (NWV == 4 && !S2D && !F32) {
+    if (p.lean4) {
       bf_launch_one<MW, NW, NWV, S2D, PF, F32, REF, true>(grid, lds_bytes, stream, p, plan_txt);
       return;
     }
@@ -1236,6 +1303,7 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
   p.ldsw_off = tl.ldsw_off; p.lds_dummy = tl.lds_dummy; p.act = act;
   p.dma = tl.dma; p.ni_slots = tl.ni_slots; p.n_slots = tl.n_slots; p.bufu = tl.bufu; p.bufs = tl.dma == 1 ? tl.bufu : 0;
   p.ring = ring ? 1 : 0;
+  p.lean4 = (!s2d && NWV == 4 && T == 9 && tl.CKb == 2 && tl.dma == 2 && out_f32 == nullptr && g_bf_lean4) ? 1 : 0;
 #ifdef YOGO_DIAG
   p.dbg = g_diag_dbg;
   if (g_diag_nodma && (tl.lds_dummy + 1) * 16 <= BF_LDS_MAX) p.dma = 0;  // synchronous staging through registers
