@@ -69,7 +69,11 @@ def test_layout_round_trip():
 
 
 CASES = [(2, 16, 32, 20, 37, 3, 1), (1, 32, 64, 21, 40, 3, 2), (2, 64, 128, 13, 19, 3, 1), (1, 128, 128, 25, 33, 3, 2),
-         (2, 128, 128, 9, 129, 3, 1), (1, 128, 12, 7, 11, 1, 1), (1, 24, 40, 11, 9, 3, 1), (1, 16, 32, 3, 600, 3, 1), (1, 16, 32, 70, 45, 3, 1)]
+         (2, 128, 128, 9, 129, 3, 1), (1, 128, 12, 7, 11, 1, 1), (1, 24, 40, 11, 9, 3, 1), (1, 16, 32, 3, 600, 3, 1), (1, 16, 32, 70, 45, 3, 1),
+         # round 2: the chunk ring of the 128-channel stride-2 data gradient (tails, tiny tiles, several images) and the unrolled
+         # step loop of the 4-wavefront tiles (one and two chunks, stride 1 and 2, odd sizes)
+         (3, 128, 128, 7, 5, 3, 2), (2, 128, 128, 64, 70, 3, 2), (1, 256, 128, 31, 29, 3, 2), (2, 32, 64, 33, 35, 3, 2), (1, 32, 32, 50, 37, 3, 1),
+         (2, 16, 16, 41, 23, 3, 1)]
 
 
 @pytest.mark.parametrize("case", CASES)

@@ -184,14 +184,14 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
       if (i < p.ngs) {                                                                                                \
         const int c_ = (int)(grc[i] & 0xFFFFu), r_ = (int)(grc[i] >> 16);                                             \
         const bool ok_ = (c_ < wc_) && (r_ < rmax_);                                                                  \
-        dma16(rs_g, lb_ + i * NT * 16, ok_ ? glc[i] + gorg_ : (int)OOB);                                              \
+        if (!WB_DIAG(4)) dma16(rs_g, lb_ + i * NT * 16, (ok_ && !WB_DIAG(8)) ? glc[i] + gorg_ : (int)OOB);              \
       }                                                                                                               \
     }                                                                                                                 \
     _Pragma("unroll") for (int i = 0; i < WGB_XSLOTS; ++i) {                                                          \
       if (i < p.nxs) {                                                                                                \
         const int c_ = (int)(xrc[i] & 0xFFFFu), r_ = (int)(xrc[i] >> 16);                                             \
         const bool ok_ = ((unsigned)(iy0_ + r_) < (unsigned)p.IH) && ((unsigned)(ix0_ + c_) < (unsigned)p.IW);        \
-        dma16(rs_x, lb_ + (p.ngs + i) * NT * 16, ok_ ? xlc[i] + xorg_ : (int)OOB);                                    \
+        if (!WB_DIAG(4)) dma16(rs_x, lb_ + (p.ngs + i) * NT * 16, (ok_ && !WB_DIAG(8)) ? xlc[i] + xorg_ : (int)OOB);    \
       }                                                                                                               \
     }                                                                                                                 \
   }
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
         const unsigned char* pb = buf + lean_b0 + (r * S) * p.xw * 64;
 #pragma unroll
         for (int kx = 0; kx < 4; ++kx) {
-          if (kx < ksteps_row) {   // (uniform)
+          if (kx < ksteps_row && !WB_DIAG(2)) {   // (uniform)
             bf16x8 av[MPW], bvv[NPW][TM];
             av[0] = lds_tr8(pa0, kx * 1024, kx * 1024 + 256);
             if constexpr (MPW == 2) av[1] = lds_tr8(pa1, kx * 1024, kx * 1024 + 256);
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
 #pragma unroll
               for (int t = 0; t < TM; ++t)
                 bvv[q][t] = lds_tr8(pb + q * xblk, kx * 1024 * S + t * 64, kx * 1024 * S + t * 64 + 256 * S);
-            WB_MFMA(av, bvv);
+            if (!WB_DIAG(1)) { WB_MFMA(av, bvv); }
             if (do_bias) {   // the NBW * TG wavefronts that hold the same gradient operand take turns summing it
               if (--bias_turn < 0) {
                 bias_turn = NBW * TG - 1;
