@@ -48,6 +48,21 @@ if __name__ == "__main__":
     bits = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0, 1]
     lib = H.lib()
     lib.yogo_diag_wgrad_bf16.argtypes = [ctypes.c_int]
+    if os.environ.get("WB_STAMPS"):   # per-workgroup time sums of wave 0 (s_memtime ticks): wait + barrier / DMA issue / step loop
+        lib.yogo_diag_wgrad_bf16_stamps.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        st = torch.zeros(1 << 16, dtype=torch.int64, device="cuda")
+        for w in which:
+          for dbits in bits:
+            lib.yogo_diag_wgrad_bf16(dbits)
+            lib.yogo_diag_wgrad_bf16_stamps(None, 0)
+            bench(w, B, *LAYERS[w], reps=5)
+            lib.yogo_diag_wgrad_bf16_stamps(st.data_ptr(), st.numel() * 8)
+            bench(w, B, *LAYERS[w], reps=1)
+            torch.cuda.synchronize()
+            h = st.view(-1, 4).cpu().double()
+            h = h[h[:, 3] != 0]
+            print(f"  {w} diag={dbits}: workgroups {h.shape[0]}; per workgroup: wait+barrier {h[:, 0].mean():.0f}, DMA issue {h[:, 1].mean():.0f}, steps {h[:, 2].mean():.0f}, loop total {h[:, 3].mean():.0f} ticks")
+        sys.exit(0)
     for r in range(rounds):
         for b in bits:
             lib.yogo_diag_wgrad_bf16(b)

@@ -16,6 +16,8 @@
 // offsets (which the buffer unit writes as zeros).  One barrier per unit, up to two units in flight ahead of the MFMAs.  Split-K slabs + the fixed-order reduction of
 // wgrad_f32.hip (clamp, OIHW, bias) finish the gradient.
 #include "common.h"
+#include <type_traits>
+#include <utility>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -41,14 +43,22 @@ struct WgradBf16Params {
   int depth;                          // LDS buffers in the ring (2 or 3): units in flight ahead of the MFMAs = depth - 1
 #ifdef YOGO_DIAG
   int diag;                           // diagnostic build: experiment bits for in-process A/B runs (tools/ab_wgrad_bf16.py)
+  unsigned long long* stamps;         // diagnostic build: [workgroup][4] s_memtime sums of wave 0: wait + barrier, DMA issue, step loop, whole loop
 #endif
 };
 #ifdef YOGO_DIAG
 #define WB_DIAG(BIT) (p.diag & (BIT))
 static int g_wb_diag = 0;
+static unsigned long long* g_wb_stamps = nullptr;
+static size_t g_wb_stamps_bytes = 0;
 extern "C" int yogo_diag_wgrad_bf16(int bits) { g_wb_diag = bits; return YOGO_OK; }
+extern "C" int yogo_diag_wgrad_bf16_stamps(void* buf, size_t bytes) { g_wb_stamps = reinterpret_cast<unsigned long long*>(buf); g_wb_stamps_bytes = bytes; return YOGO_OK; }
+#define WB_T() (p.stamps ? __builtin_amdgcn_s_memtime() : 0ull)
+#define WB_STAMP(ACC) if (p.stamps) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ACC += t_ - tk_; tk_ = t_; __builtin_amdgcn_sched_barrier(0); }
 #else
 #define WB_DIAG(BIT) 0
+#define WB_T() 0ull
+#define WB_STAMP(ACC)
 #endif
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -84,6 +94,12 @@ __device__ __forceinline__ bf16x8 lds_tr8(const unsigned char* base, int off0, i
   const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(base + off0));
   const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(base + off1));
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a compile-time unrolled loop whose index can feed constexpr
+template <class F, int... I>
+__device__ __forceinline__ void wb_static_for(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
 }
 
 // MPW: co-blocks per wavefront (the wavefront grid is MBW x NBW x KS x kernel rows; a workgroup covers MBW * MPW co-blocks and
@@ -166,8 +182,11 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
 
   // the unit whose DMA is issued next: (image, row group, column chunk), stepped without divisions
   int iu_cw = u_begin % p.nchunk_w, iu_rg = (u_begin / p.nchunk_w) % p.nrowg, iu_b = u_begin / (p.nchunk_w * p.nrowg);
-#define WB_ISSUE(BUF)                                                                                                 \
-  {                                                                                                                   \
+// geometry of the unit whose DMA goes out next (scalars), then one slot at a time: the lean loop spreads the slots over its
+// steps -- issued in one block behind the barrier, the DMA of 12 wavefronts (address checks + 96 kilobyte-pieces through the
+// CU's one address unit) kept the matrix pipe idle for a quarter of every unit (stamps: 1.5 k of 9 k ticks, plus the skew
+// it leaves between the wavefronts at the next barrier)
+#define WB_ISSUE_PREP(BUF)                                                                                            \
     const int b_ = iu_b, oy0_ = iu_rg * R, ox0_ = iu_cw * p.base_w + min(iu_cw, p.rem_w);                             \
     const int wc_ = p.base_w + (iu_cw < p.rem_w ? 1 : 0);                                                             \
     if (++iu_cw == p.nchunk_w) {                                                                                      \
@@ -179,21 +198,24 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
     const unsigned lb_ = (unsigned)(((BUF) * p.bufu + wave * 64) * 16);  /* the dynamic LDS block starts at LDS address 0 */ \
     const int gorg_ = (oy0_ * p.OW + ox0_) * 16, rmax_ = p.OH - oy0_;                                                 \
     const int iy0_ = oy0_ * S - p.pad, ix0_ = ox0_ * S - p.pad;                                                       \
-    const int xorg_ = (iy0_ * p.IW + ix0_) * 16;                                                                      \
-    _Pragma("unroll") for (int i = 0; i < WGB_GSLOTS; ++i) {                                                          \
-      if (i < p.ngs) {                                                                                                \
+    const int xorg_ = (iy0_ * p.IW + ix0_) * 16;
+#define WB_ISSUE_G(i)                                                                                                 \
+      if ((i) < p.ngs && !WB_DIAG(4)) {                                                                               \
         const int c_ = (int)(grc[i] & 0xFFFFu), r_ = (int)(grc[i] >> 16);                                             \
-        const bool ok_ = (c_ < wc_) && (r_ < rmax_);                                                                  \
-        if (!WB_DIAG(4)) dma16(rs_g, lb_ + i * NT * 16, (ok_ && !WB_DIAG(8)) ? glc[i] + gorg_ : (int)OOB);              \
-      }                                                                                                               \
-    }                                                                                                                 \
-    _Pragma("unroll") for (int i = 0; i < WGB_XSLOTS; ++i) {                                                          \
-      if (i < p.nxs) {                                                                                                \
+        const bool ok_ = (c_ < wc_) && (r_ < rmax_) && !WB_DIAG(8);                                                   \
+        dma16(rs_g, lb_ + (i) * NT * 16, ok_ ? glc[i] + gorg_ : (int)OOB);                                            \
+      }
+#define WB_ISSUE_X(i)                                                                                                 \
+      if ((i) < p.nxs && !WB_DIAG(4)) {                                                                               \
         const int c_ = (int)(xrc[i] & 0xFFFFu), r_ = (int)(xrc[i] >> 16);                                             \
-        const bool ok_ = ((unsigned)(iy0_ + r_) < (unsigned)p.IH) && ((unsigned)(ix0_ + c_) < (unsigned)p.IW);        \
-        if (!WB_DIAG(4)) dma16(rs_x, lb_ + (p.ngs + i) * NT * 16, (ok_ && !WB_DIAG(8)) ? xlc[i] + xorg_ : (int)OOB);    \
-      }                                                                                                               \
-    }                                                                                                                 \
+        const bool ok_ = ((unsigned)(iy0_ + r_) < (unsigned)p.IH) && ((unsigned)(ix0_ + c_) < (unsigned)p.IW) && !WB_DIAG(8); \
+        dma16(rs_x, lb_ + (p.ngs + (i)) * NT * 16, ok_ ? xlc[i] + xorg_ : (int)OOB);                                  \
+      }
+#define WB_ISSUE(BUF)                                                                                                 \
+  {                                                                                                                   \
+    WB_ISSUE_PREP(BUF)                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < WGB_GSLOTS; ++i) { WB_ISSUE_G(i) }                                          \
+    _Pragma("unroll") for (int i = 0; i < WGB_XSLOTS; ++i) { WB_ISSUE_X(i) }                                          \
   }
 
   // ---- per-lane operand addressing for the transposed reads ----------------------------------------------------------
@@ -246,53 +268,79 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
   if (u_begin < u_end) WB_ISSUE(0)
   if (p.depth == 3 && u_begin + 1 < u_end) WB_ISSUE(1)
   int ib = 0;
+  [[maybe_unused]] unsigned long long tw_ = 0, ti_ = 0, tc_ = 0, t0_ = WB_T(), tk_ = t0_;
+  // (LEAN: one copy of the unit loop per number of 16-pixel steps in a row, so that the steps of a unit unroll completely)
+  auto unit_loop = [&](auto kr_tag) {
+  [[maybe_unused]] constexpr int KR = decltype(kr_tag)::value;
   for (int u = u_begin; u < u_end; ++u) {
     wait_dma((p.depth == 3 && u + 1 < u_end) ? nslots : 0);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    WB_STAMP(tw_)
     const int ahead = p.depth - 1;
-    if (u + ahead < u_end) {
-      int nb_ = ib + ahead;
-      nb_ = nb_ >= p.depth ? nb_ - p.depth : nb_;
-      WB_ISSUE(nb_)
+    const bool issue_ = u + ahead < u_end;
+    int nb_ = ib + ahead;
+    nb_ = nb_ >= p.depth ? nb_ - p.depth : nb_;
+    if constexpr (!LEAN) {
+      if (issue_) WB_ISSUE(nb_)
     }
+    WB_STAMP(ti_)
     const unsigned char* buf = smem_b + ib * p.bufu * 16;
     ib = ib + 1 == p.depth ? 0 : ib + 1;
     if constexpr (LEAN) {
+      // the next unit's DMA: its slots ride behind the MFMAs of the first step of every row (KSL slots per row)
+      constexpr int KSL = (WGB_GSLOTS + WGB_XSLOTS + R - 1) / R;
+      WB_ISSUE_PREP(nb_)
       // ---- lean step loop (KS = 1, 64-byte pixels): a wavefront beside two MFMA-busy partners issues an instruction only every
-      //      5-10 cycles, so the loop is kept to the ds_reads and the MFMAs themselves -- rows and 16-pixel steps are walked by
-      //      (unrolled) loops instead of a division per step, and every step-dependent part of an operand address (step * 1 KB,
-      //      tap * 64 B, second pixel half + 256 B) is an immediate of the ds_read; the per-lane bases move once per row.
+      //      5-10 cycles, so the loop is kept to the ds_reads and the MFMAs themselves -- the R x KR steps of a unit are unrolled,
+      //      every step-dependent part of an operand address (step * 1 KB, tap * 64 B, second pixel half + 256 B) is an immediate
+      //      of the ds_read, and the operands of step e + 1 are requested before the MFMAs of step e (two register sets): with
+      //      one set the 10 transposed reads of a step and its 6 MFMAs alternated, and the three wavefronts of a SIMD did not
+      //      cover each other (stamps: reads alone 4.5 k, MFMAs alone 4.4 k, together 8.2 k ticks per unit).
+      constexpr int NS = R * KR;
       const unsigned char* pa0 = buf + lean_a0;
       const unsigned char* pa1 = buf + lean_a0 + R * p.wce * 64;
+      const unsigned char* pb0 = buf + lean_b0;
+      const int rowb = S * p.xw * 64;
+      bf16x8 av[2][MPW], bvv[2][NPW][TM];
+      auto fetch = [&](auto e_tag) {
+        constexpr int e = decltype(e_tag)::value, set = e & 1, r = e / KR, kx = e % KR;
+        av[set][0] = lds_tr8(pa0, e * 1024, e * 1024 + 256);
+        const unsigned char* pb = pb0 + r * rowb;
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const unsigned char* pb = buf + lean_b0 + (r * S) * p.xw * 64;
+        for (int q = 0; q < NPW; ++q)
 #pragma unroll
-        for (int kx = 0; kx < 4; ++kx) {
-          if (kx < ksteps_row && !WB_DIAG(2)) {   // (uniform)
-            bf16x8 av[MPW], bvv[NPW][TM];
-            av[0] = lds_tr8(pa0, kx * 1024, kx * 1024 + 256);
-            if constexpr (MPW == 2) av[1] = lds_tr8(pa1, kx * 1024, kx * 1024 + 256);
+          for (int t = 0; t < TM; ++t)
+            bvv[set][q][t] = lds_tr8(pb + q * xblk, kx * 1024 * S + t * 64, kx * 1024 * S + t * 64 + 256 * S);
+        if constexpr (MPW == 2) av[set][1] = lds_tr8(pa1, e * 1024, e * 1024 + 256);
+      };
+      if (!WB_DIAG(2)) {
+      fetch(std::integral_constant<int, 0>{});
+      auto step = [&](auto e_tag) {
+        constexpr int e = decltype(e_tag)::value, set = e & 1, r = e / KR, kx = e % KR;
+        if constexpr (e + 1 < NS) fetch(std::integral_constant<int, e + 1>{});
+        if (!WB_DIAG(1)) { WB_MFMA(av[set], bvv[set]); }
+        if (kx == 0 && issue_) {
 #pragma unroll
-            for (int q = 0; q < NPW; ++q)
-#pragma unroll
-              for (int t = 0; t < TM; ++t)
-                bvv[q][t] = lds_tr8(pb + q * xblk, kx * 1024 * S + t * 64, kx * 1024 * S + t * 64 + 256 * S);
-            if (!WB_DIAG(1)) { WB_MFMA(av, bvv); }
-            if (do_bias) {   // the NBW * TG wavefronts that hold the same gradient operand take turns summing it
-              if (--bias_turn < 0) {
-                bias_turn = NBW * TG - 1;
-#pragma unroll
-                for (int m = 0; m < MPW; ++m)
-#pragma unroll
-                  for (int j = 0; j < 8; ++j) bsum[m] += (float)av[m][j];
-              }
-            }
+          for (int j = 0; j < KSL; ++j) {
+            constexpr int dummy = 0; (void)dummy;
+            const int sl = r * KSL + j;   // (a compile-time constant after unrolling)
+            if (sl < WGB_GSLOTS) { WB_ISSUE_G(sl) }
+            else if (sl < WGB_GSLOTS + WGB_XSLOTS) { WB_ISSUE_X(sl - WGB_GSLOTS) }
           }
         }
-        pa0 += ksteps_row * 1024;
-        pa1 += ksteps_row * 1024;
+        if (do_bias) {   // the NBW * TG wavefronts that hold the same gradient operand take turns summing it
+          if (--bias_turn < 0) {
+            bias_turn = NBW * TG - 1;
+#pragma unroll
+            for (int m = 0; m < MPW; ++m)
+#pragma unroll
+              for (int j = 0; j < 8; ++j) bsum[m] += (float)av[set][m][j];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      wb_static_for(step, std::make_integer_sequence<int, NS>{});
       }
     } else
     if (cnt > 0) {
@@ -325,8 +373,29 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
         }
       }
     }
+    WB_STAMP(tc_)
   }
+  };
+  if constexpr (LEAN) {
+    switch (ksteps_row) {
+      case 1: unit_loop(std::integral_constant<int, 1>{}); break;
+      case 2: unit_loop(std::integral_constant<int, 2>{}); break;
+      case 3: unit_loop(std::integral_constant<int, 3>{}); break;
+      default: unit_loop(std::integral_constant<int, 4>{}); break;
+    }
+  } else {
+    unit_loop(std::integral_constant<int, 1>{});
+  }
+#ifdef YOGO_DIAG
+  if (p.stamps && tid == 0) {
+    unsigned long long* d = p.stamps + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4;
+    d[0] = tw_; d[1] = ti_; d[2] = tc_; d[3] = __builtin_amdgcn_s_memtime() - t0_;
+  }
+#endif
 #undef WB_ISSUE
+#undef WB_ISSUE_PREP
+#undef WB_ISSUE_G
+#undef WB_ISSUE_X
 #undef WB_LOAD
 #undef WB_MFMA
 #undef WB_BIAS
@@ -489,6 +558,11 @@ extern "C" int yogo_conv2d_wgrad_bf16(const void* x, const void* g, float* dw, f
   p.xw = pl.xw;
 #ifdef YOGO_DIAG
   p.diag = g_wb_diag;
+  {
+    const size_t nwg = (size_t)pl.grid.x * pl.grid.y * pl.grid.z;
+    p.stamps = (g_wb_stamps && nwg * 32 <= g_wb_stamps_bytes) ? g_wb_stamps : nullptr;
+    if (p.stamps) (void)hipMemsetAsync(p.stamps, 0, nwg * 32, stream);
+  }
 #endif
   p.units = pl.units; p.units_per_split = pl.units_per_split; p.ngs = pl.ngs; p.nxs = pl.nxs; p.bufu = pl.bufu; p.depth = pl.depth; p.xcb = pl.xcb;
   if (yogo_launch_log_enabled())
