@@ -270,8 +270,15 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
   int ib = 0;
   [[maybe_unused]] unsigned long long tw_ = 0, ti_ = 0, tc_ = 0, t0_ = WB_T(), tk_ = t0_;
   // (LEAN: one copy of the unit loop per number of 16-pixel steps in a row, so that the steps of a unit unroll completely)
-  auto unit_loop = [&](auto kr_tag) {
+  // LEAN2: the pixel-split tilings (KS > 1: the 16/32/64-channel layers) with whole ROWS dealt to the splits (row r belongs to
+  // split r mod KS) instead of single steps: a wavefront's steps then have affine addresses -- a per-wavefront base plus
+  // immediates -- and unroll like the lean loop; the generic loop divides and multiplies its way to every operand address
+  // (and, with the DMA switched off entirely, still takes 0.65 of the layer-1 kernel's 0.76 ms: it is bound by instruction
+  // issue, not by memory).  Needs R % KS == 0 and the pixel size of the staged input image known at compile time.
+  constexpr bool LEAN2_OK = KS > 1 && !ROT && (R % KS == 0) && MPW == 1 && NPW == 1;
+  auto unit_loop = [&](auto kr_tag, auto mode_tag) {
   [[maybe_unused]] constexpr int KR = decltype(kr_tag)::value;
+  [[maybe_unused]] constexpr bool LEAN2 = decltype(mode_tag)::value == 2;
   for (int u = u_begin; u < u_end; ++u) {
     wait_dma((p.depth == 3 && u + 1 < u_end) ? nslots : 0);
     __builtin_amdgcn_s_barrier();
@@ -281,7 +288,7 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
     const bool issue_ = u + ahead < u_end;
     int nb_ = ib + ahead;
     nb_ = nb_ >= p.depth ? nb_ - p.depth : nb_;
-    if constexpr (!LEAN) {
+    if constexpr (!LEAN && !LEAN2) {
       if (issue_) WB_ISSUE(nb_)
     }
     WB_STAMP(ti_)
@@ -342,6 +349,43 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
       };
       wb_static_for(step, std::make_integer_sequence<int, NS>{});
       }
+    } else if constexpr (LEAN2) {
+      constexpr int RJ = (R / KS) > 0 ? R / KS : 1, NS2 = RJ * KR, XPB = PACK2 ? 32 : 64;  // (RJ >= 1 wherever LEAN2_OK holds)
+      constexpr int KSL = (WGB_GSLOTS + WGB_XSLOTS + RJ - 1) / RJ;
+      WB_ISSUE_PREP(nb_)
+      const int rowb = S * p.xw * XPB;
+      const unsigned char* pa = buf + gbase + lane_px * 64 + ks * (KR * 1024);
+      const unsigned char* pb0 = buf + xbase + ((T == 1 ? 0 : tg) * p.xw + lane_px * S) * XPB + ks * rowb;
+      bf16x8 av[2][MPW], bvv[2][NPW][TM];
+      auto fetch = [&](auto e_tag) {
+        constexpr int e = decltype(e_tag)::value, set = e & 1, j = e / KR, kx = e % KR;
+        av[set][0] = lds_tr8(pa, (j * KS * KR + kx) * 1024, (j * KS * KR + kx) * 1024 + 256);
+        const unsigned char* pb = pb0 + (j * KS) * rowb;
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+          bvv[set][0][t] = lds_tr8(pb, (kx * 16 * S + (PACK2 ? 2 * t : t)) * XPB, (kx * 16 * S + (PACK2 ? 2 * t : t)) * XPB + 4 * S * XPB);
+      };
+      if (!WB_DIAG(2)) {
+        fetch(std::integral_constant<int, 0>{});
+        auto step = [&](auto e_tag) {
+          constexpr int e = decltype(e_tag)::value, set = e & 1, j = e / KR, kx = e % KR;
+          if constexpr (e + 1 < NS2) fetch(std::integral_constant<int, e + 1>{});
+          if (!WB_DIAG(1)) { WB_MFMA(av[set], bvv[set]); }
+          if (kx == 0 && issue_) {
+#pragma unroll
+            for (int jj = 0; jj < KSL; ++jj) {
+              const int sl = j * KSL + jj;   // (a compile-time constant after unrolling)
+              if (sl < WGB_GSLOTS) { WB_ISSUE_G(sl) }
+              else if (sl < WGB_GSLOTS + WGB_XSLOTS) { WB_ISSUE_X(sl - WGB_GSLOTS) }
+            }
+          }
+          WB_BIAS(av[set])
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        wb_static_for(step, std::make_integer_sequence<int, NS2>{});
+      } else if (issue_) {
+        WB_ISSUE(nb_)   // (diagnostic: no operand reads -- the DMA still has to go out; the iterators were advanced by PREP above)
+      }
     } else
     if (cnt > 0) {
       if constexpr (NPW == 1 && MPW == 1) {  // operands of step i+1 are fetched before the MFMAs of step i
@@ -378,13 +422,24 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
   };
   if constexpr (LEAN) {
     switch (ksteps_row) {
-      case 1: unit_loop(std::integral_constant<int, 1>{}); break;
-      case 2: unit_loop(std::integral_constant<int, 2>{}); break;
-      case 3: unit_loop(std::integral_constant<int, 3>{}); break;
-      default: unit_loop(std::integral_constant<int, 4>{}); break;
+      case 1: unit_loop(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}); break;
+      case 2: unit_loop(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}); break;
+      case 3: unit_loop(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}); break;
+      default: unit_loop(std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{}); break;
+    }
+  } else if constexpr (LEAN2_OK) {
+    if (p.xcb == (PACK2 ? 2 : 4) && !WB_DIAG(32)) {
+      switch (ksteps_row) {
+        case 1: unit_loop(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}); break;
+        case 2: unit_loop(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}); break;
+        case 3: unit_loop(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{}); break;
+        default: unit_loop(std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{}); break;
+      }
+    } else {
+      unit_loop(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
     }
   } else {
-    unit_loop(std::integral_constant<int, 1>{});
+    unit_loop(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
   }
 #ifdef YOGO_DIAG
   if (p.stamps && tid == 0) {
