@@ -40,6 +40,9 @@ if __name__ == "__main__":
                 continue
             pro, loop, epi = (h[:, 1] - h[:, 0]).mean(), (h[:, 2] - h[:, 1]).mean(), (h[:, 3] - h[:, 2]).mean()
             print(f"  {w} pp={pp}: wgs={h.shape[0]} prologue={pro:.0f} loop={loop:.0f} epilogue={epi:.0f} ticks; span={(h[:, 3].max() - h[:, 0].min()):.0f}")
+            if not pp and float(h[:, 4].abs().sum()) > 0:   # single- / two-buffer loop: decode, first request, first landing, second chunk
+                t = lambda k: (h[:, k] - h[:, 1]).clamp(min=0).mean()
+                print(f"     after the loop stamp: offsets decoded +{t(4):.0f}, chunk 0 requested +{t(5):.0f}, landed (barrier) +{t(6):.0f}, chunk 1 landed +{t(7):.0f}")
             if pp:
                 g0, g1 = h[:, 4:8].mean(0), h[:, 8:12].mean(0)
                 print(f"     wave0 fetch={g0[0]:.0f} barrier={g0[1]:.0f} mfma={g0[2]:.0f} barrier={g0[3]:.0f} | wave4 fetch={g1[0]:.0f} barrier={g1[1]:.0f} mfma={g1[2]:.0f} barrier={g1[3]:.0f}")

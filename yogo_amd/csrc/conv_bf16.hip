@@ -689,8 +689,11 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
       ++dnext;                      \
     }                               \
   }
+    [[maybe_unused]] const unsigned long long t_dec = BF_STAMP();   // (diagnostic: the slot offsets are decoded)
     DMA_ISSUE(0)
     ACC_ZERO()
+    [[maybe_unused]] const unsigned long long t_iss = BF_STAMP();   // (... chunk 0 is requested, the accumulators are zero)
+    [[maybe_unused]] unsigned long long t_land = 0, t_c1 = 0;
     constexpr bool LEAN4 = PP && NWV == 4;   // (the kernel's PP flag selects the unrolled step loop for the 4-wavefront tiles)
     for (int c = 0; c < p.nchunk; ++c) {
       // dma = 2 (at most two chunks): ONE buffer, the next chunk is fetched after the MFMAs -- half the LDS, so more
@@ -700,6 +703,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
         DMA_ISSUE(c)
       }
       __syncthreads();  // chunk c has landed (every wave drained its DMA) and nobody reads the other buffer any more
+      if (c == 0) t_land = BF_STAMP();
+      if (c == 1) t_c1 = BF_STAMP();
       // two buffers: chunk c + 1 is requested slot by slot between the MFMA clusters of chunk c
       dnext = 0;
       dchunk = c + 1;
@@ -768,6 +773,12 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
         ++dnext;
       }
     }
+#ifdef YOGO_DIAG
+    if (p.stamps && tid == 0) {   // [4..7] of a stamp row, single- / two-buffer loop: offsets decoded, chunk 0 requested, landed, chunk 1 landed
+      unsigned long long* d = p.stamps + (size_t)widx * 16;
+      d[4] = t_dec; d[5] = t_iss; d[6] = t_land; d[7] = t_c1;
+    }
+#endif
     }  // two-buffer loop
     }  // !PP
 #undef DMA_ISSUE
