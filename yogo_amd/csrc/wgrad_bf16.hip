@@ -198,7 +198,9 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
     const unsigned lb_ = (unsigned)(((BUF) * p.bufu + wave * 64) * 16);  /* the dynamic LDS block starts at LDS address 0 */ \
     const int gorg_ = (oy0_ * p.OW + ox0_) * 16, rmax_ = p.OH - oy0_;                                                 \
     const int iy0_ = oy0_ * S - p.pad, ix0_ = ox0_ * S - p.pad;                                                       \
-    const int xorg_ = (iy0_ * p.IW + ix0_) * 16;
+    const int xorg_ = (iy0_ * p.IW + ix0_) * 16;                                                                      \
+    /* input columns this chunk's VALID gradient columns touch: the rest of the staged width is zero-filled, not fetched */ \
+    const int xneed_ = (wc_ - 1) * S + (T == 1 ? 1 : 3);
 #define WB_ISSUE_G(i)                                                                                                 \
       if ((i) < p.ngs && !WB_DIAG(4)) {                                                                               \
         const int c_ = (int)(grc[i] & 0xFFFFu), r_ = (int)(grc[i] >> 16);                                             \
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
 #define WB_ISSUE_X(i)                                                                                                 \
       if ((i) < p.nxs && !WB_DIAG(4)) {                                                                               \
         const int c_ = (int)(xrc[i] & 0xFFFFu), r_ = (int)(xrc[i] >> 16);                                             \
-        const bool ok_ = ((unsigned)(iy0_ + r_) < (unsigned)p.IH) && ((unsigned)(ix0_ + c_) < (unsigned)p.IW) && !WB_DIAG(8); \
+        const bool ok_ = ((unsigned)(iy0_ + r_) < (unsigned)p.IH) && ((unsigned)(ix0_ + c_) < (unsigned)p.IW) && (c_ < xneed_) && !WB_DIAG(8); \
         dma16(rs_x, lb_ + (p.ngs + (i)) * NT * 16, ok_ ? xlc[i] + xorg_ : (int)OOB);                                  \
       }
 #define WB_ISSUE(BUF)                                                                                                 \
