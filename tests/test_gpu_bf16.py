@@ -73,7 +73,11 @@ CASES = [(2, 16, 32, 20, 37, 3, 1), (1, 32, 64, 21, 40, 3, 2), (2, 64, 128, 13, 
          # round 2: the chunk ring of the 128-channel stride-2 data gradient (tails, tiny tiles, several images) and the unrolled
          # step loop of the 4-wavefront tiles (one and two chunks, stride 1 and 2, odd sizes)
          (3, 128, 128, 7, 5, 3, 2), (2, 128, 128, 64, 70, 3, 2), (1, 256, 128, 31, 29, 3, 2), (2, 32, 64, 33, 35, 3, 2), (1, 32, 32, 50, 37, 3, 1),
-         (2, 16, 16, 41, 23, 3, 1)]
+         (2, 16, 16, 41, 23, 3, 1),
+         # weight-gradient step loops unrolled per steps-per-row count (16 / 32 / 48 / 64 staged columns), pixel-split and
+         # two-co-block tilings, tall (8-row) and short units
+         (1, 16, 32, 9, 12, 3, 1), (1, 16, 32, 66, 60, 3, 1), (2, 64, 128, 10, 14, 3, 1), (1, 64, 128, 7, 64, 3, 1), (2, 32, 64, 17, 30, 3, 1),
+         (1, 128, 128, 12, 60, 3, 2)]
 
 
 @pytest.mark.parametrize("case", CASES)
