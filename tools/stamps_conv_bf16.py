@@ -30,6 +30,7 @@ if __name__ == "__main__":
             lib.yogo_diag_conv_bf16_pp(pp)
             lib.yogo_diag_conv_bf16(dbg, 0, None, 0)
             BC.bench(w[:-1], B, *BC.LAYERS[w[:-1]], w[-1], reps=5)          # warm clocks, un-stamped timing
+            st.zero_()
             lib.yogo_diag_conv_bf16(dbg, 0, st.data_ptr(), st.numel() * 8)
             BC.bench(w[:-1], B, *BC.LAYERS[w[:-1]], w[-1], reps=1)
             torch.cuda.synchronize()
@@ -43,6 +44,9 @@ if __name__ == "__main__":
             if not pp and float(h[:, 4].abs().sum()) > 0:   # single- / two-buffer loop: decode, first request, first landing, second chunk
                 t = lambda k: (h[:, k] - h[:, 1]).clamp(min=0).mean()
                 print(f"     after the loop stamp: offsets decoded +{t(4):.0f}, chunk 0 requested +{t(5):.0f}, landed (barrier) +{t(6):.0f}, chunk 1 landed +{t(7):.0f}")
+            if pp and float(h[:, 12].abs().sum()) > 0:
+                t = lambda k: (h[:, k] - h[:, 1]).clamp(min=0).mean()
+                print(f"     after the loop stamp: decoded +{t(12):.0f}, chunk 0 requested and accumulators zeroed +{t(13):.0f}, landed +{t(14):.0f}, barrier passed +{t(15):.0f}")
             if pp:
                 g0, g1 = h[:, 4:8].mean(0), h[:, 8:12].mean(0)
                 print(f"     wave0 fetch={g0[0]:.0f} barrier={g0[1]:.0f} mfma={g0[2]:.0f} barrier={g0[3]:.0f} | wave4 fetch={g1[0]:.0f} barrier={g1[1]:.0f} mfma={g1[2]:.0f} barrier={g1[3]:.0f}")

@@ -432,8 +432,24 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
       int r_ = (int)__umulhi((unsigned)rm0, inv_lw) + (one_lw & (rm0 != 0));
       int x_ = rm0 - r_ * lw;
       const int rowb = p.IW * 16, kcb = p.IH * p.IW * 16;
+      if constexpr (PP && NWV == 8) {
+        // ping-pong tiles (fixed 5 + 5 layout): the weight slices of chunk 0 are requested BEFORE the input slots are decoded --
+        // their offsets cost a dozen instructions each, and the first chunk's round trip then runs under the rest of the decode
+        // (the first chunk is 7-9 k of a tile's 47-68 k ticks)
 #pragma unroll
-      for (int i = 0; i < PF; ++i) {
+        for (int i = 5; i < 10; ++i) {
+          const int w_ = tid + (i - 5) * NT;
+          const bool wok = w_ < wtotal;
+          const int R_ = w_ >> BM_SHIFT;
+          const int wi_ = ((tbase + (R_ >> p.ckb_shift)) * p.Kb + (R_ & (p.CKb - 1))) * p.Mpad + m0 + (w_ & (BM - 1));
+          voffv[i] = wok ? wi_ * 16 : (int)OOB;
+        }
+        if (!BF_DBG(4))
+          bf_dma16x5<NT * 16>(bf_make_rsrc(p.wp, p.T * p.Kb * p.Mpad * 16), (unsigned)(wave * 64 * 16) + (unsigned)(5 * NT * 16), 0, voffv[5], voffv[6],
+                              voffv[7], voffv[8], voffv[9]);
+      }
+#pragma unroll
+      for (int i = 0; i < ((PP && NWV == 8) ? 5 : PF); ++i) {
         const int e = tid + i * NT;
         if (i < ni) {  // uniform (ping-pong layout: ni = PF / 2 slots are reserved for the input tile, unused ones fetch nothing)
           const int iy_ = iy0 + r_, ix_ = ix0 + x_;
@@ -511,11 +527,19 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
   __builtin_amdgcn_sched_barrier(0);              \
   __builtin_amdgcn_s_barrier();                   \
   __builtin_amdgcn_sched_barrier(0);
-      PP_DMA_IN(la0, 0)
-      PP_DMA_W(la0, 0)
+      [[maybe_unused]] const unsigned long long tp_dec = BF_STAMP();   // (diagnostic: slots decoded, per-lane bases formed)
+      PP_DMA_IN(la0, 0)   // (the weight slices of chunk 0 went out in front of the slot decode above)
       ACC_ZERO()
+      [[maybe_unused]] const unsigned long long tp_iss = BF_STAMP();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      [[maybe_unused]] const unsigned long long tp_land = BF_STAMP();
       PP_BARRIER()                 // chunk 0 has landed for everybody
+#ifdef YOGO_DIAG
+      if (p.stamps && tid == 0) {   // [12..15] of a stamp row: decoded, requested + zeroed, landed, barrier passed
+        unsigned long long* d = p.stamps + (size_t)widx * 16;
+        d[12] = tp_dec; d[13] = tp_iss; d[14] = tp_land; d[15] = __builtin_amdgcn_s_memtime();
+      }
+#endif
       if (grp) { PP_BARRIER() }    // the trailing half starts one phase later
       u32x4 av[PS][MW], bv[PS][NW];
 #ifdef YOGO_DIAG_PHASES
