@@ -31,7 +31,7 @@ H, W, NUM_CLASSES = 772, 1032, 7
 ANCHOR_W, ANCHOR_H = 0.0425, 0.0555
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same table: dense bf16 matrix peak
-BF16_MFMA_SUSTAINED_TFLOPS = 1650.0  # tools/mfma_peak_bf16.hip on this pool: bare v_mfma_f32_32x32x16_bf16 loop, random operands (1.65 GHz)
+BF16_MFMA_SUSTAINED_TFLOPS = 1875.0  # tools/probes/mfma_shapes2.hip on this pool: bare v_mfma_f32_32x32x16_bf16 loop, 2 wavefronts per SIMD, random operands, all CUs (16x16x32: 2110)
 HBM_PEAK_GBS = 8000.0           # same table, "HBM3E peak BW" (6.29 TB/s measured copy)
 TRAIN_GFLOP_PER_IMG = 66.48
 
