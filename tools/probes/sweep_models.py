@@ -27,12 +27,19 @@ for name, fn in MODELS.items():
                 lab = O.synthetic_labels(B, m.Sx, m.Sy, K=4, num_classes=5, seed=3).cuda()
                 tr = HipTrainer(m, YOGOLoss().cuda(), total_steps=4, half=half)
                 tr.step(x, lab)
+                first = tr.loss_components()["loss"]
                 tr.step(x, lab)
-                losses[half] = tr.loss_components()["loss"]
-            rel = abs(losses[True] - losses[False]) / max(1e-6, abs(losses[False]))
-            flag = "" if rel < 5e-2 else "   <-- MISMATCH"
-            bad += rel >= 5e-2
-            print(f"{name:16s} {H}x{W} B={B} rgb={int(rgb)}: fp32 {losses[False]:.4f}  bf16 {losses[True]:.4f}  rel {rel:.3e}{flag}", flush=True)
+                losses[half] = (first, tr.loss_components()["loss"])
+            # step 1 = forward parity (tight); step 2 also carries one AdamW update of ~all-clamped gradients at random init, where a
+            # few per cent of sign flips between bf16 and fp32 gradients (cosine 0.94-1.0 per tensor, tools/probes/triple_dbg.py) move the
+            # loss of the widest models by several per cent -- loose bound
+            rel1 = abs(losses[True][0] - losses[False][0]) / max(1e-6, abs(losses[False][0]))
+            rel = abs(losses[True][1] - losses[False][1]) / max(1e-6, abs(losses[False][1]))
+            ok = rel1 < 5e-3 and rel < 0.15
+            flag = "" if ok else "   <-- MISMATCH"
+            bad += not ok
+            print(f"{name:16s} {H}x{W} B={B} rgb={int(rgb)}: step 1 fp32 {losses[False][0]:.4f} bf16 {losses[True][0]:.4f} rel {rel1:.2e} | "
+                  f"step 2 fp32 {losses[False][1]:.4f} bf16 {losses[True][1]:.4f} rel {rel:.2e}{flag}", flush=True)
         except Exception as e:
             bad += 1
             print(f"{name:16s} {H}x{W} B={B} rgb={int(rgb)}: ERROR {type(e).__name__}: {str(e)[:150]}", flush=True)
