@@ -107,6 +107,15 @@ int yogo_loss_fwd_bwd(const float* pred, const float* label, float* grad, float*
                       int Sy, int Sx, float no_obj_weight, float iou_weight, float classify_weight, float label_smoothing,
                       yogo_stream_t stream);
 
+/* The trainer's fused form of the three calls above (yogo_decode_fwd + yogo_loss_fwd_bwd + yogo_decode_bwd_bf16) for TRAINING mode
+ * (class logits pass through the decode): replaces YOGO.forward's decode (yogo/model.py:277-313), YOGOLoss.forward
+ * (yogo/yogo_loss.py:38-129) and the autograd of both inside Trainer.train's step (yogo/train.py:309-322).  One pass over the
+ * cells; the decoded prediction and its gradient never go to memory.  graw8c / loss_out / workspace as in the separate calls. */
+int yogo_decode_loss_bwd_bf16(const float* raw, const float* label, const float* cxs, const float* cys, void* graw8c, float* loss_out,
+                              void* workspace, int B, int P, int Sy, int Sx, float anchor_w, float anchor_h, float width_multiplier,
+                              float height_multiplier, float no_obj_weight, float iou_weight, float classify_weight,
+                              float label_smoothing, yogo_stream_t stream);
+
 /* ---- post-process: format_preds, yogo/utils/prediction_formatting.py:23-93, batched over images ------------------------ */
 int yogo_format_preds_workspace_bytes(int B, int Sy, int Sx, size_t* bytes);
 /* out_rows [B][cap][P], out_cells [B][cap] (int64 cell index y*Sx+x), out_count [B] (int32).

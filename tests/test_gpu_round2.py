@@ -275,3 +275,50 @@ def test_host_tensor_at_the_boundary_is_an_error_not_a_fault():
     with torch.no_grad():
         y = net(torch.zeros(1, 1, 64, 160, dtype=torch.uint8, device="cuda"))
     assert tuple(y.shape) == (1, 8, 8, 20) and bool(torch.isfinite(y).all())
+
+
+@pytest.mark.parametrize("shape", [(3, 12, 25, 33), (2, 7, 9, 11), (1, 69, 5, 6), (2, 12, 97, 129)])
+def test_fused_decode_loss_backward_is_the_three_calls(shape):
+    """yogo_decode_loss_bwd_bf16 (the trainer's one-pass form) against yogo_decode_fwd + yogo_loss_fwd_bwd + yogo_decode_bwd_bf16:
+    the same statements in one kernel -> the gradient units and the four loss values are identical bit for bit.  Labels with
+    and without objects, boxes that leave the unit square (clamp derivatives), raw widths beyond the exp clamp."""
+    from yogo_amd import _hip as h
+
+    B, P, Sy, Sx = shape
+    C = P - 5
+    g = torch.Generator().manual_seed(B * 1000 + P)
+    raw = torch.randn(B, P, Sy, Sx, generator=g) * 1.5
+    raw[:, 2:4] += 1.0
+    raw[0, 2, 0, 0] = 90.0   # beyond the exp clamp of the decode
+    lab = torch.zeros(B, 6, Sy, Sx)
+    obj = torch.rand(B, Sy, Sx, generator=g) < 0.3
+    lab[:, 0] = obj.float()
+    x1 = torch.rand(B, Sy, Sx, generator=g) * 0.8
+    y1 = torch.rand(B, Sy, Sx, generator=g) * 0.8
+    lab[:, 1], lab[:, 2] = x1, y1
+    lab[:, 3] = x1 + 0.02 + torch.rand(B, Sy, Sx, generator=g) * 0.15
+    lab[:, 4] = y1 + 0.02 + torch.rand(B, Sy, Sx, generator=g) * 0.15
+    lab[:, 5] = torch.randint(0, C, (B, Sy, Sx), generator=g).float()
+    raw, lab = raw.cuda(), lab.cuda()
+    cxs = (torch.arange(Sx, dtype=torch.float32) / Sx).expand(Sy, Sx).contiguous().cuda()
+    cys = (torch.arange(Sy, dtype=torch.float32) / Sy)[:, None].expand(Sy, Sx).contiguous().cuda()
+    aw, ah, wm, hm = 0.0425, 0.0555, 1.0, 1.3
+    w_no, w_iou, w_cls, ls = 0.5, 5.0, 1.0, 0.01
+    st = h.stream_ptr()
+    nws = h.query_size("yogo_loss_workspace_bytes", B, Sy, Sx) // 4
+    # the three calls
+    pred = torch.empty_like(raw)
+    h.call("yogo_decode_fwd", raw, pred, cxs, cys, B, P, Sy, Sx, aw, ah, wm, hm, 0, st)
+    gpred, out3, ws3 = torch.empty_like(raw), torch.empty(4, device="cuda"), torch.empty(nws, device="cuda")
+    h.call("yogo_loss_fwd_bwd", pred, lab, gpred, out3, ws3, B, P, Sy, Sx, w_no, w_iou, w_cls, ls, st)
+    Pb = ((P + 15) // 16) * 2
+    g3 = torch.full((B, Pb, Sy, Sx, 8), float("nan"), dtype=torch.bfloat16, device="cuda")
+    h.call("yogo_decode_bwd_bf16", raw, pred, gpred, g3, B, P, Sy, Sx, 0, st)
+    # the fused call
+    g1 = torch.full((B, Pb, Sy, Sx, 8), float("nan"), dtype=torch.bfloat16, device="cuda")
+    out1, ws1 = torch.empty(4, device="cuda"), torch.empty(nws, device="cuda")
+    h.call("yogo_decode_loss_bwd_bf16", raw, lab, cxs, cys, g1, out1, ws1, B, P, Sy, Sx, aw, ah, wm, hm, w_no, w_iou, w_cls, ls, st)
+    torch.cuda.synchronize()
+    assert torch.equal(g1.view(torch.int16), g3.view(torch.int16))
+    assert torch.equal(out1, out3) and bool(torch.isfinite(out1).all())
+    assert float(g1.float().abs().max()) > 0

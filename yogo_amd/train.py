@@ -32,6 +32,8 @@ from yogo_amd.engine import get_engine
 from yogo_amd.model import YOGO
 from yogo_amd.yogo_loss import YOGOLoss
 
+_FUSED_DECODE_LOSS = True   # bf16 training: decode + loss + decode backward as one kernel (yogo_decode_loss_bwd_bf16)
+
 
 def cosine_lr(step: int, base_lr: float, t_max: int, eta_min: float) -> float:
     """closed form of torch.optim.lr_scheduler.CosineAnnealingLR after ``step`` scheduler steps"""
@@ -277,19 +279,30 @@ class HipTrainer:
                 raw, saved = eng.forward(imgs, need_grad=True)
             B, P, Sy, Sx = raw.shape
             aw, ah, wm, hm = m._decode_scalars()
-            pred = torch.empty_like(raw)
-            _hip.call("yogo_decode_fwd", raw, pred, m._Cxs, m._Cys, B, P, Sy, Sx, aw, ah, wm, hm, int(bool(m.inference)), st)
-            # ---- loss forward + backward (one kernel) -------------------------------------------------------------
             L = self.loss
-            gpred = torch.empty_like(raw)
             out = torch.empty(4, dtype=torch.float32, device=raw.device)
             ws = torch.empty(_hip.query_size("yogo_loss_workspace_bytes", B, Sy, Sx) // 4, dtype=torch.float32, device=raw.device)
             lab = labels if (labels.dtype == torch.float32 and labels.is_contiguous()) else labels.contiguous().float()
-            _hip.call("yogo_loss_fwd_bwd", pred, lab, gpred, out, ws, B, P, Sy, Sx, float(L.no_obj_weight), float(L.iou_weight),
-                      float(L.classify_weight), float(L.label_smoothing), st)
-            # ---- backward: decode, then the backbone (clamp fused into the gradient kernels) -------------------------
             hook = self._on_layer_done if self.world > 1 else None
-            if self.half:   # the head's gradient goes straight to bf16 NCHW8c
+            fused = self.half and not m.inference and _FUSED_DECODE_LOSS
+            if fused:
+                # ---- decode + loss forward/backward + decode backward in one pass over the cells (bit-identical to the three calls
+                #      below; the decoded prediction and its gradient never go to memory) ------------------------------------------
+                g8 = torch.empty(B, ((P + 15) // 16) * 2, Sy, Sx, 8, dtype=torch.bfloat16, device=raw.device)
+                _hip.call("yogo_decode_loss_bwd_bf16", raw, lab, m._Cxs, m._Cys, g8, out, ws, B, P, Sy, Sx, aw, ah, wm, hm,
+                          float(L.no_obj_weight), float(L.iou_weight), float(L.classify_weight), float(L.label_smoothing), st)
+                backward_bf16_train(eng, saved, g8, grad_out=self.flat.grad_views, on_layer=hook)
+            else:
+                pred = torch.empty_like(raw)
+                _hip.call("yogo_decode_fwd", raw, pred, m._Cxs, m._Cys, B, P, Sy, Sx, aw, ah, wm, hm, int(bool(m.inference)), st)
+                # ---- loss forward + backward (one kernel) -------------------------------------------------------------
+                gpred = torch.empty_like(raw)
+                _hip.call("yogo_loss_fwd_bwd", pred, lab, gpred, out, ws, B, P, Sy, Sx, float(L.no_obj_weight), float(L.iou_weight),
+                          float(L.classify_weight), float(L.label_smoothing), st)
+            # ---- backward: decode, then the backbone (clamp fused into the gradient kernels) -------------------------
+            if fused:
+                pass
+            elif self.half:   # the head's gradient goes straight to bf16 NCHW8c
                 g8 = torch.empty(B, ((P + 15) // 16) * 2, Sy, Sx, 8, dtype=torch.bfloat16, device=raw.device)
                 _hip.call("yogo_decode_bwd_bf16", raw, pred, gpred, g8, B, P, Sy, Sx, int(bool(m.inference)), st)
                 backward_bf16_train(eng, saved, g8, grad_out=self.flat.grad_views, on_layer=hook)
