@@ -635,3 +635,192 @@ def adamw_step(p, g, m, v, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-
 def cosine_lr(step: int, base_lr: float, t_max: int, eta_min: float) -> float:
     """closed form of torch CosineAnnealingLR after ``step`` scheduler steps."""
     return eta_min + (base_lr - eta_min) * (1 + math.cos(math.pi * step / t_max)) / 2
+
+
+# ---------------------------------------------------------------------------
+# bf16-STORAGE emulation of the training step (test infrastructure, like everything in this file)
+#
+# The reference trains under autocast (yogo/train.py:309-322); the HIP path stores activations and activation gradients
+# as bf16 and feeds bf16 weights to the matrix cores, with fp32 accumulation, fp32/fp64 statistics and fp32 parameter
+# gradients.  A plain fp32 step can only bound such a step loosely (bf16 rounding of eight layers of activations moves
+# every gradient by ~1 %).  This function restates the SAME arithmetic as `yogo_forward` + `yogo_loss` + autograd, but
+# rounds to bf16 exactly where the HIP path stores bf16 -- so the whole step can be held to ~1e-3, and a kernel error of
+# a few per cent is no longer hidden behind "bf16 noise".  Rounding points (file:kernel of yogo_amd/csrc):
+#   * weights multiplied as bf16 (conv_bf16.hip:conv_bf16_pack_kernel; layer 0: conv_first_mfma.hip `wa`)
+#   * block without BatchNorm: y = bf16(act(conv + bias) * mask); LeakyReLU sign taken from that value (sign map / stored y)
+#   * block with BatchNorm: z = bf16(conv + bias); batch statistics of the STORED z (layer 0 on the matrix cores: of the
+#     unrounded convolution, from the exact patch Gram matrix); y = bf16(act(z * sc + sh)), sc = invstd * gamma,
+#     sh = fma(-mean, sc, beta)   (bn.hip:bn_apply_act_8c_kernel)
+#   * head: fp32 output; loss in fp32; d loss / d raw rounded to bf16 (decode_loss.hip:decode_loss_bwd_bf16_kernel)
+#   * BatchNorm backward on bf16 g and z, dz = bf16(...) (bn.hip:bn_bwd_*_8c_kernel); data gradients dx = bf16(convT(g, bf16 w)
+#     * act'(previous block) * mask); weight / bias gradients fp32 from the bf16 tensors
+#   * layer 0 backward: the fused sums of conv_first.hip:conv_first_bn_wgrad_kernel (+ the Gram form of sum xhat * patch)
+# ---------------------------------------------------------------------------
+def _rb(t: torch.Tensor) -> torch.Tensor:
+    """round to bf16 (nearest even) and widen again"""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _act_bwd_factor(ref: torch.Tensor, act: Optional[str]) -> torch.Tensor:
+    """csrc/common.h:act_bwd_factor -- leaky: by the sign of the OUTPUT, silu: from the PRE-activation"""
+    if act == "leaky":
+        return torch.where(ref > 0, torch.ones_like(ref), torch.full_like(ref, LEAKY_SLOPE))
+    if act == "silu":
+        s = torch.sigmoid(ref)
+        return s * (1 + ref * (1 - s))
+    return torch.ones_like(ref)
+
+
+def l0_on_matrix_cores(spec: list, x: torch.Tensor) -> bool:
+    """the shapes yogo_conv_first_mfma_supported takes (uint8, 1 -> <=16 channels, stride 2, even sizes, BatchNorm, no dropout)"""
+    co, k, s, hb, hbn, act, dp = spec[0]
+    H, W = x.shape[-2:]
+    return bool(x.dtype == torch.uint8 and x.shape[1] == 1 and co <= 16 and s == 2 and k == 3 and H % 2 == 0 and W % 2 == 0
+                and H >= 4 and W >= 4 and hbn)
+
+
+def bf16_train_step(
+    x: torch.Tensor, sd: Dict[str, torch.Tensor], spec: list, label: torch.Tensor, anchor_w: float, anchor_h: float,
+    no_obj_weight: float = 0.5, iou_weight: float = 5.0, classify_weight: float = 1.0, label_smoothing: float = 0.01,
+    clip: float = 0.0, drop_masks: Optional[Dict[int, torch.Tensor]] = None, taps: Optional[Dict[str, torch.Tensor]] = None,
+) -> Tuple[float, Dict[str, float], Dict[str, torch.Tensor], Dict[str, torch.Tensor]]:
+    """One bf16-storage training step's loss and parameter gradients (train mode, batch statistics).
+
+    Returns (loss, components, grads by state-dict name, new running statistics).  ``clip`` > 0 clamps every gradient
+    tensor to +-clip (yogo/model.py:76-77).  ``taps`` (optional dict) receives intermediate tensors: "y{i}", "z{i}", "g{i}"
+    (gradient w.r.t. block i's output) for layer-wise bisection.
+    """
+    n = len(spec)
+    B = x.shape[0]
+    f64 = torch.float64
+    l0_mfma = l0_on_matrix_cores(spec, x)
+    cur = x.float()   # (uint8 is exact in bf16; a float image is used as it is by the direct layer-0 kernels)
+    saved = []
+    new_stats: Dict[str, torch.Tensor] = {}
+    for i, (co, k, s, hb, hbn, act, dp) in enumerate(spec):
+        pre = conv_prefix(spec, i)
+        w = sd[pre + "weight"].float()
+        wq = w if (i == 0 and not l0_mfma) else _rb(w)   # the direct layer-0 kernels multiply fp32 weights
+        bias = sd[pre + "bias"].float() if hb else None
+        a = F.conv2d(cur, wq, bias, stride=s, padding=1 if k == 3 else 0)
+        S = {"x": cur, "wq": wq, "act": act, "bn": bool(hbn), "k": k, "s": s}
+        mask = drop_masks.get(i) if (drop_masks is not None and dp > 0) else None
+        last = i == n - 1
+        if hbn:
+            bpre = f"model.{i}.1."
+            z = _rb(a)
+            src = a if (i == 0) else z      # layer 0: statistics of the unrounded convolution (Gram form / fp32 epilogue sums)
+            cnt = src.numel() // src.shape[1]
+            mean64 = src.to(f64).mean(dim=(0, 2, 3))
+            var64 = (src.to(f64) ** 2).mean(dim=(0, 2, 3)) - mean64 ** 2
+            var64 = var64.clamp_min(0)
+            mean = mean64.float()
+            invstd = (1.0 / torch.sqrt(var64 + BN_EPS)).float()
+            gamma, beta = sd[bpre + "weight"].float(), sd[bpre + "bias"].float()
+            sc = invstd * gamma
+            sh = torch.addcmul(beta, -mean, sc)
+            y = _rb(_act(z * sc[None, :, None, None] + sh[None, :, None, None], act))
+            unbiased = var64 * cnt / max(cnt - 1, 1)
+            new_stats[bpre + "running_mean"] = ((1 - BN_MOMENTUM) * sd[bpre + "running_mean"].to(f64) + BN_MOMENTUM * mean64).float()
+            new_stats[bpre + "running_var"] = ((1 - BN_MOMENTUM) * sd[bpre + "running_var"].to(f64) + BN_MOMENTUM * unbiased).float()
+            new_stats[bpre + "num_batches_tracked"] = sd[bpre + "num_batches_tracked"] + 1
+            S.update(z=z, mean=mean, invstd=invstd, gamma=gamma, beta=beta, y=y)
+        elif last:
+            y = a   # fp32 head
+            S.update(y=y)
+        else:
+            v = _act(a, act)
+            if mask is not None:
+                v = v * mask[:, :, None, None]
+            y = _rb(v)
+            S.update(y=y, pre=_rb(a) if act == "silu" else None, mask=mask)
+        if taps is not None:
+            taps[f"y{i}"] = y
+            if hbn:
+                taps[f"z{i}"] = S["z"]
+        saved.append(S)
+        cur = y
+    raw = cur
+    # ---- decode + loss (fp32), gradient w.r.t. the head output, rounded to bf16 ------------------------------------------
+    raw_l = raw.detach().clone().requires_grad_(True)
+    Sy, Sx = raw.shape[2:]
+    if "_Cxs" in sd:
+        cxs, cys = sd["_Cxs"], sd["_Cys"]
+    else:
+        cxs, cys = make_grids(Sx, Sy)
+    pred = decode(raw_l, cxs, cys, anchor_w, anchor_h)
+    loss, comps = yogo_loss(pred, label.float(), no_obj_weight, iou_weight, classify_weight, label_smoothing)
+    (g,) = torch.autograd.grad(loss, raw_l)
+    g = _rb(g)
+    grads: Dict[str, torch.Tensor] = {}
+
+    def fin(t: torch.Tensor) -> torch.Tensor:
+        return torch.clamp(t, -clip, clip) if clip > 0 else t
+
+    for i in range(n - 1, -1, -1):
+        co, k, s, hb, hbn, act, dp = spec[i]
+        S = saved[i]
+        pre = conv_prefix(spec, i)
+        if taps is not None:
+            taps[f"g{i}"] = g
+        N = g.numel() // g.shape[1]
+        if hbn and i == 0 and not hb and act in (None, "leaky"):
+            # conv_first_bn_wgrad_kernel + finalize (what the engine runs for a bias-free first conv + BatchNorm with no /
+            # LeakyReLU activation): dz never exists; dW = c1 (A1 - S1/N P - S2/N A2)
+            z, mean, invstd, gamma, beta = S["z"], S["mean"], S["invstd"], S["gamma"], S["beta"]
+            xh = (z - mean[None, :, None, None]) * invstd[None, :, None, None]
+            yb = torch.addcmul(beta[None, :, None, None], gamma[None, :, None, None], xh)
+            gb = g * _act_bwd_factor(yb, act)
+            S1 = gb.to(f64).sum(dim=(0, 2, 3))
+            S2 = (gb.to(f64) * xh.to(f64)).sum(dim=(0, 2, 3))
+            cin = S["x"].shape[1]
+            patches = F.unfold(S["x"], kernel_size=3, padding=1, stride=s).to(f64)          # [B, cin*9, L]
+            A1 = torch.einsum("bcl,bjl->cj", gb.reshape(B, co, -1).to(f64), patches)           # [co, cin*9]
+            P = patches.sum(dim=(0, 2))                                                         # [cin*9]
+            if l0_mfma:   # Gram form: sum xhat * patch_j from the UNROUNDED convolution, with the weights the forward used
+                G = torch.einsum("bjl,bkl->jk", patches, patches)
+                Wm = S["wq"].reshape(co, -1).to(f64)
+                A2 = invstd.to(f64)[:, None] * (Wm @ G - mean.to(f64)[:, None] * P[None, :])
+            else:
+                A2 = torch.einsum("bcl,bjl->cj", xh.reshape(B, co, -1).to(f64), patches)
+            c1 = (gamma * invstd).to(f64)
+            dW = c1[:, None] * (A1 - (S1 / N)[:, None] * P[None, :] - (S2 / N)[:, None] * A2)
+            grads[pre + "weight"] = fin(dW.float().reshape(co, cin, 3, 3))
+            grads["model.0.1.weight"] = fin(S2.float())
+            grads["model.0.1.bias"] = fin(S1.float())
+            break
+        if hbn:
+            z, mean, invstd, gamma, beta = S["z"], S["mean"], S["invstd"], S["gamma"], S["beta"]
+            xh = (z - mean[None, :, None, None]) * invstd[None, :, None, None]
+            ge = g * _act_bwd_factor(torch.addcmul(beta[None, :, None, None], xh, gamma[None, :, None, None]), act)
+            S1 = ge.to(f64).sum(dim=(0, 2, 3))
+            S2 = (ge.to(f64) * xh.to(f64)).sum(dim=(0, 2, 3))
+            bpre = f"model.{i}.1."
+            grads[bpre + "weight"] = fin(S2.float())
+            grads[bpre + "bias"] = fin(S1.float())
+            mg = (S1.float() * (1.0 / float(N)))[None, :, None, None]
+            mgx = (S2.float() * (1.0 / float(N)))[None, :, None, None]
+            g = _rb((invstd * gamma)[None, :, None, None] * (ge - mg - xh * mgx))
+        # ---- weight / bias gradient: fp32 sums over the bf16 tensors ---------------------------------------------------------
+        xl = S["x"].detach().clone().requires_grad_(True)
+        wl = S["wq"].detach().clone().requires_grad_(True)
+        o = F.conv2d(xl, wl, None, stride=s, padding=1 if k == 3 else 0)
+        need_dx = i > 0
+        gs = torch.autograd.grad(o, (xl, wl) if need_dx else (wl,), g)
+        dW = gs[-1]
+        grads[pre + "weight"] = fin(dW)
+        if hb:
+            grads[pre + "bias"] = fin(g.to(f64).sum(dim=(0, 2, 3)).float())
+        if not need_dx:
+            break
+        dx = gs[0]
+        Sp = saved[i - 1]
+        if not Sp["bn"]:   # the data gradient's epilogue applies the previous block's activation derivative and dropout mask
+            if Sp["act"] == "leaky":
+                dx = dx * _act_bwd_factor(Sp["y"], "leaky")
+            elif Sp["act"] == "silu":
+                dx = dx * _act_bwd_factor(Sp["pre"], "silu")
+            if Sp.get("mask") is not None:
+                dx = dx * Sp["mask"][:, :, None, None]
+        g = _rb(dx)
+    return float(loss.detach()), comps, grads, new_stats

@@ -6,8 +6,9 @@ conv_bf16_kernel<2,4,8,...> needs OH*OW >= 4096; the planner picks other band wi
       fp32-head variants the training step uses) at 772x1032 against F.conv2d + autograd in fp32 ON THE CPU on bf16-rounded
       inputs, with the per-kernel bf16 tolerances of test_gpu_bf16.py (8e-3 of the output range for one bf16 rounding, 1e-4
       of max|g| for fp32-accumulated weight gradients); weight gradients also at B = 128 (the split-K plan depends on B);
-  (B) one full bf16 HipTrainer.step at 772x1032 is compared with the CPU oracle's fp32 step (loss, every gradient tensor,
-      running statistics);
+  (B) one full bf16 HipTrainer.step at 772x1032 is compared with the CPU oracle's bf16-storage emulation of the step
+      (O.bf16_train_step rounds where the HIP path stores bf16): loss 1e-3, every gradient tensor max|d| <= 1e-2 max|g| and
+      cosine >= 0.999, running statistics 1e-3;
   (C) the production batch 128 -- exactly bench.py's step -- with the launch log proving which instantiations / planner
       parameters ran: they must include every conv_bf16_kernel<...> and wgrad_bf16_kernel<...> row of the committed
       rocprofv3 summary (profiles/r*_kernel_stats.txt) and nothing the per-layer tests did not launch too.  Numerics through
@@ -192,55 +193,37 @@ def _model(B, seed=0):
 
 
 def _oracle_step(sd, x, lab, device):
+    """the oracle's bf16-storage emulation of the step (rounds where the HIP path stores bf16): loss, gradients, running stats"""
     spec = O.arch("base_model", C)
-    names = [k for k, v in sd.items() if k.startswith("model.") and v.is_floating_point() and "running" not in k]
-    sdd = {k: v.to(device) for k, v in sd.items()}
-    leaf = {k: sdd[k].clone().requires_grad_(True) for k in names}
-    sdl = dict(sdd)
-    sdl.update(leaf)
-    ns = {}
-    pred = O.yogo_forward(x.to(device), sdl, spec, 0.0425, 0.0555, train=True, new_stats=ns)
-    loss, _ = O.yogo_loss(pred, lab.to(device))
-    loss.backward()
-    return float(loss.detach()), {k: v.grad.detach() for k, v in leaf.items()}, ns
+    loss, _, grads, ns = O.bf16_train_step(x, sd, spec, lab, 0.0425, 0.0555)
+    return loss, grads, ns
 
 
-def _compare_step(tr, model, loss_ref, grads_ref, stats_ref, cos_min, ratio_tol, what):
+def _compare_step(tr, model, loss_ref, grads_ref, stats_ref, what):
+    from _util import BF16_STEP_LOSS_RTOL, assert_grads_match_bf16_oracle
+
     got = tr.loss_components()
-    assert abs(got["loss"] - loss_ref) < 2e-2 * abs(loss_ref), (what, got, loss_ref)
+    assert abs(got["loss"] - loss_ref) < BF16_STEP_LOSS_RTOL * abs(loss_ref), (what, got, loss_ref)
     off = 0
     flat = tr.flat.grad
-    worst = (1.0, None)
+    mine = {}
     for name, p in model.named_parameters():
         n = p.numel()
-        a = flat[off:off + n].double()
-        b_ = grads_ref[name].reshape(-1).to(a.device).double()
+        mine[name] = flat[off:off + n].view(p.shape).cpu()
         off += n
-        blk = model.model[int(name.split(".")[1])] if name.split(".")[1].isdigit() else None
-        if name.endswith(".0.bias") and isinstance(blk, torch.nn.Sequential) and any(isinstance(q, torch.nn.BatchNorm2d) for q in blk):
-            # a conv bias in front of BatchNorm: the gradient is mathematically zero (BatchNorm removes the mean); both sides hold
-            # rounding noise only -- bounded against the scale of the same block's weight gradient instead of compared
-            wmax = float(grads_ref[name.replace(".bias", ".weight")].abs().max())
-            assert float(a.abs().max()) < 1e-2 * wmax and float(b_.abs().max()) < 1e-2 * wmax, (what, name)
-            continue
-        cos = float((a * b_).sum() / (a.norm() * b_.norm() + 1e-30))
-        ratio = float(a.norm() / (b_.norm() + 1e-30))
-        print(f"[{what}] {name:24s} cos {cos:.5f} norm ratio {ratio:.4f}")
-        if cos < worst[0]:
-            worst = (cos, name)
-        # bf16 activations and activation gradients through 8 layers: direction and scale of every gradient tensor are kept
-        assert cos > cos_min and abs(ratio - 1) < ratio_tol, (what, name, cos, ratio)
+    worst = assert_grads_match_bf16_oracle(mine, grads_ref, what)
     sd = model.state_dict()
     for k, v in stats_ref.items():
         if "num_batches" in k:
             assert int(sd[k]) == int(v)
         else:
-            torch.testing.assert_close(sd[k].cpu(), v.cpu(), rtol=2e-2, atol=2e-2)
+            torch.testing.assert_close(sd[k].cpu(), v.cpu(), rtol=1e-3, atol=1e-4)
     return worst
 
 
 def test_bf16_training_step_at_772x1032_vs_cpu_oracle():
-    """(B): one bf16 step at the production image size, B = 2, against the oracle's fp32 step on the CPU"""
+    """(B): one bf16 step at the production image size, B = 2, against the oracle's bf16-storage emulation of the same step on
+    the CPU (O.bf16_train_step): loss 1e-3, every gradient tensor max|d| <= 1e-2 max|g| and cosine >= 0.999"""
     from yogo_amd.train import HipTrainer
     from yogo_amd.yogo_loss import YOGOLoss
 
@@ -252,14 +235,14 @@ def test_bf16_training_step_at_772x1032_vs_cpu_oracle():
     tr = HipTrainer(m, YOGOLoss().cuda(), total_steps=10, half=True)
     tr.step(x.cuda(), lab.cuda())
     loss_ref, grads_ref, ns = _oracle_step(sd0, x, lab, "cpu")
-    _compare_step(tr, m, loss_ref, grads_ref, ns, 0.95, 0.1, "B=2 vs CPU oracle")
+    _compare_step(tr, m, loss_ref, grads_ref, ns, "B=2 vs bf16-emulating CPU oracle")
 
 
 def test_production_batch_step_and_kernel_set():
     """(C): bench.py's step (B = 128, bf16) on 64 copies of (B)'s two images: the launch log must contain every
     conv_bf16_kernel / wgrad_bf16_kernel instantiation of the committed rocprofv3 summary and -- when the per-layer tests (A)
     ran in this session -- nothing the per-layer tests did not launch too; loss, gradients and batch statistics must
-    reproduce the oracle's fp32 step on the two images (same batch statistics, mean-reduced loss)"""
+    reproduce the oracle's bf16-storage emulation of the step on the two images (same batch statistics, mean-reduced loss)"""
     from yogo_amd.train import HipTrainer
     from yogo_amd.yogo_loss import YOGOLoss
 
@@ -293,4 +276,4 @@ def test_production_batch_step_and_kernel_set():
         conv = {k for k in launched if k.startswith(("conv_bf16_kernel", "wgrad_bf16_kernel"))}
         assert conv <= SEEN, f"launched at B=128 but not covered by the per-layer parity tests: {sorted(conv - SEEN)}"
     loss_ref, grads_ref, ns = _oracle_step(sd0, x2, lab2, "cpu")
-    _compare_step(tr, m, loss_ref, grads_ref, ns, 0.95, 0.1, "B=128 (64 x 2 images) vs CPU oracle on the 2 images")
+    _compare_step(tr, m, loss_ref, grads_ref, ns, "B=128 (64 x 2 images) vs bf16-emulating CPU oracle on the 2 images")

@@ -1,9 +1,15 @@
-"""every registered architecture through one fp32 and one bf16 training step at a few image sizes (experiments / smoke)"""
+"""every registered architecture through two bf16 training steps at a few image sizes, held to the oracle's bf16-storage
+emulation (oracle/yogo_oracle.py:bf16_train_step): step-1 loss 1e-3, every gradient tensor max|d| <= 1e-2 max|g| and cosine
+>= 0.999, step-2 loss (after one AdamW update on either side) 1e-2.  The fp32 path's two losses are printed beside them for
+information: bf16 storage moves a gradient tensor by ~1 % against fp32, and Adam's first update lr * sign(g) turns that into
+several per cent of the second loss on the wide models (the loss falls by 50-80 % in that one step) -- a property of bf16
+storage, which is why the bound is taken against the emulation and not against fp32."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "oracle"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
 import torch
 import yogo_oracle as O
+from _util import BF16_STEP_LOSS_RTOL, assert_grads_match_bf16_oracle
 from yogo_amd.model import YOGO
 from yogo_amd.model_defns import MODELS
 from yogo_amd.train import HipTrainer
@@ -14,32 +20,44 @@ for name, fn in MODELS.items():
     if name == "convnext_small":
         continue
     for (H, W, B, rgb) in ((96, 128, 2, False), (193, 258, 3, False), (130, 70, 1, True)):
-        losses = {}
         try:
+            x = torch.randint(0, 256, (B, 3 if rgb else 1, H, W), dtype=torch.uint8, generator=torch.Generator().manual_seed(2))
+            res = {}
             for half in (False, True):
                 torch.manual_seed(1)
-                m = YOGO((H, W), 0.0425, 0.0555, 5, is_rgb=rgb, model_func=fn).cuda()
+                m = YOGO((H, W), 0.0425, 0.0555, 5, is_rgb=rgb, model_func=fn, clip_value=1e9).cuda()
                 m.train()
                 for mod in m.modules():
                     if isinstance(mod, torch.nn.Dropout2d):
                         mod.p = 0.0
-                x = torch.randint(0, 256, (B, 3 if rgb else 1, H, W), dtype=torch.uint8, generator=torch.Generator().manual_seed(2)).cuda()
-                lab = O.synthetic_labels(B, m.Sx, m.Sy, K=4, num_classes=5, seed=3).cuda()
+                sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+                lab = O.synthetic_labels(B, m.Sx, m.Sy, K=4, num_classes=5, seed=3)
                 tr = HipTrainer(m, YOGOLoss().cuda(), total_steps=4, half=half)
-                tr.step(x, lab)
+                tr.step(x.cuda(), lab.cuda())
                 first = tr.loss_components()["loss"]
-                tr.step(x, lab)
-                losses[half] = (first, tr.loss_components()["loss"])
-            # step 1 = forward parity (tight); step 2 also carries one AdamW update of ~all-clamped gradients at random init, where a
-            # few per cent of sign flips between bf16 and fp32 gradients (cosine 0.94-1.0 per tensor, tools/probes/triple_dbg.py) move the
-            # loss of the widest models by several per cent -- loose bound
-            rel1 = abs(losses[True][0] - losses[False][0]) / max(1e-6, abs(losses[False][0]))
-            rel = abs(losses[True][1] - losses[False][1]) / max(1e-6, abs(losses[False][1]))
-            ok = rel1 < 5e-3 and rel < 0.15
-            flag = "" if ok else "   <-- MISMATCH"
+                grads, off = {}, 0
+                for pname, p in m.named_parameters():
+                    grads[pname] = tr.flat.grad[off:off + p.numel()].view(p.shape).cpu().clone()
+                    off += p.numel()
+                tr.step(x.cuda(), lab.cuda())
+                res[half] = (first, tr.loss_components()["loss"], grads, sd0, lab, tr.lr, tr.wd)
+            first, second, grads, sd0, lab, lr, wd = res[True]
+            spec = O.arch(name, 5)
+            l1, _, gref, _ = O.bf16_train_step(x, sd0, spec, lab, 0.0425, 0.0555)
+            sd1 = dict(sd0)
+            for k, g in gref.items():
+                sd1[k], _, _ = O.adamw_step(sd0[k], g, torch.zeros_like(g), torch.zeros_like(g), 1, lr, weight_decay=wd)
+            l2, _, _, _ = O.bf16_train_step(x, sd1, spec, lab, 0.0425, 0.0555)
+            rel1, rel2 = abs(first - l1) / abs(l1), abs(second - l2) / abs(l2)
+            try:
+                worst = assert_grads_match_bf16_oracle(grads, gref, name, verbose=False)
+                gok = True
+            except AssertionError as e:
+                worst, gok = (0.0, str(e)[:120]), False
+            ok = gok and rel1 < BF16_STEP_LOSS_RTOL and rel2 < 1e-2
             bad += not ok
-            print(f"{name:16s} {H}x{W} B={B} rgb={int(rgb)}: step 1 fp32 {losses[False][0]:.4f} bf16 {losses[True][0]:.4f} rel {rel1:.2e} | "
-                  f"step 2 fp32 {losses[False][1]:.4f} bf16 {losses[True][1]:.4f} rel {rel:.2e}{flag}", flush=True)
+            print(f"{name:16s} {H}x{W} B={B} rgb={int(rgb)}: bf16 {first:.4f} -> {second:.4f} | emulation {l1:.4f} -> {l2:.4f} rel {rel1:.1e} / {rel2:.1e} "
+                  f"worst cos {worst[0]:.5f} ({worst[1]}) | fp32 path {res[False][0]:.4f} -> {res[False][1]:.4f}{'' if ok else '   <-- MISMATCH'}", flush=True)
         except Exception as e:
             bad += 1
             print(f"{name:16s} {H}x{W} B={B} rgb={int(rgb)}: ERROR {type(e).__name__}: {str(e)[:150]}", flush=True)

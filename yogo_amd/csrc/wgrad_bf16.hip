@@ -563,6 +563,14 @@ bool wb_plan(int B, int N, int M, int IH, int IW, int ks, int stride, WbPlan* pl
   return true;
 }
 
+// rows of the bias partial-sum region behind the slabs: one per slab, times -- on the lean KS = 1 path -- the NBW * TG wavefronts
+// that share a gradient operand and each write their own row (the kernel's `brow`).  ONE definition for the workspace query,
+// the launcher's pointer arithmetic and the reduction's row count, so they cannot drift apart.
+int wb_bias_rows(const WbPlan& pl, int T) {
+  const bool lean = pl.KS == 1;   // (= the kernel's LEAN: KS = 1 tilings never pack two taps)
+  return pl.nsplit * pl.KS * (lean ? pl.NBW * (T == 1 ? 1 : 3) : 1);
+}
+
 template <int MBW, int NBW, int NPW, int KS, int T, int S, int R, int MPW = 1, bool ROT = false, bool PACK2 = false>
 void wb_launch_one(const WgradBf16Params& p, const WbPlan& pl, hipStream_t stream) {
   static bool s = false;
@@ -591,8 +599,8 @@ extern "C" int yogo_conv2d_wgrad_bf16_workspace_bytes(int B, int Cin, int Cout, 
                  "wgrad_bf16_workspace_bytes: bad arguments");
   WbPlan pl;
   YOGO_CHECK_ARG(wb_plan(B, Cin, Cout, IH, IW, ks, stride, &pl), "wgrad_bf16: no LDS plan");
-  // slabs + bias partial rows (at most 6 per slab row on the lean path: one per wavefront sharing a gradient operand)
-  *bytes = ((size_t)pl.nsplit * pl.KS * ks * ks * pl.Mpad * pl.Npad + (size_t)pl.nsplit * pl.KS * 6 * pl.Mpad) * sizeof(float);
+  // slabs + bias partial rows
+  *bytes = ((size_t)pl.nsplit * pl.KS * ks * ks * pl.Mpad * pl.Npad + (size_t)wb_bias_rows(pl, ks * ks) * pl.Mpad) * sizeof(float);
   return YOGO_OK;
 }
 
@@ -649,7 +657,6 @@ extern "C" int yogo_conv2d_wgrad_bf16(const void* x, const void* g, float* dw, f
     }
   }
   YOGO_CHECK_LAUNCH("conv2d_wgrad_bf16");
-  const bool lean = pl.KS == 1;   // (= the kernel's LEAN: KS = 1 tilings never pack two taps)
-  const int nbias = pl.nsplit * pl.KS * (lean ? pl.NBW * (T == 1 ? 1 : 3) : 1);
+  const int nbias = wb_bias_rows(pl, T);
   return yogo_internal_wgrad_reduce(p.slab, pl.nsplit * pl.KS, T, Cout, Cin, pl.Mpad, pl.Npad, clip, dw, p.bias_part, nbias, db, stream);
 }
