@@ -349,7 +349,10 @@ def main():
                     "achieved": round(achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                     "calls_timed": len(sel), "avg_call_ms": round(ms / max(1, len(sel)), 4),
+                    "traffic_source": "profiles/traffic.json: HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 + "
+                                      "WRITE_SIZE, tools/collect_profile.sh) -- a committed constant, not measured in this run",
                     "sustained_mfma_peak_measured": BF16_MFMA_SUSTAINED_TFLOPS,
+                    "sustained_mfma_peak_source": "constant: tools/probes/mfma_shapes2.hip on this pool (round 2), not measured in this run",
                     "frac_of_sustained": round(achieved / BF16_MFMA_SUSTAINED_TFLOPS, 4),
                     "algorithmic_gbs": round(sum(e[6] for e in sel) / max(ms, 1e-9) / 1e6, 1),
                     "all_bf16_conv_gbs": round(sum(e[6] for e in allc) / max(ms_of(allc), 1e-9) / 1e6, 1)}
@@ -362,6 +365,7 @@ def main():
             roof = {"bound": "mfma", "kernel": "conv_igemm_f32_kernel<4,2> (fwd+dgrad of the 128-channel 3x3 layers)",
                     "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "traffic_source": "profiles/traffic.json (committed rocprofv3 --pmc passes), not measured in this run",
                     "calls_timed": len(sel), "avg_call_ms": round(ms / max(1, len(sel)), 4)}
         value = world * B * args.steps / dt
         rec = {

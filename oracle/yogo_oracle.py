@@ -751,6 +751,8 @@ def bf16_train_step(
     pred = decode(raw_l, cxs, cys, anchor_w, anchor_h)
     loss, comps = yogo_loss(pred, label.float(), no_obj_weight, iou_weight, classify_weight, label_smoothing)
     (g,) = torch.autograd.grad(loss, raw_l)
+    if taps is not None:
+        taps["graw_f32"] = g
     g = _rb(g)
     grads: Dict[str, torch.Tensor] = {}
 
@@ -801,6 +803,8 @@ def bf16_train_step(
             mg = (S1.float() * (1.0 / float(N)))[None, :, None, None]
             mgx = (S2.float() * (1.0 / float(N)))[None, :, None, None]
             g = _rb((invstd * gamma)[None, :, None, None] * (ge - mg - xh * mgx))
+            if taps is not None:
+                taps[f"dz{i}"] = g
         # ---- weight / bias gradient: fp32 sums over the bf16 tensors ---------------------------------------------------------
         xl = S["x"].detach().clone().requires_grad_(True)
         wl = S["wq"].detach().clone().requires_grad_(True)

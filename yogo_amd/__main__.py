@@ -7,6 +7,10 @@ from yogo_amd.utils.argparsers import global_parser
 
 
 def main(argv=None) -> None:
+    # (the `yogo` console script of pyproject.toml lands here: worker processes must be fresh interpreters, never forks of a
+    #  parent that may have touched the GPU)
+    if torch.multiprocessing.get_start_method(allow_none=True) != "spawn":
+        torch.multiprocessing.set_start_method("spawn", force=True)
     p = global_parser()
     args = p.parse_args(argv)
     if args.task == "train":

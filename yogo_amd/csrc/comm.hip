@@ -96,6 +96,7 @@ extern "C" int yogo_comm_init(int rank, int world, const void* unique_id, void**
 extern "C" int yogo_comm_allreduce_flat(void* comm, float* buf, size_t count, hipStream_t stream) {
   YOGO_CHECK_ARG(comm && buf, "comm_allreduce_flat: null pointer");
   if (count == 0) return YOGO_OK;
+  if (!rccl_load()) return YOGO_ERR_HIP;   // (a handle from another copy of the library: never call through a null entry)
   if (int rc = g_rccl.all_reduce(buf, buf, count, RCCL_FLOAT32, RCCL_SUM, comm, stream)) return rccl_fail("ncclAllReduce", rc);
   return YOGO_OK;
 }
@@ -104,6 +105,7 @@ extern "C" int yogo_comm_allreduce_flat(void* comm, float* buf, size_t count, hi
 extern "C" int yogo_comm_broadcast_flat(void* comm, void* buf, size_t bytes, int root, hipStream_t stream) {
   YOGO_CHECK_ARG(comm && buf && root >= 0, "comm_broadcast_flat: bad arguments");
   if (bytes == 0) return YOGO_OK;
+  if (!rccl_load()) return YOGO_ERR_HIP;
   if (int rc = g_rccl.broadcast(buf, buf, bytes, RCCL_UINT8, root, comm, stream)) return rccl_fail("ncclBroadcast", rc);
   return YOGO_OK;
 }

@@ -255,6 +255,40 @@ class HipTrainer:
             for b in bufs:
                 dist.broadcast(b, src=src, group=self.pg)
 
+    def _bn_buffers(self) -> List[torch.Tensor]:
+        """running_mean / running_var / num_batches_tracked of every BatchNorm, in module order"""
+        out: List[torch.Tensor] = []
+        for mod in self.model.modules():
+            if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm) and mod.running_mean is not None:
+                out += [mod.running_mean, mod.running_var, mod.num_batches_tracked]
+        return out
+
+    def broadcast_buffers(self, src: int = 0) -> None:
+        """rank-0 BatchNorm statistics to every rank.  torch DDP's default ``broadcast_buffers=True`` does this in front of every
+        forward (yogo/train.py:155-159), so in the reference every rank validates -- and averages its validation loss,
+        yogo/train.py:400 -- with RANK 0's running statistics.  Training-mode forwards use batch statistics and never read the
+        buffers, so ONE broadcast in front of evaluation gives the same numbers as the reference's per-step broadcast; the
+        Trainer calls this before ``_validate`` / ``test``.  The float buffers travel as one flat tensor (one collective)."""
+        if self.world <= 1:
+            return
+        bufs = self._bn_buffers()
+        fl = [b for b in bufs if b.is_floating_point()]
+        cnt = [b for b in bufs if not b.is_floating_point()]
+        if not fl:
+            return
+        flat = torch.cat([b.reshape(-1).float() for b in fl] + [b.reshape(-1).float() for b in cnt])
+        if self._rccl is not None:
+            st = torch.cuda.current_stream().cuda_stream
+            _hip.call("yogo_comm_broadcast_flat", self._rccl, flat, flat.numel() * 4, src, st)
+        else:
+            dist.broadcast(flat, src=src, group=self.pg)
+        off = 0
+        for b in fl + cnt:
+            n = b.numel()
+            b.copy_(flat[off:off + n].view(b.shape).to(b.dtype))
+            off += n
+        self.engine.generation += 1   # folded inference weights derive from the running statistics
+
     @torch.no_grad()
     def step(self, imgs: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
         """one optimisation step on this rank's shard; returns the 4-float device loss record"""

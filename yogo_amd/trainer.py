@@ -96,6 +96,10 @@ class HipBackend:
     def optimizer_state_dict(self) -> dict:
         return self.opt.state_dict()
 
+    def sync_eval_state(self) -> None:
+        """rank 0's BatchNorm running statistics to every rank before evaluation (DDP's broadcast_buffers, yogo/train.py:155-159)"""
+        self.opt.broadcast_buffers()
+
     def set_global_step(self, step: int) -> None:
         self.opt.global_step = int(step)
 
@@ -139,7 +143,7 @@ class Trainer:
         if self._world_size > 1 and not torch.distributed.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ["MASTER_PORT"] = str(self.config["master_port"])
-            torch.cuda.set_device(self._rank)
+            torch.cuda.set_device(self._torch_device())
             torch.distributed.init_process_group(backend=self.config.get("dist_backend", "nccl"), rank=self._rank,
                                                  world_size=self._world_size)
 
@@ -258,6 +262,8 @@ class Trainer:
                 self.net.load_state_dict(ckpt["model_state_dict"])
             else:
                 warnings.warn(f"no best model found at {best} for testing...")
+        if hasattr(self.backend, "sync_eval_state"):
+            self.backend.sync_eval_state()
         test_metrics = self.test(self.test_dataloader, self._torch_device(), self.config, self.net, rank=self._rank, backend=self.backend)
         if self._rank == 0:
             if test_metrics is not None:
@@ -275,10 +281,14 @@ class Trainer:
             return
         net_state = self.net.training
         self.net.eval()
-        val_loss = None
+        if hasattr(self.backend, "sync_eval_state"):
+            self.backend.sync_eval_state()   # every rank validates with rank 0's running statistics, as under DDP
+        # a zero tensor on the device, as the reference starts (yogo/train.py:385): a rank whose shard of the validation set is
+        # empty still takes part in the all-reduce below
+        val_loss = torch.zeros(1, dtype=torch.float32, device=self._torch_device())
         for imgs, labels in self.validate_dataloader:
             _, loss = self.backend.eval_batch(imgs, labels)
-            val_loss = loss.clone() if val_loss is None else val_loss + loss
+            val_loss = val_loss + loss.reshape(-1)[:1].to(val_loss.dtype)
         if self._world_size > 1:
             torch.distributed.all_reduce(val_loss, op=torch.distributed.ReduceOp.SUM)
             val_loss = val_loss / self._world_size
@@ -390,10 +400,31 @@ def build_config(args) -> dict:
     }
 
 
+def visible_gpu_count() -> int:
+    """GPUs this process may use, counted WITHOUT creating a HIP context in the caller: the parent of a multi-GPU job must stay
+    off the GPU (its children are fresh interpreters, one per device).  ``torch.cuda.device_count()`` asks the driver for the
+    count only (no context, no allocation); honouring HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES is the driver's job."""
+    return int(torch.cuda.device_count())
+
+
 def do_training(args) -> None:
-    """parse args, then one training process per visible GPU (yogo/train.py:606-656)"""
+    """parse args, then one training process per visible GPU (yogo/train.py:606-656).
+
+    Two launches are supported:
+      * ``yogo train ...`` on its own: the parent counts the devices (no HIP context) and ``mp.spawn``s one fresh interpreter per
+        GPU, as the reference does (yogo/train.py:654-656);
+      * under a launcher -- ``python -m torch.distributed.run --nproc-per-node N -m yogo_amd train ...`` --
+        RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT come from the environment and this process IS one rank."""
     config = build_config(args)
-    world_size = torch.cuda.device_count()
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ:
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        local = int(os.environ.get("LOCAL_RANK", rank))
+        if os.environ.get("MASTER_PORT"):
+            config["master_port"] = os.environ["MASTER_PORT"]
+        config["compute_device"] = f"cuda:{local}"
+        Trainer.train_from_ddp(rank, world, config)
+        return
+    world_size = visible_gpu_count()
     if world_size == 0:
         raise RuntimeError("at least 1 gpu is required for training; the hot path is HIP-only (no CPU compute path)")
     if world_size == 1:

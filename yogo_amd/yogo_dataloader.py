@@ -98,8 +98,15 @@ class DeviceLoader:
 
     def __iter__(self):
         dev = torch.device(self.device) if self.device is not None else torch.device("cuda", torch.cuda.current_device())
+        multi = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
         for item in self.loader:
             if item is None:
+                # every sample of the batch was unreadable (the robust collate of yogo/data/utils.py:49-63 returned nothing).  A
+                # single process just skips it; under data parallelism a rank that skips a step issues one gradient all-reduce
+                # fewer than its peers and the job hangs -- fail loudly instead
+                if multi:
+                    raise RuntimeError("yogo_amd: a whole batch of this rank was unreadable; in a data-parallel run every rank must "
+                                       "take the same number of steps (fix or remove the unreadable files)")
                 continue
             imgs, rows = item
             imgs = imgs.to(dev, non_blocking=True)
