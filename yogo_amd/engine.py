@@ -593,7 +593,11 @@ def forward_bf16_train(eng: Engine, x: torch.Tensor) -> Tuple[torch.Tensor, List
 
 
 def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
-                        grad_out: Optional[Dict[int, torch.Tensor]] = None, on_layer=None) -> List[Optional[torch.Tensor]]:
+                        grad_out: Optional[Dict[int, torch.Tensor]] = None, on_layer=None,
+                        trace: Optional[dict] = None) -> List[Optional[torch.Tensor]]:
+    """``trace`` (tests / probes only): a dict that receives clones of the activation gradients as they exist between the
+    kernels -- ("g", i): gradient w.r.t. block i's output, ("dz", i): BatchNorm-backward output of block i -- so that every
+    kernel of a real step can be checked against the oracle given its ACTUAL inputs (tests/_util.py, teacher-forced check)."""
     st, dev, clip = _hip.stream_ptr(), graw.device, float(eng.clip)
     grads: Dict[int, torch.Tensor] = {}
 
@@ -622,6 +626,8 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
         # layer 0 with BatchNorm and no conv bias: BatchNorm backward, activation derivative and the weight gradient share ONE
         # sweep over (image, g, z) -- dz is never written (see conv_first_bn_wgrad_kernel)
         fuse0 = _FUSE_LAYER0_BWD and i == 0 and L.bn is not None and L.conv.bias is None and L.act in (ACT_NONE, ACT_LEAKY)
+        if trace is not None:
+            trace[("g", i)] = g.clone()
         if L.bn is not None and not fuse0:
             bn = L.bn
             gamma = _f32(bn.weight.detach()) if bn.weight is not None else torch.ones(L.cout, device=dev)
@@ -636,6 +642,8 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
             if bn.weight is not None:
                 grads[id(bn.weight)] = dgamma
                 grads[id(bn.bias)] = dbeta
+            if trace is not None:
+                trace[("dz", i)] = g.clone()
         # ---- weight / bias gradient: independent of everything downstream -> second stream -------------------------------
         # Everything the side stream touches is allocated here, from the MAIN stream's pool, and kept alive until the main
         # stream has waited for the side stream (end of this function): no record_stream bookkeeping, no allocator stalls.

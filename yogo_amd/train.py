@@ -111,6 +111,9 @@ class HipTrainer:
         self.engine = get_engine(model.model)
         self.engine.invalidate_packed()
         self.last_loss: Optional[torch.Tensor] = None   # 4 device floats: total, iou, objectness, classification
+        # tests / probes only: set to a dict and the next bf16 step leaves its forward records ("saved"), the head output ("raw")
+        # and the activation gradients between the kernels (engine.backward_bf16_train) in it
+        self.trace: Optional[dict] = None
         # ---- data-parallel exchange -----------------------------------------------------------------------------------
         if comm not in ("torch", "rccl"):
             raise ValueError("comm must be 'torch' (torch.distributed) or 'rccl' (librccl through the C ABI)")
@@ -309,6 +312,8 @@ class HipTrainer:
                 from yogo_amd.engine import backward_bf16_train, forward_bf16_train
 
                 raw, saved = forward_bf16_train(eng, imgs)
+                if self.trace is not None:
+                    self.trace["saved"], self.trace["raw"] = saved, raw
             else:
                 raw, saved = eng.forward(imgs, need_grad=True)
             B, P, Sy, Sx = raw.shape
@@ -325,7 +330,7 @@ class HipTrainer:
                 g8 = torch.empty(B, ((P + 15) // 16) * 2, Sy, Sx, 8, dtype=torch.bfloat16, device=raw.device)
                 _hip.call("yogo_decode_loss_bwd_bf16", raw, lab, m._Cxs, m._Cys, g8, out, ws, B, P, Sy, Sx, aw, ah, wm, hm,
                           float(L.no_obj_weight), float(L.iou_weight), float(L.classify_weight), float(L.label_smoothing), st)
-                backward_bf16_train(eng, saved, g8, grad_out=self.flat.grad_views, on_layer=hook)
+                backward_bf16_train(eng, saved, g8, grad_out=self.flat.grad_views, on_layer=hook, trace=self.trace)
             else:
                 pred = torch.empty_like(raw)
                 _hip.call("yogo_decode_fwd", raw, pred, m._Cxs, m._Cys, B, P, Sy, Sx, aw, ah, wm, hm, int(bool(m.inference)), st)
@@ -339,7 +344,7 @@ class HipTrainer:
             elif self.half:   # the head's gradient goes straight to bf16 NCHW8c
                 g8 = torch.empty(B, ((P + 15) // 16) * 2, Sy, Sx, 8, dtype=torch.bfloat16, device=raw.device)
                 _hip.call("yogo_decode_bwd_bf16", raw, pred, gpred, g8, B, P, Sy, Sx, int(bool(m.inference)), st)
-                backward_bf16_train(eng, saved, g8, grad_out=self.flat.grad_views, on_layer=hook)
+                backward_bf16_train(eng, saved, g8, grad_out=self.flat.grad_views, on_layer=hook, trace=self.trace)
             else:
                 graw = torch.empty_like(raw)
                 _hip.call("yogo_decode_bwd", raw, pred, gpred, graw, B, P, Sy, Sx, int(bool(m.inference)), st)
