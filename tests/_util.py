@@ -41,11 +41,12 @@ def rel_err(a, b):
 
 
 # ---- a bf16 training step of the HIP path against the oracle's bf16-storage emulation (O.bf16_train_step), END TO END ----
-# Tolerances (stated once, used by every bf16 whole-step test): loss 1e-3 relative, per gradient tensor cosine >= 0.999,
-# running statistics 1e-3.  The elementwise bounds live in the teacher-forced check further down -- the comment there says why
-# an end-to-end max-norm bound on the gradients is the wrong instrument for a bf16 network with LeakyReLU.
+# Tolerances (stated once, used by every bf16 whole-step test): loss 1e-3 relative, per gradient tensor cosine >= 0.995
+# (measured over 11 architectures x 3 sizes, tools/probes/sweep_models.py: 0.9970 ... 1.0000; against the fp32 oracle the same
+# tensors sit at 0.90 ... 0.99), running statistics 1e-3.  The elementwise bounds live in the teacher-forced check further
+# down -- the comment there says why two correct bf16 implementations cannot agree more closely than this END TO END.
 BF16_STEP_LOSS_RTOL = 1e-3
-BF16_STEP_COS_MIN = 0.999
+BF16_STEP_COS_MIN = 0.995
 
 
 def is_conv_bias_before_bn(name, names):
@@ -85,8 +86,9 @@ def assert_grads_match_bf16_oracle(got, want, what, cos_min=BF16_STEP_COS_MIN, v
 # by one bf16 ulp between any two correct implementations (measured: tools/probes/bf16_bisect.py).  That alone is harmless
 # noise -- but LeakyReLU'(0) is discontinuous: where an activation is within that noise of zero, its derivative is 1 on one
 # side and 0.01 on the other, and on sparse-label batches a handful of pixels carry most of a gradient tensor, so ONE such flip
-# can move an element by 10 % of the tensor's maximum although the tensors agree to cosine 0.9999.  So the whole step is held
-# to loss 1e-3 and per-tensor cosine >= 0.999 (end to end), and each KERNEL is held tightly here with its actual inputs:
+# can move an element by 10 % of the tensor's maximum, and the tensors below a BatchNorm (whose backward spreads every value over
+# its channel) to cosine 0.997-0.9999.  So the whole step is held to loss 1e-3 and per-tensor cosine >= 0.995 (end to end), and
+# each KERNEL is held tightly here with its actual inputs:
 #   stored bf16 tensors: at most ONE bf16 ulp (|d| <= 2^-7 max(|a|, |b|)), plus 8e-6 of the tensor's range for values formed by
 #     cancellation, and at most 2 % of the elements differing at all;
 #   BatchNorm statistics 1e-5; parameter gradients 2e-4 of the tensor's maximum (layer 0: 2e-3, its sums cancel ~1000-fold).

@@ -452,7 +452,7 @@ def test_bf16_dropout_masks():
 def test_bf16_training_other_architectures(name, hw, rgb):
     """two bf16 optimisation steps of other registered ModelDefns (SiLU blocks keep their pre-activation for the backward pass;
     widths 4..384; rgb input; the direct layer-0 kernels at odd sizes) against the oracle's bf16-storage emulation
-    (O.bf16_train_step): step 1 -- end to end loss 1e-3 and every gradient tensor cosine >= 0.999, and TEACHER-FORCED every
+    (O.bf16_train_step): step 1 -- end to end loss 1e-3 and every gradient tensor cosine >= 0.995, and TEACHER-FORCED every
     stored tensor / statistic / parameter gradient given the step's own inputs (one bf16 ulp, 2e-4 of max|g|: tests/_util.py);
     then the oracle applies AdamW to ITS gradients and emulates step 2: the HIP path's second loss (its own gradients -> fused
     AdamW -> repacked bf16 weights -> forward) must agree to 2e-2 (the loss falls by 50-80 % in this one step, and Adam's first
@@ -478,6 +478,8 @@ def test_bf16_training_other_architectures(name, hw, rgb):
     tr.step(x.cuda(), lab.cuda())
     torch.cuda.synchronize()
     spec = O.arch(name, 5)
+    teacher_forced_bf16_step_check(O, tr, m, x, lab, spec, sd0, f"{name} {H_}x{W_}")
+    tr.trace = None
     loss_ref, _, grads_ref, _ = O.bf16_train_step(x, sd0, spec, lab, 0.0425, 0.0555)
     got = tr.loss_components()["loss"]
     assert abs(got - loss_ref) < BF16_STEP_LOSS_RTOL * abs(loss_ref), (name, got, loss_ref)
@@ -486,8 +488,6 @@ def test_bf16_training_other_architectures(name, hw, rgb):
         mine[pname] = tr.flat.grad[off:off + p.numel()].view(p.shape).cpu()
         off += p.numel()
     assert_grads_match_bf16_oracle(mine, grads_ref, f"{name} {H_}x{W_}")
-    teacher_forced_bf16_step_check(O, tr, m, x, lab, spec, sd0, f"{name} {H_}x{W_}")
-    tr.trace = None
     # ---- step 2: the oracle's own AdamW update of its own gradients, then its emulation of the second step
     sd1 = dict(sd0)
     for k, g in grads_ref.items():

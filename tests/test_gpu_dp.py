@@ -74,7 +74,7 @@ def test_two_ranks_on_one_card(tmp_path, half):
         got[k] = res[0]["grad_sum"][off:off + n].view(sd0[k].shape)
         off += n
     if half:
-        # same end-to-end bound as every bf16 whole-step test (tests/_util.py): cosine >= 0.999 per tensor (it was 0.85 against the
+        # same end-to-end bound as every bf16 whole-step test (tests/_util.py): cosine >= 0.995 per tensor (it was 0.85 against the
         # fp32 oracle); the elementwise, per-kernel bounds are the teacher-forced checks of test_gpu_bf16 / test_gpu_production_shapes
         from _util import assert_grads_match_bf16_oracle
 

@@ -1,5 +1,5 @@
 """every registered architecture through two bf16 training steps at a few image sizes, held to the oracle's bf16-storage
-emulation (oracle/yogo_oracle.py:bf16_train_step): step-1 loss 1e-3, every gradient tensor cosine >= 0.999, step-2 loss (after
+emulation (oracle/yogo_oracle.py:bf16_train_step): step-1 loss 1e-3, every gradient tensor cosine >= 0.995, step-2 loss (after
 one AdamW update on either side) 2e-2.  The fp32 path's two losses are printed beside them for
 information: bf16 storage moves a gradient tensor by ~1 % against fp32, and Adam's first update lr * sign(g) turns that into
 several per cent of the second loss on the wide models (the loss falls by 50-80 % in that one step) -- a property of bf16
