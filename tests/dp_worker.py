@@ -36,8 +36,11 @@ def main():
     x, lab = xs[rank * Bper:(rank + 1) * Bper].cuda(), labs[rank * Bper:(rank + 1) * Bper].cuda()
     tr.step(x, lab)
     torch.cuda.synchronize()
+    sd1 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    tr.broadcast_buffers()     # what the Trainer does in front of validation: rank 0's BatchNorm statistics everywhere
+    torch.cuda.synchronize()
     torch.save({"sd0": sd0, "grad_sum": tr.flat.grad.cpu(), "flat": tr.flat.flat.cpu(), "loss": tr.loss_components(),
-                "sd1": {k: v.detach().cpu() for k, v in model.state_dict().items()}, "split_off": tr.split_off},
+                "sd1": sd1, "sd2": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, "split_off": tr.split_off},
                os.path.join(outdir, f"rank{rank}.pt"))
     dist.barrier()
     tr.close()

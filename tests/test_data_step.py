@@ -1,9 +1,11 @@
 """The step in front of the hot path: label files -> label tensors, batch flips with their boxes.
 
-CPU tests pin the oracle's restatement by hand-computed answers (yogo/data/yogo_dataset.py:24-46, data_transforms.py:51-98
-cannot be imported here: they need torchvision.datasets / transforms / io and ruamel -- parity of this step is otherwise
-unpinned) and cover the host-side parser; GPU tests compare the HIP kernels with the oracle bit for bit."""
+CPU tests pin the oracle's restatement by hand-computed answers AND by golden vectors written by the reference's own functions
+(tests/golden/make_golden_data.py imports yogo/data/yogo_dataset.py:24-133 and data_transforms.py:51-98 on stubs of their
+torchvision / ruamel imports -> tests/golden/data_step.npz), and cover the host-side parser; GPU tests compare the HIP kernels
+with the oracle and with those vectors bit for bit."""
 
+import numpy as np
 import pytest
 import torch
 
@@ -182,3 +184,93 @@ def test_flips_match_oracle(shape, dtype):
     torch.manual_seed(1)
     wi, wl = O.random_flips_with_bbs(img, lab)
     assert torch.equal(ci.cpu(), wi) and torch.equal(cl.cpu(), wl)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Golden vectors written by the REAL reference functions (tests/golden/make_golden_data.py imports yogo/data/yogo_dataset.py and
+# yogo/data/data_transforms.py on stubs of their torchvision / ruamel imports): the oracle, the host-side parser and the HIP
+# kernels are all held to them bit for bit.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _golden():
+    import json
+
+    from _util import load_npz
+
+    z = load_npz("data_step.npz")
+    return z, json.loads(str(z["meta"]))
+
+
+def test_oracle_rasteriser_matches_reference_vectors():
+    z, meta = _golden()
+    for c in meta["rast"]:
+        rows = torch.from_numpy(z[f"rast/{c['name']}/rows"])
+        want = torch.from_numpy(z[f"rast/{c['name']}/out"])
+        assert torch.equal(O.format_labels_tensor(rows, c["Sx"], c["Sy"]), want), c
+    for c in meta["rast_err"]:
+        rows = torch.from_numpy(z[f"rast_err/{c['name']}/rows"])
+        if c["raises"] == "IndexError":
+            with pytest.raises(IndexError):
+                O.format_labels_tensor(rows, c["Sx"], c["Sy"])
+        else:
+            O.format_labels_tensor(rows, c["Sx"], c["Sy"])
+
+
+def test_label_files_match_reference_vectors(tmp_path):
+    """the host-side parser (yogo_amd.data.load_labels: csv sniffing, header row, area filter, empty files) against the rows the
+    reference's load_labels returned, and the oracle's rasteriser on those rows against the reference's label_file_to_tensor"""
+    from yogo_amd import data as D
+
+    z, meta = _golden()
+    for f in meta["files"]:
+        path = tmp_path / f["name"]
+        path.write_text(f["text"])
+        rows = D.load_labels(path, meta["classes"])
+        want_rows = z[f"file/{f['name']}/rows"]
+        assert np.array_equal(np.asarray(rows, dtype=np.float64).reshape(-1, 5), want_rows), f["name"]
+        for (Sx, Sy) in ((129, 97), (33, 25)):
+            want = torch.from_numpy(z[f"file/{f['name']}/{Sx}x{Sy}"])
+            got = O.label_rows_to_tensor(torch.tensor(rows, dtype=torch.float32).reshape(-1, 5), Sx, Sy)
+            assert torch.equal(got, want), (f["name"], Sx, Sy)
+
+
+def test_oracle_flips_match_reference_vectors():
+    z, meta = _golden()
+    for c in meta["flips"]:
+        n = c["name"]
+        img, lab = torch.from_numpy(z[f"flip/{n}/img"]), torch.from_numpy(z[f"flip/{n}/lab"])
+        hi, hl = O.hflip_with_bbs(img, lab)
+        vi, vl = O.vflip_with_bbs(img, lab)
+        bi, bl = O.vflip_with_bbs(*O.hflip_with_bbs(img, lab))
+        for tag, (gi, gl) in (("h", (hi, hl)), ("v", (vi, vl)), ("hv", (bi, bl)), ("h0", (img, lab)), ("v0", (img, lab))):
+            assert torch.equal(gi, torch.from_numpy(z[f"flip/{n}/{tag}/img"])), (n, tag)
+            assert torch.equal(gl, torch.from_numpy(z[f"flip/{n}/{tag}/lab"])), (n, tag)
+
+
+@pytest.mark.gpu
+def test_hip_data_step_matches_reference_vectors(tmp_path):
+    """labels_rasterize_kernel / flip kernels (data_aug.hip) against the vectors of the reference's own functions, bit for bit"""
+    from yogo_amd import data as D
+
+    z, meta = _golden()
+    for c in meta["rast"]:
+        rows = torch.from_numpy(z[f"rast/{c['name']}/rows"])
+        want = torch.from_numpy(z[f"rast/{c['name']}/out"])
+        assert torch.equal(D.format_labels_tensor(rows.cuda(), c["Sx"], c["Sy"]).cpu(), want), c
+    for c in meta["rast_err"]:
+        rows = torch.from_numpy(z[f"rast_err/{c['name']}/rows"])
+        if c["raises"] == "IndexError":
+            with pytest.raises(IndexError):
+                D.format_labels_tensor(rows.cuda(), c["Sx"], c["Sy"])
+    for f in meta["files"]:
+        path = tmp_path / f["name"]
+        path.write_text(f["text"])
+        for (Sx, Sy) in ((129, 97), (33, 25)):
+            got = D.label_file_to_tensor(path, Sx, Sy, meta["classes"])
+            assert torch.equal(got.cpu(), torch.from_numpy(z[f"file/{f['name']}/{Sx}x{Sy}"])), (f["name"], Sx, Sy)
+    for c in meta["flips"]:
+        n = c["name"]
+        img, lab = torch.from_numpy(z[f"flip/{n}/img"]), torch.from_numpy(z[f"flip/{n}/lab"])
+        for tag, (h, v) in (("h", (True, False)), ("v", (False, True)), ("hv", (True, True))):
+            gi, gl = D.flip_batch(img.cuda(), lab.cuda(), h, v)
+            assert torch.equal(gi.cpu(), torch.from_numpy(z[f"flip/{n}/{tag}/img"])), (n, tag)
+            assert torch.equal(gl.cpu(), torch.from_numpy(z[f"flip/{n}/{tag}/lab"])), (n, tag)

@@ -80,6 +80,26 @@ def _worker(rank, world, port, tmp):
     want = torch.cat([sum(g[n] for g in all_g).flatten() / world for n in names])
     torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-7)
     assert abs(cosine_lr(0, 3e-4, 10, 3e-5) - 3e-4) < 1e-12 and abs(cosine_lr(10, 3e-4, 10, 3e-5) - 3e-5) < 1e-12
+    # BatchNorm buffers: ranks drift apart in training (per-rank batch statistics, no SyncBN), HipTrainer.broadcast_buffers hands
+    # everyone rank 0's before evaluation (DDP's broadcast_buffers, yogo/train.py:155-159): one flat broadcast
+    with torch.no_grad():
+        for name_, b_ in model.named_buffers():
+            if "running_mean" in name_:
+                b_.fill_(float(rank) + 0.25)
+            elif "running_var" in name_:
+                b_.fill_(2.0 + rank)
+            elif "num_batches" in name_:
+                b_.fill_(7 + rank)
+    gen0 = tr.engine.generation
+    tr.broadcast_buffers()
+    for name_, b_ in model.named_buffers():
+        if "running_mean" in name_:
+            assert bool((b_ == 0.25).all()), name_
+        elif "running_var" in name_:
+            assert bool((b_ == 2.0).all()), name_
+        elif "num_batches" in name_:
+            assert int(b_) == 7 and b_.dtype == torch.long, name_
+    assert tr.engine.generation == gen0 + 1      # folded inference weights derive from these buffers: caches must be dropped
     flat.publish_grads()
     assert all(p.grad is not None and p.grad.data_ptr() == flat.grad_views[id(p)].data_ptr() for p in model.parameters())
     if rank == 0:

@@ -42,6 +42,11 @@ def test_two_ranks_on_one_card(tmp_path, half):
     assert 0 < res[0]["split_off"] < res[0]["flat"].numel()
     # BatchNorm statistics stay per rank (the reference has no SyncBN): different shards -> different running means
     assert not torch.equal(res[0]["sd1"]["model.0.1.running_mean"], res[1]["sd1"]["model.0.1.running_mean"])
+    # ... until the Trainer is about to evaluate: HipTrainer.broadcast_buffers hands every rank rank 0's statistics (DDP's
+    # broadcast_buffers=True, yogo/train.py:155-159) -- running_mean / running_var / num_batches_tracked of every BatchNorm
+    for k, v in res[0]["sd1"].items():
+        if "running" in k or "num_batches" in k:
+            assert torch.equal(res[1]["sd2"][k], v) and torch.equal(res[0]["sd2"][k], v), k
     # oracle: per-rank gradients (own batch statistics), clamped per rank, averaged, one AdamW step
     sd0 = res[0]["sd0"]
     Himg, Wimg, C, Bper = 96, 128, 5, 2

@@ -285,3 +285,71 @@ def test_production_batch_step_and_kernel_set():
         assert conv <= SEEN, f"launched at B=128 but not covered by the per-layer parity tests: {sorted(conv - SEEN)}"
     loss_ref, grads_ref, ns = _oracle_step(sd0, x2, lab2, "cpu")
     _compare_step(tr, m, loss_ref, grads_ref, ns, "B=128 (64 x 2 images) vs bf16-emulating CPU oracle on the 2 images")
+
+
+# ---- BASELINE configs[1]: fp32 forward + loss at 772x1032, batch 64 ------------------------------------------------------------------
+def _fp32_kernels(lines):
+    out = set()
+    for ln in lines:
+        m = re.match(r"\s*((?:conv_igemm_f32_kernel|conv_first_kernel)[^|]*)\|", ln)
+        if m:
+            out.add(re.sub(r"\s+", "", m.group(1)))
+    return out
+
+
+def test_fp32_train_forward_and_loss_at_772x1032():
+    """configs[1] (what bench.py::fp32_forward_loss times): the fp32 TRAIN-mode forward (BatchNorm batch statistics, decode) + fused
+    loss kernel at the production image size.  B = 2 against the oracle's fp32 forward + loss on the CPU (yogo/model.py:267-313,
+    yogo/yogo_loss.py:38-129; prediction rtol 1e-4 / atol 1e-4 of its range, loss + components 1e-4, running statistics 2e-4);
+    then batch 64 = 32 copies of the two images: same batch statistics, so the same prediction per copy and the same mean loss --
+    with the launch log showing the conv_igemm_f32_kernel<...> instantiations of the batch-64 run (incl. <4, 2, .>, the kernel of
+    the bench line's fp32 roofline): the kernels bench.py measures are the kernels held to the oracle here"""
+    from yogo_amd.model import YOGO
+    from yogo_amd.yogo_loss import YOGOLoss
+
+    h = H()
+    torch.manual_seed(31)
+    m = YOGO((HI, WI), 0.0425, 0.0555, C).cuda()
+    m.train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout2d):
+            mod.p = 0.0
+    sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    x2 = O.synthetic_images(2, HI, WI, seed=32)
+    lab2 = O.synthetic_labels(2, m.Sx, m.Sy, K=64, num_classes=C, seed=33)
+    L = YOGOLoss().cuda()
+    spec = O.arch("base_model", C)
+    ns = {}
+    with torch.no_grad():
+        want = O.yogo_forward(x2, sd0, spec, 0.0425, 0.0555, train=True, new_stats=ns)
+        wloss, wcomps = O.yogo_loss(want, lab2)
+    seen = {}
+    for B in (2, 64):
+        m.load_state_dict(sd0)
+        rep = B // 2
+        x, lab = x2.cuda().repeat(rep, 1, 1, 1), lab2.cuda().repeat(rep, 1, 1, 1)
+        h.launch_log(True)
+        with torch.no_grad():
+            out = m(x)
+            loss, comps = L(out, lab)
+        torch.cuda.synchronize()
+        h.launch_log(False)
+        seen[B] = _fp32_kernels(h.read_launch_log())
+        scale = float(want.abs().max())
+        for r in (0, rep - 1):   # first and last copy
+            d = float((out[2 * r:2 * r + 2].cpu() - want).abs().max())
+            assert d < 1e-4 * scale + 1e-4, (B, r, d, scale)
+        assert abs(float(loss) - float(wloss)) < 1e-4 * abs(float(wloss)), (B, float(loss), float(wloss))
+        for k in wcomps:
+            assert abs(comps[k] - wcomps[k]) < 1e-4 * abs(wcomps[k]) + 1e-6, (B, k, comps[k], wcomps[k])
+        sd = m.state_dict()
+        for k, v in ns.items():
+            if "num_batches" in k:
+                assert int(sd[k]) == int(v)
+            elif "running_mean" in k or B == 2:
+                torch.testing.assert_close(sd[k].cpu(), v, rtol=2e-4, atol=2e-4)
+            # (running_var at B = 64: the unbiased n / (n - 1) factor differs by < 1e-6 at these element counts -- same bound)
+            else:
+                torch.testing.assert_close(sd[k].cpu(), v, rtol=2e-4, atol=2e-4)
+    assert any(k.startswith("conv_igemm_f32_kernel<4,2") for k in seen[64]), seen[64]   # the kernel of bench.py's fp32 roofline line
+    print("fp32 kernels at B=64:", sorted(seen[64]))

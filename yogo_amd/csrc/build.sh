@@ -12,8 +12,20 @@ DEFS=()
 if [[ "${1:-}" == "diag" ]]; then OBJ="$HERE/obj_diag"; LIBNAME="libyogo_hip_diag.so"; DEFS=(-DYOGO_DIAG -DYOGO_DIAG_PHASES); fi
 # diag-coarse: start / loop / epilogue / end stamps only (the per-phase sums of the ping-pong loop cost it scalar registers)
 if [[ "${1:-}" == "diag-coarse" ]]; then OBJ="$HERE/obj_diagc"; LIBNAME="libyogo_hip_diag.so"; DEFS=(-DYOGO_DIAG); fi
-mkdir -p "$OUT" "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+# variant TAG FILE [-DNAME=VALUE ...]: libyogo_hip_TAG.so = the product objects with FILE.hip recompiled under the given macros
+# (in-process A/B of a compile-time choice: tools/ab_variants.py loads several such libraries side by side).  Build the product first.
+if [[ "${1:-}" == "variant" ]]; then
+  TAG="$2"; FILE="$3"; shift 3
+  VOBJ="$HERE/obj_var"; mkdir -p "$VOBJ" "$OUT"
+  extra=(); case "$FILE" in nms|decode_loss) extra=(-ffp-contract=off) ;; esac
+  "$HIPCC" -O3 --offload-arch=gfx950 -fPIC -std=c++17 -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -I"$HERE" -I"$HERE/../../include" "$@" "${extra[@]}" -c "$HERE/$FILE.hip" -o "$VOBJ/${TAG}_$FILE.o"
+  objs=(); for o in "$HERE/obj"/*.o; do [[ "$(basename "$o")" == "$FILE.o" ]] || objs+=("$o"); done
+  "$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" "$VOBJ/${TAG}_$FILE.o" -ldl -o "$OUT/libyogo_hip_$TAG.so"
+  echo "built $OUT/libyogo_hip_$TAG.so"
+  exit 0
+fi
+mkdir -p "$OUT" "$OBJ"
 COMMON=(-O3 --offload-arch=gfx950 -fPIC -std=c++17 -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -I"$HERE" -I"$HERE/../../include" "${DEFS[@]}")
 pids=()
 for f in "$HERE"/*.hip; do
