@@ -454,9 +454,8 @@ def test_bf16_training_other_architectures(name, hw, rgb):
     widths 4..384; rgb input; the direct layer-0 kernels at odd sizes) against the oracle's bf16-storage emulation
     (O.bf16_train_step): step 1 -- end to end loss 1e-3 and every gradient tensor cosine >= 0.995, and TEACHER-FORCED every
     stored tensor / statistic / parameter gradient given the step's own inputs (one bf16 ulp, 2e-4 of max|g|: tests/_util.py);
-    then the oracle applies AdamW to ITS gradients and emulates step 2: the HIP path's second loss (its own gradients -> fused
-    AdamW -> repacked bf16 weights -> forward) must agree to 2e-2 (the loss falls by 50-80 % in this one step, and Adam's first
-    update is lr * sign(g): a gradient component that is rounding noise moves its weight either way; measured <= 8e-3)"""
+    then the update: the fused AdamW on the step's own gradients against the oracle's AdamW, and the SECOND step's loss against
+    the emulation started from the step's own updated parameters (1e-3)"""
     from _util import BF16_STEP_LOSS_RTOL, assert_grads_match_bf16_oracle, teacher_forced_bf16_step_check
     from yogo_amd.model import YOGO
     from yogo_amd.model_defns import MODELS
@@ -488,12 +487,18 @@ def test_bf16_training_other_architectures(name, hw, rgb):
         mine[pname] = tr.flat.grad[off:off + p.numel()].view(p.shape).cpu()
         off += p.numel()
     assert_grads_match_bf16_oracle(mine, grads_ref, f"{name} {H_}x{W_}")
-    # ---- step 2: the oracle's own AdamW update of its own gradients, then its emulation of the second step
-    sd1 = dict(sd0)
-    for k, g in grads_ref.items():
-        sd1[k], _, _ = O.adamw_step(sd0[k], g, torch.zeros_like(g), torch.zeros_like(g), 1, tr.lr, weight_decay=tr.wd)
+    # ---- the update and step 2, again with the step's own tensors (the END-TO-END second loss is ill-conditioned: the loss falls by
+    # 50-80 % in this one step and Adam's first update is lr * sign(g), so gradient components that are rounding noise move their
+    # weights either way -- measured 1e-4 ... 1e-1 between two correct implementations on the wide models):
+    #   (i) the fused AdamW kernel on the step's OWN gradients == the oracle's AdamW on those gradients;
+    #   (ii) the second step's loss == the emulation's loss from the step's OWN updated parameters (repacked bf16 weights, forward,
+    #        decode, loss), 1e-3.
+    sd1 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    for k, g in mine.items():
+        want_p, _, _ = O.adamw_step(sd0[k], g, torch.zeros_like(g), torch.zeros_like(g), 1, tr.lr, weight_decay=tr.wd)
+        assert float((sd1[k] - want_p).abs().max()) < 2e-6 + 1e-5 * tr.lr, (name, k)
     loss2_ref, _, _, _ = O.bf16_train_step(x, sd1, spec, lab, 0.0425, 0.0555)
     tr.step(x.cuda(), lab.cuda())
     got2 = tr.loss_components()["loss"]
-    print(f"{name} {H_}x{W_}: loss {got:.5f} -> {got2:.5f}; oracle {loss_ref:.5f} -> {loss2_ref:.5f}")
-    assert abs(got2 - loss2_ref) < 2e-2 * abs(loss2_ref), (name, got2, loss2_ref)
+    print(f"{name} {H_}x{W_}: loss {got:.5f} -> {got2:.5f}; oracle {loss_ref:.5f} -> {loss2_ref:.5f} (from the step's own parameters)")
+    assert abs(got2 - loss2_ref) < BF16_STEP_LOSS_RTOL * abs(loss2_ref), (name, got2, loss2_ref)
