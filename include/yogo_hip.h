@@ -124,6 +124,16 @@ int yogo_format_preds_workspace_bytes(int B, int Sy, int Sx, size_t* bytes);
 int yogo_format_preds_batched(const float* pred, float* out_rows, long long* out_cells, int* out_count, void* workspace,
                               int B, int P, int Sy, int Sx, int cap, double obj_thresh, double iou_thresh, int box_format,
                               double min_class_confidence_threshold, yogo_stream_t stream);
+/* The inference driver's fused form of yogo_decode_fwd + yogo_format_preds_batched (SURVEY.md 8(b) `decode_nms_batched`): `raw` is
+ * the head's output BEFORE YOGO.forward's decode (yogo/model.py:277-313); the kernel decodes each value where it loads it, so the
+ * decoded [B, 5+C, Sy, Sx] tensor that `yogo infer` hands from the model to format_preds (yogo/infer.py:45,73) never goes through
+ * memory.  Rows, cells and counts are bit-identical to the two separate calls.  cxs / cys / anchor / multipliers / inference as
+ * yogo_decode_fwd, the rest as yogo_format_preds_batched (same workspace query).                                              */
+int yogo_decode_format_preds_batched(const float* raw, const float* cxs, const float* cys, float* out_rows, long long* out_cells,
+                                     int* out_count, void* workspace, int B, int P, int Sy, int Sx, int cap, float anchor_w,
+                                     float anchor_h, float width_multiplier, float height_multiplier, int inference,
+                                     double obj_thresh, double iou_thresh, int box_format, double min_class_confidence_threshold,
+                                     yogo_stream_t stream);
 
 /* ---- bf16 path: the bf16-autocast forward of `yogo infer` (yogo/infer.py:313-317) and half-precision training
  * (yogo/train.py:315-318, --half) -------------------------------------------------------------------------------------------

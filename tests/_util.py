@@ -90,13 +90,14 @@ def assert_grads_match_bf16_oracle(got, want, what, cos_min=BF16_STEP_COS_MIN, v
 # its channel) to cosine 0.997-0.9999.  So the whole step is held to loss 1e-3 and per-tensor cosine >= 0.995 (end to end), and
 # each KERNEL is held tightly here with its actual inputs:
 #   stored bf16 tensors: at most ONE bf16 ulp (|d| <= 2^-7 max(|a|, |b|)), plus 8e-6 of the tensor's range for values formed by
-#     cancellation, and at most 2 % of the elements differing at all;
-#   BatchNorm statistics 1e-5; parameter gradients 2e-4 of the tensor's maximum (layer 0: 2e-3, its sums cancel ~1000-fold).
+#     cancellation, and at most 0.2 % of the elements differing at all (measured, 772x1032 and ten other shapes: <= 2.7e-4);
+#   BatchNorm statistics 1e-5; parameter gradients 5e-5 of the tensor's maximum (measured <= 6e-6; layer 0: 5e-4, its sums cancel
+#     ~1000-fold).
 TF_ULP = 2.0 ** -7
 TF_FLOOR = 8e-6
-TF_FLIP_FRAC = 0.02
-TF_GRAD_RTOL = 2e-4
-TF_GRAD_RTOL_L0 = 2e-3
+TF_FLIP_FRAC = 2e-3
+TF_GRAD_RTOL = 5e-5
+TF_GRAD_RTOL_L0 = 5e-4
 
 
 def from8c_cpu(t, C):

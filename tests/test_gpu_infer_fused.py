@@ -1,0 +1,101 @@
+"""The inference driver's fused decode + threshold + NMS (`yogo_decode_format_preds_batched`, SURVEY.md 8(b) `decode_nms_batched`)
+against the two separate calls it replaces (yogo/model.py:277-313 -> yogo/utils/prediction_formatting.py:23-93, call sites
+yogo/infer.py:45,73).  The bar is bit-identity of rows, cells and counts with `format_preds_batched(decode(raw))`; that two-pass
+form is itself held bit-exact to the oracle's format_preds on the same decoded tensor in test_gpu_parity.py, which pins the fused
+form by transitivity (the decode's own transcendental rounding is the one thing the CPU oracle cannot reproduce bit for bit)."""
+import pytest
+import torch
+
+import yogo_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _raw_cases():
+    g = torch.Generator().manual_seed(90)
+    Sx, Sy, B = 129, 97, 5
+    dense = torch.randn(B, 12, Sy, Sx, generator=g) * 1.5
+    dense[:, 4] += 2.0                                   # ~90 % of the cells pass 0.5: the NMS worst case
+    sparse = torch.randn(B, 12, Sy, Sx, generator=g)
+    sparse[:, 4] = torch.randn(B, Sy, Sx, generator=g) - 2.5
+    # objects seen by 2-4 neighbouring cells with nearly the same box: suppression has work to do
+    for b in range(B):
+        ys = torch.randint(1, Sy - 2, (120,), generator=g)
+        xs = torch.randint(1, Sx - 2, (120,), generator=g)
+        for y, x in zip(ys.tolist(), xs.tolist()):
+            sparse[b, 4, y, x] = 2.0 + torch.rand(1, generator=g).item()
+            for dy, dx in ((0, 1), (1, 0), (1, 1))[: int(torch.randint(1, 4, (1,), generator=g))]:
+                sparse[b, :, y + dy, x + dx] = sparse[b, :, y, x] + 0.05 * torch.randn(12, generator=g)
+    odd = torch.randn(3, 9, 7, 11, generator=g)          # 4 classes, a grid that is no multiple of anything
+    odd[0, 2, 1, 1] = 95.0                               # width clamp at exp(80) -> inf
+    odd[0, 4, 1, 1] = 4.0
+    odd[1, 5:, 2, 3] = float("nan")                      # NaN class logits
+    odd[1, 4, 2, 3] = 5.0
+    odd[1, 4, 0, 0] = float("nan")                       # NaN objectness: not > thresh
+    odd[2, 4] = -20.0                                    # nothing passes
+    return {"dense": dense, "sparse": sparse, "odd": odd}
+
+
+def _two_pass(raw, grids, scal, inference, **kw):
+    from yogo_amd.utils.prediction_formatting import RawPredictions, format_preds_batched
+
+    rp = RawPredictions(raw, grids[0], grids[1], *scal, inference)
+    return format_preds_batched(rp.decoded(), **kw), format_preds_batched(rp, **kw)
+
+
+@pytest.mark.parametrize("kind", ["dense", "sparse", "odd"])
+def test_fused_decode_format_preds_is_bit_identical_to_the_two_passes(kind):
+    raw = _raw_cases()[kind].cuda()
+    B, P, Sy, Sx = raw.shape
+    cxs, cys = (t.cuda() for t in O.make_grids(Sx, Sy))
+    total = 0
+    for inference in (True, False):
+        for scal in ((0.0425, 0.0555, 1.0, 1.0), (0.05, 0.07, 1.0, 772 / 193)):
+            for kw in (dict(), dict(box_format="xyxy", min_class_confidence_threshold=0.3), dict(iou_thresh=0.0),
+                       dict(obj_thresh=0.8, iou_thresh=0.2)):
+                (r0, c0, n0), (r1, c1, n1) = _two_pass(raw, (cxs, cys), scal, inference, **kw)
+                assert torch.equal(n0, n1), (kind, inference, kw)
+                for b, n in enumerate(n0.cpu().tolist()):
+                    assert torch.equal(c0[b, :n], c1[b, :n]), (kind, inference, kw, b)
+                    # bitwise (NaN rows included): compare the float32 bit patterns
+                    assert torch.equal(r0[b, :n].view(torch.int32), r1[b, :n].view(torch.int32)), (kind, inference, kw, b)
+                    total += n
+    assert total > 0
+    if kind == "odd":
+        (_, c, n), _ = _two_pass(raw, (cxs, cys), (0.0425, 0.0555, 1.0, 1.0), True)
+        assert int(n[2]) == 0 and int(n[0]) > 0 and 1 * 11 + 1 in c[0, : int(n[0])].tolist()
+
+
+def test_forward_raw_feeds_the_inference_outputs_without_a_decode_pass(tmp_path):
+    """YOGO.forward_raw -> save_predictions / class counts / numpy rows: same files and arrays as from model(x), with ONE
+    nms_batched_kernel<true> launch per output and no decode_fwd_kernel launch (launch log)"""
+    import numpy as np
+
+    from yogo_amd import _hip
+    from yogo_amd.model import YOGO
+    from yogo_amd.utils import format_to_numpy_batched, get_prediction_class_counts, save_predictions
+
+    torch.manual_seed(5)
+    m = YOGO((193, 258), 0.0425, 0.0555, 7, inference=True).cuda().eval()
+    x = O.synthetic_images(4, 193, 258, seed=91).cuda()
+    for half in (False, True):
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=half):
+            full = m(x)
+            _hip.launch_log(True)
+            raw = m.forward_raw(x)
+            names = [str(tmp_path / f"a{int(half)}_{i}.txt") for i in range(4)]
+            save_predictions(names, raw, obj_thresh=0.4, iou_thresh=0.5)
+            counts = get_prediction_class_counts(raw, obj_thresh=0.4)
+            arrs = format_to_numpy_batched([0, 1, 2, 3], raw, 193, 258)
+            log = _hip.read_launch_log()
+            _hip.launch_log(False)
+        assert sum("nms_batched_kernel<true>" in ln for ln in log) == 3, log
+        assert not any("decode_fwd_kernel" in ln or "nms_batched_kernel<false>" in ln for ln in log), log
+        assert torch.equal(raw.decoded(), full)
+        ref = [str(tmp_path / f"b{int(half)}_{i}.txt") for i in range(4)]
+        save_predictions(ref, full, obj_thresh=0.4, iou_thresh=0.5)
+        assert [open(n).read() for n in names] == [open(n).read() for n in ref]
+        assert any(open(n).read() for n in names)
+        assert torch.equal(counts, get_prediction_class_counts(full, obj_thresh=0.4))
+        for a, b in zip(arrs, format_to_numpy_batched([0, 1, 2, 3], full, 193, 258)):
+            assert np.array_equal(a, b, equal_nan=True)

@@ -85,5 +85,50 @@ if mf:
         for r in rows[:28]:
             f.write(f"{r[1][:66]:66s} {r[2]:8d} {r[3]:14.0f} {r[4]:10.3f} {r[5]:9.2f} {r[6]:10.2f} {r[7]:7.2f}\n")
     print(open(f"profiles/{tag}_mfma_util.txt").read())
+# ---- inference path (tools/infer_profile.py) -----------------------------------------------------------------------------
+def stats_table(pattern, header, n=24):
+    f = one(pattern) or one(pattern.replace("/", "/*/", 1))
+    if not f:
+        return []
+    out = [header, f"{'kernel':78s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>6s}"]
+    for r in list(csv.DictReader(open(f)))[:n]:
+        name = r["Name"].replace("(anonymous namespace)::", "").split("(")[0][:78]
+        out.append(f"{name:78s} {r['Calls']:>6s} {float(r['TotalDurationNs'])/1e6:10.3f} {float(r['AverageNs'])/1e3:10.1f} {float(r['Percentage']):6.2f}")
+    return out
+
+
+inf = []
+for leg, args in (("infer_e2e", "e2e 5"), ("infer_post", "post 10")):
+    t = stats_table(f"{leg}/*kernel_stats.csv",
+                    f"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/infer_profile.py {args}   ({tag}; batch 256, bf16 eval forward, 772x1032)")
+    if t:
+        log = os.path.join(src, leg + ".log")
+        js = [ln.strip() for ln in open(log) if ln.startswith("{")] if os.path.exists(log) else []
+        inf += t + (["# HIP-event times of the same run: " + js[-1]] if js else []) + [""]
+if inf:
+    open(f"profiles/{tag}_infer_kernel_stats.txt", "w").write("\n".join(inf))
+    print("\n".join(inf))
+itraffic = {}
+for kind, pat, mult in (("fetch", "infer_fetch/*counter_collection.csv", 2.0), ("write", "infer_write/*counter_collection.csv", 1.0)):
+    f = one(pat) or one(pat.replace("/", "/*/", 1))
+    if not f:
+        continue
+    agg = defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+        agg[k][0] += float(r["Counter_Value"]) * 1024.0 * mult
+        agg[k][1] += 1
+    for k, (tot, n) in agg.items():
+        itraffic.setdefault(k, {})[kind] = tot / n
+        itraffic[k]["n"] = n
+if itraffic:
+    with open(f"profiles/{tag}_infer_hbm_traffic.txt", "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python3 tools/infer_profile.py post 3  ({tag})\n")
+        f.write("# bytes per launch at batch 256; FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md HBM section); algorithmic: 154 MB read of the\n")
+        f.write("# [256, 12, 97, 129] fp32 head output per pass (+ 154 MB written by the separate decode)\n")
+        for k, v in sorted(itraffic.items(), key=lambda kv: -(kv[1].get("fetch", 0) + kv[1].get("write", 0)))[:10]:
+            f.write(f"{k:60s} fetch {v.get('fetch',0)/1e6:10.1f} MB  write {v.get('write',0)/1e6:10.1f} MB  n={v.get('n')}\n")
+    print(open(f"profiles/{tag}_infer_hbm_traffic.txt").read())
+    json.dump(itraffic, open("profiles/traffic_infer.json", "w"), indent=1, sort_keys=True)
 print(open(f"profiles/{tag}_kernel_stats.txt").read()[:3200])
 print(open(f"profiles/{tag}_hbm_traffic.txt").read())

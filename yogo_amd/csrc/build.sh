@@ -35,7 +35,7 @@ for f in "$HERE"/*.hip; do
     nms|decode_loss) extra=(-ffp-contract=off) ;;
   esac
   stale=0
-  for dep in "$f" "$HERE/common.h" "$HERE"/"$base"_*.inc; do
+  for dep in "$f" "$HERE"/*.h "$HERE/../../include"/*.h "$HERE"/"$base"_*.inc; do
     [[ -f "$dep" && ( ! -f "$OBJ/$base.o" || "$dep" -nt "$OBJ/$base.o" ) ]] && stale=1
   done
   if [[ "$stale" == 1 ]]; then

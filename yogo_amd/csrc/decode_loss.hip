@@ -438,6 +438,7 @@ extern "C" int yogo_decode_fwd(const float* raw, float* out, const float* cxs, c
   YOGO_CHECK_ARG(B >= 0 && P > 5 && P - 5 <= MAX_CLASSES && Sy > 0 && Sx > 0 && B <= 65535, "decode_fwd: bad shape");
   if (B == 0) return YOGO_OK;
   const int cells = Sy * Sx;
+  yogo_launch_log("decode_fwd_kernel | B=%d cells=%d P=%d inference=%d", B, cells, P, inference);
   hipLaunchKernelGGL(decode_fwd_kernel, dim3(cdiv(cells, 256), B), dim3(256), 0, stream, raw, out, cxs, cys,
                      (float)(1.0 / Sx), (float)(1.0 / Sy), anchor_w, anchor_h, width_multiplier, height_multiplier, P, cells,
                      inference);

@@ -16,6 +16,11 @@
 // Bit-exactness contract: fp32 arithmetic in the same operation order as the CPU reference, no FMA contraction
 // (-ffp-contract=off for this TU), correctly rounded division, IoU compared in double against the double threshold,
 // objectness / class thresholds compared in float32 (torch casts the Python scalar to the tensor dtype).
+//
+// DEC = true (yogo_decode_format_preds_batched) takes the head's RAW output and decodes a value where it is loaded (the
+// arithmetic of decode_fwd_kernel, decode_loss.hip: same expressions, same -ffp-contract=off, so each value has the bits the
+// separate decode pass would have stored): the decoded [B, 5+C, Sy, Sx] tensor of `yogo infer` (yogo/model.py:277-313 ->
+// yogo/infer.py:45,73) is never written or read back, and the kept rows / cells / counts are identical.
 #include "common.h"
 
 #define NMS_THREADS 1024
@@ -37,6 +42,69 @@ struct NmsParams {
   double iou_thresh;
   float min_cls;          // float32(min_class_confidence_threshold)
   int do_nms, use_cls_filter, xyxy;
+  // DEC only: the decode's operands (yogo_decode_fwd)
+  const float* cxs;       // [cells]
+  const float* cys;       // [cells]
+  float inv_sx, inv_sy, anchor_w, anchor_h, wmul, hmul;
+  int inference;          // class channels: softmax (1) or raw logits (0)
+};
+
+__device__ __forceinline__ float nms_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// One image's prediction as the kernel sees it: the decoded tensor itself (DEC = false) or the raw head output decoded per load.
+template <bool DEC>
+struct PredView {
+  const float* pred;   // [P][cells] of this image
+  const NmsParams& p;
+  __device__ __forceinline__ float at(int ch, int cell) const { return pred[(size_t)ch * p.cells + cell]; }
+  __device__ __forceinline__ float obj(int cell) const { return DEC ? nms_sigmoid(at(4, cell)) : at(4, cell); }
+  __device__ __forceinline__ void box(int cell, float& cx, float& cy, float& w, float& h) const {
+    if (DEC) {
+      cx = p.inv_sx * nms_sigmoid(at(0, cell)) + p.cxs[cell];
+      cy = p.inv_sy * nms_sigmoid(at(1, cell)) + p.cys[cell];
+      w = p.anchor_w * expf(fminf(at(2, cell), 80.f)) * p.wmul;
+      h = p.anchor_h * expf(fminf(at(3, cell), 80.f)) * p.hmul;
+    } else {
+      cx = at(0, cell);
+      cy = at(1, cell);
+      w = at(2, cell);
+      h = at(3, cell);
+    }
+  }
+  // softmax normalisation of the cell (decode_fwd_kernel's mx / sum), only for DEC && inference
+  __device__ __forceinline__ void softmax_terms(int cell, float& mx, float& sum) const {
+    const int C = p.P - 5;
+    mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, at(5 + c, cell));
+    sum = 0.f;
+    for (int c = 0; c < C; ++c) sum += expf(at(5 + c, cell) - mx);
+  }
+  // NaN-propagating max over the class channels, like torch.max
+  __device__ __forceinline__ float max_cls(int cell) const {
+    const int C = p.P - 5;
+    float smx = 0.f, ssum = 1.f;
+    const bool sm = DEC && p.inference;
+    if (sm) softmax_terms(cell, smx, ssum);
+    float mx = sm ? expf(at(5, cell) - smx) / ssum : at(5, cell);
+    for (int c = 1; c < C; ++c) {
+      const float v = sm ? expf(at(5 + c, cell) - smx) / ssum : at(5 + c, cell);
+      mx = (v > mx || v != v) ? v : mx;
+      if (mx != mx) break;
+    }
+    return mx;
+  }
+  // channels 4.. of the output row
+  __device__ __forceinline__ void tail(int cell, float* dst) const {
+    const int P = p.P;
+    dst[4] = obj(cell);
+    if (DEC && p.inference) {
+      float smx, ssum;
+      softmax_terms(cell, smx, ssum);
+      for (int c = 5; c < P; ++c) dst[c] = expf(at(c, cell) - smx) / ssum;
+    } else {
+      for (int c = 5; c < P; ++c) dst[c] = at(c, cell);
+    }
+  }
 };
 
 __device__ __forceinline__ unsigned monotone_key(float s) {
@@ -65,6 +133,7 @@ __device__ __forceinline__ int block_rank(bool flag, int* sh_wave /*[NMS_WAVES+1
   return base + wrank;
 }
 
+template <bool DEC>
 __global__ __launch_bounds__(NMS_THREADS) void nms_batched_kernel(const NmsParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem_raw);  // [npow2] during the sort
@@ -76,8 +145,8 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_batched_kernel(const NmsParam
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x;
-  const int cells = p.cells, P = p.P, C = P - 5;
-  const float* pred = p.pred + (size_t)b * P * cells;
+  const int cells = p.cells, P = p.P;
+  const PredView<DEC> pv{p.pred + (size_t)b * P * cells, p};
   int* ws_cells = p.ws_cells + (size_t)b * cells;
   float4* ws_box = p.ws_box + (size_t)b * cells;
   float* ws_area = p.ws_area + (size_t)b * cells;
@@ -86,7 +155,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_batched_kernel(const NmsParam
   int n = 0;
   for (int base = 0; base < cells; base += NMS_THREADS) {
     const int cell = base + tid;
-    const bool f = (cell < cells) && (pred[(size_t)4 * cells + cell] > p.obj_thresh);
+    const bool f = (cell < cells) && (pv.obj(cell) > p.obj_thresh);
     int tot;
     const int r = block_rank(f, sh_wave, &tot);
     if (f) ws_cells[n + r] = cell;
@@ -109,13 +178,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_batched_kernel(const NmsParam
       unsigned long long key = 0ull;
       if (i < n) {
         const int cell = ws_cells[i];
-        float mx = pred[(size_t)5 * cells + cell];
-        for (int c = 1; c < C; ++c) {
-          const float v = pred[(size_t)(5 + c) * cells + cell];
-          mx = (v > mx || v != v) ? v : mx;  // NaN-propagating max like torch.max
-          if (mx != mx) break;
-        }
-        const float score = mx * pred[(size_t)4 * cells + cell];
+        const float score = pv.max_cls(cell) * pv.obj(cell);
         key = ((unsigned long long)monotone_key(score) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
       }
       keys[i] = key;
@@ -147,8 +210,8 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_batched_kernel(const NmsParam
         const unsigned ci = 0xFFFFFFFFu - (unsigned)(keys[j] & 0xFFFFFFFFull);
         const int cell = ws_cells[ci];
         mycell[k] = cell;
-        const float cx = pred[cell], cy = pred[(size_t)cells + cell];
-        const float w = pred[(size_t)2 * cells + cell], h = pred[(size_t)3 * cells + cell];
+        float cx, cy, w, h;
+        pv.box(cell, cx, cy, w, h);
         bx1[k] = cx - 0.5f * w;
         by1[k] = cy - 0.5f * h;
         bx2[k] = cx + 0.5f * w;
@@ -250,23 +313,15 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_batched_kernel(const NmsParam
     if (k * NMS_THREADS >= n) break;  // uniform
     bool keep = ((alive >> k) & 1u) != 0u;
     const int cell = mycell[k];
-    if (keep && p.use_cls_filter) {
-      float mx = pred[(size_t)5 * cells + cell];
-      for (int c = 1; c < C; ++c) {
-        const float v = pred[(size_t)(5 + c) * cells + cell];
-        mx = (v > mx || v != v) ? v : mx;
-        if (mx != mx) break;
-      }
-      keep = mx > p.min_cls;
-    }
+    if (keep && p.use_cls_filter) keep = pv.max_cls(cell) > p.min_cls;
     int tot;
     const int r = block_rank(keep, sh_wave, &tot);
     if (keep) {
       const int pos = nout + r;
       if (pos < p.cap) {
         float* dst = rows + (size_t)pos * P;
-        const float cx = pred[cell], cy = pred[(size_t)cells + cell];
-        const float w = pred[(size_t)2 * cells + cell], h = pred[(size_t)3 * cells + cell];
+        float cx, cy, w, h;
+        pv.box(cell, cx, cy, w, h);
         if (p.xyxy) {
           dst[0] = cx - 0.5f * w;
           dst[1] = cy - 0.5f * h;
@@ -278,7 +333,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_batched_kernel(const NmsParam
           dst[2] = w;
           dst[3] = h;
         }
-        for (int c = 4; c < P; ++c) dst[c] = pred[(size_t)c * cells + cell];
+        pv.tail(cell, dst);
         ocells[pos] = (long long)cell;
       }
     }
@@ -297,6 +352,39 @@ extern "C" int yogo_format_preds_workspace_bytes(int B, int Sy, int Sx, size_t* 
   return YOGO_OK;
 }
 
+template <bool DEC>
+static int launch_format_preds(NmsParams p, void* workspace, double obj_thresh, double iou_thresh, int box_format,
+                               double min_class_confidence_threshold, hipStream_t stream, const char* what) {
+  const int B = p.B, cells = p.cells;
+  char* ws = reinterpret_cast<char*>(workspace);
+  // float4 array first (16-byte alignment), then floats, then ints
+  size_t off = (16 - (reinterpret_cast<uintptr_t>(ws) & 15)) & 15;
+  p.ws_box = reinterpret_cast<float4*>(ws + off);
+  off += (size_t)B * cells * sizeof(float4);
+  p.ws_area = reinterpret_cast<float*>(ws + off);
+  off += (size_t)B * cells * sizeof(float);
+  p.ws_cells = reinterpret_cast<int*>(ws + off);
+  p.obj_thresh = (float)obj_thresh;
+  p.iou_thresh = iou_thresh;
+  p.min_cls = (float)min_class_confidence_threshold;
+  p.do_nms = iou_thresh > 0.0;
+  p.use_cls_filter = min_class_confidence_threshold > 0.0;
+  p.xyxy = box_format;
+  int npow2 = 64;
+  while (npow2 < cells) npow2 <<= 1;
+  const size_t lds = p.do_nms ? (size_t)npow2 * sizeof(unsigned long long) : 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_batched_kernel<DEC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              NMS_MAX_CELLS * 8);
+    attr_set = true;
+  }
+  yogo_launch_log("nms_batched_kernel<%s> | B=%d cells=%d P=%d nms=%d", DEC ? "true" : "false", B, cells, p.P, p.do_nms);
+  hipLaunchKernelGGL(nms_batched_kernel<DEC>, dim3(B), dim3(NMS_THREADS), lds, stream, p);
+  YOGO_CHECK_LAUNCH(what);
+  return YOGO_OK;
+}
+
 // pred [B][5+C][Sy][Sx] fp32 -> per image: count, kept rows [cap][5+C] in reference order, kept cell indices.
 // box_format: 0 = cxcywh, 1 = xyxy.  iou_thresh <= 0 disables NMS, min_class_confidence <= 0 disables the filter.
 extern "C" int yogo_format_preds_batched(const float* pred, float* out_rows, long long* out_cells, int* out_count,
@@ -310,31 +398,30 @@ extern "C" int yogo_format_preds_batched(const float* pred, float* out_rows, lon
   YOGO_CHECK_ARG(cells <= NMS_MAX_CELLS, "format_preds_batched: Sy*Sx = %d exceeds the supported %d cells", cells, NMS_MAX_CELLS);
   NmsParams p{};
   p.pred = pred; p.out_rows = out_rows; p.out_cells = out_cells; p.out_count = out_count;
-  char* ws = reinterpret_cast<char*>(workspace);
-  // float4 array first (16-byte alignment), then floats, then ints
-  size_t off = (16 - (reinterpret_cast<uintptr_t>(ws) & 15)) & 15;
-  p.ws_box = reinterpret_cast<float4*>(ws + off);
-  off += (size_t)B * cells * sizeof(float4);
-  p.ws_area = reinterpret_cast<float*>(ws + off);
-  off += (size_t)B * cells * sizeof(float);
-  p.ws_cells = reinterpret_cast<int*>(ws + off);
   p.B = B; p.P = P; p.cells = cells; p.cap = cap;
-  p.obj_thresh = (float)obj_thresh;
-  p.iou_thresh = iou_thresh;
-  p.min_cls = (float)min_class_confidence_threshold;
-  p.do_nms = iou_thresh > 0.0;
-  p.use_cls_filter = min_class_confidence_threshold > 0.0;
-  p.xyxy = box_format;
-  int npow2 = 64;
-  while (npow2 < cells) npow2 <<= 1;
-  const size_t lds = p.do_nms ? (size_t)npow2 * sizeof(unsigned long long) : 0;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_batched_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        NMS_MAX_CELLS * 8);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(nms_batched_kernel, dim3(B), dim3(NMS_THREADS), lds, stream, p);
-  YOGO_CHECK_LAUNCH("format_preds_batched");
-  return YOGO_OK;
+  return launch_format_preds<false>(p, workspace, obj_thresh, iou_thresh, box_format, min_class_confidence_threshold, stream,
+                                    "format_preds_batched");
+}
+
+// raw [B][5+C][Sy][Sx] fp32 = the head's output BEFORE the decode; everything else as yogo_format_preds_batched, whose result on
+// yogo_decode_fwd(raw) this reproduces bit for bit (rows, cells, counts) without the decoded tensor going through memory.
+extern "C" int yogo_decode_format_preds_batched(const float* raw, const float* cxs, const float* cys, float* out_rows,
+                                                long long* out_cells, int* out_count, void* workspace, int B, int P, int Sy,
+                                                int Sx, int cap, float anchor_w, float anchor_h, float width_multiplier,
+                                                float height_multiplier, int inference, double obj_thresh, double iou_thresh,
+                                                int box_format, double min_class_confidence_threshold, hipStream_t stream) {
+  YOGO_CHECK_ARG(raw && cxs && cys && out_rows && out_cells && out_count && workspace, "decode_format_preds_batched: null pointer");
+  YOGO_CHECK_ARG(B > 0 && P > 5 && Sy > 0 && Sx > 0 && cap > 0, "decode_format_preds_batched: bad shape");
+  YOGO_CHECK_ARG(box_format == 0 || box_format == 1, "invalid box format %d; valid box formats are 0 (cxcywh), 1 (xyxy)", box_format);
+  const int cells = Sy * Sx;
+  YOGO_CHECK_ARG(cells <= NMS_MAX_CELLS, "decode_format_preds_batched: Sy*Sx = %d exceeds the supported %d cells", cells, NMS_MAX_CELLS);
+  NmsParams p{};
+  p.pred = raw; p.out_rows = out_rows; p.out_cells = out_cells; p.out_count = out_count;
+  p.B = B; p.P = P; p.cells = cells; p.cap = cap;
+  p.cxs = cxs; p.cys = cys;
+  p.inv_sx = (float)(1.0 / Sx); p.inv_sy = (float)(1.0 / Sy);   // as yogo_decode_fwd
+  p.anchor_w = anchor_w; p.anchor_h = anchor_h; p.wmul = width_multiplier; p.hmul = height_multiplier;
+  p.inference = inference;
+  return launch_format_preds<true>(p, workspace, obj_thresh, iou_thresh, box_format, min_class_confidence_threshold, stream,
+                                   "decode_format_preds_batched");
 }

@@ -3,7 +3,8 @@
 Same arguments, output files and return value as the reference.  Per batch: ONE forward (fp32, or the bf16 matrix-core path
 under ``half`` -- the reference's bf16 autocast, infer.py:313-317) and, per requested output, ONE batched threshold + NMS
 launch for the whole batch (``save_predictions`` / ``format_to_numpy_batched`` / ``get_prediction_class_counts``) instead of the
-reference's per-image Python loops over ``format_preds`` (infer.py:45,73).  No ``torch.compile``: there is no graph to trace,
+reference's per-image Python loops over ``format_preds`` (infer.py:45,73); unless the decoded tensor itself is asked for, the box
+decode runs inside that launch's loads (``YOGO.forward_raw``).  No ``torch.compile``: there is no graph to trace,
 the model is already a fixed sequence of hand-written kernels.
 """
 from __future__ import annotations
@@ -117,7 +118,9 @@ def predict(
             continue
         x = img_batch.to(device, non_blocking=True)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bool(half)):
-            res = model(x)
+            # the decoded tensor itself is only needed for drawing and for return_full_predictions; every other output goes
+            # through the threshold + NMS kernel, which decodes the head's raw output as it loads it
+            res = model(x) if (draw_boxes or return_full_predictions) else model.forward_raw(x)
         if draw_boxes:
             for k in range(img_batch.shape[0]):
                 bbox_img = draw_yogo_prediction(img=img_batch[k, ...], prediction=res[k, ...], obj_thresh=obj_thresh, iou_thresh=iou_thresh,

@@ -247,7 +247,7 @@ class YOGO(nn.Module):
             self._scalars = (float(self.anchor_w), float(self.anchor_h), float(self.width_multiplier), float(self.height_multiplier))
         return self._scalars
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def _backbone(self, x: torch.Tensor) -> torch.Tensor:
         # we get either raw uint8 tensors or float tensors
         if x.ndim == 3:
             x.unsqueeze_(0)
@@ -256,7 +256,20 @@ class YOGO(nn.Module):
             x = x.float()
         eng = get_engine(self.model)
         eng.clip = self._clip
-        raw = self.model(x)
+        return self.model(x)
+
+    @torch.no_grad()
+    def forward_raw(self, x: torch.Tensor):
+        """the backbone + head WITHOUT the box decode, wrapped with the decode's operands: what ``format_preds_batched`` /
+        ``save_predictions`` / ``get_prediction_class_counts`` / ``format_to_numpy_batched`` take in place of ``model(x)`` to run the
+        decode inside the threshold + NMS kernel (the `yogo infer` path, yogo/infer.py:311-380, with no decoded tensor in memory)"""
+        from yogo_amd.utils.prediction_formatting import RawPredictions
+
+        raw = self._backbone(x)
+        return RawPredictions(raw, self._Cxs, self._Cys, *self._decode_scalars(), bool(self.inference))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        raw = self._backbone(x)
         aw, ah, wm, hm = self._decode_scalars()
         if torch.is_grad_enabled() and raw.requires_grad:
             return _DecodeFn.apply(raw, self._Cxs, self._Cys, aw, ah, wm, hm, bool(self.inference))

@@ -83,3 +83,19 @@ def synthetic_dense_predictions(B: int, Sx: int, Sy: int, num_classes: int = 7, 
     out[:, 4] = torch.where(fire, 0.5 + u, u)
     out[:, 5:] = torch.softmax(torch.randn(B, num_classes, Sy, Sx, device=device, generator=g) * 2, dim=1)
     return out
+
+
+def raw_from_predictions(pred: torch.Tensor, cxs: torch.Tensor, cys: torch.Tensor, anchor_w: float = 0.0425,
+                         anchor_h: float = 0.0555) -> torch.Tensor:
+    """a head output whose box decode (yogo/model.py:277-313, inference mode) gives `pred` back up to rounding: the input of the
+    fused decode + threshold + NMS kernel for the 'realistic' / 'dense' post-process workloads above"""
+    B, P, Sy, Sx = pred.shape
+    eps = 1e-4
+    raw = torch.empty_like(pred)
+    raw[:, 0] = torch.logit(((pred[:, 0] - cxs) * Sx).clamp(eps, 1 - eps))
+    raw[:, 1] = torch.logit(((pred[:, 1] - cys) * Sy).clamp(eps, 1 - eps))
+    raw[:, 2] = torch.log(pred[:, 2] / anchor_w)
+    raw[:, 3] = torch.log(pred[:, 3] / anchor_h)
+    raw[:, 4] = torch.logit(pred[:, 4].clamp(eps, 1 - eps))
+    raw[:, 5:] = torch.log(pred[:, 5:].clamp_min(1e-12))
+    return raw

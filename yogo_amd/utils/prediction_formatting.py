@@ -6,7 +6,7 @@ image from a Python loop; here the whole batch is one kernel launch and the per-
 """
 from __future__ import annotations
 
-from typing import List, Literal, Optional, Tuple, get_args
+from typing import List, Literal, Optional, Tuple, Union, get_args
 
 import torch
 
@@ -15,8 +15,46 @@ from yogo_amd import _hip
 BoxFormat = Literal["xyxy", "cxcywh"]
 
 
+class RawPredictions:
+    """The head's output of a batch BEFORE the box decode, with the decode's operands (``YOGO.forward_raw``).  Handed to
+    ``format_preds_batched`` (and everything built on it) in place of ``model(x)``, the decode of yogo/model.py:277-313 runs inside
+    the threshold + NMS kernel's loads (``yogo_decode_format_preds_batched``): the decoded tensor never goes through memory and the
+    rows / cells / counts are bit-identical to ``format_preds_batched(model(x))``.  ``decoded()`` gives that tensor when it is
+    wanted after all."""
+
+    def __init__(self, raw: torch.Tensor, cxs: torch.Tensor, cys: torch.Tensor, anchor_w: float, anchor_h: float,
+                 width_multiplier: float, height_multiplier: float, inference: bool):
+        if raw.ndim != 4:
+            raise ValueError(f"RawPredictions expects (B, pred_shape, Sy, Sx), got {tuple(raw.shape)}")
+        _hip.require_cuda(raw, "the raw prediction")
+        Sy, Sx = raw.shape[2:]
+        if tuple(cxs.shape) != (Sy, Sx) or tuple(cys.shape) != (Sy, Sx):
+            raise RuntimeError(f"yogo_amd: grid buffers {tuple(cxs.shape)} do not match the network output grid ({Sy}, {Sx})")
+        self.raw = raw.detach().contiguous().float()
+        self.cxs, self.cys = cxs.contiguous(), cys.contiguous()
+        self.scalars = (float(anchor_w), float(anchor_h), float(width_multiplier), float(height_multiplier))
+        self.inference = bool(inference)
+
+    @property
+    def shape(self) -> torch.Size:
+        return self.raw.shape
+
+    @property
+    def device(self) -> torch.device:
+        return self.raw.device
+
+    def decoded(self) -> torch.Tensor:
+        B, P, Sy, Sx = self.raw.shape
+        out = torch.empty_like(self.raw)
+        if B:
+            with torch.cuda.device(self.raw.device):
+                _hip.call("yogo_decode_fwd", self.raw, out, self.cxs, self.cys, B, P, Sy, Sx, *self.scalars, int(self.inference),
+                          _hip.stream_ptr())
+        return out
+
+
 def format_preds_batched(
-    pred: torch.Tensor,
+    pred: Union[torch.Tensor, RawPredictions],
     obj_thresh: float = 0.5,
     iou_thresh: float = 0.5,
     box_format: BoxFormat = "cxcywh",
@@ -26,14 +64,17 @@ def format_preds_batched(
 
     Image b's result is ``rows[b, :counts[b]]`` -- the same rows in the same order ``format_preds(pred[b])`` returns;
     ``cells`` are the flat grid-cell indices (y*Sx + x) the rows came from.  No host synchronisation happens here.
+    A ``RawPredictions`` (``YOGO.forward_raw``) is decoded inside the kernel, with the same result as its decoded tensor.
     """
-    if pred.ndim != 4:
+    raw = pred if isinstance(pred, RawPredictions) else None
+    if len(pred.shape) != 4:
         raise ValueError(f"format_preds_batched expects (B, pred_shape, Sy, Sx), got {tuple(pred.shape)}")
     if box_format not in get_args(BoxFormat):
         raise ValueError(f"invalid box format {box_format}; valid box formats are {get_args(BoxFormat)}")
-    _hip.require_cuda(pred, "pred")
+    if raw is None:
+        _hip.require_cuda(pred, "pred")
     B, P, Sy, Sx = pred.shape
-    p = pred.detach().contiguous().float()
+    p = raw.raw if raw is not None else pred.detach().contiguous().float()
     cap = Sy * Sx
     dev = pred.device
     rows = torch.empty(B, cap, P, dtype=torch.float32, device=dev)
@@ -43,8 +84,13 @@ def format_preds_batched(
         return rows, cells, counts
     with torch.cuda.device(dev):
         ws = torch.empty(_hip.query_size("yogo_format_preds_workspace_bytes", B, Sy, Sx), dtype=torch.uint8, device=dev)
-        _hip.call("yogo_format_preds_batched", p, rows, cells, counts, ws, B, P, Sy, Sx, cap, float(obj_thresh), float(iou_thresh),
-                  0 if box_format == "cxcywh" else 1, float(min_class_confidence_threshold), _hip.stream_ptr())
+        tail = (float(obj_thresh), float(iou_thresh), 0 if box_format == "cxcywh" else 1, float(min_class_confidence_threshold),
+                _hip.stream_ptr())
+        if raw is not None:
+            _hip.call("yogo_decode_format_preds_batched", p, raw.cxs, raw.cys, rows, cells, counts, ws, B, P, Sy, Sx, cap, *raw.scalars,
+                      int(raw.inference), *tail)
+        else:
+            _hip.call("yogo_format_preds_batched", p, rows, cells, counts, ws, B, P, Sy, Sx, cap, *tail)
     return rows, cells, counts
 
 
