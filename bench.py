@@ -131,7 +131,7 @@ def _timed_gpu(fn, reps=5):
 def inference_extras(model, dev, B: int = 256):
     """BASELINE configs[4] (secondary to the training metric): `yogo infer` at batch 256 -- eval forward + box decode + batched
     threshold / NMS (format_preds_batched) end to end on synthetic images (the network of this run, after its training steps),
-    and the NMS kernel alone on 'dense' predictions (93 % of the cells fire, what a random-init network gives: the worst
+    (`YOGO.forward_raw` -> the fused decode + threshold + NMS kernel), and the NMS kernel alone on 'dense' predictions (93 % of the cells fire, what a random-init network gives: the worst
     case) and on 'realistic' ones (100 objects per image).  Roofline of decode / NMS: HBM, algorithmic bytes 0.60 MB per image
     (SURVEY.md 8d)."""
     from yogo_amd.synthetic import synthetic_dense_predictions, synthetic_images, synthetic_predictions
@@ -147,12 +147,17 @@ def inference_extras(model, dev, B: int = 256):
             ms16 = _timed_gpu(lambda: model(x))
 
             def e2e():
-                format_preds_batched(model(x))
+                format_preds_batched(model.forward_raw(x))   # decode inside the threshold + NMS kernel's loads
             ms_e2e = _timed_gpu(e2e)
         dense = synthetic_dense_predictions(B, model.Sx, model.Sy, NUM_CLASSES, device=dev)
         ms_nd = _timed_gpu(lambda: format_preds_batched(dense), reps=2)
         real = synthetic_predictions(B, model.Sx, model.Sy, NUM_CLASSES, K=100, device=dev)
         ms_nr = _timed_gpu(lambda: format_preds_batched(real))
+        from yogo_amd.synthetic import raw_from_predictions
+        from yogo_amd.utils.prediction_formatting import RawPredictions
+
+        rp = RawPredictions(raw_from_predictions(real, model._Cxs, model._Cys), model._Cxs, model._Cys, *model._decode_scalars(), True)
+        ms_fr = _timed_gpu(lambda: format_preds_batched(rp), reps=20)
         raw = torch.randn(B, 5 + NUM_CLASSES, model.Sy, model.Sx, device=dev)
         dec = torch.empty_like(raw)
         from yogo_amd import _hip
@@ -166,10 +171,15 @@ def inference_extras(model, dev, B: int = 256):
     out["end_to_end_bf16_forward_decode_nms_images_per_s"] = round(B / ms_e2e * 1e3, 1)
     out["threshold_nms_dense_images_per_s"] = round(B / ms_nd * 1e3, 1)
     out["threshold_nms_realistic_images_per_s"] = round(B / ms_nr * 1e3, 1)
+    out["fused_decode_threshold_nms_realistic_images_per_s"] = round(B / ms_fr * 1e3, 1)
     out["roofline_decode"] = {"bound": "hbm", "achieved": round(2 * B * img_bytes / ms_dec / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(2 * B * img_bytes / ms_dec / 1e6 / HBM_PEAK_GBS, 4), "avg_call_ms": round(ms_dec, 4)}
     out["roofline_nms_realistic"] = {"bound": "hbm", "achieved": round(B * img_bytes / ms_nr / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": round(B * img_bytes / ms_nr / 1e6 / HBM_PEAK_GBS, 4), "avg_call_ms": round(ms_nr, 4)}
+    out["roofline_fused_decode_nms_realistic"] = {"bound": "hbm", "achieved": round(B * img_bytes / ms_fr / 1e6, 1), "peak": HBM_PEAK_GBS,
+                                                  "unit": "GB/s", "frac": round(B * img_bytes / ms_fr / 1e6 / HBM_PEAK_GBS, 4),
+                                                  "avg_call_ms": round(ms_fr, 4),
+                                                  "replaces_ms": round(ms_dec + ms_nr, 4)}
     out["note"] = ("eval-mode base_model at batch 256 (fp32 forward at 64); dense = 93 % of the 12 513 cells fire with overlapping boxes "
                    "(NMS worst case, bound by the greedy suppression chain), realistic = 100 objects per image")
     model.train()

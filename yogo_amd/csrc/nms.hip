@@ -138,6 +138,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_batched_kernel(const NmsParam
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem_raw);  // [npow2] during the sort
   __shared__ int sh_wave[NMS_WAVES + 1];
+  __shared__ int sh_cnt[NMS_SLOTS][NMS_WAVES];
   __shared__ float4 kept_box[64];
   __shared__ float kept_area[64];
   __shared__ int kept_n;
@@ -152,13 +153,42 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_batched_kernel(const NmsParam
   float* ws_area = p.ws_area + (size_t)b * cells;
 
   // ---- 1. ordered compaction of candidates --------------------------------------------------------------------
+  // every lane's objectness loads are issued before the first use (one round trip instead of one per 1024 cells), the 16 x 16
+  // per-(slot, wavefront) counts go to LDS in one step, and each lane sums the prefix of its own slots from there
+  unsigned fire = 0u;
+  {
+    float ob[NMS_SLOTS];
+#pragma unroll
+    for (int k = 0; k < NMS_SLOTS; ++k) {
+      const int cell = k * NMS_THREADS + tid;
+      ob[k] = (cell < cells) ? pv.at(4, cell) : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NMS_SLOTS; ++k) {
+      const int cell = k * NMS_THREADS + tid;
+      const float o = DEC ? nms_sigmoid(ob[k]) : ob[k];
+      const bool f = (cell < cells) && (o > p.obj_thresh);
+      const unsigned long long bal = __ballot(f);
+      if (f) fire |= 1u << k;
+      if (lane == 0) sh_cnt[k][wave] = __popcll(bal);
+    }
+  }
+  __syncthreads();
   int n = 0;
-  for (int base = 0; base < cells; base += NMS_THREADS) {
-    const int cell = base + tid;
-    const bool f = (cell < cells) && (pv.obj(cell) > p.obj_thresh);
-    int tot;
-    const int r = block_rank(f, sh_wave, &tot);
-    if (f) ws_cells[n + r] = cell;
+#pragma unroll
+  for (int k = 0; k < NMS_SLOTS; ++k) {
+    if (k * NMS_THREADS >= cells) break;  // uniform
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NMS_WAVES; ++w) {
+      const int c = sh_cnt[k][w];
+      if (w < wave) base += c;
+      tot += c;
+    }
+    const bool f = ((fire >> k) & 1u) != 0u;
+    const unsigned long long bal = __ballot(f);
+    // rank inside the wavefront = fired lanes below this one in slot k
+    if (f) ws_cells[n + base + __popcll(bal & ((1ull << lane) - 1ull))] = k * NMS_THREADS + tid;
     n += tot;
   }
   __syncthreads();
