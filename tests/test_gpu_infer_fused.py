@@ -99,3 +99,39 @@ def test_forward_raw_feeds_the_inference_outputs_without_a_decode_pass(tmp_path)
         assert torch.equal(counts, get_prediction_class_counts(full, obj_thresh=0.4))
         for a, b in zip(arrs, format_to_numpy_batched([0, 1, 2, 3], full, 193, 258)):
             assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_nms_degenerate_boxes_bit_exact_vs_oracle():
+    """zero-area, negative-extent, infinite, NaN, identical and exactly-touching boxes: the kernel skips the IoU division when the
+    intersection is not positive -- the kept rows must still be the CPU algorithm's (torchvision nms semantics: 0/0 = NaN does
+    not suppress, no eps), index for index"""
+    from yogo_amd.utils import format_preds_batched
+
+    g = torch.Generator().manual_seed(93)
+    B, Sy, Sx = 6, 16, 16
+    pred = O.synthetic_predictions(B, Sx, Sy, num_classes=7, K=40, seed=94)
+    pred[:, 4] = torch.rand(B, Sy, Sx, generator=g) * 0.6 + 0.4
+    flat = pred.view(B, 12, Sy * Sx)
+    n = Sy * Sx
+    idx = torch.randperm(n, generator=g)
+    flat[:, 2, idx[:30]] = 0.0                                   # zero width
+    flat[:, 3, idx[20:50]] = 0.0                                 # zero height (some both)
+    flat[:, 2, idx[50:70]] = -0.05                               # negative extent
+    flat[:, 2, idx[70:75]] = float("inf")
+    flat[:, 0, idx[75:80]] = float("nan")
+    flat[:, :4, idx[80:110]] = flat[:, :4, idx[110:140]]         # identical boxes (IoU exactly 1)
+    # exactly touching neighbours: same size, centres one width apart in binary-exact numbers
+    flat[:, 0, idx[140:150]] = 0.25
+    flat[:, 0, idx[150:160]] = 0.375
+    flat[:, 1, idx[140:160]] = 0.5
+    flat[:, 2, idx[140:160]] = 0.125
+    flat[:, 3, idx[140:160]] = 0.125
+    for kw in (dict(), dict(iou_thresh=0.01), dict(iou_thresh=0.999, box_format="xyxy")):
+        rows, cells, counts = format_preds_batched(pred.cuda(), **kw)
+        rows, cells, counts = rows.cpu(), cells.cpu(), counts.cpu()
+        for b in range(B):
+            want, wcells = O.format_preds(pred[b], return_cells=True, **kw)
+            k = int(counts[b])
+            assert k == want.shape[0], (kw, b, k, want.shape[0])
+            assert torch.equal(cells[b, :k], wcells), (kw, b)
+            assert torch.equal(rows[b, :k].view(torch.int32), want.view(torch.int32)), (kw, b)

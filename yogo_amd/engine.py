@@ -112,6 +112,7 @@ class Engine:
         self.clip: float = 0.0  # > 0: clamp parameter gradients to +-clip (set by YOGO from clip_value)
         # optional per-launch HIP-event timing (bench.py): list of (kind, layer, mw, flops, start_event, end_event)
         self.prof: Optional[list] = None
+        self.prof_only: Optional[set] = None   # bracket only the launches whose `mw` tag is in this set (bench.py's timed region)
         self._open = None
         # bumped whenever a kernel writes parameters or BatchNorm buffers through raw pointers (AdamW on the flat buffer,
         # bn_finalize / bn_stats_from_gram on the running statistics): torch's _version does not see those writes, so every
@@ -120,7 +121,7 @@ class Engine:
 
     def _tick(self, kind: str, layer: int, flops: float, mw: int = 0, nbytes: float = 0.0) -> None:
         """open a HIP-event bracket around one kernel call (bench.py): algorithmic FLOPs and bytes of that call"""
-        if self.prof is not None:
+        if self.prof is not None and (self.prof_only is None or mw in self.prof_only):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             self._open = (kind, layer, mw, flops, e0, e1, nbytes)

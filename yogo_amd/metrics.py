@@ -5,7 +5,8 @@ NMS kernel), then mAP, confusion matrix, per-class accuracy / precision / recall
 The reference delegates the statistics to ``torchmetrics`` (MeanAveragePrecision, MulticlassConfusionMatrix, MulticlassAccuracy,
 MulticlassROC(thresholds=500), MulticlassPrecision, MulticlassRecall, MulticlassCalibrationError(n_bins=30)), which is not
 installable here; they are restated below from their published definitions (COCO evaluation protocol for mAP) with plain
-torch / numpy on the host -- these are a few thousand matched rows per test set, not a hot path.  PARITY UNPINNED against a
+torch / numpy on the host (the one-box-per-image form ``Metrics`` feeds to mAP is evaluated with array operations over all
+images at once: a test split with 10^5 objects takes seconds).  PARITY UNPINNED against a
 real torchmetrics (none available); pinned by hand-computed cases in tests/test_metrics.py.
 
 Quirks of the reference that are kept on purpose:
@@ -101,12 +102,71 @@ class MeanAveragePrecision:
         d_ign = d_ign | (~dm & out_of_range[None, :])
         return ds, dm, d_ign, int((~g_ign).sum())
 
-    def compute(self) -> Dict[str, torch.Tensor]:
+    @staticmethod
+    def _accumulate(precision, recall, ki, ai, mis, scores, dm, dig, npig) -> None:
+        """precision at the 101 recall points and the final recall of one (class, area) cell, written for every max-det index in mis"""
+        T, R = len(_IOU_THRS), len(_REC_THRS)
+        order = np.argsort(-scores, kind="mergesort")
+        dm, dig = dm[:, order], dig[:, order]
+        tps = np.cumsum(dm & ~dig, axis=1, dtype=np.float64)
+        fps = np.cumsum(~dm & ~dig, axis=1, dtype=np.float64)
+        nd = tps.shape[1]
+        for ti in range(T):
+            tp, fp = tps[ti], fps[ti]
+            rc = tp / npig
+            pr = tp / (tp + fp + np.spacing(1))
+            pr = np.maximum.accumulate(pr[::-1])[::-1]           # precision envelope
+            inds = np.searchsorted(rc, _REC_THRS, side="left")
+            q = np.zeros(R)
+            ok = inds < nd
+            q[ok] = pr[inds[ok]]
+            for mi in mis:
+                recall[ti, ki, ai, mi] = rc[-1] if nd else 0
+                precision[ti, :, ki, ai, mi] = q
+
+    def _compute_single_box_images(self, classes, precision, recall) -> None:
+        """the case ``Metrics`` produces (yogo/metrics.py:204-234: every matched pair is its own image with at most one detection
+        and one ground truth): the per-image greedy matching collapses to one IoU per image, so a (class, area) cell is a few
+        array operations over all images, and the three max-det settings (>= 1) give the same cell."""
+        N = len(self._images)
+        d_has = np.array([len(im[1]) == 1 for im in self._images])
+        g_has = np.array([len(im[4]) == 1 for im in self._images])
+        d_box, g_box = np.zeros((N, 4)), np.zeros((N, 4))
+        d_score, d_lab, g_lab = np.zeros(N), np.full(N, -1, dtype=np.int64), np.full(N, -1, dtype=np.int64)
+        for i, (db, ds, dl, gb, gl) in enumerate(self._images):
+            if d_has[i]:
+                d_box[i], d_score[i], d_lab[i] = db[0], ds[0], dl[0]
+            if g_has[i]:
+                g_box[i], g_lab[i] = gb[0], gl[0]
+        d_area = (d_box[:, 2] - d_box[:, 0]) * (d_box[:, 3] - d_box[:, 1])
+        g_area = (g_box[:, 2] - g_box[:, 0]) * (g_box[:, 3] - g_box[:, 1])
+        lt, rb = np.maximum(d_box[:, :2], g_box[:, :2]), np.minimum(d_box[:, 2:], g_box[:, 2:])
+        wh = np.clip(rb - lt, 0, None)
+        inter = wh[:, 0] * wh[:, 1]
+        union = d_area + g_area - inter
+        with np.errstate(divide="ignore", invalid="ignore"):
+            iou = np.where(union > 0, inter / union, 0.0)
+        thr = np.minimum(_IOU_THRS, 1 - 1e-10)[:, None]
+        for ki, cls in enumerate(classes):
+            dsel, gsel = d_has & (d_lab == cls), g_has & (g_lab == cls)
+            for ai, area in enumerate(_AREAS.values()):
+                g_ign = gsel & ((g_area < area[0]) | (g_area > area[1]))
+                npig = int((gsel & ~g_ign).sum())
+                if npig == 0:
+                    continue
+                dm = (dsel & gsel)[None, :] & (iou[None, :] >= thr)
+                dig = (dm & g_ign[None, :]) | (~dm & ((d_area < area[0]) | (d_area > area[1]))[None, :])
+                self._accumulate(precision, recall, ki, ai, range(len(_MAX_DETS)), d_score[dsel], dm[:, dsel], dig[:, dsel], npig)
+
+    def compute(self, _general: bool = False) -> Dict[str, torch.Tensor]:
         classes = sorted({int(c) for im in self._images for c in np.concatenate((im[2], im[4]))})
         T, R, K, A, M = len(_IOU_THRS), len(_REC_THRS), len(classes), len(_AREAS), len(_MAX_DETS)
         precision = -np.ones((T, R, K, A, M))
         recall = -np.ones((T, K, A, M))
-        for ki, cls in enumerate(classes):
+        single = not _general and all(len(im[1]) <= 1 and len(im[4]) <= 1 for im in self._images)
+        if single:
+            self._compute_single_box_images(classes, precision, recall)
+        for ki, cls in enumerate([] if single else classes):
             imgs = [im for im in self._images if (im[2] == cls).any() or (im[4] == cls).any()]
             for ai, area in enumerate(_AREAS.values()):
                 for mi, max_det in enumerate(_MAX_DETS):
@@ -116,26 +176,8 @@ class MeanAveragePrecision:
                     npig = sum(e[3] for e in ev)
                     if npig == 0:
                         continue
-                    scores = np.concatenate([e[0] for e in ev])
-                    order = np.argsort(-scores, kind="mergesort")
-                    dm = np.concatenate([e[1] for e in ev], axis=1)[:, order]
-                    dig = np.concatenate([e[2] for e in ev], axis=1)[:, order]
-                    tps = np.cumsum(dm & ~dig, axis=1, dtype=np.float64)
-                    fps = np.cumsum(~dm & ~dig, axis=1, dtype=np.float64)
-                    for ti in range(T):
-                        tp, fp = tps[ti], fps[ti]
-                        nd = len(tp)
-                        rc = tp / npig
-                        pr = tp / (tp + fp + np.spacing(1))
-                        recall[ti, ki, ai, mi] = rc[-1] if nd else 0
-                        for i in range(nd - 1, 0, -1):          # precision envelope
-                            if pr[i] > pr[i - 1]:
-                                pr[i - 1] = pr[i]
-                        inds = np.searchsorted(rc, _REC_THRS, side="left")
-                        q = np.zeros(R)
-                        ok = inds < nd
-                        q[ok] = pr[inds[ok]]
-                        precision[ti, :, ki, ai, mi] = q
+                    self._accumulate(precision, recall, ki, ai, (mi,), np.concatenate([e[0] for e in ev]),
+                                     np.concatenate([e[1] for e in ev], axis=1), np.concatenate([e[2] for e in ev], axis=1), npig)
 
         def mean_valid(x):
             x = x[x > -1]
