@@ -102,9 +102,8 @@ def test_forward_raw_feeds_the_inference_outputs_without_a_decode_pass(tmp_path)
 
 
 def test_nms_degenerate_boxes_bit_exact_vs_oracle():
-    """zero-area, negative-extent, infinite, NaN, identical and exactly-touching boxes: the kernel skips the IoU division when the
-    intersection is not positive -- the kept rows must still be the CPU algorithm's (torchvision nms semantics: 0/0 = NaN does
-    not suppress, no eps), index for index"""
+    """zero-area, negative-extent, infinite, NaN, identical and exactly-touching boxes: the kept rows must be the CPU algorithm's
+    (torchvision nms semantics: 0/0 = NaN does not suppress, no eps), index for index"""
     from yogo_amd.utils import format_preds_batched
 
     g = torch.Generator().manual_seed(93)
