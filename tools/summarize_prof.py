@@ -16,8 +16,8 @@ os.makedirs("profiles", exist_ok=True)
 
 
 def one(pattern):
-    f = glob.glob(os.path.join(src, pattern))
-    return f[0] if f else None
+    f = sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)   # a re-collected leg leaves two files: take the newest
+    return f[-1] if f else None
 
 
 stats = one("stats/*kernel_stats.csv") or one("stats/*/*kernel_stats.csv")
