@@ -66,41 +66,42 @@ class YOGO(nn.Module):
     ):
         super().__init__()
         self.device = device
-
+        self.inference = inference
         self.model = model_func(num_classes, is_rgb).to(device)
         self.model_version = model_func.__name__
 
-        self.register_buffer("img_size", torch.tensor(img_size))
-        self.register_buffer("anchor_w", torch.tensor(anchor_w))
-        self.register_buffer("anchor_h", torch.tensor(anchor_h))
-        self.register_buffer("num_classes", torch.tensor(num_classes))
-        self.register_buffer("clip_value", torch.tensor(clip_value))
-        self.register_buffer("is_rgb", torch.tensor(is_rgb))
-        self.register_buffer("normalize_images", torch.tensor(normalize_images))
+        given = {"img_size": img_size, "anchor_w": anchor_w, "anchor_h": anchor_h, "num_classes": num_classes,
+                 "clip_value": clip_value, "is_rgb": is_rgb, "normalize_images": normalize_images}
+        for name in self._BUFFERS_BEFORE_GRID:
+            self.register_buffer(name, torch.tensor(given[name]))
+        self.Sx, self.Sy = self.get_grid_size()
+        for name, grid in zip(("_Cxs", "_Cys"), self._cell_grids(self.Sx, self.Sy, self.device)):
+            self.register_buffer(name, grid)
+        for name, value in self._BUFFERS_AFTER_GRID.items():
+            self.register_buffer(name, torch.tensor(value))
 
-        self.inference = inference
-
-        Sx, Sy = self.get_grid_size()
-        self.Sx, self.Sy = Sx, Sy
-
-        # grids as the reference builds them: linspace, not k/S (yogo/model.py:48-61)
-        _Cxs = torch.linspace(0, 1 - 1 / Sx, Sx).expand(Sy, -1).to(self.device)
-        _Cys = torch.linspace(0, 1 - 1 / Sy, Sy).expand(1, -1).transpose(0, 1).expand(Sy, Sx).to(self.device)
-        self.register_buffer("_Cxs", _Cxs.clone())
-        self.register_buffer("_Cys", _Cys.clone())
-
-        self.register_buffer("height_multiplier", torch.tensor(1.0))
-        self.register_buffer("width_multiplier", torch.tensor(1.0))
-
-        if tuning:
-            self.model.apply(self.set_bn_eval)
-        else:
-            self.model.apply(self.init_network_weights)
+        self.model.apply(self.set_bn_eval if tuning else self.init_network_weights)
 
         # gradient clipping: the reference registers one clamp hook per parameter (yogo/model.py:76-77); here the
         # clamp is fused into the kernels that finish each parameter gradient.
         self._clip = float(clip_value)
         self._scalars: Optional[Tuple[float, float, float, float]] = None
+
+    # The eleven buffers of a YOGO checkpoint, in state_dict order (= the order the reference registers them in,
+    # yogo/model.py:24-65; tests/golden/ckpt_keys.json): seven constructor scalars, the two cell-origin grids, then the two
+    # crop multipliers that only resize_model changes.
+    _BUFFERS_BEFORE_GRID = ("img_size", "anchor_w", "anchor_h", "num_classes", "clip_value", "is_rgb", "normalize_images")
+    _BUFFERS_AFTER_GRID = {"height_multiplier": 1.0, "width_multiplier": 1.0}
+    # buffers that checkpoints written by older versions lack, with the values they implied (yogo/model.py:100-109)
+    _LEGACY_BUFFER_DEFAULTS = {"is_rgb": False, "clip_value": 1.0, "height_multiplier": 1.0, "width_multiplier": 1.0}
+
+    @staticmethod
+    def _cell_grids(Sx: int, Sy: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
+        """x / y origin of every grid cell as [Sy, Sx] tensors, from linspace as the reference builds them (yogo/model.py:48-61) --
+        not k / S, which differs in the last bit for some k"""
+        xs = torch.linspace(0, 1 - 1 / Sx, Sx)    # on the host, like the reference: a device linspace may round differently
+        ys = torch.linspace(0, 1 - 1 / Sy, Sy)
+        return xs[None, :].expand(Sy, Sx).clone().to(device), ys[:, None].expand(Sy, Sx).clone().to(device)
 
     @staticmethod
     def init_network_weights(module: nn.Module):
@@ -116,46 +117,24 @@ class YOGO(nn.Module):
 
     @classmethod
     def from_pth(cls, pth_path: PathLike, inference: bool = False) -> Tuple["YOGO", Dict[str, Any]]:
-        pth_path = Path(pth_path)
-        loaded_pth = torch.load(pth_path, map_location="cpu", weights_only=False)
+        ckpt = torch.load(Path(pth_path), map_location="cpu", weights_only=False)
+        state = ckpt["model_state_dict"]
+        for name, value in cls._LEGACY_BUFFER_DEFAULTS.items():
+            state.setdefault(name, torch.tensor(value))
+        # (normalize_images used to live beside the state dict)
+        state.setdefault("normalize_images", torch.tensor(ckpt.get("normalize_images", False)))
 
-        global_step = loaded_pth.get("step", 0)
-        model_version = loaded_pth.get("model_version", None)
-        class_names = loaded_pth.get("class_names", None)
-
-        params = loaded_pth["model_state_dict"]
-        img_size = params["img_size"]
-        anchor_w = params["anchor_w"]
-        anchor_h = params["anchor_h"]
-        num_classes = params["num_classes"]
-
-        # be permissive of older pth files
-        params.setdefault("is_rgb", torch.tensor(False))
-        params.setdefault("clip_value", torch.tensor(1.0))
-        params.setdefault("height_multiplier", torch.tensor(1.0))
-        params.setdefault("width_multiplier", torch.tensor(1.0))
-        if "normalize_images" not in params:
-            params["normalize_images"] = torch.tensor(loaded_pth.get("normalize_images", False))
-
+        h, w = (int(v) for v in state["img_size"])
         model = cls(
-            (int(img_size[0]), int(img_size[1])),
-            anchor_w.item(),
-            anchor_h.item(),
-            num_classes=int(num_classes.item()),
-            is_rgb=bool(params["is_rgb"].item()),
-            inference=inference,
-            tuning=True,
-            model_func=get_model_func(model_version),
-            clip_value=float(params["clip_value"].item()),
+            (h, w), state["anchor_w"].item(), state["anchor_h"].item(), num_classes=int(state["num_classes"].item()),
+            is_rgb=bool(state["is_rgb"].item()), inference=inference, tuning=True,
+            model_func=get_model_func(ckpt.get("model_version", None)), clip_value=float(state["clip_value"].item()),
         )
-        model.load_state_dict(params)
+        model.load_state_dict(state)
         if inference:
             model.eval()
-        return model, {
-            "step": global_step,
-            "class_names": class_names,
-            "normalize_images": params["normalize_images"],
-        }
+        return model, {"step": ckpt.get("step", 0), "class_names": ckpt.get("class_names", None),
+                       "normalize_images": state["normalize_images"]}
 
     def to(self, device, *args, **kwargs):
         self.device = device
@@ -231,13 +210,12 @@ class YOGO(nn.Module):
         # the new grids live where the old ones do (``self.device`` goes stale under ``.cuda()`` -- only ``.to()`` updates it,
         # in the reference too; a host grid handed to the decode kernel would be a GPU memory fault, not an error)
         dev = self._Cxs.device
-        _Cxs = torch.linspace(0, 1 - 1 / Sx, Sx, device=dev).expand(Sy, -1)
-        _Cys = torch.linspace(0, 1 - 1 / Sy, Sy, device=dev).expand(1, -1).transpose(0, 1).expand(Sy, Sx)
+        grids = self._cell_grids(Sx, Sy, dev)
         self.register_buffer("height_multiplier", torch.tensor(org_img_height / crop_size[0], device=dev))
         self.register_buffer("width_multiplier", torch.tensor(org_img_width / crop_size[1], device=dev))
         self.register_buffer("img_size", torch.tensor(crop_size, device=dev))
-        self.register_buffer("_Cxs", _Cxs.clone())
-        self.register_buffer("_Cys", _Cys.clone())
+        self.register_buffer("_Cxs", grids[0])
+        self.register_buffer("_Cys", grids[1])
         self._scalars = None
 
     def _decode_scalars(self) -> Tuple[float, float, float, float]:
