@@ -85,6 +85,58 @@ if mf:
         for r in rows[:28]:
             f.write(f"{r[1][:66]:66s} {r[2]:8d} {r[3]:14.0f} {r[4]:10.3f} {r[5]:9.2f} {r[6]:10.2f} {r[7]:7.2f}\n")
     print(open(f"profiles/{tag}_mfma_util.txt").read())
+# ---- LDS conflicts and instruction mix (tools/collect_counters_extra.sh) ---------------------------------------------------------
+def per_kernel(pattern):
+    f = one(pattern) or one(pattern.replace("/", "/*/", 1))
+    agg, nl = defaultdict(lambda: defaultdict(float)), defaultdict(lambda: defaultdict(int))
+    if f:
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            nl[k][r["Counter_Name"]] += 1
+    return agg, nl
+
+
+lds, lds_n = per_kernel("lds/*counter_collection.csv")
+ins, ins_n = per_kernel("insts/*counter_collection.csv")
+if lds or ins:
+    keys = sorted(set(lds) | set(ins), key=lambda k: -ins.get(k, {}).get("SQ_INSTS_MFMA", 0.0) - ins.get(k, {}).get("SQ_INSTS_VALU", 0.0) * 1e-3)
+    with open(f"profiles/{tag}_lds_insts.txt", "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --pmc LDSBankConflict LdsUtil | SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAVES (separate passes) "
+                f"--output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-inference  ({tag})\n")
+        f.write("# per launch (mean): LDS bank-conflict cycles in % of the LDS-active cycles, LDS utilisation in %, wavefront instructions by kind in thousands\n")
+        f.write(f"{'kernel':62s} {'launches':>8s} {'bank_conf%':>10s} {'lds_util%':>10s} {'k_mfma':>9s} {'k_lds':>9s} {'k_valu':>9s} {'k_salu':>9s} {'k_vmem':>9s} {'lds/mfma':>9s}\n")
+        for k in keys[:26]:
+            n = max(ins_n.get(k, {}).get("SQ_INSTS_VALU", 0), lds_n.get(k, {}).get("LDSBankConflict", 0), 1)
+            g = lambda d, dn, c: (d.get(k, {}).get(c, 0.0) / max(dn.get(k, {}).get(c, 0), 1))
+            mf, ld = g(ins, ins_n, "SQ_INSTS_MFMA"), g(ins, ins_n, "SQ_INSTS_LDS")
+            f.write(f"{k[:62]:62s} {n:8d} {g(lds, lds_n, 'LDSBankConflict'):10.2f} {g(lds, lds_n, 'LdsUtil'):10.2f} {mf/1e3:9.0f} {ld/1e3:9.0f} "
+                    f"{g(ins, ins_n, 'SQ_INSTS_VALU')/1e3:9.0f} {g(ins, ins_n, 'SQ_INSTS_SALU')/1e3:9.0f} {g(ins, ins_n, 'SQ_INSTS_VMEM')/1e3:9.0f} {ld / mf if mf else 0:9.2f}\n")
+    print(open(f"profiles/{tag}_lds_insts.txt").read())
+
+act, act_n = per_kernel("active/*counter_collection.csv")
+if act:
+    rows = []
+    for k, c in act.items():
+        cyc = c["GRBM_GUI_ACTIVE"] / 8.0
+        if cyc <= 0 or not k:
+            continue
+        simd = cyc * 1024.0
+        nl_ = max(act_n[k]["GRBM_GUI_ACTIVE"], 1)
+        rows.append((c["GRBM_GUI_ACTIVE"], k, nl_, cyc / nl_, 4 * c["SQ_ACTIVE_INST_VALU"] / simd, 4 * c["SQ_ACTIVE_INST_LDS"] / simd,
+                     4 * c["SQ_ACTIVE_INST_VMEM"] / simd, 4 * c["SQ_ACTIVE_INST_SCA"] / simd))
+    rows.sort(reverse=True)
+    with open(f"profiles/{tag}_issue_util.txt", "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE "
+                f"--output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-inference  ({tag})\n")
+        f.write("# share of a SIMD's cycles with an instruction of that kind executing: SQ_ACTIVE_INST_* (counted in units of 4 cycles -- a wave64 vector\n")
+        f.write("# instruction occupies the 16-lane SIMD for 4) x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8).  valu near 1 = bound by vector-ALU issue;\n")
+        f.write("# the scalar column uses the same normalisation (one scalar unit serves the CU's four SIMDs: read it as relative between kernels)\n")
+        f.write(f"{'kernel':62s} {'launches':>8s} {'cycles/launch':>14s} {'valu':>6s} {'lds':>6s} {'vmem':>6s} {'scalar':>7s}\n")
+        for r in rows[:26]:
+            f.write(f"{r[1][:62]:62s} {r[2]:8d} {r[3]:14.0f} {r[4]:6.2f} {r[5]:6.2f} {r[6]:6.2f} {r[7]:7.2f}\n")
+    print(open(f"profiles/{tag}_issue_util.txt").read())
+
 # ---- inference path (tools/infer_profile.py) -----------------------------------------------------------------------------
 def stats_table(pattern, header, n=24):
     f = one(pattern) or one(pattern.replace("/", "/*/", 1))
