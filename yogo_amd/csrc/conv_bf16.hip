@@ -60,6 +60,12 @@ struct ConvBf16Params {
   int dma, ni_slots, n_slots, bufu;
   int bufs;  // LDS units between the buffers of consecutive chunks: bufu (two buffers) or 0 (dma = 2: one buffer, see below)
   int lean4; // 4-wavefront 3x3 tiles, 16-channel chunks, one LDS buffer: the unrolled step loop
+  // rowdma (with lean4): the input tile is staged ROW by ROW -- one LDS-DMA piece = 64 consecutive units of one tile row of one
+  // channel block, rows at a fixed pitch of lwp (64 or 128) units.  Row index, row validity, the row's byte offset and the LDS
+  // address of a piece are SCALARS; the per-lane part (column offset, column validity) is the same for every piece and is
+  // formed once.  The per-lane slot decode this replaces was ~16 vector instructions per slot and a quarter of the vector
+  // instructions of a 16/32-channel tile, whose throughput is bound by vector-instruction issue (profiles/r03_issue_util.txt).
+  int rowdma, lwp;
   int ring;  // stride-2 data gradient of the 128-channel tile: 16-channel chunks in a ring of 4 LDS buffers (fixed 2 + 3 slot layout)
 #ifdef YOGO_DIAG
   // diagnostic build only (bash build.sh diag -> libyogo_hip_diag.so; tools/bench_conv_bf16.py): ablation bits and phase stamps.
@@ -253,7 +259,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
   const int rows_in = (i_hi - i_lo) * p.a + span_y;
   const int iy0 = i_lo * p.a + p.dy_min;
   const int ix0 = j0 * p.a + p.dx_min;
-  const int lw = (bw - 1) * p.a + p.span_x;
+  const int lw_need = (bw - 1) * p.a + p.span_x;   // units of a tile row the MFMAs read
+  const int lw = (NWV == 4 && !S2D && p.rowdma) ? p.lwp : lw_need;   // row pitch of the LDS image
 
   int boff[NW], opix[NW];
   bool pvalid[NW], pvalid1[NW];
@@ -420,6 +427,23 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
     const int ni = p.ni_slots, ns = p.n_slots;
     const int wtotal = total - itotal;
     i32x16 voffv = {};  // the slot offsets: a register vector, so that a slot can also be picked at run time (relative indexing)
+    [[maybe_unused]] int vcol0 = (int)OOB, vcol1 = (int)OOB;   // rowdma: this lane's column byte offset in segment 0 / 1 of a tile row
+    const bool rowdma = NWV == 4 && !S2D && p.rowdma != 0;      // (uniform)
+    if (rowdma) {
+      const int c0 = lane, c1 = 64 + lane;
+      const int x0 = ix0 + c0, x1 = ix0 + c1;
+      vcol0 = (c0 < lw_need && x0 >= 0 && x0 < p.IW) ? x0 * 16 : (int)OOB;
+      vcol1 = (c1 < lw_need && x1 >= 0 && x1 < p.IW) ? x1 * 16 : (int)OOB;
+      // weight pieces of this wavefront: piece wave + NWV * j = units [64 * piece, 64 * piece + 64) of the chunk's slices
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int w_ = (wave + NWV * j) * 64 + lane;
+        const bool wok = w_ < wtotal;
+        const int R_ = w_ >> BM_SHIFT;
+        const int wi_ = ((tbase + (R_ >> p.ckb_shift)) * p.Kb + (R_ & (p.CKb - 1))) * p.Mpad + m0 + (w_ & (BM - 1));
+        voffv[j] = wok ? wi_ * 16 : (int)OOB;
+      }
+    } else
     {
       // input element tid + i*NT -> (channel block kc, tile row r, tile column x): slot 0 by division, every further slot by
       // stepping (NT = skc*per_kb + sr*lw + sx) with two carries -- adds and compares instead of quarter-rate multiplies
@@ -483,6 +507,28 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
       else if (i < ns) { if (!BF_DBG(16)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(lb_ + i * NT), 16, voffv[i], (C) * so_w, 0, 0); } \
     }                                                                                                                  \
   }
+// rowdma: the rows of chunk C's input tile (CKb channel blocks x the rows_in rows this tile reads x lwp / 64 segments) dealt
+// round-robin to the wavefronts, then this wavefront's weight pieces.  Rows outside the image are zero-filled (all lanes out of range).
+#define DMA_ISSUE_ROWS(C)                                                                                              \
+  {                                                                                                                    \
+    const int nseg_ = p.lwp >> 6, npr_ = rows_in * nseg_, rowb_ = p.IW * 16;                                           \
+    u32x4* lbase_ = smem4 + ((C) & 1) * p.bufs;                                                                        \
+    for (int kb_ = 0; kb_ < p.CKb; ++kb_) {                                                                            \
+      for (int rs_ = wave; rs_ < npr_; rs_ += NWV) {                                                                   \
+        const int r_ = nseg_ == 2 ? rs_ >> 1 : rs_, sg_ = nseg_ == 2 ? rs_ & 1 : 0;                                    \
+        const int iy_ = iy0 + r_;                                                                                      \
+        const bool rok_ = iy_ >= 0 && iy_ < p.IH;                                                                      \
+        const int so_ = rok_ ? (C) * so_i + (kb_ * p.IH + iy_) * rowb_ : 0;                                            \
+        const int vo_ = rok_ ? (sg_ ? vcol1 : vcol0) : (int)OOB;                                                       \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_i, (lds_ptr_t)(lbase_ + (kb_ * rows_in + r_) * p.lwp + sg_ * 64), 16, vo_, so_, 0, 0); \
+      }                                                                                                                \
+    }                                                                                                                  \
+    const int npw_ = wtotal >> 6;                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                                    \
+      if (wave + NWV * j < npw_)                                                                                       \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(lbase_ + p.ldsw_off + (wave + NWV * j) * 64), 16, voffv[j], (C) * so_w, 0, 0); \
+    }                                                                                                                  \
+  }
 // one slot of chunk C, chosen at run time: issued between the MFMA clusters of the previous chunk, so the DMA instructions
 // never hold up the matrix cores.  The slot's offset comes out of the register array by relative indexing (voffv[I]), the
 // descriptor / scalar offset / LDS address are scalar selects -- no branches.
@@ -496,6 +542,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
   }
 #else
 #define DMA_ISSUE(C) (void)ns, (void)so_i, (void)so_w, (void)rs_i, (void)rs_w, (void)voffv;
+#define DMA_ISSUE_ROWS(C) (void)vcol0, (void)vcol1;
 #define DMA_ONE(I, C) (void)(I), (void)voffv;
 #endif
     if constexpr (PP && NWV == 8) {
@@ -714,7 +761,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
     }                               \
   }
     [[maybe_unused]] const unsigned long long t_dec = BF_STAMP();   // (diagnostic: the slot offsets are decoded)
-    DMA_ISSUE(0)
+    if (rowdma) DMA_ISSUE_ROWS(0) else DMA_ISSUE(0)
     ACC_ZERO()
     [[maybe_unused]] const unsigned long long t_iss = BF_STAMP();   // (... chunk 0 is requested, the accumulators are zero)
     [[maybe_unused]] unsigned long long t_land = 0, t_c1 = 0;
@@ -724,7 +771,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
       // workgroups per CU cover each other's latencies, which matters more than overlap inside a workgroup that short
       if (p.dma == 2 && c > 0) {
         __syncthreads();
-        DMA_ISSUE(c)
+        if (rowdma) DMA_ISSUE_ROWS(c) else DMA_ISSUE(c)
       }
       __syncthreads();  // chunk c has landed (every wave drained its DMA) and nobody reads the other buffer any more
       if (c == 0) t_land = BF_STAMP();
@@ -1175,6 +1222,39 @@ bool bf_plan(int OH, int OW, int a, int T, int span, int Kb, int MW, int NW, int
   return true;
 }
 
+// Row-staged tiling of the single-buffer 4-wavefront kernels (ConvBf16Params::rowdma): rows at a pitch of 64 or 128 units, so
+// the band may be as wide as the pitch allows at no extra LDS -- fewer bands, less halo, fewer pieces.  16-channel chunks only.
+bool bf_plan_rows(int OH, int OW, int a, int T, int span, int Kb, int MW, int NW, int NWV, int budget, BfTiling* out, int* lwp_out) {
+  const int BM = 32 * MW, PT = 32 * NWV * NW, CKb = 2;
+  if (Kb % CKb || Kb / CKb > 2 || T * CKb * BM / 64 > 8 * NWV) return false;
+  long long best_score = -1;
+  BfTiling best{};
+  int best_lwp = 0;
+  for (int ncb = 1; ncb <= 24 && ncb <= OW; ++ncb) {
+    const int TW = cdiv(OW, ncb);
+    const int bw_min = OW - (cdiv(OW, TW) - 1) * TW;
+    if (cdiv(OW, TW) != ncb || bw_min <= 0) continue;
+    const int LW = (TW - 1) * a + span;
+    const int lwp = LW <= 64 ? 64 : (LW <= 128 ? 128 : 0);
+    if (!lwp) continue;
+    const int nrow_lat = min(OH, 1 + cdiv(PT - 1, bw_min));
+    const int rows_max = (nrow_lat - 1) * a + span;
+    const int units_in = CKb * rows_max * lwp, wunits = T * CKb * BM;
+    const int bytes = (units_in + wunits) * 16;
+    if (bytes > budget) continue;
+    const long long staged = (long long)ncb * cdiv(OH * TW, PT) * rows_max * lwp;  // staged units per channel block and image
+    if (best_score < 0 || staged < best_score) {
+      best_score = staged;
+      best = BfTiling{ncb, TW, cdiv(OH * TW, PT), CKb, rows_max, LW, units_in, units_in + wunits, bytes, 2, 0, 0, units_in + wunits};
+      best_lwp = lwp;
+    }
+  }
+  if (best_score < 0) return false;
+  *out = best;
+  *lwp_out = best_lwp;
+  return true;
+}
+
 }  // namespace
 
 // =========================================================================================================
@@ -1222,6 +1302,12 @@ extern "C" int yogo_conv_bf16_pack_multi(const void* table, int n, int total_blo
 // channel blocks of a bf16 NCHW8c tensor with C channels AS THE NEXT LAYER READS IT (padded to 16 channels = 2 blocks)
 extern "C" int yogo_bf16_channel_blocks(int C) { return bf_kb_of(C); }
 
+#ifdef BF_NO_ROWDMA   // (A/B variant builds: bash build.sh variant slot conv_bf16 -DBF_NO_ROWDMA)
+static bool g_bf_rowdma = false;
+#else
+static bool g_bf_rowdma = true;
+#endif
+// (diagnostic build: yogo_diag_conv_bf16_rowdma(0) keeps the per-lane slot staging of the lean 4-wavefront tiles)
 static bool g_bf_lean4 = true; // (diagnostic build: yogo_diag_conv_bf16_lean4(0) selects the generic step loop of the 4-wavefront tiles)
 static bool g_bf_ring = true; // (diagnostic build: yogo_diag_conv_bf16_ring(0) selects the two-buffer loop of the stride-2 data gradient)
 static bool g_bf_pp = true;   // (diagnostic build: yogo_diag_conv_bf16_pp(0) selects the interleaved main loop for A/B runs)
@@ -1229,6 +1315,7 @@ static bool g_bf_pp = true;   // (diagnostic build: yogo_diag_conv_bf16_pp(0) se
 extern "C" int yogo_diag_conv_bf16_pp(int on) { g_bf_pp = on != 0; return YOGO_OK; }
 extern "C" int yogo_diag_conv_bf16_ring(int on) { g_bf_ring = on != 0; return YOGO_OK; }
 extern "C" int yogo_diag_conv_bf16_lean4(int on) { g_bf_lean4 = on != 0; return YOGO_OK; }
+extern "C" int yogo_diag_conv_bf16_rowdma(int on) { g_bf_rowdma = on != 0; return YOGO_OK; }
 // diagnostic build only: ablation bits, synchronous staging, and a caller-owned stamp buffer ([workgroups][4] u64)
 static int g_diag_dbg = 0, g_diag_nodma = 0;
 static unsigned long long* g_diag_stamps = nullptr;
@@ -1310,6 +1397,21 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
     yogo_set_error("conv_bf16: no LDS tiling fits (K=%d M=%d OW=%d a=%d)", K, M, OW, a);
     return YOGO_ERR_ARG;
   }
+  // the lean single-buffer 4-wavefront tiles (3x3, 16-channel chunks): stage the input row by row when that keeps the
+  // workgroups-per-CU level of the slot plan
+  int rowdma = 0, lwp = 0;
+  // (stride 1 only: measured -2.5 ... -5 % on the 16 <-> 32 channel layer in both directions, +1 % on the stride-2 forward, whose
+  //  87-unit rows need two pieces each)
+  if (!s2d && a == 1 && NWV == 4 && T == 9 && tl.CKb == 2 && tl.dma == 2 && out_f32 == nullptr && g_bf_lean4 && g_bf_rowdma) {
+    const int ladder[3] = {40 * 1024, 53 * 1024, BF_LDS_BUDGET};
+    int level = 0;
+    while (level < 2 && tl.lds_bytes > ladder[level]) ++level;
+    BfTiling tr;
+    if (tl.lds_bytes <= ladder[level] && bf_plan_rows(OHt, OWt, a, T, ks, Kb, MW, NW, NWV, ladder[level], &tr, &lwp)) {
+      tl = tr;
+      rowdma = 1;
+    }
+  }
   dim3 grid(tl.ncb * tl.tiles_per_band, (Mpad / (32 * MW)) * (s2d ? 2 : 1), B);
   if (stats_rows) *stats_rows = B * (int)grid.x;
   if (stats_mpad) *stats_mpad = Mpad;
@@ -1339,6 +1441,7 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
   p.dma = tl.dma; p.ni_slots = tl.ni_slots; p.n_slots = tl.n_slots; p.bufu = tl.bufu; p.bufs = tl.dma == 1 ? tl.bufu : 0;
   p.ring = ring ? 1 : 0;
   p.lean4 = (!s2d && NWV == 4 && T == 9 && tl.CKb == 2 && tl.dma == 2 && out_f32 == nullptr && g_bf_lean4) ? 1 : 0;
+  p.rowdma = rowdma; p.lwp = lwp;
 #ifdef YOGO_DIAG
   p.dbg = g_diag_dbg;
   if (g_diag_nodma && (tl.lds_dummy + 1) * 16 <= BF_LDS_MAX) p.dma = 0;  // synchronous staging through registers
@@ -1365,9 +1468,9 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
   }
   char plan_txt[256] = "";
   if (yogo_launch_log_enabled())
-    snprintf(plan_txt, sizeof(plan_txt), "K=%d M=%d in=%dx%d out=%dx%d a=%d s2d=%d T=%d ncb=%d TW=%d tiles_per_band=%d CKb=%d nchunk=%d rows=%d LW=%d lds=%d dma=%d slots=%d+%d grid=%ux%ux%u",
+    snprintf(plan_txt, sizeof(plan_txt), "K=%d M=%d in=%dx%d out=%dx%d a=%d s2d=%d T=%d ncb=%d TW=%d tiles_per_band=%d CKb=%d nchunk=%d rows=%d LW=%d lds=%d dma=%d slots=%d+%d rowpitch=%d grid=%ux%ux%u",
              K, M, IH, IW, OH, OW, a, s2d, T, tl.ncb, tl.TW, tl.tiles_per_band, tl.CKb, Kb / tl.CKb, tl.rows_max, tl.LW, lds_bytes, p.dma, tl.ni_slots,
-             tl.n_slots - tl.ni_slots, grid.x, grid.y, grid.z);
+             tl.n_slots - tl.ni_slots, rowdma ? lwp : 0, grid.x, grid.y, grid.z);
 #define BFLAUNCH__(MW_, NW_, NWV_, S2D_, PF_, F32_, REF_)                                                               \
   bf_launch_t<MW_, NW_, NWV_, S2D_, PF_, F32_, REF_>(grid, lds_bytes, stream, p, use_pp, plan_txt)
 #define BFLAUNCH_(MW_, NW_, NWV_, S2D_, PF_, F32_)                             \
