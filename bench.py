@@ -364,7 +364,7 @@ def main():
             ms = ms_of(sel)
             fl = sum(e[3] for e in sel)
             achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            traffic = tj.get("conv_bf16_kernel<4,2,8,false,10,false,0,true>", {}).get("hbm_bytes_per_launch")
+            traffic = next((v.get("hbm_bytes_per_launch") for k, v in tj.items() if k.startswith("conv_bf16_kernel<4,2,8,false,10,false,0,true")), None)
             allc = [e for e in prof_all if e[0] in ("fwd", "dgrad") and e[2] in (30, 34)]
             roof = {"bound": "mfma", "kernel": "conv_bf16_kernel<4,2,8,false,10,false,0,true> (stride-1 bf16 convolutions with 128 GEMM rows: "
                                                "forward of layers 3/5/6, data gradient of layers 5/6)",

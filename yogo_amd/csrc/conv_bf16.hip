@@ -202,7 +202,12 @@ __device__ __forceinline__ void bf_static_for(F&& f, std::integer_sequence<int, 
 //   wavefronts wait for LDS / issue DMA at the same moments and the pipe idles (47 % busy measured, profiles/r02_*).
 //   The LDS-DMA is issued from inline asm with a counted / explicit vmcnt: hipcc would otherwise drain it (vmcnt(0)) in front
 //   of every later LDS read.
-template <int MW, int NW, int NWV, bool S2D, int PF, bool OUT_F32, int REF, bool PP = false>
+// LEPI (4-wavefront tiles with the unrolled step loop): the epilogue's LEAN order of operations only -- the launcher selects
+//   it when no BatchNorm sums, SiLU, second output or non-LeakyReLU reference is asked for (every launch of the base_model
+//   training step).  Merged with the general order behind a run-time test (the default of the 4-wavefront tiles) the unrolled
+//   group loop carries both paths' live values through every join: with the stores switched off, the epilogue ARITHMETIC of the
+//   16 -> 32 channel forward was 0.23 ms of its 0.77 ms (tools/stamps_conv_bf16.py, ablation bits 1 / 256).
+template <int MW, int NW, int NWV, bool S2D, int PF, bool OUT_F32, int REF, bool PP = false, bool LEPI = false>
 __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Params p) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem4[];
   constexpr int BM = 32 * MW;
@@ -903,7 +908,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
   // 8-wavefront tiles take the request to write a sign map at run time (their registers do not decide the occupancy), so the
   // forward kernels of the 128-channel layers stay ONE kernel; the 4-wavefront tiles have a variant (REF = 3) for it
   constexpr bool SIGN_OUT = REF == 3 || (REF == 0 && NWV == 8 && !OUT_F32);
-  const bool write_signs = REF == 3 || (SIGN_OUT && p.signs != nullptr);  // uniform
+  const bool write_signs = (REF == 3 || (SIGN_OUT && p.signs != nullptr)) && !BF_DBG(512);  // uniform  (diagnostic bit 512: no sign map)
   unsigned sg[(REF == 2 || SIGN_OUT) ? NC : 1][NW][SW];
   if constexpr (REF == 2) {
     const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)(p.signs + (size_t)b * plane * 2 * sq), (short)0, (int)plane * 2 * sq, 0x00020000);
@@ -1007,6 +1012,12 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
     // (the 4-wavefront tiles and the bf16-reference variant keep ONE merged loop with the test inside: split, they need more
     //  registers than their occupancy allows)
     constexpr bool SPLIT = NWV == 8 && REF != 1;
+    if (BF_DBG(256)) {   // (diagnostic: no epilogue arithmetic and no stores -- what the group loop costs altogether)
+    } else
+    if constexpr (LEPI) {
+      constexpr int MODE = 0;
+#include "conv_bf16_epi_groups.inc"
+    } else
     if constexpr (SPLIT) {
       auto epi_groups = [&](auto mode_tag) {
         constexpr int MODE = decltype(mode_tag)::value;
@@ -1018,7 +1029,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
       constexpr int MODE = 2;
 #include "conv_bf16_epi_groups.inc"
     }
-    if constexpr (SIGN_OUT && MW > 1) if (write_signs) {  // the sign bytes of a pixel go out together
+    if constexpr (SIGN_OUT) if (write_signs) {  // the sign bytes of a pixel go out together
       const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)(p.signs + (size_t)b * plane * 2 * sq), (short)0, (int)plane * 2 * sq, 0x00020000);
 #pragma unroll
       for (int c = 0; c < NC; ++c)
@@ -1028,8 +1039,10 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
           if constexpr (MW == 4) {
             const u32x2 t = {sg[c][n][0], sg[c][n][SW - 1]};
             __builtin_amdgcn_raw_buffer_store_b64(t, rs_s, vs, 0, 0);
-          } else {
+          } else if constexpr (MW == 2) {
             __builtin_amdgcn_raw_buffer_store_b32(sg[c][n][0], rs_s, vs, 0, 0);
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)sg[c][n][0], rs_s, vs, 0, 0);
           }
         }
     }
@@ -1330,17 +1343,17 @@ extern "C" int yogo_diag_conv_bf16(int dbg_bits, int no_dma, void* stamps, size_
 
 namespace {
 
-template <int MW, int NW, int NWV, bool S2D, int PF, bool F32, int REF, bool PP>
+template <int MW, int NW, int NWV, bool S2D, int PF, bool F32, int REF, bool PP, bool LEPI = false>
 void bf_launch_one(dim3 grid, int lds_bytes, hipStream_t stream, const ConvBf16Params& p, const char* plan_txt) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<MW, NW, NWV, S2D, PF, F32, REF, PP>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<MW, NW, NWV, S2D, PF, F32, REF, PP, LEPI>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, BF_LDS_MAX);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_bf16_kernel<MW, NW, NWV, S2D, PF, F32, REF, PP>), grid, dim3(64 * NWV), lds_bytes, stream, p);
-  yogo_launch_log("conv_bf16_kernel<%d, %d, %d, %s, %d, %s, %d, %s> | %s", MW, NW, NWV, S2D ? "true" : "false", PF, F32 ? "true" : "false", REF,
-                  PP ? "true" : "false", plan_txt);
+  hipLaunchKernelGGL((conv_bf16_kernel<MW, NW, NWV, S2D, PF, F32, REF, PP, LEPI>), grid, dim3(64 * NWV), lds_bytes, stream, p);
+  yogo_launch_log("conv_bf16_kernel<%d, %d, %d, %s, %d, %s, %d, %s, %s> | %s", MW, NW, NWV, S2D ? "true" : "false", PF, F32 ? "true" : "false", REF,
+                  PP ? "true" : "false", LEPI ? "true" : "false", plan_txt);
 }
 // the ping-pong main loop exists for the 8-wavefront tiles with bf16 output (two wavefronts per SIMD)
 template <int MW, int NW, int NWV, bool S2D, int PF, bool F32, int REF>
@@ -1353,6 +1366,18 @@ void bf_launch_t(dim3 grid, int lds_bytes, hipStream_t stream, const ConvBf16Par
   }
   if constexpr (NWV == 4 && !S2D && !F32) {
     if (p.lean4) {
+      // the epilogue's general order of operations (kernel: `general`) is only compiled into the LEPI = false instantiation
+      const bool general = p.stats_part != nullptr || p.act == ACT_SILU || p.out_pre != nullptr || ((REF == 1 || REF == 2) && p.ref_act != ACT_LEAKY);
+#ifndef BF_NO_LEPI   // (A/B variant builds: bash build.sh variant nolepi conv_bf16 -DBF_NO_LEPI)
+      if constexpr (REF != 1) {
+        if (!general) {
+          bf_launch_one<MW, NW, NWV, S2D, PF, F32, REF, true, true>(grid, lds_bytes, stream, p, plan_txt);
+          return;
+        }
+      }
+#else
+      (void)general;
+#endif
       bf_launch_one<MW, NW, NWV, S2D, PF, F32, REF, true>(grid, lds_bytes, stream, p, plan_txt);
       return;
     }
