@@ -9,7 +9,7 @@
 One JSON line on rank 0.  A "step" is one optimisation step over one per-GPU batch resident in HBM (weak scaling:
 per-GPU batch fixed, the images are sharded over ranks, one RCCL all-reduce of the flat gradient per step).
 `roofline` is measured live with HIP events (torch.cuda.Event on the stream the kernels are launched on) around every
-launch of the dominant kernel -- conv_bf16_kernel<4,2,8,false,10,false,0,true> (the stride-1 bf16 convolutions with 128 GEMM rows, ping-pong main loop) by
+launch of the dominant kernel -- conv_bf16_kernel<4,2,8,false,10,false,0,true,false> (the stride-1 bf16 convolutions with 128 GEMM rows, ping-pong main loop) by
 default, conv_igemm_f32_kernel<4,2> under --dtype f32;
 `cpu_baseline` times the CPU oracle (oracle/yogo_oracle.py: the reference's algorithm on torch CPU ops) on a bounded
 sample of the same workload -- a reported baseline, never the target.
@@ -358,7 +358,7 @@ def main():
             except Exception:
                 tj = {}
         if args.dtype == "bf16":
-            # dominant kernel: conv_bf16_kernel<4,2,8,false,10,false,0,true> = every stride-1 convolution with 128 GEMM rows (forward
+            # dominant kernel: conv_bf16_kernel<4,2,8,false,10,false,0,true,false> = every stride-1 convolution with 128 GEMM rows (forward
             # of layers 3/5/6, data gradient of layers 5/6).  Algorithmic FLOPs per launch: 2*B*Cout*Cin*k*k*OH*OW.
             sel = [e for e in prof if e[0] in ("fwd", "dgrad") and e[2] == 34]
             ms = ms_of(sel)
@@ -366,7 +366,7 @@ def main():
             achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             traffic = next((v.get("hbm_bytes_per_launch") for k, v in tj.items() if k.startswith("conv_bf16_kernel<4,2,8,false,10,false,0,true")), None)
             allc = [e for e in prof_all if e[0] in ("fwd", "dgrad") and e[2] in (30, 34)]
-            roof = {"bound": "mfma", "kernel": "conv_bf16_kernel<4,2,8,false,10,false,0,true> (stride-1 bf16 convolutions with 128 GEMM rows: "
+            roof = {"bound": "mfma", "kernel": "conv_bf16_kernel<4,2,8,false,10,false,0,true,false> (stride-1 bf16 convolutions with 128 GEMM rows: "
                                                "forward of layers 3/5/6, data gradient of layers 5/6)",
                     "achieved": round(achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
