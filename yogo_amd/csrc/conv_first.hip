@@ -563,6 +563,106 @@ __global__ __launch_bounds__(CF_THREADS, GRAM ? 3 : 2) void conv_first_bn_wgrad_
 #undef CFB_PIXEL
 }
 
+// The sweep above for the shape the bf16 training step runs (uint8 one-channel image, stride 2, even sizes, caller-held Gram
+// matrix, Cout a multiple of 8, no activation or LeakyReLU), written for the PACKED fp32 pipe.  The sweep is bound by vector-
+// instruction issue (0.77 of the SIMD cycles, profiles/r03_issue_util.txt; a wave64 instruction holds its SIMD for 4 cycles), and
+// v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 do two lanes' worth per instruction: every quantity lives as a PAIR of adjacent
+// channels -- (z, g) unpacked from the bf16 pairs of the unit, xh, the activation factor, gb, S1, S2 -- and
+// A1[c..c+1][j] += gb[c..c+1] * patch_j is one packed FMA with the patch value broadcast.  Same arithmetic per element, same
+// summation order, so the sums are bit-identical to conv_first_bn_wgrad_kernel's.
+typedef float cf_f32x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(CF_THREADS, 3) void conv_first_bn_wgrad_pk_kernel(const ConvFirstBnWgradParams p) {
+  constexpr int NJ = 9, PER = 2 * NJ + 2, COC = 8, NP = COC / 2;
+  __shared__ float red[4][COC * PER];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y;
+  const int npix = p.OH * p.OW;
+  const int pbase = blockIdx.x * (CF_THREADS * CFW_PPT);
+  const int ncol = p.Cout * PER + NJ + NJ * NJ;
+  const unsigned char* ib = reinterpret_cast<const unsigned char*>(p.in) + (size_t)b * p.IH * p.IW;
+  float* prow = p.part + (size_t)(b * gridDim.x + blockIdx.x) * ncol;
+  for (int e = tid; e < NJ + NJ * NJ; e += CF_THREADS) prow[p.Cout * PER + e] = 0.f;   // P / G: the finalize reads the caller's
+  const bool leaky = p.act == ACT_LEAKY;   // (uniform; the launcher takes ACT_NONE / ACT_LEAKY only)
+  for (int co0 = 0; co0 < p.Cout; co0 += COC) {
+    cf_f32x2 a1[NP][NJ], s1[NP], s2[NP], mu[NP], is[NP], ga[NP], be[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int c = co0 + 2 * q;
+      mu[q] = cf_f32x2{p.mean[c], p.mean[c + 1]};
+      is[q] = cf_f32x2{p.invstd[c], p.invstd[c + 1]};
+      ga[q] = cf_f32x2{p.gamma[c], p.gamma[c + 1]};
+      be[q] = cf_f32x2{p.beta[c], p.beta[c + 1]};
+      s1[q] = s2[q] = cf_f32x2{0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) a1[q][j] = cf_f32x2{0.f, 0.f};
+    }
+    for (int k = 0; k < CFW_PPT; ++k) {
+      const int pix = pbase + k * CF_THREADS + tid;
+      const bool ok = pix < npix;
+      const int pc = ok ? pix : 0;
+      const int oy = pc / p.OW, ox = pc - oy * p.OW;
+      float x[NJ];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int iy = 2 * oy + kh - 1;  // <= IH - 1 (even sizes)
+        const bool rok = ok && iy >= 0;
+        const int o_ = rok ? iy * p.IW + 2 * ox : 0;  // bytes o_ - 2 .. o_ + 1
+        const unsigned hi_ = *reinterpret_cast<const unsigned short*>(ib + o_);
+        const unsigned lo_ = *reinterpret_cast<const unsigned short*>(ib + ((rok && ox > 0) ? o_ - 2 : o_));
+        x[kh * 3 + 0] = (rok && ox > 0) ? (float)(lo_ >> 8) : 0.f;
+        x[kh * 3 + 1] = rok ? (float)(hi_ & 0xFFu) : 0.f;
+        x[kh * 3 + 2] = rok ? (float)(hi_ >> 8) : 0.f;
+      }
+      const size_t u = ((size_t)b * p.Mb + (co0 >> 3)) * npix + pc;
+      cf_u32x4 gw = p.g[u];
+      const cf_u32x4 zw = p.z[u];
+      if (!ok) gw = cf_u32x4{0u, 0u, 0u, 0u};   // a pixel beyond the tail contributes gb = 0 to every sum
+      const unsigned gws[4] = {gw.x, gw.y, gw.z, gw.w}, zws[4] = {zw.x, zw.y, zw.z, zw.w};
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        // the two bf16 of a dword, widened: low half << 16, high half masked
+        const cf_f32x2 gv = {__builtin_bit_cast(float, gws[q] << 16), __builtin_bit_cast(float, gws[q] & 0xFFFF0000u)};
+        const cf_f32x2 zv = {__builtin_bit_cast(float, zws[q] << 16), __builtin_bit_cast(float, zws[q] & 0xFFFF0000u)};
+        const cf_f32x2 xh = (zv - mu[q]) * is[q];
+        cf_f32x2 gb = gv;
+        if (leaky) {
+          const cf_f32x2 yb = __builtin_elementwise_fma(ga[q], xh, be[q]);
+          const cf_f32x2 f = {yb.x > 0.f ? 1.f : LEAKY_SLOPE, yb.y > 0.f ? 1.f : LEAKY_SLOPE};
+          gb = gv * f;
+        }
+        s1[q] += gb;
+        s2[q] = __builtin_elementwise_fma(gb, xh, s2[q]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) a1[q][j] = __builtin_elementwise_fma(gb, cf_f32x2{x[j], x[j]}, a1[q][j]);
+      }
+    }
+    // cross-lane sums (DPP), then the four wavefronts through LDS -- the column layout of conv_first_bn_wgrad_kernel
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = 2 * q + h;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const float v1 = wave_sum(h ? a1[q][j].y : a1[q][j].x);
+          if (lane == 0) red[wave][c * PER + j] = v1;
+        }
+        const float t1 = wave_sum(h ? s1[q].y : s1[q].x), t2 = wave_sum(h ? s2[q].y : s2[q].x);
+        if (lane == 0) {
+          red[wave][c * PER + 2 * NJ] = t1;
+          red[wave][c * PER + 2 * NJ + 1] = t2;
+        }
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < COC * PER; e += CF_THREADS) {
+      const int c = e / PER, kk = e - c * PER;
+      if (!(kk >= NJ && kk < 2 * NJ)) prow[(co0 + c) * PER + kk] = red[0][e] + red[1][e] + red[2][e] + red[3][e];   // (the A2 columns come from the Gram matrix)
+    }
+    __syncthreads();
+  }
+}
+
 // sums [Cout*(2*NJ+2) + NJ (+ NJ*NJ)] -> dW (OIHW), dgamma, dbeta, each clamped to +-clip when clip > 0
 __global__ void conv_first_bn_wgrad_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ mean,
                                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
@@ -753,7 +853,10 @@ static int conv_first_bn_wgrad_impl(const void* in, int in_dtype, const void* g,
   p.OH = (IH - 1) / stride + 1; p.OW = (IW - 1) / stride + 1; p.ext_gram = ext_gram;
   if (B == 0) return YOGO_OK;
   dim3 grid(first_wgrad_tiles(p.OH, p.OW), B);
-  if (in_dtype == 0 && Cin == 1 && stride == 2 && IH % 2 == 0 && IW % 2 == 0 && (long long)IH * IW < (1ll << 31))
+  const bool fast = in_dtype == 0 && Cin == 1 && stride == 2 && IH % 2 == 0 && IW % 2 == 0 && (long long)IH * IW < (1ll << 31);
+  if (fast && ext_gram && Cout % 8 == 0 && (act == ACT_NONE || act == ACT_LEAKY))
+    hipLaunchKernelGGL(conv_first_bn_wgrad_pk_kernel, grid, dim3(CF_THREADS), 0, stream, p);
+  else if (fast)
     hipLaunchKernelGGL((conv_first_bn_wgrad_kernel<uint8_t, 1, 8, true, true>), grid, dim3(CF_THREADS), 0, stream, p);
   else if (in_dtype == 0 && Cin == 1) hipLaunchKernelGGL((conv_first_bn_wgrad_kernel<uint8_t, 1, 8, true>), grid, dim3(CF_THREADS), 0, stream, p);
   else if (in_dtype == 0) hipLaunchKernelGGL((conv_first_bn_wgrad_kernel<uint8_t, 3, 2, false>), grid, dim3(CF_THREADS), 0, stream, p);
