@@ -235,7 +235,7 @@ def test_layer0_on_matrix_cores(B, IH, IW, Cout, use_bias):
     assert rel_err(z.float().cpu(), z_old.float().cpu()) < 4e-3
 
 
-@pytest.mark.parametrize("B,IH,IW", [(3, 20, 24), (2, 772, 1032)])
+@pytest.mark.parametrize("B,IH,IW", [(3, 20, 24), (2, 18, 28), (2, 772, 1032)])   # (output width 14: the one-pixel-per-step kernel)
 def test_layer0_statistics_from_gram(B, IH, IW):
     """yogo_conv_first_gram + yogo_bn_stats_from_gram: patch sums are exact integers; mean / invstd / running statistics equal
     those of the convolution output (float64 reference)."""

@@ -285,6 +285,60 @@ __global__ __launch_bounds__(256) void conv_first_gram_kernel(const unsigned cha
 }
 
 // one workgroup per partial column: exact 64-bit sum over the rows -> gram (double) and gram_f32, both [90] = P[9], G[9][9]
+// The same sums with FOUR pixels per integer instruction (output width a multiple of 4, image rows 4-byte aligned): a lane takes
+// groups of 4 adjacent output pixels, builds for every tap ONE word holding that tap's byte of the 4 pixels (three aligned dword
+// loads per image row, v_perm_b32 picks the even / odd bytes, v_alignbit_b32 shifts the left neighbour in) and accumulates
+// P[j] += dot4(X_j, 1), G[j][j2] += dot4(X_j, X_j2) with v_dot4_u32_u8 -- 54 dot products per 4 pixels where the kernel above
+// spends 4 x 54 multiply-adds.  That kernel is bound by vector-instruction issue (0.88 of its SIMD cycles,
+// profiles/r03_issue_util.txt).  Exact integers either way: same partial rows, same fold.
+__global__ __launch_bounds__(256) void conv_first_gram4_kernel(const unsigned char* __restrict__ in, unsigned* __restrict__ part, int IH,
+                                                               int IW, int OH, int OW) {
+  __shared__ unsigned red[4][54];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y, owg = OW >> 2, ngroups = OH * owg;
+  const unsigned char* ib = in + (size_t)b * IH * IW;
+  unsigned acc[54];
+#pragma unroll
+  for (int q = 0; q < 54; ++q) acc[q] = 0u;
+  const int gbase = blockIdx.x * (256 * (CFG_PPT / 4));
+  for (int k = 0; k < CFG_PPT / 4; ++k) {
+    const int gi = gbase + k * 256 + tid;
+    const bool ok = gi < ngroups;
+    const int gc = ok ? gi : 0;
+    const int oy = gc / owg, ox0 = 4 * (gc - oy * owg);
+    unsigned x[9];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int iy = 2 * oy + kh - 1;  // <= IH - 1 (even sizes)
+      const bool rok = ok && iy >= 0;
+      const unsigned* row = reinterpret_cast<const unsigned*>(ib + (size_t)(rok ? iy : 0) * IW + 2 * ox0);   // 4-byte aligned
+      const unsigned d1 = rok ? row[0] : 0u, d2 = rok ? row[1] : 0u;            // input columns 2 ox0 .. 2 ox0 + 7
+      const unsigned d0 = (rok && ox0 > 0) ? row[-1] : 0u;                      // ... 2 ox0 - 4 .. 2 ox0 - 1 (left border: zeros)
+      const unsigned odd = __builtin_amdgcn_perm(d2, d1, 0x07050301u);          // columns +1 +3 +5 +7  = tap kx = 2 of the 4 pixels
+      x[kh * 3 + 1] = __builtin_amdgcn_perm(d2, d1, 0x06040200u);               // columns +0 +2 +4 +6  = tap kx = 1
+      x[kh * 3 + 2] = odd;
+      x[kh * 3 + 0] = __builtin_amdgcn_alignbit(odd, d0, 24);                   // columns -1 +1 +3 +5  = tap kx = 0
+    }
+    int q = 9;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      acc[j] = __builtin_amdgcn_udot4(x[j], 0x01010101u, acc[j], false);
+#pragma unroll
+      for (int j2 = j; j2 < 9; ++j2) {
+        acc[q] = __builtin_amdgcn_udot4(x[j], x[j2], acc[q], false);
+        ++q;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 54; ++q) {
+    const unsigned v = cfm_wave_sum_u32(acc[q]);
+    if (lane == 0) red[wave][q] = v;
+  }
+  __syncthreads();
+  if (tid < 54) part[((size_t)b * gridDim.x + blockIdx.x) * 54 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
 __global__ __launch_bounds__(256) void conv_first_gram_fold_kernel(const unsigned* __restrict__ part, int rows, double* __restrict__ gram,
                                                                    float* __restrict__ gram_f32) {
   __shared__ unsigned long long sh[256];
@@ -398,8 +452,14 @@ extern "C" int yogo_conv_first_gram(const void* in, void* part, double* gram, fl
   YOGO_CHECK_ARG(in && part && gram && gram_f32 && B > 0, "conv_first_gram: bad arguments");
   YOGO_CHECK_ARG(yogo_conv_first_mfma_supported(0, 1, 1, IH, IW, 2) && B <= 65535, "conv_first_gram: unsupported shape %dx%d", IH, IW);
   const int OH = IH / 2, OW = IW / 2, tiles = cdiv(OH * OW, 256 * CFG_PPT);
-  hipLaunchKernelGGL(conv_first_gram_kernel, dim3(tiles, B), dim3(256), 0, stream, reinterpret_cast<const unsigned char*>(in),
-                     reinterpret_cast<unsigned*>(part), IH, IW, OH, OW);
+  // four pixels per integer instruction when a group of 4 output pixels is three aligned dwords of an image row
+  if (OW % 4 == 0 && (reinterpret_cast<uintptr_t>(in) & 3) == 0) {
+    hipLaunchKernelGGL(conv_first_gram4_kernel, dim3(tiles, B), dim3(256), 0, stream, reinterpret_cast<const unsigned char*>(in),
+                       reinterpret_cast<unsigned*>(part), IH, IW, OH, OW);
+  } else {
+    hipLaunchKernelGGL(conv_first_gram_kernel, dim3(tiles, B), dim3(256), 0, stream, reinterpret_cast<const unsigned char*>(in),
+                       reinterpret_cast<unsigned*>(part), IH, IW, OH, OW);
+  }
   hipLaunchKernelGGL(conv_first_gram_fold_kernel, dim3(54), dim3(256), 0, stream, reinterpret_cast<const unsigned*>(part), tiles * B, gram,
                      gram_f32);
   YOGO_CHECK_LAUNCH("conv_first_gram");
