@@ -293,18 +293,22 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
 // dW[co][ci][t] = clamp(sum_s slab[s][t][co][ci]);  db[co] = clamp(sum_s bias_part[s][co])
 // 256 consecutive slab elements per workgroup, four per lane (16-byte loads, eight slabs in flight per lane); the four
 // wavefronts each add a fixed quarter of the slabs in fp64, then combine in a fixed order -> bitwise reproducible.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, int T, int M, int N,
-                                                           int Mpad, int Npad, float clip, float* __restrict__ dw,
-                                                           const float* __restrict__ bias_part, int nbias,
-                                                           float* __restrict__ db) {
-  __shared__ double sh[4][256];
+// NWAVE = 16 (many slabs): sixteen wavefronts share the slabs of a workgroup's 256 elements -- a lane's chain of dependent
+// 8-load batches is what the kernel waits for (24 us per launch, seven launches per step, with a quarter of the CUs busy), and it
+// is a quarter as long.
+template <int NWAVE>
+__global__ __launch_bounds__(64 * NWAVE) void wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, int T, int M, int N,
+                                                                  int Mpad, int Npad, float clip, float* __restrict__ dw,
+                                                                  const float* __restrict__ bias_part, int nbias,
+                                                                  float* __restrict__ db) {
+  __shared__ double sh[NWAVE][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t stride = (size_t)T * Mpad * Npad;  // Npad is a multiple of 32, Mpad*Npad of 1024
   const int nw = (int)((stride + 255) / 256);
   if ((int)blockIdx.x < nw) {
     const size_t e0 = (size_t)blockIdx.x * 256 + lane * 4;
     const bool in = e0 < stride;  // stride is a multiple of 4
-    const int per = (nslab + 3) / 4;
+    const int per = (nslab + NWAVE - 1) / NWAVE;
     const int k0 = wave * per, k1 = min(nslab, k0 + per);
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     if (in) {
@@ -328,13 +332,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     sh[wave][lane * 4 + 0] = s0; sh[wave][lane * 4 + 1] = s1; sh[wave][lane * 4 + 2] = s2; sh[wave][lane * 4 + 3] = s3;
     __syncthreads();
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (e < stride) {
+    if (threadIdx.x < 256 && e < stride) {
       const int n = (int)(e % Npad);
       const int m = (int)((e / Npad) % Mpad);
       const int t = (int)(e / ((size_t)Npad * Mpad));
       if (m < M && n < N) {
         const int i = threadIdx.x;
-        float v = (float)(sh[0][i] + sh[1][i] + sh[2][i] + sh[3][i]);
+        double acc = 0.0;   // (fixed order, wavefront 0 first)
+#pragma unroll
+        for (int w = 0; w < NWAVE; ++w) acc += sh[w][i];
+        float v = (float)acc;
         if (clip > 0.f) v = fminf(fmaxf(v, -clip), clip);
         dw[((size_t)m * N + n) * T + t] = v;
       }
@@ -346,9 +353,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int c = threadIdx.x & 15, part = threadIdx.x >> 4;
     const int e = ((int)blockIdx.x - nw) * 16 + c;
     double s = 0.0;
-    if (e < M)
-      for (int k = part; k < nbias; k += 16) s += (double)bias_part[(size_t)k * Mpad + e];
-    shb[part * 16 + c] = s;
+    if (threadIdx.x < 256) {
+      if (e < M)
+        for (int k = part; k < nbias; k += 16) s += (double)bias_part[(size_t)k * Mpad + e];
+      shb[part * 16 + c] = s;
+    }
     __syncthreads();
     if (threadIdx.x < 16 && e < M) {
       double t = 0.0;
@@ -365,8 +374,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 extern "C" int yogo_internal_wgrad_reduce(const float* slab, int nslab, int T, int M, int N, int Mpad, int Npad, float clip, float* dw,
                                           const float* bias_part, int nbias, float* db, hipStream_t stream) {
   const int nw = (int)(((size_t)T * Mpad * Npad + 255) / 256);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nw + (db ? cdiv(M, 16) : 0)), dim3(256), 0, stream, slab, nslab, T, M, N, Mpad, Npad,
-                     clip, dw, bias_part, nbias, db);
+  if (nslab >= 64)
+    hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(nw + (db ? cdiv(M, 16) : 0)), dim3(1024), 0, stream, slab, nslab, T, M, N, Mpad, Npad,
+                       clip, dw, bias_part, nbias, db);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(nw + (db ? cdiv(M, 16) : 0)), dim3(256), 0, stream, slab, nslab, T, M, N, Mpad, Npad,
+                       clip, dw, bias_part, nbias, db);
   YOGO_CHECK_LAUNCH("wgrad_reduce");
   return YOGO_OK;
 }
@@ -502,7 +515,7 @@ static int wgrad_impl(const void* x_, const void* g_, bool bf, float* dw, float*
       return YOGO_ERR_ARG;
   }
   const int nw = (int)(((size_t)T * pl.Mpad * pl.Npad) / 64);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nw + (db ? cdiv(Cout, 256) : 0)), dim3(256), 0, stream, p.slab,
+  hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(nw + (db ? cdiv(Cout, 256) : 0)), dim3(256), 0, stream, p.slab,
                      pl.nsplit * pl.KS, T, Cout, Cin, pl.Mpad, pl.Npad, clip, dw, p.bias_part, pl.nsplit, db);
   YOGO_CHECK_LAUNCH("conv2d_wgrad");
   return YOGO_OK;
