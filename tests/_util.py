@@ -41,10 +41,13 @@ def rel_err(a, b):
 
 
 # ---- a bf16 training step of the HIP path against the oracle's bf16-storage emulation (O.bf16_train_step), END TO END ----
-# Tolerances (stated once, used by every bf16 whole-step test): loss 1e-3 relative, per gradient tensor cosine >= 0.995
-# (measured over 11 architectures x 3 sizes, tools/probes/sweep_models.py: 0.9970 ... 1.0000; against the fp32 oracle the same
-# tensors sit at 0.90 ... 0.99), running statistics 1e-3.  The elementwise bounds live in the teacher-forced check further
-# down -- the comment there says why two correct bf16 implementations cannot agree more closely than this END TO END.
+# Tolerances (stated once, used by every bf16 whole-step test): loss 1e-3 relative, per gradient tensor cosine >= 0.995, running
+# statistics 1e-3.  The cases the tests run (772x1032 and the architectures of test_gpu_bf16.py / test_gpu_dp.py) sit at 0.9970 ...
+# 1.0000.  This is NOT a bound every input meets: over the 33 (architecture, size) points of tools/probes/sweep_models.py the
+# loss is always within 7e-4, all 33 pass the teacher-forced per-kernel check below, 26 have every tensor >= 0.995 and 7 have ONE
+# tensor between 0.968 and 0.9947 (a single flipped LeakyReLU sign in a sparse gradient; against the fp32 oracle the same tensors
+# sit at 0.90 ... 0.99).  The elementwise bounds live in the teacher-forced check further down -- the comment there says why two
+# correct bf16 implementations cannot agree more closely than this END TO END.
 BF16_STEP_LOSS_RTOL = 1e-3
 BF16_STEP_COS_MIN = 0.995
 

@@ -1,15 +1,16 @@
-"""every registered architecture through two bf16 training steps at a few image sizes, held to the oracle's bf16-storage
-emulation (oracle/yogo_oracle.py:bf16_train_step): step-1 loss 1e-3, every gradient tensor cosine >= 0.995, step-2 loss (after
-one AdamW update on either side) 2e-2.  The fp32 path's two losses are printed beside them for
-information: bf16 storage moves a gradient tensor by ~1 % against fp32, and Adam's first update lr * sign(g) turns that into
-several per cent of the second loss on the wide models (the loss falls by 50-80 % in that one step) -- a property of bf16
-storage, which is why the bound is taken against the emulation and not against fp32."""
+"""every registered architecture through two bf16 training steps at a few image sizes against the oracle's bf16-storage
+emulation (oracle/yogo_oracle.py:bf16_train_step): (1) the teacher-forced check of tests/_util.py -- every kernel of the step
+against the emulation of THAT kernel on the step's own tensors (tight: one bf16 ulp, statistics 1e-5, parameter gradients 5e-5);
+(2) end to end: step-1 loss 1e-3 and every gradient tensor's cosine >= 0.995.  (1) must hold everywhere; (2) is reported: it
+depends on the input (one flipped LeakyReLU sign in front of a sparse gradient moves a tensor's cosine to 0.97-0.99 with every
+kernel right -- round 3: 33 points, teacher-forced 33 / 33, end to end 26 / 33).  The fp32 path's two losses are printed beside
+them for information."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
 import torch
 import yogo_oracle as O
-from _util import BF16_STEP_LOSS_RTOL, assert_grads_match_bf16_oracle
+from _util import BF16_STEP_LOSS_RTOL, assert_grads_match_bf16_oracle, teacher_forced_bf16_step_check
 from yogo_amd.model import YOGO
 from yogo_amd.model_defns import MODELS
 from yogo_amd.train import HipTrainer
@@ -33,15 +34,25 @@ for name, fn in MODELS.items():
                 sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
                 lab = O.synthetic_labels(B, m.Sx, m.Sy, K=4, num_classes=5, seed=3)
                 tr = HipTrainer(m, YOGOLoss().cuda(), total_steps=4, half=half)
+                tf = ""
+                if half:
+                    tr.trace = {}
                 tr.step(x.cuda(), lab.cuda())
+                if half:   # every kernel of THIS step against the emulation of that kernel on the step's own tensors (tests/_util.py)
+                    try:
+                        teacher_forced_bf16_step_check(O, tr, m, x, lab, O.arch(name, 5), sd0, name)
+                        tf = "teacher-forced ok"
+                    except AssertionError as e:
+                        tf = "TEACHER-FORCED FAIL " + str(e)[:100]
+                    tr.trace = None
                 first = tr.loss_components()["loss"]
                 grads, off = {}, 0
                 for pname, p in m.named_parameters():
                     grads[pname] = tr.flat.grad[off:off + p.numel()].view(p.shape).cpu().clone()
                     off += p.numel()
                 tr.step(x.cuda(), lab.cuda())
-                res[half] = (first, tr.loss_components()["loss"], grads, sd0, lab, tr.lr, tr.wd)
-            first, second, grads, sd0, lab, lr, wd = res[True]
+                res[half] = (first, tr.loss_components()["loss"], grads, sd0, lab, tr.lr, tr.wd, tf)
+            first, second, grads, sd0, lab, lr, wd, tf = res[True]
             spec = O.arch(name, 5)
             l1, _, gref, _ = O.bf16_train_step(x, sd0, spec, lab, 0.0425, 0.0555)
             sd1 = dict(sd0)
@@ -56,9 +67,10 @@ for name, fn in MODELS.items():
                 worst, gok = (0.0, str(e)[:120]), False
             ok = gok and rel1 < BF16_STEP_LOSS_RTOL   # (rel2, the end-to-end second loss, is printed for information: ill-conditioned)
             bad += not ok
+            tfbad = tfbad + (not tf.endswith("ok")) if "tfbad" in dir() else int(not tf.endswith("ok"))
             print(f"{name:16s} {H}x{W} B={B} rgb={int(rgb)}: bf16 {first:.4f} -> {second:.4f} | emulation {l1:.4f} -> {l2:.4f} rel {rel1:.1e} / {rel2:.1e} "
-                  f"worst cos {worst[0]:.5f} ({worst[1]}) | fp32 path {res[False][0]:.4f} -> {res[False][1]:.4f}{'' if ok else '   <-- MISMATCH'}", flush=True)
+                  f"worst cos {worst[0]:.5f} ({worst[1]}) | {tf} | fp32 path {res[False][0]:.4f} -> {res[False][1]:.4f}{'' if ok else '   <-- MISMATCH'}", flush=True)
         except Exception as e:
             bad += 1
             print(f"{name:16s} {H}x{W} B={B} rgb={int(rgb)}: ERROR {type(e).__name__}: {str(e)[:150]}", flush=True)
-print("problems:", bad)
+print("end-to-end cosine / loss outside the bounds:", bad, "| teacher-forced failures:", tfbad if "tfbad" in dir() else 0)
