@@ -1248,7 +1248,7 @@ bool bf_plan_rows(int OH, int OW, int a, int T, int span, int Kb, int MW, int NW
     const int bw_min = OW - (cdiv(OW, TW) - 1) * TW;
     if (cdiv(OW, TW) != ncb || bw_min <= 0) continue;
     const int LW = (TW - 1) * a + span;
-    const int lwp = LW <= 64 ? 64 : (LW <= 128 ? 128 : 0);
+    const int lwp = LW <= 64 ? 64 : ((LW <= 128 && a == 1) ? 128 : 0);   // (stride 2: one piece per row, or the piece count doubles)
     if (!lwp) continue;
     const int nrow_lat = min(OH, 1 + cdiv(PT - 1, bw_min));
     const int rows_max = (nrow_lat - 1) * a + span;
@@ -1425,9 +1425,9 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
   // the lean single-buffer 4-wavefront tiles (3x3, 16-channel chunks): stage the input row by row when that keeps the
   // workgroups-per-CU level of the slot plan
   int rowdma = 0, lwp = 0;
-  // (stride 1 only: measured -2.5 ... -5 % on the 16 <-> 32 channel layer in both directions, +1 % on the stride-2 forward, whose
-  //  87-unit rows need two pieces each)
-  if (!s2d && a == 1 && NWV == 4 && T == 9 && tl.CKb == 2 && tl.dma == 2 && out_f32 == nullptr && g_bf_lean4 && g_bf_rowdma) {
+  // (measured: -2.5 ... -5 % on the 16 <-> 32 channel layer in both directions; the stride-2 forward -2 ... -3.5 % with ONE piece
+  //  per row -- bands of at most 31 output columns -- and +1 % with 87-unit rows in two pieces, so its pitch stays 64)
+  if (!s2d && NWV == 4 && T == 9 && tl.CKb == 2 && tl.dma == 2 && out_f32 == nullptr && g_bf_lean4 && g_bf_rowdma) {
     const int ladder[3] = {40 * 1024, 53 * 1024, BF_LDS_BUDGET};
     int level = 0;
     while (level < 2 && tl.lds_bytes > ladder[level]) ++level;
