@@ -77,7 +77,11 @@ CASES = [(2, 16, 32, 20, 37, 3, 1), (1, 32, 64, 21, 40, 3, 2), (2, 64, 128, 13, 
          # weight-gradient step loops unrolled per steps-per-row count (16 / 32 / 48 / 64 staged columns), pixel-split and
          # two-co-block tilings, tall (8-row) and short units
          (1, 16, 32, 9, 12, 3, 1), (1, 16, 32, 66, 60, 3, 1), (2, 64, 128, 10, 14, 3, 1), (1, 64, 128, 7, 64, 3, 1), (2, 32, 64, 17, 30, 3, 1),
-         (1, 128, 128, 12, 60, 3, 2)]
+         (1, 128, 128, 12, 60, 3, 2),
+         # round 3: row-wise LDS-DMA staging of the lean 4-wavefront tiles -- widths around the 64-unit row pitch (one band of 62
+         # columns, 63 -> two bands, narrow last bands), several tiles per band, stride 2 with bands of at most 31 columns
+         (1, 16, 32, 40, 62, 3, 1), (1, 16, 32, 40, 63, 3, 1), (2, 32, 16, 23, 125, 3, 1), (1, 16, 32, 33, 130, 3, 1),
+         (1, 32, 64, 30, 124, 3, 2), (1, 32, 64, 31, 127, 3, 2)]
 
 
 @pytest.mark.parametrize("case", CASES)
