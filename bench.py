@@ -156,7 +156,7 @@ def inference_extras(model, dev, B: int = 256):
         from yogo_amd.synthetic import raw_from_predictions
         from yogo_amd.utils.prediction_formatting import RawPredictions
 
-        rp = RawPredictions(raw_from_predictions(real, model._Cxs, model._Cys), model._Cxs, model._Cys, *model._decode_scalars(), True)
+        rp = RawPredictions(raw_from_predictions(real, model._Cxs, model._Cys, *model._decode_scalars()[:2]), model._Cxs, model._Cys, *model._decode_scalars(), True)
         ms_fr = _timed_gpu(lambda: format_preds_batched(rp), reps=20)
         raw = torch.randn(B, 5 + NUM_CLASSES, model.Sy, model.Sx, device=dev)
         dec = torch.empty_like(raw)
@@ -222,6 +222,27 @@ def fp32_forward_loss(dev, B: int = 64):
                          "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)}}
 
 
+def spawn_ranks(n: int, argv) -> int:
+    """run `python -m torch.distributed.run --nproc-per-node n bench.py <argv>` as a CHILD process and relay its output"""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:   # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print(f"[bench] --gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd)}", file=sys.stderr)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:   # rank 0 prints the one JSON line; everything else the ranks print goes to stderr
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -238,6 +259,12 @@ def main():
                     help="gradient exchange transport: torch.distributed (backend above) or librccl called directly through the C ABI")
     ap.add_argument("--no-overlap", action="store_true", help="one all-reduce after backward instead of the overlapped two-part exchange")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, like the reference's `yogo train` does
+        # (yogo/train.py:645-656 counts the devices and mp.spawn()s one process per GPU).  This parent never touches the GPU
+        # (no torch.cuda call at all), never exec()s, relays rank 0's JSON line and exits with the children's status.
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -256,7 +283,7 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+        print(f"[bench] note: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; reporting n_gpus={world}", file=sys.stderr)
 
     from yogo_amd.model import YOGO
     from yogo_amd.synthetic import synthetic_images, synthetic_labels
@@ -303,13 +330,22 @@ def main():
     dominant_tag = 34 if args.dtype == "bf16" else 4
     trainer.engine.prof = []
     trainer.engine.prof_only = {dominant_tag}
+    # per step: host time to ENQUEUE the step (perf_counter around trainer.step, no sync) and one HIP event pair on the launch
+    # stream -- whether the timed region was GPU-bound or waiting for the host shows in the record itself
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    enq = []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    ev[0].record()
+    for i in range(args.steps):
+        ts = time.perf_counter()
         trainer.step(imgs, labels)
+        enq.append(time.perf_counter() - ts)
+        ev[i + 1].record()
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    gpu_step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
     prof = trainer.engine.prof
     loss_rec = trainer.loss_components()
     nb = max(1, min(args.steps, 5))
@@ -398,6 +434,11 @@ def main():
                                    "7 classes" + ("" if args.dtype == "bf16" else " -- run at fp32 storage+arithmetic"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}"},
             "roofline": roof,
+            "host_enqueue_ms_per_step": round(1e3 * _median(enq), 3),
+            "host_enqueue_ms_per_step_max": round(1e3 * max(enq), 3),
+            "gpu_ms_per_step_events": round(_median(gpu_step_ms), 3),
+            "gpu_ms_per_step_events_min_max": [round(min(gpu_step_ms), 3), round(max(gpu_step_ms), 3)],
+            "rccl_ranks": (world if (world > 1 and args.backend == "nccl") else (1 if world == 1 else 0)),
             "step_tflops": round(value * TRAIN_GFLOP_PER_IMG / 1e3, 2),
             "conv_breakdown": by_kind,
             "loss": round(loss_rec["loss"], 4),

@@ -48,7 +48,7 @@ with torch.no_grad():
             out["forward_decode_plus_postprocess_ms"] = round(timed(lambda: format_preds_batched(m(x)), reps), 3)
     else:
         pred = synthetic_predictions(B, m.Sx, m.Sy, 7, K=100, device=dev)
-        raw = raw_from_predictions(pred, m._Cxs, m._Cys)
+        raw = raw_from_predictions(pred, m._Cxs, m._Cys, *m._decode_scalars()[:2])
         rp = RawPredictions(raw, m._Cxs, m._Cys, *m._decode_scalars(), True)
         out["fused_ms"] = round(timed(lambda: format_preds_batched(rp), reps), 4)
         out["two_pass_ms"] = round(timed(lambda: format_preds_batched(rp.decoded()), reps), 4)

@@ -121,6 +121,9 @@ def predict(
             # the decoded tensor itself is only needed for drawing and for return_full_predictions; every other output goes
             # through the threshold + NMS kernel, which decodes the head's raw output as it loads it
             res = model(x) if (draw_boxes or return_full_predictions) else model.forward_raw(x)
+        # the fused launch re-runs the decode per consumer: with more than one post-process output of this batch, decode ONCE
+        if sum(map(bool, (save_preds, save_npy, count_predictions))) > 1 and hasattr(res, "decoded"):
+            res = res.decoded()
         if draw_boxes:
             for k in range(img_batch.shape[0]):
                 bbox_img = draw_yogo_prediction(img=img_batch[k, ...], prediction=res[k, ...], obj_thresh=obj_thresh, iou_thresh=iou_thresh,

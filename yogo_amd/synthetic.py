@@ -85,8 +85,7 @@ def synthetic_dense_predictions(B: int, Sx: int, Sy: int, num_classes: int = 7, 
     return out
 
 
-def raw_from_predictions(pred: torch.Tensor, cxs: torch.Tensor, cys: torch.Tensor, anchor_w: float = 0.0425,
-                         anchor_h: float = 0.0555) -> torch.Tensor:
+def raw_from_predictions(pred: torch.Tensor, cxs: torch.Tensor, cys: torch.Tensor, anchor_w: float, anchor_h: float) -> torch.Tensor:
     """a head output whose box decode (yogo/model.py:277-313, inference mode) gives `pred` back up to rounding: the input of the
     fused decode + threshold + NMS kernel for the 'realistic' / 'dense' post-process workloads above"""
     B, P, Sy, Sx = pred.shape

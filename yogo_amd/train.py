@@ -279,16 +279,27 @@ class HipTrainer:
         cnt = [b for b in bufs if not b.is_floating_point()]
         if not fl:
             return
-        flat = torch.cat([b.reshape(-1).float() for b in fl] + [b.reshape(-1).float() for b in cnt])
+        flat = torch.cat([b.reshape(-1).float() for b in fl])
+        # the integer counters (num_batches_tracked: the averaging factor of a momentum=None BatchNorm) travel as int64, bit for bit
+        icnt = torch.cat([b.reshape(-1).to(torch.int64) for b in cnt]) if cnt else None
         if self._rccl is not None:
             st = torch.cuda.current_stream().cuda_stream
             _hip.call("yogo_comm_broadcast_flat", self._rccl, flat, flat.numel() * 4, src, st)
+            if icnt is not None:
+                _hip.call("yogo_comm_broadcast_flat", self._rccl, icnt, icnt.numel() * 8, src, st)
         else:
             dist.broadcast(flat, src=src, group=self.pg)
+            if icnt is not None:
+                dist.broadcast(icnt, src=src, group=self.pg)
         off = 0
-        for b in fl + cnt:
+        for b in fl:
             n = b.numel()
             b.copy_(flat[off:off + n].view(b.shape).to(b.dtype))
+            off += n
+        off = 0
+        for b in cnt:
+            n = b.numel()
+            b.copy_(icnt[off:off + n].view(b.shape).to(b.dtype))
             off += n
         self.engine.generation += 1   # folded inference weights derive from the running statistics
 

@@ -262,6 +262,8 @@ class Trainer:
                 self.net.load_state_dict(ckpt["model_state_dict"])
             else:
                 warnings.warn(f"no best model found at {best} for testing...")
+        if self._world_size > 1 and hasattr(self.backend, "opt") and hasattr(self.backend.opt, "broadcast_parameters"):
+            self.backend.opt.broadcast_parameters()   # every rank tests rank 0's best checkpoint, not its own last weights
         if hasattr(self.backend, "sync_eval_state"):
             self.backend.sync_eval_state()
         test_metrics = self.test(self.test_dataloader, self._torch_device(), self.config, self.net, rank=self._rank, backend=self.backend)

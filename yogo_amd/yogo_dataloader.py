@@ -89,8 +89,11 @@ class DeviceLoader:
     """wraps the host DataLoader: batch -> device, label rows -> [B, 6, Sy, Sx] with one launch, flips fused.  Keeps the
     attributes the training loop touches (``dataset``, ``sampler``, ``batch_size``, ``__len__``)."""
 
-    def __init__(self, loader: DataLoader, Sx: int, Sy: int, transforms: MultiArgSequential, device=None):
+    def __init__(self, loader: DataLoader, Sx: int, Sy: int, transforms: MultiArgSequential, device=None, strict_steps: bool = False):
         self.loader, self.Sx, self.Sy, self.transforms, self.device = loader, Sx, Sy, transforms, device
+        # strict_steps (the TRAINING split only): every batch is one gradient all-reduce, so a skipped batch must fail loudly
+        # under data parallelism; validation / test loaders issue no per-step collective and may skip, as the reference does
+        self.strict_steps = strict_steps
         self.dataset, self.sampler, self.batch_size = loader.dataset, loader.sampler, loader.batch_size
 
     def __len__(self) -> int:
@@ -104,7 +107,7 @@ class DeviceLoader:
                 # every sample of the batch was unreadable (the robust collate of yogo/data/utils.py:49-63 returned nothing).  A
                 # single process just skips it; under data parallelism a rank that skips a step issues one gradient all-reduce
                 # fewer than its peers and the job hangs -- fail loudly instead
-                if multi:
+                if multi and self.strict_steps:
                     raise RuntimeError("yogo_amd: a whole batch of this rank was unreadable; in a data-parallel run every rank must "
                                        "take the same number of steps (fix or remove the unreadable files)")
                 continue
@@ -129,12 +132,12 @@ def get_dataloader(dataset_definition: DatasetDefinition, batch_size: int, Sx: i
         if len(dataset) == 0:   # type: ignore[arg-type]
             continue
         augs = augmentations if designation == "train" else []
-        d[designation] = _get_dataloader(dataset, batch_size, augs, rank, world_size, Sx, Sy, device)
+        d[designation] = _get_dataloader(dataset, batch_size, augs, rank, world_size, Sx, Sy, device, strict_steps=designation == "train")
     return d
 
 
 def _get_dataloader(dataset: Dataset, batch_size: int, augmentations: list, rank: int, world_size: int, Sx: int, Sy: int,
-                    device=None) -> DeviceLoader:
+                    device=None, strict_steps: bool = False) -> DeviceLoader:
     sampler: Iterable = DistributedSampler(dataset, rank=rank, num_replicas=world_size)   # torch defaults: shuffle, seed 0, padded
     num_workers = choose_dataloader_num_workers(len(dataset)) // world_size   # type: ignore[arg-type]
     if len(dataset) >= 1000:   # type: ignore[arg-type]
@@ -142,7 +145,7 @@ def _get_dataloader(dataset: Dataset, batch_size: int, augmentations: list, rank
     loader = DataLoader(dataset, shuffle=False, sampler=sampler, drop_last=False, pin_memory=torch.cuda.is_available(), batch_size=batch_size,
                         num_workers=num_workers, persistent_workers=num_workers > 0, generator=torch.Generator().manual_seed(SPLIT_SEED),
                         collate_fn=collate_rows, multiprocessing_context="spawn" if num_workers > 0 else None)
-    return DeviceLoader(loader, Sx, Sy, MultiArgSequential(*augmentations), device)
+    return DeviceLoader(loader, Sx, Sy, MultiArgSequential(*augmentations), device, strict_steps=strict_steps)
 
 
 def get_class_counts(d, num_classes: int, verbose: bool = True) -> torch.Tensor:
