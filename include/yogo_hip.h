@@ -147,6 +147,11 @@ int yogo_conv_bf16_packed_bytes(int Cin, int Cout, int ksize, int mode, size_t* 
 int yogo_conv_bf16_pack(const float* w_oihw, const float* scale, void* packed, int Cin, int Cout, int ksize, int mode,
                         yogo_stream_t stream);
 int yogo_conv2d_fwd_bf16_stats_shape(int B, int Cin, int Cout, int IH, int IW, int ksize, int stride, int* rows, int* mpad);
+/* Plan switch (no counterpart in the reference; cuDNN picks its algorithm behind torch.backends.cudnn.benchmark,
+ * yogo/train.py:36).  on = 1 (default): the stride-1 3x3 bf16 convolutions with 128 output channels and 64 / 128 / ... input
+ * channels (forward of yogo/model_defns.py:49-65's 128-channel blocks and their data gradients) run on the persistent
+ * 4-wavefront kernel (conv_bf16_p4_kernel); on = 0: on the tiled 8-wavefront kernel.  Results are bit-identical. */
+int yogo_conv_bf16_persistent(int on);
 /* y = chan_scale * act(conv(x) + bias); out: bf16 NCHW8c, or fp32 NCHW when out_f32 != NULL (the head);
  * stats_part (optional): BatchNorm partial (sum, sumsq) of the fp32 pre-activation */
 int yogo_conv2d_fwd_bf16(const void* in, const void* packed, const float* bias, void* out, float* out_f32,

@@ -1,0 +1,104 @@
+"""The persistent 4-wavefront convolution kernel (conv_bf16_p4_kernel) against the tiled 8-wavefront kernel it replaces
+(conv_bf16_kernel<4,2,8,...>): same MFMA sequence per accumulator and the same epilogue formula, so every output bit and every
+sign-map byte has to agree -- for the forward of yogo/model_defns.py:49-65's 128-channel blocks (bias + LeakyReLU + Dropout2d
+channel mask + sign map, or bias only in front of BatchNorm) and for their data gradients (no bias, optional channel mask).
+The tiled kernel itself is checked against CPU fp32 convolutions in test_gpu_bf16.py / test_gpu_production_shapes.py (which now
+also run through the persistent kernel where it is eligible)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _blocks(c):
+    return ((c + 15) // 16) * 2
+
+
+def _run(persistent, kind, B, Cin, H, W, seed):
+    from yogo_amd import _hip as Hh
+
+    Cout = 128
+    st = Hh.stream_ptr()
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    w = torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) * 0.05
+    x8 = torch.randn(B, _blocks(Cin), H, W, 8, device="cuda", generator=g).to(torch.bfloat16)
+    y8 = torch.full((B, _blocks(Cout), H, W, 8), 7.0, device="cuda").to(torch.bfloat16)   # poisoned: every unit must be written
+    bias = torch.randn(Cout, device="cuda", generator=g)
+    msk = (torch.rand(B, Cout, device="cuda", generator=g) > 0.2).float() / 0.8
+    Hh.call("yogo_conv_bf16_persistent", 1 if persistent else 0)
+    try:
+        Hh.launch_log(True)
+        sg = None
+        if kind == "fwd_signs":       # layer 3: bias + LeakyReLU + channel mask + sign map
+            packed = torch.empty(Hh.query_size("yogo_conv_bf16_packed_bytes", Cin, Cout, 3, 0), dtype=torch.uint8, device="cuda")
+            Hh.call("yogo_conv_bf16_pack", w, None, packed, Cin, Cout, 3, 0, st)
+            sg = torch.full((Hh.query_size("yogo_bf16_signs_bytes", B, Cout, H, W),), 0x5A, dtype=torch.uint8, device="cuda")
+            Hh.call("yogo_conv2d_fwd_bf16_signs", x8, packed, bias, y8, sg, msk, B, Cin, Cout, H, W, 3, 1, 1, st)
+        elif kind == "fwd_plain":     # layers 5 / 6: conv + bias in front of BatchNorm
+            packed = torch.empty(Hh.query_size("yogo_conv_bf16_packed_bytes", Cin, Cout, 3, 0), dtype=torch.uint8, device="cuda")
+            Hh.call("yogo_conv_bf16_pack", w, None, packed, Cin, Cout, 3, 0, st)
+            Hh.call("yogo_conv2d_fwd_bf16", x8, packed, bias, y8, None, None, None, B, Cin, Cout, H, W, 3, 1, 0, st)
+        elif kind == "fwd_leaky":     # bias + LeakyReLU, no mask, no sign map (eval-mode forward)
+            packed = torch.empty(Hh.query_size("yogo_conv_bf16_packed_bytes", Cin, Cout, 3, 0), dtype=torch.uint8, device="cuda")
+            Hh.call("yogo_conv_bf16_pack", w, None, packed, Cin, Cout, 3, 0, st)
+            Hh.call("yogo_conv2d_fwd_bf16", x8, packed, bias, y8, None, None, None, B, Cin, Cout, H, W, 3, 1, 1, st)
+        else:                         # data gradient of a 128 -> Cin... here: dy has Cin channels, dx 128 (roles as the GEMM sees them)
+            # yogo_conv2d_dgrad_bf16(dy [Cout_f], packed, dx [Cin_f]): forward conv Cin_f = 128 -> Cout_f = Cin
+            wf = torch.randn(Cin, 128, 3, 3, device="cuda", generator=g) * 0.05
+            packed = torch.empty(Hh.query_size("yogo_conv_bf16_packed_bytes", 128, Cin, 3, 1), dtype=torch.uint8, device="cuda")
+            Hh.call("yogo_conv_bf16_pack", wf, None, packed, 128, Cin, 3, 1, st)
+            Hh.call("yogo_conv2d_dgrad_bf16", x8, packed, y8, None, 0, msk if kind == "dgrad_mask" else None, B, 128, Cin, H, W, 3, 1, st)
+        torch.cuda.synchronize()
+        log = Hh.read_launch_log()
+    finally:
+        Hh.launch_log(False)
+        Hh.call("yogo_conv_bf16_persistent", 1)
+    return y8, sg, log
+
+
+CASES = [
+    # (kind, B, Cin, H, W)
+    ("fwd_plain", 2, 128, 97, 129),     # layers 5 / 6 of base_model at 772x1032
+    ("dgrad", 2, 128, 97, 129),
+    ("fwd_signs", 2, 64, 193, 258),     # layer 3
+    ("fwd_leaky", 3, 128, 13, 17),      # fewer tiles than CUs, one partial tile per image
+    ("fwd_signs", 1, 64, 40, 300),      # several column bands
+    ("dgrad_mask", 2, 96, 31, 45),      # 6 chunks
+    ("fwd_plain", 1, 128, 5, 700),      # short and wide: bands of a few rows
+    ("fwd_signs", 5, 128, 3, 3),        # one pixel group in use
+    ("fwd_plain", 40, 128, 97, 129),    # 1 000 tiles: every workgroup walks several tiles, image changes at the seams
+    ("fwd_signs", 24, 64, 193, 258),
+]
+
+
+@pytest.mark.parametrize("kind,B,Cin,H,W", CASES)
+def test_persistent_kernel_is_bit_identical_to_the_tiled_kernel(kind, B, Cin, H, W):
+    y_old, s_old, log_old = _run(False, kind, B, Cin, H, W, seed=11)
+    y_new, s_new, log_new = _run(True, kind, B, Cin, H, W, seed=11)
+    assert any(ln.startswith("conv_bf16_kernel<4, 2, 8") for ln in log_old), log_old
+    assert any(ln.startswith("conv_bf16_p4_kernel") for ln in log_new), log_new
+    plan = next(ln for ln in log_old if ln.startswith("conv_bf16_kernel<4, 2, 8"))
+    if " CKb=2 " in plan:
+        # the tiled kernel stepped through K in 16-channel chunks too: the same MFMA sequence per accumulator, bit for bit
+        assert torch.equal(y_old.view(torch.int16), y_new.view(torch.int16)), (
+            f"{(y_old.float() - y_new.float()).abs().max().item()} max abs difference, "
+            f"{(y_old.view(torch.int16) != y_new.view(torch.int16)).float().mean().item()} of the values differ")
+        if s_old is not None:
+            assert torch.equal(s_old, s_new)
+    else:
+        # small images: the tiled kernel takes 32- or 64-channel chunks (tap-major inside a chunk), a different fp32 summation
+        # order -- the two bf16 results may differ by one rounding step on a few values, the sign map where a value is ~0
+        a, b = y_old.float(), y_new.float()
+        ulp = 2.0 ** -7 * torch.maximum(a.abs(), b.abs()) + 1e-6 * a.abs().max()
+        assert bool(((a - b).abs() <= ulp).all()), f"{((a - b).abs() - ulp).max().item()} beyond one bf16 step"
+        assert (a != b).float().mean().item() < 5e-3
+        if s_old is not None:
+            assert (s_old != s_new).float().mean().item() < 5e-3
+
+
+def test_persistent_kernel_repeats_itself():
+    """two launches on the same input give the same bits (no read of a buffer before its LDS-DMA has landed)"""
+    a, sa, _ = _run(True, "fwd_signs", 16, 128, 97, 129, seed=5)
+    for _ in range(3):
+        b, sb, _ = _run(True, "fwd_signs", 16, 128, 97, 129, seed=5)
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16)) and torch.equal(sa, sb)
