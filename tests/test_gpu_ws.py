@@ -1,4 +1,4 @@
-"""The persistent 4-wavefront convolution kernel (conv_bf16_p4_kernel) against the tiled 8-wavefront kernel it replaces
+"""The persistent wavefront-specialised convolution kernel (conv_bf16_ws_kernel) against the tiled 8-wavefront kernel it replaces
 (conv_bf16_kernel<4,2,8,...>): same MFMA sequence per accumulator and the same epilogue formula, so every output bit and every
 sign-map byte has to agree -- for the forward of yogo/model_defns.py:49-65's 128-channel blocks (bias + LeakyReLU + Dropout2d
 channel mask + sign map, or bias only in front of BatchNorm) and for their data gradients (no bias, optional channel mask).
@@ -76,7 +76,7 @@ def test_persistent_kernel_is_bit_identical_to_the_tiled_kernel(kind, B, Cin, H,
     y_old, s_old, log_old = _run(False, kind, B, Cin, H, W, seed=11)
     y_new, s_new, log_new = _run(True, kind, B, Cin, H, W, seed=11)
     assert any(ln.startswith("conv_bf16_kernel<4, 2, 8") for ln in log_old), log_old
-    assert any(ln.startswith("conv_bf16_p4_kernel") for ln in log_new), log_new
+    assert any(ln.startswith("conv_bf16_ws_kernel<") for ln in log_new), log_new
     plan = next(ln for ln in log_old if ln.startswith("conv_bf16_kernel<4, 2, 8"))
     if " CKb=2 " in plan:
         # the tiled kernel stepped through K in 16-channel chunks too: the same MFMA sequence per accumulator, bit for bit

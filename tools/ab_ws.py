@@ -1,6 +1,6 @@
-"""In-process A/B of the persistent 4-wavefront kernel against the tiled 8-wavefront kernel (yogo_conv_bf16_persistent 1 / 0):
+"""In-process A/B of the persistent wavefront-specialised kernel against the tiled 8-wavefront kernel (yogo_conv_bf16_persistent 1 / 0):
 the launches of the training step the persistent kernel takes, alternating, one device, one process.
-    python tools/ab_p4.py [rounds] [B] [which]"""
+    python tools/ab_ws.py [rounds] [B] [which]"""
 import collections
 import contextlib
 import io

@@ -1,7 +1,7 @@
-"""stamps of the persistent 4-wavefront kernel (diagnostic library): per workgroup -- lifetime, ticks inside the chunk bodies, the
+"""stamps of the persistent wavefront-specialised kernel (diagnostic library): per workgroup -- lifetime, ticks inside the chunk bodies, the
 tile seams (epilogue arithmetic), the next-tile decode, and the wait + barrier statement of step 8; with ablation bits
 (1 = no output stores, 2 = no seam arithmetic, 4 = no LDS-DMA).
-    bash yogo_amd/csrc/build.sh diag && python tools/stamps_p4.py [B] [which] [dbg,dbg,...]"""
+    bash yogo_amd/csrc/build.sh diag && python tools/stamps_ws.py [B] [which] [dbg,dbg,...]"""
 import ctypes
 import os
 import sys
@@ -37,7 +37,7 @@ if __name__ == "__main__":
                 print("  (no stamps)")
                 continue
             life = h[:, 1] - h[:, 0]
-            nt = h[:, 5] + 1
-            print(f"  {w} dbg={dbg}: wgs={h.shape[0]} tiles/wg={nt.mean():.1f} life={life.mean():.0f} (max {life.max():.0f}) chunks={h[:, 2].mean():.0f} "
-                  f"seam={h[:, 3].mean():.0f} prep={h[:, 4].mean():.0f} x8={h[:, 6].mean():.0f} | per tile: life {(life / nt).mean():.0f} chunks {(h[:, 2] / nt).mean():.0f} "
-                  f"seam {(h[:, 3] / nt).mean():.0f} prep {(h[:, 4] / nt).mean():.0f} x8 {(h[:, 6] / nt).mean():.0f}; span={(h[:, 1].max() - h[:, 0].min()):.0f}")
+            nt = h[:, 5]
+            print(f"  {w} dbg={dbg}: wgs={h.shape[0]} tiles/wg={nt.mean():.1f} life={life.mean():.0f} (max {life.max():.0f}) | compute per tile: life {(life / nt).mean():.0f} "
+                  f"chunks {(h[:, 2] / nt).mean():.0f} seam {(h[:, 3] / nt).mean():.0f} x8 {(h[:, 6] / nt).mean():.0f} | loader per tile: work {(h[:, 8] / nt).mean():.0f} "
+                  f"wait+barrier {(h[:, 9] / nt).mean():.0f}")

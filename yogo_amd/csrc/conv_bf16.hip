@@ -14,7 +14,7 @@
 // At bf16 every layer of the network is HBM-bound on MI355X (ridge ~312 FLOP/B, the widest layer offers ~230), so the
 // kernel is built around few, wide memory operations rather than around MFMA issue.
 #include "common.h"
-#include "conv_bf16_p4.h"
+#include "conv_bf16_ws.h"
 #include <type_traits>
 #include <utility>
 #include <cstdlib>
@@ -1324,9 +1324,9 @@ static bool g_bf_rowdma = true;
 // (diagnostic build: yogo_diag_conv_bf16_rowdma(0) keeps the per-lane slot staging of the lean 4-wavefront tiles)
 static bool g_bf_lean4 = true; // (diagnostic build: yogo_diag_conv_bf16_lean4(0) selects the generic step loop of the 4-wavefront tiles)
 static bool g_bf_ring = true; // (diagnostic build: yogo_diag_conv_bf16_ring(0) selects the two-buffer loop of the stride-2 data gradient)
-static bool g_bf_p4 = true;   // the persistent 4-wavefront kernel (conv_bf16_p4.hip) takes the launches it is eligible for
+static bool g_bf_ws = true;   // the persistent wavefront-specialised kernel (conv_bf16_ws.hip) takes the launches it is eligible for
 // Plan switch (A/B runs and the bit-identity tests of the two kernels): 0 = every launch goes to conv_bf16_kernel
-extern "C" int yogo_conv_bf16_persistent(int on) { g_bf_p4 = on != 0; return YOGO_OK; }
+extern "C" int yogo_conv_bf16_persistent(int on) { g_bf_ws = on != 0; return YOGO_OK; }
 static bool g_bf_pp = true;   // (diagnostic build: yogo_diag_conv_bf16_pp(0) selects the interleaved main loop for A/B runs)
 #ifdef YOGO_DIAG
 extern "C" int yogo_diag_conv_bf16_pp(int on) { g_bf_pp = on != 0; return YOGO_OK; }
@@ -1396,10 +1396,10 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
                      int ref_act, void* signs, bool signs_read, const float* chan_scale, float* stats_part, int B, int K, int M, int IH, int IW, int OH,
                      int OW, int ks, int a, int s2d, int act, hipStream_t stream, int* stats_rows, int* stats_mpad) {
   const int T = ks * ks, pad = ks == 3 ? 1 : 0;
-  // stride-1 3x3 convolutions with 128 output channels and the lean epilogue: the persistent 4-wavefront kernel
-  if (in != nullptr && g_bf_p4 && !s2d && a == 1 && ks == 3 && out_f32 == nullptr && out_pre == nullptr && act_ref == nullptr && !signs_read &&
-      stats_part == nullptr && (act == ACT_NONE || act == ACT_LEAKY) && conv_bf16_p4_eligible(K, M, IH, IW, B)) {
-    ConvP4Params q{};
+  // stride-1 3x3 convolutions with 128 output channels and the lean epilogue: the persistent wavefront-specialised kernel
+  if (in != nullptr && g_bf_ws && !s2d && a == 1 && ks == 3 && out_f32 == nullptr && out_pre == nullptr && act_ref == nullptr && !signs_read &&
+      stats_part == nullptr && (act == ACT_NONE || act == ACT_LEAKY) && conv_bf16_ws_eligible(K, M, IH, IW, B)) {
+    ConvWsParams q{};
     q.in = in; q.wp = packed; q.bias = bias; q.out = out; q.signs = reinterpret_cast<unsigned char*>(signs); q.chan_scale = chan_scale;
     q.B = B; q.Kb = bf_kb_of(K); q.IH = IH; q.IW = IW; q.act = act;
 #ifdef YOGO_DIAG
@@ -1407,7 +1407,7 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
     q.stamps = (g_diag_stamps != nullptr && g_diag_stamps_bytes >= 256 * 128) ? g_diag_stamps : nullptr;
     if (q.stamps) (void)hipMemsetAsync(g_diag_stamps, 0, 256 * 128, stream);
 #endif
-    if (conv_bf16_p4_plan(&q)) return launch_conv_bf16_p4(q, stream);
+    if (conv_bf16_ws_plan(&q)) return launch_conv_bf16_ws(q, stream);
   }
   const int MW = bf_pick_mw(M);
   const bool small_n = s2d || a == 2;  // two accumulator sets / four-fold input tile: half the pixel groups per wavefront

@@ -1,0 +1,41 @@
+// Persistent, wavefront-specialised form of the stride-1 3x3 bf16 convolution with 128 GEMM rows (conv_bf16_ws.hip).
+#pragma once
+#include "common.h"
+
+// 8 wavefronts per workgroup, one workgroup per CU: wavefronts 0-3 COMPUTE (one per SIMD; 128 output channels x 64 pixels each
+// = 8 accumulator tiles of 32x32 in 128 asm-owned AGPRs), wavefronts 4-7 LOAD (LDS-DMA of the next chunk, global stores of the
+// previous tile's output) -- wavefronts w and w + 4 share a SIMD.  A workgroup tile is 128 channels x 256 consecutive pixels
+// of a column band.
+#define WS_PT 256                     // pixels per workgroup tile
+#define WS_NT 256                     // lanes of a team
+#define WS_NI 4                       // input slots (16-byte elements per loader lane and 16-channel chunk)
+#define WS_LDSW_OFF (WS_NI * WS_NT)   // first unit of the weight slices inside a chunk buffer
+#define WS_BUFU (WS_LDSW_OFF + 9 * 2 * 128)
+#define WS_BUFB (WS_BUFU * 16)        // bytes per chunk buffer (53 248)
+#define WS_STG (2 * WS_BUFB)          // output staging: [2 regions][4 wavefronts][4 units][64 lanes] x 16 B = 32 KB
+#define WS_EB (WS_STG + 32768)        // [128] fp32 bias
+#define WS_ES (WS_EB + 512)           // [2][128] fp32 channel scale (by tile parity)
+#define WS_LDS_BYTES (WS_ES + 1024)
+
+struct ConvWsParams {
+  const void* in;     // bf16 NCHW8c [B][Kb][IH][IW] units
+  const void* wp;     // packed weights [9][Kb][128] units
+  const float* bias;  // [128] or null
+  void* out;          // bf16 NCHW8c [B][16][IH][IW] units
+  unsigned char* signs;     // optional LeakyReLU sign map of the output (see ConvBf16Params::signs)
+  const float* chan_scale;  // optional [B][128]
+  int B, Kb, IH, IW;
+  int ncb, TW, tiles_per_band, gx, ntiles;
+  unsigned m_gx, m_tpb, m_bw, m_bwl, m_lw, m_lwl;
+  int nchunk, act;
+#ifdef YOGO_DIAG
+  int dbg;                      // 1 = no output stores, 2 = no epilogue arithmetic, 4 = no DMA
+  unsigned long long* stamps;   // [workgroups][16]
+#endif
+};
+
+// true when the kernel takes the launch (stride 1, 3x3, M = 128, K a multiple of 32 and >= 64, lean epilogue)
+bool conv_bf16_ws_eligible(int K, int M, int IH, int IW, int B);
+// fills the tiling part of `p` (ncb, TW, ..., magic numbers); false when no tiling fits the kernel's fixed LDS layout
+bool conv_bf16_ws_plan(ConvWsParams* p);
+int launch_conv_bf16_ws(const ConvWsParams& p, hipStream_t stream);

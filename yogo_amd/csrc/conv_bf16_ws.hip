@@ -1,0 +1,653 @@
+// Persistent, wavefront-specialised bf16 convolution for the stride-1 3x3 layers with 128 output channels (forward of layers
+// 3/5/6 and the data gradients of layers 5/6 of base_model: yogo/model_defns.py:49-65 and their autograd) -- the dominant kernel
+// of the training step.  Same arithmetic, accumulation order and epilogue formula as conv_bf16_kernel<4,2,8,...,PP>
+// (conv_bf16.hip): outputs are bit-identical (tests/test_gpu_ws.py).
+//
+// Why this shape.  Measured on the first persistent form (4 wavefronts of 128 x 96 outputs with 192 AGPR accumulators, one per
+// SIMD, everything issued from the MFMA wavefronts; round 4, gpurun_out/r4_p4_stamps1.log): parity-green and exactly as fast
+// as the tiled kernel -- every vector-memory instruction (an LDS-DMA piece, a 16-byte output store) blocks the issuing
+// wavefront for ~60 cycles (MI355X_MICROARCH.md "LDS-DMA piece issue cost"), ~40 of which no MFMA of that SIMD covers, and a
+// tile needs 120 pieces + 24 stores per wavefront: 5 k of a tile's 33 k cycles, next to 4.5-8 k of epilogue arithmetic at
+// the seam and 2 k of next-tile address decode.  So the vector-memory work moves to wavefronts of its own:
+//   * wavefronts 0-3 COMPUTE: one per SIMD, 128 channels x 64 pixels each (8 accumulator tiles of 32x32 in a[0:127], owned by
+//     the asm statements below: named literally, listed as clobbers; hipcc never allocates AGPRs here).  Their instruction
+//     stream is MFMAs, the 6 ds_read_b128 per 8 MFMAs of the next K step in the MFMA gaps, one ds_write_b128 per step while
+//     the previous tile's output is handed over, and one s_barrier per 16-channel chunk;
+//   * wavefronts 4-7 LOAD (wavefront w + 4 shares its SIMD with w: tools/probes/wave_simd.hip): per chunk period they issue the
+//     13 LDS-DMA pieces each of the NEXT chunk (across tile seams: the stream never stops), decode the next tile's addresses,
+//     and move the previous tile's output from the LDS staging area to global memory (4 x 1 KB per period and loader);
+//   * the output STORES of tile t overlap tile t + 1: at the seam the compute wavefronts read their accumulators out, apply
+//     bias / channel scale / LeakyReLU / bf16 conversion / the half-wave exchange; the first 8 of a lane's 16 16-byte units go
+//     straight to the LDS staging area (2 regions x 4 units x 1 KB per wavefront), the other 8 are parked in VGPRs and follow
+//     in period 2 of the next tile (one ds_write_b128 per K step); the loaders store the staging area in periods 1 and 3.
+//     One barrier per chunk orders everything: DMA landed (loaders wait vmcnt first), staging written (compute waits
+//     lgkmcnt), staging read, buffers free.
+#include "conv_bf16_ws.h"
+#include <type_traits>
+#include <utility>
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define WS_ACC_CLOBBER "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95","a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127"
+
+// accumulator tile (mb, n) = a[16 * (2 mb + n) : +15]
+#define WS_MFMA(TILE, AOP, BOP) \
+  "v_mfma_f32_32x32x16_bf16 a[16*" #TILE ":16*" #TILE "+15], %[" #AOP "], %[" #BOP "], a[16*" #TILE ":16*" #TILE "+15]\n\t"
+#define WS_MFMA0(TILE, AOP, BOP) \
+  "v_mfma_f32_32x32x16_bf16 a[16*" #TILE ":16*" #TILE "+15], %[" #AOP "], %[" #BOP "], 0\n\t"
+// operand reads of tap T1 (kernel column KX1): weights at pa + T1 * 4 KB + mb * 512 B, input at the row base + KX1 * 16 B
+// (T1 / KX1 name "n" operands of the statement, or are literal numbers)
+#define WS_RDA(DST, MB, T1) "ds_read_b128 %[" #DST "], %[pa] offset:4096*" T1 "+512*" #MB "\n\t"
+#define WS_RDB(DST, SRC, KX1) "ds_read_b128 %[" #DST "], %[" #SRC "] offset:16*" KX1 "\n\t"
+
+namespace {
+
+__device__ __forceinline__ int ws_udivm(int n, unsigned m) { return (int)__umulhi((unsigned)n, m); }   // n / d, m = ceil(2^32 / d), d > 1
+__device__ __forceinline__ int ws_udivm1(int n, int d, unsigned m) { return d == 1 ? n : (int)__umulhi((unsigned)n, m); }
+__device__ __forceinline__ i32x4 ws_rsrc(const void* ptr, unsigned bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
+  return i32x4{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
+}
+// one LDS-DMA piece (64 lanes x 16 bytes -> LDS bytes [lds, lds + 1024))
+__device__ __forceinline__ void ws_dma1(i32x4 rs, unsigned lds, int voff, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds" ::"v"(voff), "s"(lds), "s"(rs), "s"(soff) : "memory");
+}
+// four pieces of one descriptor with one scalar offset: LDS destinations lds + k * 4 KB (the input slots of a chunk)
+__device__ __forceinline__ void ws_dma4(i32x4 rs, unsigned lds, int v0, int v1, int v2, int v3, unsigned soff) {
+  asm volatile(
+      "s_mov_b32 m0, %5\n\ts_nop 4\n\tbuffer_load_dwordx4 %0, %4, %6 offen lds\n\t"
+      "s_add_u32 m0, m0, 4096\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %4, %6 offen lds\n\t"
+      "s_add_u32 m0, m0, 4096\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %4, %6 offen lds\n\t"
+      "s_add_u32 m0, m0, 4096\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %4, %6 offen lds"
+      ::"v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(rs), "s"(lds), "s"(soff) : "memory", "scc");
+}
+// nine pieces of one descriptor with one per-lane offset: LDS destinations lds + j * 4 KB, scalar offsets soff + j * step (the
+// weight slices of the nine taps): three scalar instructions per piece -- a loader beside an MFMA-saturating partner issues
+// about one instruction per 10 cycles, whatever its kind
+__device__ __forceinline__ void ws_dma9(i32x4 rs, unsigned lds, int voff, unsigned soff, unsigned step) {
+  unsigned so;
+#define WS_P9 "s_add_u32 m0, m0, 4096\n\ts_add_u32 %0, %0, %5\n\tbuffer_load_dwordx4 %1, %2, %0 offen lds\n\t"
+  asm volatile("s_mov_b32 m0, %3\n\ts_mov_b32 %0, %4\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %0 offen lds\n\t" WS_P9 WS_P9 WS_P9 WS_P9 WS_P9 WS_P9 WS_P9 WS_P9
+               : "=&s"(so)
+               : "v"(voff), "s"(rs), "s"(lds), "s"(soff), "s"(step)
+               : "memory", "scc");
+#undef WS_P9
+}
+// 64 lanes x 4 bytes -> LDS bytes [lds, lds + 256)
+__device__ __forceinline__ void ws_dma_dword(i32x4 rs, unsigned lds, int voff, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 4\n\tbuffer_load_dword %0, %2, %3 offen lds" ::"v"(voff), "s"(lds), "s"(rs), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void ws_store16(u32x4 data, int voff, i32x4 rs, unsigned soff) {
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" ::"v"(data), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+
+template <class F, int... I>
+__device__ __forceinline__ void ws_static_for(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+
+// ---- the asm statements of a K step (tap) of a compute wavefront ---------------------------------------------------------
+// first half: accumulator rows mb = 0, 1 (4 MFMAs) with the 6 operand reads of the NEXT step in their gaps.  The reads are
+// retired by the lgkmcnt(0) that ends the second half (ws_sb), which names their destinations "+v".
+template <bool ZERO, int T1, int KX1>
+__device__ __forceinline__ void ws_sa(const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1, u32x4& an0, u32x4& an1, u32x4& an2, u32x4& an3,
+                                      u32x4& bn0, u32x4& bn1, unsigned pa, unsigned pb0, unsigned pb1) {
+#define WS_SA_BODY(M)                                                                                         \
+  M(0, a0, b0) WS_RDA(an0, 0, "%[t1]") WS_RDB(bn0, pb0, "%[kx1]") M(1, a0, b1) WS_RDA(an1, 1, "%[t1]") WS_RDB(bn1, pb1, "%[kx1]") \
+  M(2, a1, b0) WS_RDA(an2, 2, "%[t1]") M(3, a1, b1) WS_RDA(an3, 3, "%[t1]")
+#define WS_SA_OPS                                                                                                        \
+  : [an0] "=&v"(an0), [an1] "=&v"(an1), [an2] "=&v"(an2), [an3] "=&v"(an3), [bn0] "=&v"(bn0), [bn1] "=&v"(bn1)            \
+  : [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1), [pa] "v"(pa), [pb0] "v"(pb0), [pb1] "v"(pb1), [t1] "n"(T1), [kx1] "n"(KX1) \
+  : "memory", WS_ACC_CLOBBER
+  if constexpr (ZERO) asm volatile(WS_SA_BODY(WS_MFMA0) WS_SA_OPS);
+  else asm volatile(WS_SA_BODY(WS_MFMA) WS_SA_OPS);
+#undef WS_SA_BODY
+#undef WS_SA_OPS
+}
+// second half: rows mb = 2, 3; optionally one parked output unit goes to the staging area (ds_write_b128 at stg + SOFF); ends
+// by retiring the first half's operand reads (and the staging write)
+template <bool ZERO, bool STAGE, int SOFF>
+__device__ __forceinline__ void ws_sb(const u32x4& a2, const u32x4& a3, const u32x4& b0, const u32x4& b1, u32x4& an0, u32x4& an1, u32x4& an2, u32x4& an3,
+                                      u32x4& bn0, u32x4& bn1, unsigned stg, const u32x4& sdata) {
+#define WS_SB_OPS                                                                                                        \
+  : [an0] "+v"(an0), [an1] "+v"(an1), [an2] "+v"(an2), [an3] "+v"(an3), [bn0] "+v"(bn0), [bn1] "+v"(bn1)                  \
+  : [a2] "v"(a2), [a3] "v"(a3), [b0] "v"(b0), [b1] "v"(b1), [stg] "v"(stg), [sd] "v"(sdata), [soff] "n"(SOFF)             \
+  : "memory", WS_ACC_CLOBBER
+#define WS_SB_BODY(M, ST) M(4, a2, b0) ST M(5, a2, b1) M(6, a3, b0) M(7, a3, b1) "s_waitcnt lgkmcnt(0)"
+#define WS_STW "ds_write_b128 %[stg], %[sd] offset:%[soff]\n\t"
+  if constexpr (ZERO) {
+    if constexpr (STAGE) asm volatile(WS_SB_BODY(WS_MFMA0, WS_STW) WS_SB_OPS);
+    else asm volatile(WS_SB_BODY(WS_MFMA0, "") WS_SB_OPS);
+  } else {
+    if constexpr (STAGE) asm volatile(WS_SB_BODY(WS_MFMA, WS_STW) WS_SB_OPS);
+    else asm volatile(WS_SB_BODY(WS_MFMA, "") WS_SB_OPS);
+  }
+#undef WS_SB_BODY
+#undef WS_SB_OPS
+}
+// step 8, first part: row mb = 0, then the chunk's barrier (the loaders arrive with the next chunk landed)
+__device__ __forceinline__ void ws_x8(const u32x4& a0, const u32x4& b0, const u32x4& b1) {
+  asm volatile(WS_MFMA(0, a0, b0) WS_MFMA(1, a0, b1) "s_barrier" : : [a0] "v"(a0), [b0] "v"(b0), [b1] "v"(b1) : "memory", WS_ACC_CLOBBER);
+}
+// step 8, second part: rows mb = 1..3 with the operand reads of the next chunk's step 0 (the other buffer) up front
+__device__ __forceinline__ void ws_y8(const u32x4& a1, const u32x4& a2, const u32x4& a3, const u32x4& b0, const u32x4& b1, u32x4& an0, u32x4& an1,
+                                      u32x4& an2, u32x4& an3, u32x4& bn0, u32x4& bn1, unsigned pa, unsigned pb0, unsigned pb1) {
+  asm volatile(WS_MFMA(2, a1, b0) WS_RDA(an0, 0, "0") WS_RDB(bn0, pb0, "0") WS_MFMA(3, a1, b1) WS_RDA(an1, 1, "0") WS_RDB(bn1, pb1, "0")
+               WS_MFMA(4, a2, b0) WS_RDA(an2, 2, "0") WS_MFMA(5, a2, b1) WS_RDA(an3, 3, "0") WS_MFMA(6, a3, b0) WS_MFMA(7, a3, b1) "s_waitcnt lgkmcnt(0)"
+               : [an0] "=&v"(an0), [an1] "=&v"(an1), [an2] "=&v"(an2), [an3] "=&v"(an3), [bn0] "=&v"(bn0), [bn1] "=&v"(bn1)
+               : [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [b0] "v"(b0), [b1] "v"(b1), [pa] "v"(pa), [pb0] "v"(pb0), [pb1] "v"(pb1)
+               : "memory", WS_ACC_CLOBBER);
+}
+// ... without reads (the tile's last chunk: the seam comes first, the next tile's operands after it)
+__device__ __forceinline__ void ws_y8_last(const u32x4& a1, const u32x4& a2, const u32x4& a3, const u32x4& b0, const u32x4& b1) {
+  asm volatile(WS_MFMA(2, a1, b0) WS_MFMA(3, a1, b1) WS_MFMA(4, a2, b0) WS_MFMA(5, a2, b1) WS_MFMA(6, a3, b0) WS_MFMA(7, a3, b1)
+               :
+               : [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [b0] "v"(b0), [b1] "v"(b1)
+               : "memory", WS_ACC_CLOBBER);
+}
+// operand reads of a chunk's step 0 without MFMAs
+__device__ __forceinline__ void ws_prefetch(u32x4& an0, u32x4& an1, u32x4& an2, u32x4& an3, u32x4& bn0, u32x4& bn1, unsigned pa, unsigned pb0, unsigned pb1) {
+  asm volatile(WS_RDA(an0, 0, "0") WS_RDA(an1, 1, "0") WS_RDA(an2, 2, "0") WS_RDA(an3, 3, "0") WS_RDB(bn0, pb0, "0") WS_RDB(bn1, pb1, "0")
+               "s_waitcnt lgkmcnt(0)"
+               : [an0] "=&v"(an0), [an1] "=&v"(an1), [an2] "=&v"(an2), [an3] "=&v"(an3), [bn0] "=&v"(bn0), [bn1] "=&v"(bn1)
+               : [pa] "v"(pa), [pb0] "v"(pb0), [pb1] "v"(pb1)
+               : "memory");
+}
+
+template <int IDX>
+__device__ __forceinline__ float ws_acc_read() {
+  float r;
+  asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(r) : "n"(IDX));
+  return r;
+}
+
+#ifdef YOGO_DIAG
+#define WS_DBG(BIT) (p.dbg & (BIT))
+#define WS_STAMP() (p.stamps ? __builtin_amdgcn_s_memtime() : 0ull)
+#else
+#define WS_DBG(BIT) 0
+#define WS_STAMP() 0ull
+#endif
+
+template <int N> using WsIC = std::integral_constant<int, N>;
+
+}  // namespace
+
+// MODE: the epilogue the seam is compiled for -- 0: conv + bias (layers 5 / 6 forward, every data gradient without a channel
+// mask); 1: + LeakyReLU (eval-mode forward); 2: channel scale + LeakyReLU + sign map (layer 3 forward of the training step);
+// 3: everything behind run-time tests.  The seam is bound by vector-instruction issue (nothing else runs on the SIMD's vector
+// ALU while the accumulators are read out), so the instructions a launch does not need are compiled out.
+#ifndef WS_PRIO_COMPUTE
+#define WS_PRIO_COMPUTE 3
+#endif
+#ifndef WS_PRIO_LOADER
+#define WS_PRIO_LOADER 0
+#endif
+template <int MODE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_bf16_ws_kernel(const ConvWsParams p) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 smem4[];
+  constexpr unsigned OOB = 0x80000000u;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int team = wave >> 2, tw = wave & 3;   // team 0 computes, team 1 loads; wavefronts tw and tw + 4 share a SIMD
+  const int ttid = tid & 255;                  // thread index inside the team
+  [[maybe_unused]] const unsigned long long t_start = WS_STAMP();
+  float* ldsf = reinterpret_cast<float*>(smem4);
+
+  const int OH = p.IH, OW = p.IW;
+  const int plane = OH * OW, plane16 = plane * 16;
+  const int nck = p.nchunk;
+
+  // ---- tile walk: virtual block lin = slot + k * G, remapped so that an XCD's workgroups share a contiguous run of tiles
+  const unsigned NV = (unsigned)p.ntiles, G = gridDim.x, slot = blockIdx.x;
+  const unsigned xq = NV >> 3, xr = NV & 7;
+  struct TileS { int b, j0, bw, p0, p1, lastband; };
+  auto find_tile = [&](unsigned& k, TileS& t) -> bool {   // (uniform) next non-empty tile of this workgroup from ordinal k on
+    for (;; ++k) {
+      const unsigned lin = slot + k * G;
+      if (lin >= NV) return false;
+      const unsigned xcd = lin & 7;
+      const int widx = (int)((xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3));
+      const int b = ws_udivm1(widx, p.gx, p.m_gx);
+      const int bx = widx - b * p.gx;
+      const int cb = ws_udivm1(bx, p.tiles_per_band, p.m_tpb);
+      const int tb = bx - cb * p.tiles_per_band;
+      const int j0 = cb * p.TW;
+      const int bw = min(p.TW, OW - j0);
+      const int NPb = OH * bw;
+      const int p0 = tb * WS_PT;
+      if (p0 >= NPb) continue;
+      t.b = b; t.j0 = j0; t.bw = bw; t.p0 = p0; t.p1 = min(p0 + WS_PT, NPb); t.lastband = cb == p.ncb - 1;
+      return true;
+    }
+  };
+  // per-lane geometry of the two pixel groups of wavefront tw (compute: operand addresses; loader: output offsets of its partner)
+  auto decode_pix = [&](const TileS& t, unsigned (&pbr)[2], int (&vo)[2], unsigned& lw16) {
+    // (the lane's constants are re-derived from a laundered thread index: kept live across the tile loop they are spilled)
+    int t_ = threadIdx.x;
+    asm volatile("" : "+v"(t_));
+    const int l31 = t_ & 31, half = (t_ >> 5) & 1;
+    const unsigned m_bw = t.lastband ? p.m_bwl : p.m_bw;
+    const int bw = t.bw;   // >= 2 (planner)
+    const int i_lo = ws_udivm(t.p0, m_bw), i_hi = ws_udivm(t.p1 - 1, m_bw);
+    const int rows_in = i_hi - i_lo + 3;
+    const int lw = bw + 2;
+    const int per_kb = rows_in * lw;
+    lw16 = (unsigned)lw * 16u;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int pp = t.p0 + (tw * 2 + n) * 32 + l31;
+      const bool pv = pp < t.p1;
+      const int pc = pv ? pp : (t.p1 - 1);
+      const int i = ws_udivm(pc, m_bw), j = pc - i * bw;
+      pbr[n] = (unsigned)((i - i_lo) * lw + j + half * per_kb) * 16u;
+      vo[n] = pv ? (i * OW + t.j0 + j) * 16 + half * plane16 : (int)OOB;
+    }
+  };
+
+  unsigned k_ord = 0;
+  TileS T{};
+  if (!find_tile(k_ord, T)) return;
+
+  // bias (the same for every tile) and a unit channel scale when there is none
+  if (tid < 128) {
+    ldsf[WS_EB / 4 + tid] = p.bias != nullptr ? p.bias[tid] : 0.f;
+    if (p.chan_scale == nullptr) {
+      ldsf[WS_ES / 4 + tid] = 1.f;
+      ldsf[WS_ES / 4 + 128 + tid] = 1.f;
+    }
+  }
+  __syncthreads();
+
+  if (team == 1) {
+    if (WS_PRIO_LOADER) __builtin_amdgcn_s_setprio(WS_PRIO_LOADER);
+    // =====================================================================================================================
+    // LOADERS: per chunk period -- request the next chunk (13 LDS-DMA pieces per wavefront), move the staging region written
+    // in the previous period to global memory, wait for the requests, barrier.
+    // =====================================================================================================================
+    const int rowb = p.IW * 16, kcb = p.IH * p.IW * 16;
+    const unsigned ibytes = (unsigned)p.Kb * kcb, obytes = 16u * plane16, wbytes = 9u * p.Kb * 2048u;
+    const unsigned so_i = 2u * kcb;                  // bytes between the 16-channel chunks of an image
+    const unsigned wstep = (unsigned)p.Kb * 2048u;   // bytes between the taps of the packed weights
+    const i32x4 rs_w = ws_rsrc(p.wp, wbytes);
+    const int lane16 = WS_DBG(4) ? (int)OOB : lane * 16;
+    const int kbw = tw >> 1, colh = tw & 1;          // this wavefront's weight pieces: channel block of the chunk, column half
+    const bool has_scale = p.chan_scale != nullptr;
+    const i32x4 rs_sc = ws_rsrc(p.chan_scale, has_scale ? (unsigned)p.B * 512u : 0u);
+    auto issue_scale = [&](int b, int par) {   // [128] channel scale of image b -> es[par] (loaders 0 and 1, 64 floats each)
+      if (has_scale && tw < 2)
+        ws_dma_dword(rs_sc, (unsigned)__builtin_amdgcn_readfirstlane(WS_ES + par * 512 + tw * 256), lane * 4,
+                     (unsigned)__builtin_amdgcn_readfirstlane((b * 128 + tw * 64) * 4));
+    };
+    // DMA source offsets of the 4 input slots: element ttid + i * 256 of the flattened [2][rows_in][lw] tile -> (channel
+    // block, row, column): slot 0 by division, the others by stepping with two carries
+    auto decode_slots = [&](const TileS& t, int (&voff)[WS_NI]) {
+      const unsigned m_bw = t.lastband ? p.m_bwl : p.m_bw;
+      const int bw = t.bw;
+      const int i_lo = ws_udivm(t.p0, m_bw), i_hi = ws_udivm(t.p1 - 1, m_bw);
+      const int rows_in = i_hi - i_lo + 3;
+      const int iy0 = i_lo - 1, ix0 = t.j0 - 1;
+      const int lw = bw + 2;
+      const int per_kb = rows_in * lw;
+      const unsigned inv_lw = t.lastband ? p.m_lwl : p.m_lw;
+      const unsigned inv_perkb = 0xFFFFFFFFu / (unsigned)per_kb + 1u;
+      const int skc = ws_udivm(WS_NT, inv_perkb);
+      const int srm = WS_NT - skc * per_kb;
+      const int sr = ws_udivm(srm, inv_lw);
+      const int sx = srm - sr * lw;
+      int kc_ = ws_udivm(ttid, inv_perkb);
+      const int rm0 = ttid - kc_ * per_kb;
+      int r_ = ws_udivm(rm0, inv_lw);
+      int x_ = rm0 - r_ * lw;
+#pragma unroll
+      for (int i = 0; i < WS_NI; ++i) {
+        const int iy_ = iy0 + r_, ix_ = ix0 + x_;
+        const bool ok = (kc_ < 2) && (iy_ >= 0) && (iy_ < p.IH) && (ix_ >= 0) && (ix_ < p.IW) && !WS_DBG(4);
+        voff[i] = ok ? kc_ * kcb + iy_ * rowb + ix_ * 16 : (int)OOB;
+        x_ += sx; r_ += sr; kc_ += skc;
+        if (x_ >= lw) { x_ -= lw; ++r_; }
+        if (r_ >= rows_in) { r_ -= rows_in; ++kc_; }
+      }
+    };
+    // the 13 pieces of chunk `cn` of the tile described by (rs, voff) -> buffer `buf`
+    auto request = [&](i32x4 rs, const int (&voff)[WS_NI], int cn, int buf) {
+      const unsigned lb = (unsigned)buf * WS_BUFB;
+      const unsigned soi = (unsigned)cn * so_i;
+      static_assert(WS_NI == 4, "ws_dma4 issues the four input slots");
+      // the input tile first (HBM latency), then the weight slices (L2 hits)
+      ws_dma4(rs, lb + (unsigned)(tw * 64 * 16), voff[0], voff[1], voff[2], voff[3], soi);
+      const unsigned wb = (unsigned)(((2 * cn + kbw) * 128 + colh * 64) * 16);
+      ws_dma9(rs_w, lb + (unsigned)((WS_LDSW_OFF + kbw * 128 + colh * 64) * 16), lane16, wb, wstep);
+    };
+    // the 8 staged units of compute wavefront tw (unit index U0 .. U0 + 7 of the PREVIOUS tile; unit = 2 q + n, q = 2 mb + gp:
+    // channel block 2 q, pixel group n) -> global memory; returns with the eight stores in flight
+    const unsigned stg_rd = (unsigned)(WS_STG + tw * 4096 + lane * 16);
+    auto drain8 = [&](int U0, const int (&vop)[2], i32x4 rs_o) {
+      const unsigned char* base = reinterpret_cast<const unsigned char*>(smem4) + stg_rd;
+      u32x4 d[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) d[u] = *reinterpret_cast<const u32x4*>(base + (u >> 2) * 16384 + (u & 3) * 1024);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int q = (U0 + u) >> 1;
+        ws_store16(d[u], (u & 1) ? vop[1] : vop[0], rs_o, (unsigned)(2 * q) * (unsigned)plane16);
+      }
+    };
+
+    int voff[WS_NI];
+    unsigned pbr_[2], lw16_;
+    int vo[2], vo_prev[2] = {(int)OOB, (int)OOB};
+    decode_slots(T, voff);
+    decode_pix(T, pbr_, vo, lw16_);
+    i32x4 rs_in = ws_rsrc(reinterpret_cast<const unsigned char*>(p.in) + (size_t)T.b * ibytes, ibytes);
+    i32x4 rs_out = ws_rsrc(reinterpret_cast<unsigned char*>(p.out) + (size_t)T.b * obytes, obytes);
+    i32x4 rs_out_prev = ws_rsrc(p.out, 0u);
+    int tpar = 0;
+    issue_scale(T.b, 0);
+    request(rs_in, voff, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // (#1) chunk 0 of the first tile has landed
+    [[maybe_unused]] unsigned long long t_wait = 0, t_work = 0;
+    bool has_next = true;
+    while (has_next) {
+      TileS Tn{};
+      for (int c = 0; c < nck; ++c) {
+        [[maybe_unused]] const unsigned long long tw0 = WS_STAMP();
+        if (c + 1 < nck) {
+          request(rs_in, voff, c + 1, (c + 1) & 1);
+        } else {   // the tile's last period: the next tile's first chunk (nchunk is even: buffer 0)
+          unsigned kn = k_ord + 1;
+          has_next = find_tile(kn, Tn);
+          k_ord = kn;
+          if (has_next) {
+            decode_slots(Tn, voff);
+            rs_in = ws_rsrc(reinterpret_cast<const unsigned char*>(p.in) + (size_t)Tn.b * ibytes, ibytes);
+            issue_scale(Tn.b, tpar ^ 1);
+            request(rs_in, voff, 0, 0);
+          }
+        }
+        // period 1: the units the seam staged; period 3: the parked units compute staged in period 2
+        const bool dr = c == 1 || c == 3;   // (uniform)
+        if (dr) drain8(c == 1 ? 0 : 8, vo_prev, rs_out_prev);
+        [[maybe_unused]] const unsigned long long tw1 = WS_STAMP();
+        // requests are older than this period's stores: all but the 8 youngest operations have to be done
+        if (dr) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        t_work += tw1 - tw0;
+        t_wait += WS_STAMP() - tw1;
+      }
+      // the tile that was computed becomes the one whose output is handed over
+#pragma unroll
+      for (int n = 0; n < 2; ++n) vo_prev[n] = WS_DBG(1) ? (int)OOB : vo[n];
+      rs_out_prev = rs_out;
+      if (has_next) {
+        decode_pix(Tn, pbr_, vo, lw16_);
+        rs_out = ws_rsrc(reinterpret_cast<unsigned char*>(p.out) + (size_t)Tn.b * obytes, obytes);
+        tpar ^= 1;
+      }
+    }
+    // the last tile's output: (compute: seam) barrier, staged half, barrier, (compute: parked half) barrier, second half
+    __builtin_amdgcn_s_barrier();
+    drain8(0, vo_prev, rs_out_prev);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
+    drain8(8, vo_prev, rs_out_prev);
+#ifdef YOGO_DIAG
+    if (p.stamps && ttid == 0) {
+      unsigned long long* d = p.stamps + (size_t)blockIdx.x * 16;
+      d[8] = t_work; d[9] = t_wait;
+    }
+#endif
+    return;
+  }
+
+  // =======================================================================================================================
+  // COMPUTE
+  // =======================================================================================================================
+  if (WS_PRIO_COMPUTE) __builtin_amdgcn_s_setprio(WS_PRIO_COMPUTE);
+  const unsigned a_b0 = (unsigned)(WS_LDSW_OFF + half * 128 + l31) * 16u;
+  const unsigned stg_wr = (unsigned)(WS_STG + tw * 4096 + lane * 16);
+  unsigned pbr[2], lw16;
+  int vo[2];
+  decode_pix(T, pbr, vo, lw16);
+  int tpar = 0;
+  __builtin_amdgcn_s_barrier();   // (#1)
+  u32x4 A0[4], B0[2], A1[4], B1[2];   // the two operand sets
+  ws_prefetch(A0[0], A0[1], A0[2], A0[3], B0[0], B0[1], a_b0, pbr[0], pbr[1]);
+  u32x4 hold[8];                      // parked output units 8..15 of the PREVIOUS tile (unit = 2 (2 mb + gp) + n: rows mb = 2, 3)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) hold[i] = u32x4{0u, 0u, 0u, 0u};
+  const bool leaky = MODE == 3 ? p.act == ACT_LEAKY : (MODE == 1 || MODE == 2);
+  const bool write_signs = MODE == 3 ? p.signs != nullptr : MODE == 2;
+  constexpr bool SCALED = MODE >= 2;   // (modes 0 / 1: no channel scale -- the launcher checks)
+  [[maybe_unused]] unsigned long long t_chunks = 0, t_seam = 0, t_x8 = 0;
+
+  // one 16-channel chunk: 9 K steps.  P = parity of the chunk (LDS buffer AND operand set of step 0); FIRST: the tile's first
+  // chunk; STC = 1: steps 0..7 hand the parked units over (period 2); LAST: the tile's last chunk (no prefetch)
+  auto chunk = [&](auto first_tag, auto stc_tag, auto p_tag, auto last_tag) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    constexpr int STC = decltype(stc_tag)::value;
+    constexpr int P = decltype(p_tag)::value;
+    constexpr bool LAST = decltype(last_tag)::value;
+    const unsigned pa = a_b0 + P * WS_BUFB;
+    auto one = [&](auto s_tag) {
+      constexpr int S = decltype(s_tag)::value;
+      constexpr bool EVEN = ((P + S) & 1) == 0;   // operand set of this step: 0 when even
+      u32x4(&Ac)[4] = EVEN ? A0 : A1;
+      u32x4(&Bc)[2] = EVEN ? B0 : B1;
+      u32x4(&An)[4] = EVEN ? A1 : A0;
+      u32x4(&Bn)[2] = EVEN ? B1 : B0;
+      if constexpr (S < 8) {
+        constexpr int T1 = S + 1, KY1 = T1 / 3, KX1 = T1 % 3;
+        const unsigned rowo = (unsigned)KY1 * lw16 + P * WS_BUFB;
+        ws_sa<FIRST && S == 0, T1, KX1>(Ac[0], Ac[1], Bc[0], Bc[1], An[0], An[1], An[2], An[3], Bn[0], Bn[1], pa, pbr[0] + rowo, pbr[1] + rowo);
+        constexpr bool STAGE = STC == 1;
+        constexpr int HI = STAGE ? S : 0;
+        ws_sb<FIRST && S == 0, STAGE, (S >> 2) * 16384 + (S & 3) * 1024>(Ac[2], Ac[3], Bc[0], Bc[1], An[0], An[1], An[2], An[3], Bn[0], Bn[1], stg_wr, hold[HI]);
+      } else {
+        [[maybe_unused]] const unsigned long long tx0 = WS_STAMP();
+        ws_x8(Ac[0], Bc[0], Bc[1]);
+        t_x8 += WS_STAMP() - tx0;
+        if constexpr (LAST) {
+          ws_y8_last(Ac[1], Ac[2], Ac[3], Bc[0], Bc[1]);
+        } else {
+          const unsigned bo = (1 - P) * WS_BUFB;
+          ws_y8(Ac[1], Ac[2], Ac[3], Bc[0], Bc[1], An[0], An[1], An[2], An[3], Bn[0], Bn[1], a_b0 + bo, pbr[0] + bo, pbr[1] + bo);
+        }
+      }
+    };
+    ws_static_for(one, std::make_integer_sequence<int, 9>{});
+  };
+  using TT = std::true_type;
+  using FT = std::false_type;
+
+  for (;;) {
+    [[maybe_unused]] const unsigned long long tc0 = WS_STAMP();
+    chunk(TT{}, WsIC<0>{}, WsIC<0>{}, FT{});
+    chunk(FT{}, WsIC<0>{}, WsIC<1>{}, FT{});
+    chunk(FT{}, WsIC<1>{}, WsIC<0>{}, FT{});   // period 2: the parked units go to the staging area
+    if (nck == 4) {
+      chunk(FT{}, WsIC<0>{}, WsIC<1>{}, TT{});
+    } else {
+      chunk(FT{}, WsIC<0>{}, WsIC<1>{}, FT{});
+      for (int c = 4; c + 2 < nck; c += 2) {
+        chunk(FT{}, WsIC<0>{}, WsIC<0>{}, FT{});
+        chunk(FT{}, WsIC<0>{}, WsIC<1>{}, FT{});
+      }
+      chunk(FT{}, WsIC<0>{}, WsIC<0>{}, FT{});
+      chunk(FT{}, WsIC<0>{}, WsIC<1>{}, TT{});
+    }
+    [[maybe_unused]] const unsigned long long ts0 = WS_STAMP();
+    t_chunks += ts0 - tc0;
+    // ---- seam: the accumulators of T -> parked bf16 units (every unit of the previous tile has been handed over)
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results are in the accumulator file
+    {
+      const float* eb = ldsf + WS_EB / 4;
+      const float* es = ldsf + WS_ES / 4 + tpar * 128;
+      unsigned sg[2][2] = {{0u, 0u}, {0u, 0u}};
+      auto group = [&](auto q_tag) {
+        constexpr int Q = decltype(q_tag)::value, MB = Q >> 1, GP = Q & 1;
+        const int cl = MB * 32 + 16 * GP + 4 * half;   // local channel of group A; group B = cl + 8
+        const float4 bA = *reinterpret_cast<const float4*>(eb + cl), bB = *reinterpret_cast<const float4*>(eb + cl + 8);
+        const float ba[8] = {bA.x, bA.y, bA.z, bA.w, bB.x, bB.y, bB.z, bB.w};
+        float sa[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, bs[8];
+        if constexpr (SCALED) {
+          const float4 sA = *reinterpret_cast<const float4*>(es + cl), sB = *reinterpret_cast<const float4*>(es + cl + 8);
+          sa[0] = sA.x; sa[1] = sA.y; sa[2] = sA.z; sa[3] = sA.w; sa[4] = sB.x; sa[5] = sB.y; sa[6] = sB.z; sa[7] = sB.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bs[i] = SCALED ? ba[i] * sa[i] : ba[i];
+        auto pix = [&](auto n_tag) {
+          constexpr int N = decltype(n_tag)::value;
+          constexpr int R0 = (MB * 2 + N) * 16 + 8 * GP;
+          float v[8];
+          // fma(acc, scale, bias * scale); without a channel scale acc + bias -- the same bits (fma(a, 1, b) = round(a + b))
+#define WS_V(I) v[I] = SCALED ? fmaf(ws_acc_read<R0 + I>(), sa[I], bs[I]) : ws_acc_read<R0 + I>() + bs[I];
+          WS_V(0) WS_V(1) WS_V(2) WS_V(3) WS_V(4) WS_V(5) WS_V(6) WS_V(7)
+#undef WS_V
+          if (leaky) {   // max(v, 0.01 v) as a bare v_max_f32 (the arithmetic of conv_bf16_epi_groups.inc's lean order)
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) {
+              typedef float f32x2_t __attribute__((ext_vector_type(2)));
+              const f32x2_t sv = (f32x2_t){v[i], v[i + 1]} * (f32x2_t){LEAKY_SLOPE, LEAKY_SLOPE};
+              asm("v_max_f32 %0, %1, %2" : "=v"(v[i]) : "v"(v[i]), "v"(sv.x));
+              asm("v_max_f32 %0, %1, %2" : "=v"(v[i + 1]) : "v"(v[i + 1]), "v"(sv.y));
+            }
+          }
+          if (write_signs) {
+            unsigned mA = 0;
+#pragma unroll
+            for (int i = 7; i >= 0; --i)
+              asm("v_cmp_lt_f32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(mA) : "v"(v[i]) : "vcc");
+            sg[N][Q >> 2] |= mA << (8 * (Q & 3));
+          }
+          bf16x8 o;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] = (__bf16)v[i];
+          const u32x4 w = __builtin_bit_cast(u32x4, o);
+          const auto r0 = __builtin_amdgcn_permlane32_swap(w.x, w.z, false, false);
+          const auto r1 = __builtin_amdgcn_permlane32_swap(w.y, w.w, false, false);
+          const u32x4 unit = {r0[0], r1[0], r0[1], r1[1]};
+          constexpr int U = Q * 2 + N;
+          if constexpr (U < 8) *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(smem4) + stg_wr + (U >> 2) * 16384 + (U & 3) * 1024) = unit;
+          else hold[U - 8] = unit;
+        };
+        ws_static_for(pix, std::make_integer_sequence<int, 2>{});
+      };
+      if (!WS_DBG(2)) ws_static_for(group, std::make_integer_sequence<int, 8>{});
+      if (write_signs) {   // the 8 sign bytes of a pixel (this lane's half of the 128 channels) go out together
+        const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)(p.signs + (size_t)T.b * plane * 16), (short)0, plane * 16, 0x00020000);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const int vs = vo[n] < 0 ? (int)OOB : (vo[n] >> 4) * 8;
+          const u32x2 tsg = {sg[n][0], sg[n][1]};
+          __builtin_amdgcn_raw_buffer_store_b64(tsg, rs_s, vs, 0, 0);
+        }
+      }
+    }
+    unsigned kn = k_ord + 1;
+    const bool has_next = find_tile(kn, T);
+    k_ord = kn;
+    t_seam += WS_STAMP() - ts0;
+    if (!has_next) break;
+    decode_pix(T, pbr, vo, lw16);
+    tpar ^= 1;
+    ws_prefetch(A0[0], A0[1], A0[2], A0[3], B0[0], B0[1], a_b0, pbr[0], pbr[1]);   // (the last period's barrier: chunk 0 has landed)
+  }
+  // ---- the last tile's output: staged half (written by the seam), then the parked half
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_s_barrier();   // (the loaders have read the staged half)
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+    *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(smem4) + stg_wr + (u >> 2) * 16384 + (u & 3) * 1024) = hold[u];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#ifdef YOGO_DIAG
+  if (p.stamps && tid == 0) {
+    unsigned long long* d = p.stamps + (size_t)blockIdx.x * 16;
+    d[0] = t_start; d[1] = __builtin_amdgcn_s_memtime(); d[2] = t_chunks; d[3] = t_seam; d[5] = k_ord; d[6] = t_x8;
+  }
+#endif
+}
+
+// =========================================================================================================
+// host side: eligibility, tiling, launch
+// =========================================================================================================
+bool conv_bf16_ws_eligible(int K, int M, int IH, int IW, int B) {
+  const int Kb = round_up(K, 16) / 8;
+  if (M != 128 || Kb < 8 || (Kb % 4) != 0) return false;   // nchunk = Kb / 2 even and >= 4
+  if (IH < 3 || IW < 3 || B <= 0) return false;
+  if ((long long)Kb * IH * IW * 16 >= (1ll << 31) || (long long)16 * IH * IW * 16 >= (1ll << 31)) return false;   // per-image descriptors, bit 31 = "out of range"
+  return true;
+}
+
+// column bands of TW output columns, tiles of 256 consecutive pixels of a band (row-major inside the band): the staged input
+// tile of a chunk ([2 channel blocks][rows + 2][TW + 2] units) has to fit the 4 x 256 input slots; among the fitting band
+// counts take the one with the fewest tiles per image (MFMA work), then the fewest staged units
+bool conv_bf16_ws_plan(ConvWsParams* p) {
+  const int OH = p->IH, OW = p->IW;
+  long long best = -1;
+  int best_ncb = 0;
+  for (int ncb = 1; ncb <= 48 && ncb <= OW; ++ncb) {
+    const int TW = cdiv(OW, ncb);
+    const int bw_min = OW - (cdiv(OW, TW) - 1) * TW;
+    if (cdiv(OW, TW) != ncb || bw_min < 2) continue;
+    // rows a 256-pixel tile can touch in a band of width bw: a tile starts anywhere in a row
+    auto rows_of = [&](int bw) { return min(OH, 1 + cdiv(WS_PT - 1, bw)) + 2; };
+    const int need = 2 * max(rows_of(TW) * (TW + 2), rows_of(bw_min) * (bw_min + 2));
+    if (need > WS_NI * WS_NT) continue;
+    const long long tiles = (long long)(ncb - 1) * cdiv(OH * TW, WS_PT) + cdiv(OH * bw_min, WS_PT);
+    const long long staged = (long long)(ncb - 1) * cdiv(OH * TW, WS_PT) * rows_of(TW) * (TW + 2) + (long long)cdiv(OH * bw_min, WS_PT) * rows_of(bw_min) * (bw_min + 2);
+    const long long score = tiles * 100000000ll + staged;
+    if (best < 0 || score < best) { best = score; best_ncb = ncb; }
+  }
+  if (best < 0) return false;
+  p->ncb = best_ncb;
+  p->TW = cdiv(OW, best_ncb);
+  p->tiles_per_band = cdiv(OH * p->TW, WS_PT);
+  p->gx = p->ncb * p->tiles_per_band;
+  p->ntiles = p->B * p->gx;
+  auto magic = [](int d) -> unsigned { return d <= 1 ? 0xFFFFFFFFu : (unsigned)(((1ull << 32) + (unsigned)d - 1ull) / (unsigned)d); };
+  const int bw_last = OW - (p->ncb - 1) * p->TW;
+  p->m_gx = magic(p->gx); p->m_tpb = magic(p->tiles_per_band);
+  p->m_bw = magic(p->TW); p->m_bwl = magic(bw_last);
+  p->m_lw = magic(p->TW + 2); p->m_lwl = magic(bw_last + 2);
+  p->nchunk = p->Kb / 2;
+  return true;
+}
+
+int launch_conv_bf16_ws(const ConvWsParams& p, hipStream_t stream) {
+  static int n_cu = 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_ws_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_ws_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_ws_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_ws_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES);
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+    attr_set = true;
+  }
+  if (p.ntiles <= 0) return YOGO_OK;
+  // one persistent workgroup per CU; a multiple of 8 so that a workgroup's tiles stay inside one XCD's run
+  int grid = min(p.ntiles, n_cu);
+  if (grid >= 8) grid &= ~7;
+  const bool leaky = p.act == ACT_LEAKY, sc = p.chan_scale != nullptr, sg = p.signs != nullptr;
+  const int mode = (!sc && !sg) ? (leaky ? 1 : 0) : ((sc && sg && leaky) ? 2 : 3);
+  if (mode == 0) hipLaunchKernelGGL(conv_bf16_ws_kernel<0>, dim3(grid), dim3(512), WS_LDS_BYTES, stream, p);
+  else if (mode == 1) hipLaunchKernelGGL(conv_bf16_ws_kernel<1>, dim3(grid), dim3(512), WS_LDS_BYTES, stream, p);
+  else if (mode == 2) hipLaunchKernelGGL(conv_bf16_ws_kernel<2>, dim3(grid), dim3(512), WS_LDS_BYTES, stream, p);
+  else hipLaunchKernelGGL(conv_bf16_ws_kernel<3>, dim3(grid), dim3(512), WS_LDS_BYTES, stream, p);
+  if (yogo_launch_log_enabled())
+    yogo_launch_log("conv_bf16_ws_kernel<%d> | Kb=%d in=%dx%d ncb=%d TW=%d tiles_per_band=%d nchunk=%d ntiles=%d grid=%d lds=%d act=%d signs=%d scale=%d", mode, p.Kb, p.IH,
+                    p.IW, p.ncb, p.TW, p.tiles_per_band, p.nchunk, p.ntiles, grid, WS_LDS_BYTES, p.act, p.signs != nullptr, p.chan_scale != nullptr);
+  YOGO_CHECK_LAUNCH("conv_bf16_ws");
+  return YOGO_OK;
+}
