@@ -20,7 +20,7 @@ if [[ "${1:-}" == "variant" ]]; then
   VOBJ="$HERE/obj_var"; mkdir -p "$VOBJ" "$OUT"
   extra=(); case "$FILE" in nms|decode_loss) extra=(-ffp-contract=off) ;; esac
   "$HIPCC" -O3 --offload-arch=gfx950 -fPIC -std=c++17 -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -I"$HERE" -I"$HERE/../../include" "$@" "${extra[@]}" -c "$HERE/$FILE.hip" -o "$VOBJ/${TAG}_$FILE.o"
-  objs=(); for o in "$HERE/obj"/*.o; do [[ "$(basename "$o")" == "$FILE.o" ]] || objs+=("$o"); done
+  objs=(); for f in "$HERE"/*.hip; do b="$(basename "$f" .hip)"; [[ "$b" == "$FILE" ]] || objs+=("$HERE/obj/$b.o"); done
   "$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" "$VOBJ/${TAG}_$FILE.o" -ldl -o "$OUT/libyogo_hip_$TAG.so"
   echo "built $OUT/libyogo_hip_$TAG.so"
   exit 0
@@ -33,6 +33,7 @@ for f in "$HERE"/*.hip; do
   extra=()
   case "$base" in
     nms|decode_loss) extra=(-ffp-contract=off) ;;
+    conv_bf16_ws) extra=(-save-temps=obj) ;;   # the assembly is audited below (asm-owned accumulator registers)
   esac
   stale=0
   for dep in "$f" "$HERE"/*.h "$HERE/../../include"/*.h "$HERE"/"$base"_*.inc; do
@@ -44,5 +45,20 @@ for f in "$HERE"/*.hip; do
   fi
 done
 for p in "${pids[@]:-}"; do [[ -n "$p" ]] && wait "$p"; done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$OBJ"/*.o -ldl -o "$OUT/$LIBNAME"
+# conv_bf16_ws.hip keeps its accumulators in AGPRs that only its asm statements name (cdna_hip_programming.md 5.7 item 4): the
+# compiler must not spill, use scratch, or touch an accumulator register outside those statements
+WS_S="$OBJ/conv_bf16_ws-hip-amdgcn-amd-amdhsa-gfx950.s"
+if [[ -f "$WS_S" ]]; then
+  bad=$(awk '/;;#ASMSTART/{a=1} /;;#ASMEND/{a=0} { if (!a && $0 ~ /v_accvgpr_|scratch_/ && $0 !~ /^[ \t]*;/) n++ } END { print n+0 }' "$WS_S")
+  spill=$(grep -E "\.vgpr_spill_count:|\.private_segment_fixed_size:" "$WS_S" | awk '{ s += $2 } END { print s+0 }')
+  if [[ "$bad" != 0 || "$spill" != 0 ]]; then
+    echo "conv_bf16_ws audit FAILED: $bad compiler accumulator / scratch instructions outside the asm statements, spill / scratch total $spill" >&2
+    # (the diagnostic build's stamps cost registers: its numbers are timings, not results -- a warning there, an error in the product)
+    if [[ "${#DEFS[@]}" == 0 ]]; then rm -f "$OBJ/conv_bf16_ws.o"; exit 1; fi
+  else
+    echo "conv_bf16_ws audit ok (no compiler v_accvgpr_* / scratch outside the asm statements, no spills)"
+  fi
+fi
+objs=(); for f in "$HERE"/*.hip; do objs+=("$OBJ/$(basename "$f" .hip).o"); done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -ldl -o "$OUT/$LIBNAME"
 echo "built $OUT/$LIBNAME"

@@ -9,13 +9,15 @@
 #define WS_PT 256                     // pixels per workgroup tile
 #define WS_NT 256                     // lanes of a team
 #define WS_NI 4                       // input slots (16-byte elements per loader lane and 16-channel chunk)
-#define WS_LDSW_OFF (WS_NI * WS_NT)   // first unit of the weight slices inside a chunk buffer
-#define WS_BUFU (WS_LDSW_OFF + 9 * 2 * 128)
-#define WS_BUFB (WS_BUFU * 16)        // bytes per chunk buffer (53 248)
-#define WS_STG (2 * WS_BUFB)          // output staging: [2 regions][4 wavefronts][4 units][64 lanes] x 16 B = 32 KB
+// LDS: two weight buffers (chunk parity), a ring of three input buffers (the input tile comes from HBM and is requested two
+// chunk periods ahead, the weight slices are L2 hits and are requested one period ahead), the output staging area, bias / scale
+#define WS_WB (9 * 2 * 128 * 16)      // bytes of a chunk's weight slices [tap][2 channel blocks][128 channels] (36 864)
+#define WS_IB (WS_NI * WS_NT * 16)    // bytes of an input buffer (16 384)
+#define WS_I0 (2 * WS_WB)             // first input buffer
+#define WS_STG (WS_I0 + 3 * WS_IB)    // output staging: [2 regions][4 wavefronts][4 units][64 lanes] x 16 B = 32 KB
 #define WS_EB (WS_STG + 32768)        // [128] fp32 bias
 #define WS_ES (WS_EB + 512)           // [2][128] fp32 channel scale (by tile parity)
-#define WS_LDS_BYTES (WS_ES + 1024)
+#define WS_LDS_BYTES (WS_ES + 1024)   // 157 184
 
 struct ConvWsParams {
   const void* in;     // bf16 NCHW8c [B][Kb][IH][IW] units

@@ -31,9 +31,15 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-#define WS_ACC_CLOBBER "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95","a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127"
-
+// The eight 32x32 accumulator tiles of a compute wavefront are a[0:127], OWNED BY THE ASM STATEMENTS: named literally and listed
+// as clobbers, so the kernel descriptor allocates them.  A clobber does not reserve a register, though: in the seam hipcc may park
+// values of its own in "free" AGPRs (v_accvgpr_write) -- seen in round 4 on the 256-register instantiations, where the first
+// accumulator rows came out wrong.  Pinning the tiles to "+a" C++ variables instead makes hipcc shuffle 16-register tuples
+// between every statement (1 700 v_accvgpr moves, 190-400 spilled registers).  So: the seam is kept within the arch VGPRs
+// (sched_barrier between its groups), and build.sh AUDITS the assembly of this file: no compiler v_accvgpr_* outside the asm
+// statements, .vgpr_spill_count 0, no scratch (cdna_hip_programming.md 5.7 item 4).
 // accumulator tile (mb, n) = a[16 * (2 mb + n) : +15]
+#define WS_ACC_CLOBBER "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95","a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127"
 #define WS_MFMA(TILE, AOP, BOP) \
   "v_mfma_f32_32x32x16_bf16 a[16*" #TILE ":16*" #TILE "+15], %[" #AOP "], %[" #BOP "], a[16*" #TILE ":16*" #TILE "+15]\n\t"
 #define WS_MFMA0(TILE, AOP, BOP) \
@@ -47,6 +53,12 @@ namespace {
 
 __device__ __forceinline__ int ws_udivm(int n, unsigned m) { return (int)__umulhi((unsigned)n, m); }   // n / d, m = ceil(2^32 / d), d > 1
 __device__ __forceinline__ int ws_udivm1(int n, int d, unsigned m) { return d == 1 ? n : (int)__umulhi((unsigned)n, m); }
+// lane index, re-derived at every use (volatile: never merged with an earlier copy that would have to stay live or be spilled)
+__device__ __forceinline__ int ws_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
 __device__ __forceinline__ i32x4 ws_rsrc(const void* ptr, unsigned bytes) {
   const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
   return i32x4{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
@@ -81,7 +93,7 @@ __device__ __forceinline__ void ws_dma_dword(i32x4 rs, unsigned lds, int voff, u
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 4\n\tbuffer_load_dword %0, %2, %3 offen lds" ::"v"(voff), "s"(lds), "s"(rs), "s"(soff) : "memory");
 }
 __device__ __forceinline__ void ws_store16(u32x4 data, int voff, i32x4 rs, unsigned soff) {
-  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" ::"v"(data), "v"(voff), "s"(rs), "s"(soff) : "memory");
+  asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen" ::"v"(data), "v"(voff), "s"(rs), "s"(soff) : "memory");   // (s_nop: descriptor from v_readfirstlane)
 }
 
 template <class F, int... I>
@@ -93,8 +105,8 @@ __device__ __forceinline__ void ws_static_for(F&& f, std::integer_sequence<int, 
 // first half: accumulator rows mb = 0, 1 (4 MFMAs) with the 6 operand reads of the NEXT step in their gaps.  The reads are
 // retired by the lgkmcnt(0) that ends the second half (ws_sb), which names their destinations "+v".
 template <bool ZERO, int T1, int KX1>
-__device__ __forceinline__ void ws_sa(const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1, u32x4& an0, u32x4& an1, u32x4& an2, u32x4& an3,
-                                      u32x4& bn0, u32x4& bn1, unsigned pa, unsigned pb0, unsigned pb1) {
+__device__ __forceinline__ void ws_sa(const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1,
+                                      u32x4& an0, u32x4& an1, u32x4& an2, u32x4& an3, u32x4& bn0, u32x4& bn1, unsigned pa, unsigned pb0, unsigned pb1) {
 #define WS_SA_BODY(M)                                                                                         \
   M(0, a0, b0) WS_RDA(an0, 0, "%[t1]") WS_RDB(bn0, pb0, "%[kx1]") M(1, a0, b1) WS_RDA(an1, 1, "%[t1]") WS_RDB(bn1, pb1, "%[kx1]") \
   M(2, a1, b0) WS_RDA(an2, 2, "%[t1]") M(3, a1, b1) WS_RDA(an3, 3, "%[t1]")
@@ -110,14 +122,16 @@ __device__ __forceinline__ void ws_sa(const u32x4& a0, const u32x4& a1, const u3
 // second half: rows mb = 2, 3; optionally one parked output unit goes to the staging area (ds_write_b128 at stg + SOFF); ends
 // by retiring the first half's operand reads (and the staging write)
 template <bool ZERO, bool STAGE, int SOFF>
-__device__ __forceinline__ void ws_sb(const u32x4& a2, const u32x4& a3, const u32x4& b0, const u32x4& b1, u32x4& an0, u32x4& an1, u32x4& an2, u32x4& an3,
-                                      u32x4& bn0, u32x4& bn1, unsigned stg, const u32x4& sdata) {
+__device__ __forceinline__ void ws_sb(const u32x4& a2, const u32x4& a3, const u32x4& b0, const u32x4& b1,
+                                      u32x4& an0, u32x4& an1, u32x4& an2, u32x4& an3, u32x4& bn0, u32x4& bn1, unsigned stg, const u32x2& sda,
+                                      const u32x2& sdb) {
 #define WS_SB_OPS                                                                                                        \
   : [an0] "+v"(an0), [an1] "+v"(an1), [an2] "+v"(an2), [an3] "+v"(an3), [bn0] "+v"(bn0), [bn1] "+v"(bn1)                  \
-  : [a2] "v"(a2), [a3] "v"(a3), [b0] "v"(b0), [b1] "v"(b1), [stg] "v"(stg), [sd] "v"(sdata), [soff] "n"(SOFF)             \
+  : [a2] "v"(a2), [a3] "v"(a3), [b0] "v"(b0), [b1] "v"(b1), [stg] "v"(stg), [sda] "v"(sda), [sdb] "v"(sdb), [soff] "n"(SOFF) \
   : "memory", WS_ACC_CLOBBER
 #define WS_SB_BODY(M, ST) M(4, a2, b0) ST M(5, a2, b1) M(6, a3, b0) M(7, a3, b1) "s_waitcnt lgkmcnt(0)"
-#define WS_STW "ds_write_b128 %[stg], %[sd] offset:%[soff]\n\t"
+// (a parked unit is un-swapped: this lane's 8 bytes of channel block cb go to the lower 512 B of the unit, those of cb + 1 above)
+#define WS_STW "ds_write_b64 %[stg], %[sda] offset:%[soff]\n\tds_write_b64 %[stg], %[sdb] offset:%[soff]+512\n\t"
   if constexpr (ZERO) {
     if constexpr (STAGE) asm volatile(WS_SB_BODY(WS_MFMA0, WS_STW) WS_SB_OPS);
     else asm volatile(WS_SB_BODY(WS_MFMA0, "") WS_SB_OPS);
@@ -133,8 +147,9 @@ __device__ __forceinline__ void ws_x8(const u32x4& a0, const u32x4& b0, const u3
   asm volatile(WS_MFMA(0, a0, b0) WS_MFMA(1, a0, b1) "s_barrier" : : [a0] "v"(a0), [b0] "v"(b0), [b1] "v"(b1) : "memory", WS_ACC_CLOBBER);
 }
 // step 8, second part: rows mb = 1..3 with the operand reads of the next chunk's step 0 (the other buffer) up front
-__device__ __forceinline__ void ws_y8(const u32x4& a1, const u32x4& a2, const u32x4& a3, const u32x4& b0, const u32x4& b1, u32x4& an0, u32x4& an1,
-                                      u32x4& an2, u32x4& an3, u32x4& bn0, u32x4& bn1, unsigned pa, unsigned pb0, unsigned pb1) {
+__device__ __forceinline__ void ws_y8(const u32x4& a1, const u32x4& a2,
+                                      const u32x4& a3, const u32x4& b0, const u32x4& b1, u32x4& an0, u32x4& an1, u32x4& an2, u32x4& an3, u32x4& bn0,
+                                      u32x4& bn1, unsigned pa, unsigned pb0, unsigned pb1) {
   asm volatile(WS_MFMA(2, a1, b0) WS_RDA(an0, 0, "0") WS_RDB(bn0, pb0, "0") WS_MFMA(3, a1, b1) WS_RDA(an1, 1, "0") WS_RDB(bn1, pb1, "0")
                WS_MFMA(4, a2, b0) WS_RDA(an2, 2, "0") WS_MFMA(5, a2, b1) WS_RDA(an3, 3, "0") WS_MFMA(6, a3, b0) WS_MFMA(7, a3, b1) "s_waitcnt lgkmcnt(0)"
                : [an0] "=&v"(an0), [an1] "=&v"(an1), [an2] "=&v"(an2), [an3] "=&v"(an3), [bn0] "=&v"(bn0), [bn1] "=&v"(bn1)
@@ -142,12 +157,26 @@ __device__ __forceinline__ void ws_y8(const u32x4& a1, const u32x4& a2, const u3
                : "memory", WS_ACC_CLOBBER);
 }
 // ... without reads (the tile's last chunk: the seam comes first, the next tile's operands after it)
+// (ends with the wait states between the last MFMA and the first read of an accumulator register: 16 passes)
 __device__ __forceinline__ void ws_y8_last(const u32x4& a1, const u32x4& a2, const u32x4& a3, const u32x4& b0, const u32x4& b1) {
-  asm volatile(WS_MFMA(2, a1, b0) WS_MFMA(3, a1, b1) WS_MFMA(4, a2, b0) WS_MFMA(5, a2, b1) WS_MFMA(6, a3, b0) WS_MFMA(7, a3, b1)
+  asm volatile(WS_MFMA(2, a1, b0) WS_MFMA(3, a1, b1) WS_MFMA(4, a2, b0) WS_MFMA(5, a2, b1) WS_MFMA(6, a3, b0) WS_MFMA(7, a3, b1) "s_nop 15\n\ts_nop 15"
                :
                : [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [b0] "v"(b0), [b1] "v"(b1)
                : "memory", WS_ACC_CLOBBER);
 }
+// eight consecutive accumulator registers -> VGPRs in ONE statement (hipcc pads every asm statement with a wait state).  The
+// statement also CLOBBERS every accumulator register: hipcc then cannot keep a value of its own in an AGPR across any part of the
+// seam (a clobbered register holds nothing live across the statement)
+template <int R>
+__device__ __forceinline__ void ws_acc_read8(float (&r)[8]) {
+  asm volatile(
+      "v_accvgpr_read_b32 %0, a[%8]\n\tv_accvgpr_read_b32 %1, a[%8+1]\n\tv_accvgpr_read_b32 %2, a[%8+2]\n\tv_accvgpr_read_b32 %3, a[%8+3]\n\t"
+      "v_accvgpr_read_b32 %4, a[%8+4]\n\tv_accvgpr_read_b32 %5, a[%8+5]\n\tv_accvgpr_read_b32 %6, a[%8+6]\n\tv_accvgpr_read_b32 %7, a[%8+7]"
+      : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]), "=v"(r[4]), "=v"(r[5]), "=v"(r[6]), "=v"(r[7])
+      : "n"(R)
+      : WS_ACC_CLOBBER);
+}
+
 // operand reads of a chunk's step 0 without MFMAs
 __device__ __forceinline__ void ws_prefetch(u32x4& an0, u32x4& an1, u32x4& an2, u32x4& an3, u32x4& bn0, u32x4& bn1, unsigned pa, unsigned pb0, unsigned pb1) {
   asm volatile(WS_RDA(an0, 0, "0") WS_RDA(an1, 1, "0") WS_RDA(an2, 2, "0") WS_RDA(an3, 3, "0") WS_RDB(bn0, pb0, "0") WS_RDB(bn1, pb1, "0")
@@ -155,13 +184,6 @@ __device__ __forceinline__ void ws_prefetch(u32x4& an0, u32x4& an1, u32x4& an2, 
                : [an0] "=&v"(an0), [an1] "=&v"(an1), [an2] "=&v"(an2), [an3] "=&v"(an3), [bn0] "=&v"(bn0), [bn1] "=&v"(bn1)
                : [pa] "v"(pa), [pb0] "v"(pb0), [pb1] "v"(pb1)
                : "memory");
-}
-
-template <int IDX>
-__device__ __forceinline__ float ws_acc_read() {
-  float r;
-  asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(r) : "n"(IDX));
-  return r;
 }
 
 #ifdef YOGO_DIAG
@@ -190,10 +212,9 @@ template <int MODE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_bf16_ws_kernel(const ConvWsParams p) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem4[];
   constexpr unsigned OOB = 0x80000000u;
-  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int team = wave >> 2, tw = wave & 3;   // team 0 computes, team 1 loads; wavefronts tw and tw + 4 share a SIMD
-  const int ttid = tid & 255;                  // thread index inside the team
   [[maybe_unused]] const unsigned long long t_start = WS_STAMP();
   float* ldsf = reinterpret_cast<float*>(smem4);
 
@@ -226,10 +247,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   };
   // per-lane geometry of the two pixel groups of wavefront tw (compute: operand addresses; loader: output offsets of its partner)
   auto decode_pix = [&](const TileS& t, unsigned (&pbr)[2], int (&vo)[2], unsigned& lw16) {
-    // (the lane's constants are re-derived from a laundered thread index: kept live across the tile loop they are spilled)
-    int t_ = threadIdx.x;
-    asm volatile("" : "+v"(t_));
-    const int l31 = t_ & 31, half = (t_ >> 5) & 1;
+    // (the lane's constants are re-derived from v_mbcnt: kept live across the tile loop -- or derived from threadIdx.x, which then
+    //  has to stay live -- they cost registers the 256-register instantiations do not have and end up in scratch)
+    const int ln_ = ws_lane();
+    const int l31 = ln_ & 31, half = ln_ >> 5;
     const unsigned m_bw = t.lastband ? p.m_bwl : p.m_bw;
     const int bw = t.bw;   // >= 2 (planner)
     const int i_lo = ws_udivm(t.p0, m_bw), i_hi = ws_udivm(t.p1 - 1, m_bw);
@@ -263,6 +284,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   __syncthreads();
 
   if (team == 1) {
+    // (lane indices are re-derived inside each role: a value of the prologue that both roles use stays live across the other
+    //  role's code in hipcc's layout and is spilled there)
+    const int lane = ws_lane();
+    const int ttid = tw * 64 + lane;   // thread index inside the team
     if (WS_PRIO_LOADER) __builtin_amdgcn_s_setprio(WS_PRIO_LOADER);
     // =====================================================================================================================
     // LOADERS: per chunk period -- request the next chunk (13 LDS-DMA pieces per wavefront), move the staging region written
@@ -312,28 +337,41 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (r_ >= rows_in) { r_ -= rows_in; ++kc_; }
       }
     };
-    // the 13 pieces of chunk `cn` of the tile described by (rs, voff) -> buffer `buf`
-    auto request = [&](i32x4 rs, const int (&voff)[WS_NI], int cn, int buf) {
-      const unsigned lb = (unsigned)buf * WS_BUFB;
-      const unsigned soi = (unsigned)cn * so_i;
-      static_assert(WS_NI == 4, "ws_dma4 issues the four input slots");
-      // the input tile first (HBM latency), then the weight slices (L2 hits)
-      ws_dma4(rs, lb + (unsigned)(tw * 64 * 16), voff[0], voff[1], voff[2], voff[3], soi);
+    static_assert(WS_NI == 4, "ws_dma4 issues the four input slots");
+    // weight slices of chunk cn (9 pieces of this wavefront) -> weight buffer cn & 1 (nchunk is even)
+    auto req_w = [&](int cn) {
       const unsigned wb = (unsigned)(((2 * cn + kbw) * 128 + colh * 64) * 16);
-      ws_dma9(rs_w, lb + (unsigned)((WS_LDSW_OFF + kbw * 128 + colh * 64) * 16), lane16, wb, wstep);
+      ws_dma9(rs_w, (unsigned)((cn & 1) * WS_WB + (kbw * 128 + colh * 64) * 16), lane16, wb, wstep);
     };
-    // the 8 staged units of compute wavefront tw (unit index U0 .. U0 + 7 of the PREVIOUS tile; unit = 2 q + n, q = 2 mb + gp:
-    // channel block 2 q, pixel group n) -> global memory; returns with the eight stores in flight
+    // input tile of chunk cn of the tile described by (rs, voff) (4 pieces of this wavefront) -> input buffer ib
+    auto req_i = [&](i32x4 rs, const int (&voff)[WS_NI], int cn, int ib) {
+      ws_dma4(rs, (unsigned)(WS_I0 + ib * WS_IB + tw * 64 * 16), voff[0], voff[1], voff[2], voff[3], (unsigned)cn * so_i);
+    };
+    // Output hand-over.  The 8 staged units of compute wavefront tw (units U0 .. U0 + 7; unit = 2 q + n, q = 2 mb + gp: channel
+    // block 2 q, pixel group n) are read into registers in periods 1 and 3 and stored FOUR PER PERIOD (periods 1, 2, 3 and 0 of
+    // the next tile): 16 KB per CU and period.  All eight in one period is 32 KB = 3 k cycles of the chip's write rate (~10 B/clk
+    // and CU with every CU storing, tools/probes/vmem_rate.hip), longer than the period -- the barrier then waits for the stores.
     const unsigned stg_rd = (unsigned)(WS_STG + tw * 4096 + lane * 16);
-    auto drain8 = [&](int U0, const int (&vop)[2], i32x4 rs_o) {
+    u32x4 fifo[8];
+    int f_vo[2] = {(int)OOB, (int)OOB};   // output offsets / descriptor / first unit of the tile the FIFO holds
+    i32x4 f_rs = ws_rsrc(p.out, 0u);
+    int f_u0 = 0;
+    auto fifo_fill = [&](int U0, const int (&vop)[2], i32x4 rs_o) {
       const unsigned char* base = reinterpret_cast<const unsigned char*>(smem4) + stg_rd;
-      u32x4 d[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) d[u] = *reinterpret_cast<const u32x4*>(base + (u >> 2) * 16384 + (u & 3) * 1024);
+      for (int u = 0; u < 8; ++u) fifo[u] = *reinterpret_cast<const u32x4*>(base + (u >> 2) * 16384 + (u & 3) * 1024);
+      f_vo[0] = vop[0]; f_vo[1] = vop[1]; f_rs = rs_o; f_u0 = U0;
+    };
+    auto fifo_store4 = [&](auto h_tag) {   // units 4 h .. 4 h + 3 of the FIFO
+      constexpr int Hh = decltype(h_tag)::value;
+      // (the descriptor and the unit base travel through assignments hipcc cannot prove uniform)
+      const i32x4 rs = {__builtin_amdgcn_readfirstlane(f_rs.x), __builtin_amdgcn_readfirstlane(f_rs.y), __builtin_amdgcn_readfirstlane(f_rs.z),
+                        __builtin_amdgcn_readfirstlane(f_rs.w)};
+      const int u0 = __builtin_amdgcn_readfirstlane(f_u0);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int q = (U0 + u) >> 1;
-        ws_store16(d[u], (u & 1) ? vop[1] : vop[0], rs_o, (unsigned)(2 * q) * (unsigned)plane16);
+      for (int u = 4 * Hh; u < 4 * Hh + 4; ++u) {
+        const int q = (u0 + u) >> 1;
+        ws_store16(fifo[u], (u & 1) ? f_vo[1] : f_vo[0], rs, (unsigned)(2 * q) * (unsigned)plane16);
       }
     };
 
@@ -347,34 +385,54 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     i32x4 rs_out_prev = ws_rsrc(p.out, 0u);
     int tpar = 0;
     issue_scale(T.b, 0);
-    request(rs_in, voff, 0, 0);
+    req_i(rs_in, voff, 0, 0);
+    req_i(rs_in, voff, 1, 1);
+    req_w(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // (#1) chunk 0 of the first tile has landed
+    __builtin_amdgcn_s_barrier();   // (#1) chunks 0 (and the input of chunk 1) of the first tile have landed
     [[maybe_unused]] unsigned long long t_wait = 0, t_work = 0;
     bool has_next = true;
+    int ib2 = 2;   // ring slot of the next input request (the chunk two periods ahead)
     while (has_next) {
       TileS Tn{};
       for (int c = 0; c < nck; ++c) {
         [[maybe_unused]] const unsigned long long tw0 = WS_STAMP();
-        if (c + 1 < nck) {
-          request(rs_in, voff, c + 1, (c + 1) & 1);
-        } else {   // the tile's last period: the next tile's first chunk (nchunk is even: buffer 0)
-          unsigned kn = k_ord + 1;
-          has_next = find_tile(kn, Tn);
-          k_ord = kn;
+        // oldest first: the weight slices of the NEXT chunk (needed at this period's barrier) ...
+        if (c + 1 < nck) req_w(c + 1);
+        else if (has_next) req_w(0);
+        // ... then the input tile of the chunk after it (needed one barrier later: it may stay in flight)
+        bool req = false;   // (uniform)
+        if (c + 2 < nck) {
+          req_i(rs_in, voff, c + 2, ib2);
+          req = true;
+        } else {
+          if (c + 2 == nck) {   // the request stream crosses into the next tile
+            unsigned kn = k_ord + 1;
+            has_next = find_tile(kn, Tn);
+            k_ord = kn;
+            if (has_next) {
+              decode_slots(Tn, voff);
+              rs_in = ws_rsrc(reinterpret_cast<const unsigned char*>(p.in) + (size_t)Tn.b * ibytes, ibytes);
+              issue_scale(Tn.b, tpar ^ 1);
+            }
+          }
           if (has_next) {
-            decode_slots(Tn, voff);
-            rs_in = ws_rsrc(reinterpret_cast<const unsigned char*>(p.in) + (size_t)Tn.b * ibytes, ibytes);
-            issue_scale(Tn.b, tpar ^ 1);
-            request(rs_in, voff, 0, 0);
+            req_i(rs_in, voff, c + 2 - nck, ib2);
+            req = true;
           }
         }
-        // period 1: the units the seam staged; period 3: the parked units compute staged in period 2
-        const bool dr = c == 1 || c == 3;   // (uniform)
-        if (dr) drain8(c == 1 ? 0 : 8, vo_prev, rs_out_prev);
+        ib2 = ib2 == 2 ? 0 : ib2 + 1;
+        // period 1: the units the seam staged; period 3: the parked units compute staged in period 2 -> the register FIFO;
+        // four stores in each of the periods 0 (second half of what period 3 of the previous tile read), 1, 2, 3
+        if (c == 0) fifo_store4(WsIC<1>{});
+        else if (c == 1) { fifo_fill(0, vo_prev, rs_out_prev); fifo_store4(WsIC<0>{}); }
+        else if (c == 2) fifo_store4(WsIC<1>{});
+        else if (c == 3) { fifo_fill(8, vo_prev, rs_out_prev); fifo_store4(WsIC<0>{}); }
+        const bool dr = c < 4;   // (uniform) four stores were issued
         [[maybe_unused]] const unsigned long long tw1 = WS_STAMP();
-        // requests are older than this period's stores: all but the 8 youngest operations have to be done
-        if (dr) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        // vector-memory operations retire in order: everything but this period's input request (4) and stores (4) has to be done
+        if (dr && req) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (dr || req) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         t_work += tw1 - tw0;
@@ -390,12 +448,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         tpar ^= 1;
       }
     }
-    // the last tile's output: (compute: seam) barrier, staged half, barrier, (compute: parked half) barrier, second half
+    // the last tile's output: what the FIFO still holds, then (compute: seam) barrier, staged half, barrier, (compute: parked half)
+    // barrier, second half
+    fifo_store4(WsIC<1>{});
     __builtin_amdgcn_s_barrier();
-    drain8(0, vo_prev, rs_out_prev);
+    fifo_fill(0, vo_prev, rs_out_prev);
+    fifo_store4(WsIC<0>{});
+    fifo_store4(WsIC<1>{});
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_barrier();
-    drain8(8, vo_prev, rs_out_prev);
+    fifo_fill(8, vo_prev, rs_out_prev);
+    fifo_store4(WsIC<0>{});
+    fifo_store4(WsIC<1>{});
 #ifdef YOGO_DIAG
     if (p.stamps && ttid == 0) {
       unsigned long long* d = p.stamps + (size_t)blockIdx.x * 16;
@@ -409,18 +473,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // COMPUTE
   // =======================================================================================================================
   if (WS_PRIO_COMPUTE) __builtin_amdgcn_s_setprio(WS_PRIO_COMPUTE);
-  const unsigned a_b0 = (unsigned)(WS_LDSW_OFF + half * 128 + l31) * 16u;
-  const unsigned stg_wr = (unsigned)(WS_STG + tw * 4096 + lane * 16);
+  const int lane = ws_lane(), l31 = lane & 31, half = lane >> 5;
+  const unsigned a_b0 = (unsigned)(half * 128 + l31) * 16u;
+  // staging address of this lane's 8 bytes of a unit's lower channel block (the upper block's are 512 B above)
+  const unsigned stg_wr = (unsigned)(WS_STG + tw * 4096 + l31 * 16 + half * 8);
   unsigned pbr[2], lw16;
   int vo[2];
   decode_pix(T, pbr, vo, lw16);
   int tpar = 0;
   __builtin_amdgcn_s_barrier();   // (#1)
   u32x4 A0[4], B0[2], A1[4], B1[2];   // the two operand sets
-  ws_prefetch(A0[0], A0[1], A0[2], A0[3], B0[0], B0[1], a_b0, pbr[0], pbr[1]);
-  u32x4 hold[8];                      // parked output units 8..15 of the PREVIOUS tile (unit = 2 (2 mb + gp) + n: rows mb = 2, 3)
+  ws_prefetch(A0[0], A0[1], A0[2], A0[3], B0[0], B0[1], a_b0, pbr[0] + WS_I0, pbr[1] + WS_I0);
+  // parked output units 8..15 of the PREVIOUS tile (unit = 2 (2 mb + gp) + n: rows mb = 2, 3), un-swapped: hA = this lane's
+  // 4 channels of the lower channel block, hB = of the upper one
+  u32x2 hA[8], hB[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) hold[i] = u32x4{0u, 0u, 0u, 0u};
+  for (int i = 0; i < 8; ++i) { hA[i] = u32x2{0u, 0u}; hB[i] = u32x2{0u, 0u}; }
+  unsigned ibo = WS_I0;               // input buffer of the chunk being computed (ring of three)
   const bool leaky = MODE == 3 ? p.act == ACT_LEAKY : (MODE == 1 || MODE == 2);
   const bool write_signs = MODE == 3 ? p.signs != nullptr : MODE == 2;
   constexpr bool SCALED = MODE >= 2;   // (modes 0 / 1: no channel scale -- the launcher checks)
@@ -433,7 +502,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int STC = decltype(stc_tag)::value;
     constexpr int P = decltype(p_tag)::value;
     constexpr bool LAST = decltype(last_tag)::value;
-    const unsigned pa = a_b0 + P * WS_BUFB;
+    const unsigned pa = a_b0 + P * WS_WB;
+    const unsigned ibn = ibo == WS_I0 + 2 * WS_IB ? (unsigned)WS_I0 : ibo + WS_IB;   // the next chunk's input buffer
     auto one = [&](auto s_tag) {
       constexpr int S = decltype(s_tag)::value;
       constexpr bool EVEN = ((P + S) & 1) == 0;   // operand set of this step: 0 when even
@@ -443,11 +513,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       u32x4(&Bn)[2] = EVEN ? B1 : B0;
       if constexpr (S < 8) {
         constexpr int T1 = S + 1, KY1 = T1 / 3, KX1 = T1 % 3;
-        const unsigned rowo = (unsigned)KY1 * lw16 + P * WS_BUFB;
+        const unsigned rowo = (unsigned)KY1 * lw16 + ibo;
         ws_sa<FIRST && S == 0, T1, KX1>(Ac[0], Ac[1], Bc[0], Bc[1], An[0], An[1], An[2], An[3], Bn[0], Bn[1], pa, pbr[0] + rowo, pbr[1] + rowo);
         constexpr bool STAGE = STC == 1;
         constexpr int HI = STAGE ? S : 0;
-        ws_sb<FIRST && S == 0, STAGE, (S >> 2) * 16384 + (S & 3) * 1024>(Ac[2], Ac[3], Bc[0], Bc[1], An[0], An[1], An[2], An[3], Bn[0], Bn[1], stg_wr, hold[HI]);
+        ws_sb<FIRST && S == 0, STAGE, (S >> 2) * 16384 + (S & 3) * 1024>(Ac[2], Ac[3], Bc[0], Bc[1], An[0], An[1], An[2], An[3], Bn[0], Bn[1], stg_wr, hA[HI],
+                                                                       hB[HI]);
       } else {
         [[maybe_unused]] const unsigned long long tx0 = WS_STAMP();
         ws_x8(Ac[0], Bc[0], Bc[1]);
@@ -455,12 +526,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if constexpr (LAST) {
           ws_y8_last(Ac[1], Ac[2], Ac[3], Bc[0], Bc[1]);
         } else {
-          const unsigned bo = (1 - P) * WS_BUFB;
-          ws_y8(Ac[1], Ac[2], Ac[3], Bc[0], Bc[1], An[0], An[1], An[2], An[3], Bn[0], Bn[1], a_b0 + bo, pbr[0] + bo, pbr[1] + bo);
+          ws_y8(Ac[1], Ac[2], Ac[3], Bc[0], Bc[1], An[0], An[1], An[2], An[3], Bn[0], Bn[1], a_b0 + (1 - P) * WS_WB, pbr[0] + ibn, pbr[1] + ibn);
         }
       }
     };
     ws_static_for(one, std::make_integer_sequence<int, 9>{});
+    ibo = ibn;
   };
   using TT = std::true_type;
   using FT = std::false_type;
@@ -484,7 +555,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     [[maybe_unused]] const unsigned long long ts0 = WS_STAMP();
     t_chunks += ts0 - tc0;
     // ---- seam: the accumulators of T -> parked bf16 units (every unit of the previous tile has been handed over)
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results are in the accumulator file
     {
       const float* eb = ldsf + WS_EB / 4;
       const float* es = ldsf + WS_ES / 4 + tpar * 128;
@@ -501,42 +571,60 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) bs[i] = SCALED ? ba[i] * sa[i] : ba[i];
-        auto pix = [&](auto n_tag) {
-          constexpr int N = decltype(n_tag)::value;
-          constexpr int R0 = (MB * 2 + N) * 16 + 8 * GP;
-          float v[8];
-          // fma(acc, scale, bias * scale); without a channel scale acc + bias -- the same bits (fma(a, 1, b) = round(a + b))
-#define WS_V(I) v[I] = SCALED ? fmaf(ws_acc_read<R0 + I>(), sa[I], bs[I]) : ws_acc_read<R0 + I>() + bs[I];
-          WS_V(0) WS_V(1) WS_V(2) WS_V(3) WS_V(4) WS_V(5) WS_V(6) WS_V(7)
-#undef WS_V
+        float v[2][8];
+        auto rd = [&](auto n_tag) {   // fma(acc, scale, bias * scale); without a channel scale acc + bias -- the same bits (fma(a, 1, b) = round(a + b))
+          constexpr int N = decltype(n_tag)::value, R = (MB * 2 + N) * 16 + 8 * GP;
+          float r8[8];
+          ws_acc_read8<R>(r8);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[N][i] = SCALED ? fmaf(r8[i], sa[i], bs[i]) : r8[i] + bs[i];
+        };
+        // (modes 0 / 1: both pixel groups' reads up front -- two independent chains for the scheduler; the scaled modes keep the
+        //  channel scale and the sign bytes live and have no registers for that)
+        rd(WsIC<0>{});
+        if constexpr (MODE < 2) rd(WsIC<1>{});
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          if constexpr (MODE >= 2) {
+            if (n == 1) {
+              __builtin_amdgcn_sched_barrier(0);
+              rd(WsIC<1>{});
+            }
+          }
           if (leaky) {   // max(v, 0.01 v) as a bare v_max_f32 (the arithmetic of conv_bf16_epi_groups.inc's lean order)
 #pragma unroll
             for (int i = 0; i < 8; i += 2) {
               typedef float f32x2_t __attribute__((ext_vector_type(2)));
-              const f32x2_t sv = (f32x2_t){v[i], v[i + 1]} * (f32x2_t){LEAKY_SLOPE, LEAKY_SLOPE};
-              asm("v_max_f32 %0, %1, %2" : "=v"(v[i]) : "v"(v[i]), "v"(sv.x));
-              asm("v_max_f32 %0, %1, %2" : "=v"(v[i + 1]) : "v"(v[i + 1]), "v"(sv.y));
+              const f32x2_t sv = (f32x2_t){v[n][i], v[n][i + 1]} * (f32x2_t){LEAKY_SLOPE, LEAKY_SLOPE};
+              asm("v_max_f32 %0, %1, %2" : "=v"(v[n][i]) : "v"(v[n][i]), "v"(sv.x));
+              asm("v_max_f32 %0, %1, %2" : "=v"(v[n][i + 1]) : "v"(v[n][i + 1]), "v"(sv.y));
             }
           }
           if (write_signs) {
             unsigned mA = 0;
 #pragma unroll
             for (int i = 7; i >= 0; --i)
-              asm("v_cmp_lt_f32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(mA) : "v"(v[i]) : "vcc");
-            sg[N][Q >> 2] |= mA << (8 * (Q & 3));
+              asm("v_cmp_lt_f32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(mA) : "v"(v[n][i]) : "vcc");
+            sg[n][Q >> 2] |= mA << (8 * (Q & 3));
           }
           bf16x8 o;
 #pragma unroll
-          for (int i = 0; i < 8; ++i) o[i] = (__bf16)v[i];
-          const u32x4 w = __builtin_bit_cast(u32x4, o);
-          const auto r0 = __builtin_amdgcn_permlane32_swap(w.x, w.z, false, false);
-          const auto r1 = __builtin_amdgcn_permlane32_swap(w.y, w.w, false, false);
-          const u32x4 unit = {r0[0], r1[0], r0[1], r1[1]};
-          constexpr int U = Q * 2 + N;
-          if constexpr (U < 8) *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(smem4) + stg_wr + (U >> 2) * 16384 + (U & 3) * 1024) = unit;
-          else hold[U - 8] = unit;
-        };
-        ws_static_for(pix, std::make_integer_sequence<int, 2>{});
+          for (int i = 0; i < 8; ++i) o[i] = (__bf16)v[n][i];
+          const u32x4 w = __builtin_bit_cast(u32x4, o);   // (x, y) = this lane's 4 channels of block cb, (z, w) = of block cb + 1
+          const u32x2 wa = {w.x, w.y}, wb = {w.z, w.w};
+          const int U = Q * 2 + n;   // (compile-time after unrolling)
+          if (U < 8) {   // straight to the staging area: the unit's layout is [2 channel blocks][32 pixels][16 B], 8 B per lane and block
+            unsigned char* dst = reinterpret_cast<unsigned char*>(smem4) + stg_wr + (U >> 2) * 16384 + (U & 3) * 1024;
+            *reinterpret_cast<u32x2*>(dst) = wa;
+            *reinterpret_cast<u32x2*>(dst + 512) = wb;
+          } else {
+            hA[U - 8] = wa;
+            hB[U - 8] = wb;
+          }
+        }
+        // (no hoisting of the next group's loads / reads into this one: with every group in flight at once the seam needs more than
+        //  the 128 arch VGPRs and hipcc would park the overflow in AGPRs -- the accumulators, which it does not know are live)
+        __builtin_amdgcn_sched_barrier(0);
       };
       if (!WS_DBG(2)) ws_static_for(group, std::make_integer_sequence<int, 8>{});
       if (write_signs) {   // the 8 sign bytes of a pixel (this lane's half of the 128 channels) go out together
@@ -556,19 +644,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (!has_next) break;
     decode_pix(T, pbr, vo, lw16);
     tpar ^= 1;
-    ws_prefetch(A0[0], A0[1], A0[2], A0[3], B0[0], B0[1], a_b0, pbr[0], pbr[1]);   // (the last period's barrier: chunk 0 has landed)
+    ws_prefetch(A0[0], A0[1], A0[2], A0[3], B0[0], B0[1], a_b0, pbr[0] + ibo, pbr[1] + ibo);   // (the last period's barrier: chunk 0 has landed)
   }
   // ---- the last tile's output: staged half (written by the seam), then the parked half
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_s_barrier();   // (the loaders have read the staged half)
+  {
+    // (the staging address is re-derived from v_mbcnt: live across the tile loop it costs a register the 256-register
+    //  instantiations do not have)
+    const int ln_ = ws_lane();
+    const unsigned stg2 = (unsigned)(WS_STG + tw * 4096 + (ln_ & 31) * 16 + (ln_ >> 5) * 8);
 #pragma unroll
-  for (int u = 0; u < 8; ++u)
-    *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(smem4) + stg_wr + (u >> 2) * 16384 + (u & 3) * 1024) = hold[u];
+    for (int u = 0; u < 8; ++u) {
+      unsigned char* dst = reinterpret_cast<unsigned char*>(smem4) + stg2 + (u >> 2) * 16384 + (u & 3) * 1024;
+      *reinterpret_cast<u32x2*>(dst) = hA[u];
+      *reinterpret_cast<u32x2*>(dst + 512) = hB[u];
+    }
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 #ifdef YOGO_DIAG
-  if (p.stamps && tid == 0) {
+  if (p.stamps && tw == 0 && lane == 0) {
     unsigned long long* d = p.stamps + (size_t)blockIdx.x * 16;
     d[0] = t_start; d[1] = __builtin_amdgcn_s_memtime(); d[2] = t_chunks; d[3] = t_seam; d[5] = k_ord; d[6] = t_x8;
   }
