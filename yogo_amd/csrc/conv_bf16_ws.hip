@@ -591,20 +591,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
               rd(WsIC<1>{});
             }
           }
-          if (leaky) {   // max(v, 0.01 v) as a bare v_max_f32 (the arithmetic of conv_bf16_epi_groups.inc's lean order)
+          if (leaky) {   // max(v, 0.01 v) as bare v_max_f32 (the arithmetic of conv_bf16_epi_groups.inc's lean order); ONE statement:
+            // hipcc pads every asm statement with a wait state, and the seam is bound by instruction issue
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+            float sv[8];
 #pragma unroll
             for (int i = 0; i < 8; i += 2) {
-              typedef float f32x2_t __attribute__((ext_vector_type(2)));
-              const f32x2_t sv = (f32x2_t){v[n][i], v[n][i + 1]} * (f32x2_t){LEAKY_SLOPE, LEAKY_SLOPE};
-              asm("v_max_f32 %0, %1, %2" : "=v"(v[n][i]) : "v"(v[n][i]), "v"(sv.x));
-              asm("v_max_f32 %0, %1, %2" : "=v"(v[n][i + 1]) : "v"(v[n][i + 1]), "v"(sv.y));
+              const f32x2_t t = (f32x2_t){v[n][i], v[n][i + 1]} * (f32x2_t){LEAKY_SLOPE, LEAKY_SLOPE};
+              sv[i] = t.x;
+              sv[i + 1] = t.y;
             }
+            asm("v_max_f32 %0, %0, %8\n\tv_max_f32 %1, %1, %9\n\tv_max_f32 %2, %2, %10\n\tv_max_f32 %3, %3, %11\n\t"
+                "v_max_f32 %4, %4, %12\n\tv_max_f32 %5, %5, %13\n\tv_max_f32 %6, %6, %14\n\tv_max_f32 %7, %7, %15"
+                : "+v"(v[n][0]), "+v"(v[n][1]), "+v"(v[n][2]), "+v"(v[n][3]), "+v"(v[n][4]), "+v"(v[n][5]), "+v"(v[n][6]), "+v"(v[n][7])
+                : "v"(sv[0]), "v"(sv[1]), "v"(sv[2]), "v"(sv[3]), "v"(sv[4]), "v"(sv[5]), "v"(sv[6]), "v"(sv[7]));
           }
-          if (write_signs) {
+          if (write_signs) {   // byte = sum of (v[i] > 0) << i: compare into vcc, add-with-carry shifts it in (values 7 down to 0)
             unsigned mA = 0;
-#pragma unroll
-            for (int i = 7; i >= 0; --i)
-              asm("v_cmp_lt_f32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(mA) : "v"(v[n][i]) : "vcc");
+#define WS_SGN(I) "v_cmp_lt_f32_e32 vcc, 0, %" #I "\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t"
+            asm(WS_SGN(8) WS_SGN(7) WS_SGN(6) WS_SGN(5) WS_SGN(4) WS_SGN(3) WS_SGN(2) "v_cmp_lt_f32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
+                : "+v"(mA)
+                : "v"(v[n][0]), "v"(v[n][1]), "v"(v[n][2]), "v"(v[n][3]), "v"(v[n][4]), "v"(v[n][5]), "v"(v[n][6]), "v"(v[n][7])
+                : "vcc");
+#undef WS_SGN
             sg[n][Q >> 2] |= mA << (8 * (Q & 3));
           }
           bf16x8 o;
