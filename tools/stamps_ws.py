@@ -39,5 +39,5 @@ if __name__ == "__main__":
             life = h[:, 1] - h[:, 0]
             nt = h[:, 5]
             print(f"  {w} dbg={dbg}: wgs={h.shape[0]} tiles/wg={nt.mean():.1f} life={life.mean():.0f} (max {life.max():.0f}) | compute per tile: life {(life / nt).mean():.0f} "
-                  f"chunks {(h[:, 2] / nt).mean():.0f} seam {(h[:, 3] / nt).mean():.0f} x8 {(h[:, 6] / nt).mean():.0f} | loader per tile: work {(h[:, 8] / nt).mean():.0f} "
+                  f"chunks {(h[:, 2] / nt).mean():.0f} (first {(h[:, 10] / nt).mean():.0f}, c1 {(h[:, 12] / nt).mean():.0f}, c2 {(h[:, 13] / nt).mean():.0f}, last {(h[:, 11] / nt).mean():.0f}) seam {(h[:, 3] / nt).mean():.0f} x8 {(h[:, 6] / nt).mean():.0f} | loader per tile: work {(h[:, 8] / nt).mean():.0f} "
                   f"wait+barrier {(h[:, 9] / nt).mean():.0f}")

@@ -177,6 +177,70 @@ __device__ __forceinline__ void ws_acc_read8(float (&r)[8]) {
       : WS_ACC_CLOBBER);
 }
 
+// ---- group-major K steps (the first and the last chunk of a tile): ONE MFMA per statement, so that C++ code placed between the
+// statements -- the epilogue of the other half of the accumulators -- lands in the MFMA gaps.  Accumulator rows mb = 0, 1 are
+// group 0 (tiles 0..3), rows 2, 3 group 1 (tiles 4..7); a group-major chunk runs the 9 taps of group 0, then those of group 1.
+// MFMA + the reads of ONE weight quad (row MBA, tap T1) and ONE input quad (kernel column KX1) of the next step
+template <int TILE, bool ZERO, int MBA, int T1, int KX1>
+__device__ __forceinline__ void ws_g1(const u32x4& a, const u32x4& b, u32x4& an, u32x4& bn, unsigned pa, unsigned pb) {
+#define WS_G1_OPS : [an] "=&v"(an), [bn] "=&v"(bn) : [a] "v"(a), [b] "v"(b), [pa] "v"(pa), [pb] "v"(pb), [tl] "n"(TILE), [mba] "n"(MBA), [t1] "n"(T1), [kx1] "n"(KX1) : "memory", WS_ACC_CLOBBER
+#define WS_G1_RD "ds_read_b128 %[an], %[pa] offset:4096*%[t1]+512*%[mba]\n\tds_read_b128 %[bn], %[pb] offset:16*%[kx1]"
+  if constexpr (ZERO) asm volatile("v_mfma_f32_32x32x16_bf16 a[16*%[tl]:16*%[tl]+15], %[a], %[b], 0\n\t" WS_G1_RD WS_G1_OPS);
+  else asm volatile("v_mfma_f32_32x32x16_bf16 a[16*%[tl]:16*%[tl]+15], %[a], %[b], a[16*%[tl]:16*%[tl]+15]\n\t" WS_G1_RD WS_G1_OPS);
+#undef WS_G1_OPS
+#undef WS_G1_RD
+}
+// bare MFMA; TAIL: text behind it ("s_barrier", or nothing)
+template <int TILE, bool ZERO, bool BARRIER = false>
+__device__ __forceinline__ void ws_g0(const u32x4& a, const u32x4& b) {
+#define WS_G0_OPS : : [a] "v"(a), [b] "v"(b), [tl] "n"(TILE) : "memory", WS_ACC_CLOBBER
+  if constexpr (ZERO) asm volatile("v_mfma_f32_32x32x16_bf16 a[16*%[tl]:16*%[tl]+15], %[a], %[b], 0" WS_G0_OPS);
+  else if constexpr (BARRIER) asm volatile("v_mfma_f32_32x32x16_bf16 a[16*%[tl]:16*%[tl]+15], %[a], %[b], a[16*%[tl]:16*%[tl]+15]\n\ts_barrier" WS_G0_OPS);
+  else asm volatile("v_mfma_f32_32x32x16_bf16 a[16*%[tl]:16*%[tl]+15], %[a], %[b], a[16*%[tl]:16*%[tl]+15]" WS_G0_OPS);
+#undef WS_G0_OPS
+}
+// MFMA, then the step's four operand reads are retired
+template <int TILE, bool ZERO>
+__device__ __forceinline__ void ws_gw(const u32x4& a, const u32x4& b, u32x4& an0, u32x4& an1, u32x4& bn0, u32x4& bn1) {
+#define WS_GW_OPS : [an0] "+v"(an0), [an1] "+v"(an1), [bn0] "+v"(bn0), [bn1] "+v"(bn1) : [a] "v"(a), [b] "v"(b), [tl] "n"(TILE) : "memory", WS_ACC_CLOBBER
+  if constexpr (ZERO) asm volatile("v_mfma_f32_32x32x16_bf16 a[16*%[tl]:16*%[tl]+15], %[a], %[b], 0\n\ts_waitcnt lgkmcnt(0)" WS_GW_OPS);
+  else asm volatile("v_mfma_f32_32x32x16_bf16 a[16*%[tl]:16*%[tl]+15], %[a], %[b], a[16*%[tl]:16*%[tl]+15]\n\ts_waitcnt lgkmcnt(0)" WS_GW_OPS);
+#undef WS_GW_OPS
+}
+// last step of a tile's FIRST chunk, behind the barrier: MFMA + three of the six operand quads of the next (tap-major) chunk's
+// step 0 -- weight rows MB0, MB0 + 1 and input quad pb; WAIT: retire all six (x0..x2 are the first statement's)
+template <int TILE, int MB0, bool WAIT>
+__device__ __forceinline__ void ws_g3(const u32x4& a, const u32x4& b, u32x4& an0, u32x4& an1, u32x4& bn, unsigned pa, unsigned pb, u32x4& x0, u32x4& x1,
+                                      u32x4& x2) {
+  if constexpr (WAIT)
+    asm volatile("v_mfma_f32_32x32x16_bf16 a[16*%[tl]:16*%[tl]+15], %[a], %[b], a[16*%[tl]:16*%[tl]+15]\n\t"
+                 "ds_read_b128 %[an0], %[pa] offset:512*%[mb0]\n\tds_read_b128 %[an1], %[pa] offset:512*%[mb0]+512\n\tds_read_b128 %[bn], %[pb]\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : [an0] "=&v"(an0), [an1] "=&v"(an1), [bn] "=&v"(bn), [x0] "+v"(x0), [x1] "+v"(x1), [x2] "+v"(x2)
+                 : [a] "v"(a), [b] "v"(b), [pa] "v"(pa), [pb] "v"(pb), [tl] "n"(TILE), [mb0] "n"(MB0)
+                 : "memory", WS_ACC_CLOBBER);
+  else
+    asm volatile("v_mfma_f32_32x32x16_bf16 a[16*%[tl]:16*%[tl]+15], %[a], %[b], a[16*%[tl]:16*%[tl]+15]\n\t"
+                 "ds_read_b128 %[an0], %[pa] offset:512*%[mb0]\n\tds_read_b128 %[an1], %[pa] offset:512*%[mb0]+512\n\tds_read_b128 %[bn], %[pb]"
+                 : [an0] "=&v"(an0), [an1] "=&v"(an1), [bn] "=&v"(bn)
+                 : [a] "v"(a), [b] "v"(b), [pa] "v"(pa), [pb] "v"(pb), [tl] "n"(TILE), [mb0] "n"(MB0)
+                 : "memory", WS_ACC_CLOBBER);
+}
+// operand reads of a group-major chunk's step 0 (weight rows 0, 1 and both input quads of tap 0) without MFMAs
+__device__ __forceinline__ void ws_prefetch4(u32x4& an0, u32x4& an1, u32x4& bn0, u32x4& bn1, unsigned pa, unsigned pb0, unsigned pb1) {
+  asm volatile(WS_RDA(an0, 0, "0") WS_RDA(an1, 1, "0") WS_RDB(bn0, pb0, "0") WS_RDB(bn1, pb1, "0") "s_waitcnt lgkmcnt(0)"
+               : [an0] "=&v"(an0), [an1] "=&v"(an1), [bn0] "=&v"(bn0), [bn1] "=&v"(bn1)
+               : [pa] "v"(pa), [pb0] "v"(pb0), [pb1] "v"(pb1)
+               : "memory");
+}
+// four consecutive accumulator registers -> VGPRs (see ws_acc_read8: the statement clobbers every accumulator register)
+template <int R>
+__device__ __forceinline__ void ws_acc_read4(float& r0, float& r1, float& r2, float& r3) {
+  asm volatile("v_accvgpr_read_b32 %0, a[%4]\n\tv_accvgpr_read_b32 %1, a[%4+1]\n\tv_accvgpr_read_b32 %2, a[%4+2]\n\tv_accvgpr_read_b32 %3, a[%4+3]"
+               : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)
+               : "n"(R)
+               : WS_ACC_CLOBBER);
+}
 // operand reads of a chunk's step 0 without MFMAs
 __device__ __forceinline__ void ws_prefetch(u32x4& an0, u32x4& an1, u32x4& an2, u32x4& an3, u32x4& bn0, u32x4& bn1, unsigned pa, unsigned pb0, unsigned pb1) {
   asm volatile(WS_RDA(an0, 0, "0") WS_RDA(an1, 1, "0") WS_RDA(an2, 2, "0") WS_RDA(an3, 3, "0") WS_RDB(bn0, pb0, "0") WS_RDB(bn1, pb1, "0")
@@ -188,7 +252,7 @@ __device__ __forceinline__ void ws_prefetch(u32x4& an0, u32x4& an1, u32x4& an2, 
 
 #ifdef YOGO_DIAG
 #define WS_DBG(BIT) (p.dbg & (BIT))
-#define WS_STAMP() (p.stamps ? __builtin_amdgcn_s_memtime() : 0ull)
+#define WS_STAMP() __builtin_amdgcn_s_memtime()
 #else
 #define WS_DBG(BIT) 0
 #define WS_STAMP() 0ull
@@ -198,10 +262,11 @@ template <int N> using WsIC = std::integral_constant<int, N>;
 
 }  // namespace
 
-// MODE: the epilogue the seam is compiled for -- 0: conv + bias (layers 5 / 6 forward, every data gradient without a channel
-// mask); 1: + LeakyReLU (eval-mode forward); 2: channel scale + LeakyReLU + sign map (layer 3 forward of the training step);
-// 3: everything behind run-time tests.  The seam is bound by vector-instruction issue (nothing else runs on the SIMD's vector
-// ALU while the accumulators are read out), so the instructions a launch does not need are compiled out.
+// MODE: the epilogue the kernel is compiled for, bit 0 = LeakyReLU, bit 1 = + sign map of the output, bit 2 = channel scale
+// (Dropout2d mask).  0: conv + bias (layers 5 / 6 forward, data gradients without a channel mask); 1: eval-mode forward; 7: layer 3
+// forward of the training step; 4 / 5 / 3: the other combinations a ModelDefn can ask for.  The epilogue is bound by
+// vector-instruction issue, so what a launch does not need is compiled out -- and a variant that kept every run-time flag's
+// operands live did not fit the 128 arch VGPRs.
 #ifndef WS_PRIO_COMPUTE
 #define WS_PRIO_COMPUTE 3
 #endif
@@ -393,8 +458,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     [[maybe_unused]] unsigned long long t_wait = 0, t_work = 0;
     bool has_next = true;
     int ib2 = 2;   // ring slot of the next input request (the chunk two periods ahead)
+    // the NEXT tile is looked up and decoded in period 0, behind that period's requests and stores: its ~1.5 k cycles of scalar
+    // and vector work then run while the requests are in flight and the compute wavefronts are in their longest chunk (the
+    // group-major first chunk with the previous tile's epilogue in its gaps).  (In period nchunk - 2, where the request stream
+    // needs it, it delayed the barrier by that much once per tile.)
+    TileS Tn{};
+    int voff_n[WS_NI] = {(int)OOB, (int)OOB, (int)OOB, (int)OOB}, vo_n[2] = {(int)OOB, (int)OOB};
+    i32x4 rs_in_n = rs_in, rs_out_n = rs_out;
     while (has_next) {
-      TileS Tn{};
       for (int c = 0; c < nck; ++c) {
         [[maybe_unused]] const unsigned long long tw0 = WS_STAMP();
         // oldest first: the weight slices of the NEXT chunk (needed at this period's barrier) ...
@@ -406,15 +477,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           req_i(rs_in, voff, c + 2, ib2);
           req = true;
         } else {
-          if (c + 2 == nck) {   // the request stream crosses into the next tile
-            unsigned kn = k_ord + 1;
-            has_next = find_tile(kn, Tn);
-            k_ord = kn;
-            if (has_next) {
-              decode_slots(Tn, voff);
-              rs_in = ws_rsrc(reinterpret_cast<const unsigned char*>(p.in) + (size_t)Tn.b * ibytes, ibytes);
-              issue_scale(Tn.b, tpar ^ 1);
-            }
+          if (c + 2 == nck && has_next) {   // the request stream crosses into the next tile
+#pragma unroll
+            for (int i = 0; i < WS_NI; ++i) voff[i] = voff_n[i];
+            rs_in = rs_in_n;
+            issue_scale(Tn.b, tpar ^ 1);
           }
           if (has_next) {
             req_i(rs_in, voff, c + 2 - nck, ib2);
@@ -422,13 +489,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           }
         }
         ib2 = ib2 == 2 ? 0 : ib2 + 1;
-        // period 1: the units the seam staged; period 3: the parked units compute staged in period 2 -> the register FIFO;
-        // four stores in each of the periods 0 (second half of what period 3 of the previous tile read), 1, 2, 3
-        if (c == 0) fifo_store4(WsIC<1>{});
-        else if (c == 1) { fifo_fill(0, vo_prev, rs_out_prev); fifo_store4(WsIC<0>{}); }
-        else if (c == 2) fifo_store4(WsIC<1>{});
-        else if (c == 3) { fifo_fill(8, vo_prev, rs_out_prev); fifo_store4(WsIC<0>{}); }
+        // period 0: the units the compute wavefronts wrote during the previous tile's last chunk; period 2: the parked units they
+        // staged in period 1 -> the register FIFO; four stores in each of the periods 0..3
+        if (c == 0) { fifo_fill(0, vo_prev, rs_out_prev); fifo_store4(WsIC<0>{}); }
+        else if (c == 1) fifo_store4(WsIC<1>{});
+        else if (c == 2) { fifo_fill(8, vo_prev, rs_out_prev); fifo_store4(WsIC<0>{}); }
+        else if (c == 3) fifo_store4(WsIC<1>{});
         const bool dr = c < 4;   // (uniform) four stores were issued
+        if (c == 0) {
+          unsigned kn = k_ord + 1;
+          has_next = find_tile(kn, Tn);
+          k_ord = kn;
+          if (has_next) {
+            decode_slots(Tn, voff_n);
+            decode_pix(Tn, pbr_, vo_n, lw16_);
+            rs_in_n = ws_rsrc(reinterpret_cast<const unsigned char*>(p.in) + (size_t)Tn.b * ibytes, ibytes);
+            rs_out_n = ws_rsrc(reinterpret_cast<unsigned char*>(p.out) + (size_t)Tn.b * obytes, obytes);
+          }
+        }
         [[maybe_unused]] const unsigned long long tw1 = WS_STAMP();
         // vector-memory operations retire in order: everything but this period's input request (4) and stores (4) has to be done
         if (dr && req) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -443,15 +521,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int n = 0; n < 2; ++n) vo_prev[n] = WS_DBG(1) ? (int)OOB : vo[n];
       rs_out_prev = rs_out;
       if (has_next) {
-        decode_pix(Tn, pbr_, vo, lw16_);
-        rs_out = ws_rsrc(reinterpret_cast<unsigned char*>(p.out) + (size_t)Tn.b * obytes, obytes);
+        vo[0] = vo_n[0]; vo[1] = vo_n[1];
+        rs_out = rs_out_n;
         tpar ^= 1;
       }
     }
-    // the last tile's output: what the FIFO still holds, then (compute: seam) barrier, staged half, barrier, (compute: parked half)
+    // the last tile's output: the staged half (written before the last period's barrier), barrier, (compute: the parked half)
     // barrier, second half
-    fifo_store4(WsIC<1>{});
-    __builtin_amdgcn_s_barrier();
     fifo_fill(0, vo_prev, rs_out_prev);
     fifo_store4(WsIC<0>{});
     fifo_store4(WsIC<1>{});
@@ -480,28 +556,114 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   unsigned pbr[2], lw16;
   int vo[2];
   decode_pix(T, pbr, vo, lw16);
-  int tpar = 0;
+  int tpar = 0;                       // channel-scale buffer of the tile being computed
+  int epar = 1;                       // ... of the tile whose epilogue slices are running
   __builtin_amdgcn_s_barrier();   // (#1)
   u32x4 A0[4], B0[2], A1[4], B1[2];   // the two operand sets
-  ws_prefetch(A0[0], A0[1], A0[2], A0[3], B0[0], B0[1], a_b0, pbr[0] + WS_I0, pbr[1] + WS_I0);
+  ws_prefetch4(A1[0], A1[1], B1[0], B1[1], a_b0, pbr[0] + WS_I0, pbr[1] + WS_I0);
   // parked output units 8..15 of the PREVIOUS tile (unit = 2 (2 mb + gp) + n: rows mb = 2, 3), un-swapped: hA = this lane's
   // 4 channels of the lower channel block, hB = of the upper one
   u32x2 hA[8], hB[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { hA[i] = u32x2{0u, 0u}; hB[i] = u32x2{0u, 0u}; }
   unsigned ibo = WS_I0;               // input buffer of the chunk being computed (ring of three)
-  const bool leaky = MODE == 3 ? p.act == ACT_LEAKY : (MODE == 1 || MODE == 2);
-  const bool write_signs = MODE == 3 ? p.signs != nullptr : MODE == 2;
-  constexpr bool SCALED = MODE >= 2;   // (modes 0 / 1: no channel scale -- the launcher checks)
-  [[maybe_unused]] unsigned long long t_chunks = 0, t_seam = 0, t_x8 = 0;
+  constexpr bool leaky = (MODE & 1) != 0, write_signs = (MODE & 2) != 0, SCALED = (MODE & 4) != 0;
+  [[maybe_unused]] unsigned long long t_chunks = 0, t_seam = 0, t_x8 = 0, t_gmf = 0, t_gml = 0, t_c1 = 0, t_c2 = 0;
 
-  // one 16-channel chunk: 9 K steps.  P = parity of the chunk (LDS buffer AND operand set of step 0); FIRST: the tile's first
-  // chunk; STC = 1: steps 0..7 hand the parked units over (period 2); LAST: the tile's last chunk (no prefetch)
-  auto chunk = [&](auto first_tag, auto stc_tag, auto p_tag, auto last_tag) {
-    constexpr bool FIRST = decltype(first_tag)::value;
-    constexpr int STC = decltype(stc_tag)::value;
+  // ---- the epilogue, cut into slices that run in the MFMA gaps of a group-major chunk.  Group GRP (0: accumulator rows 0, 1 =
+  //      units 0..7, straight to the staging area; 1: rows 2, 3 = units 8..15, parked) has 8 units of 8 values per lane; unit UL
+  //      takes slices 4 UL .. 4 UL + 3: [bias / scale of the channel group +] 4 accumulator reads | 4 reads | the arithmetic
+  //      (fma(acc, scale, bias * scale) or acc + bias -- the same bits --, LeakyReLU, sign byte) | bf16 + hand-over.
+  float e_r[8], e_v[8], e_ba[8], e_sa[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, e_bs[8];
+  unsigned sg[2][2] = {{0u, 0u}, {0u, 0u}};   // sign bytes of the tile in the epilogue: [pixel group][dword]
+  int vo_e[2] = {(int)OOB, (int)OOB};          // ... its output offsets / image (the sign map goes out when group 1 is through)
+  int b_e = 0;
+  auto epi = [&](auto grp_tag, auto i_tag) {
+    constexpr int GRP = decltype(grp_tag)::value, I = decltype(i_tag)::value;
+    if constexpr (I < 32) {
+      constexpr int UL = I >> 2, S = I & 3, U = GRP * 8 + UL, Q = U >> 1, N = U & 1, MB = Q >> 1, GP = Q & 1, R = (MB * 2 + N) * 16 + 8 * GP;
+      if constexpr (S == 0) {
+        if constexpr (N == 0) {
+          const float* eb = ldsf + WS_EB / 4;
+          const int cl = MB * 32 + 16 * GP + 4 * half;   // local channel of group A; group B = cl + 8
+          const float4 bA = *reinterpret_cast<const float4*>(eb + cl), bB = *reinterpret_cast<const float4*>(eb + cl + 8);
+          e_ba[0] = bA.x; e_ba[1] = bA.y; e_ba[2] = bA.z; e_ba[3] = bA.w; e_ba[4] = bB.x; e_ba[5] = bB.y; e_ba[6] = bB.z; e_ba[7] = bB.w;
+          if constexpr (SCALED) {
+            const float* es = ldsf + WS_ES / 4 + epar * 128;
+            const float4 sA = *reinterpret_cast<const float4*>(es + cl), sB = *reinterpret_cast<const float4*>(es + cl + 8);
+            e_sa[0] = sA.x; e_sa[1] = sA.y; e_sa[2] = sA.z; e_sa[3] = sA.w; e_sa[4] = sB.x; e_sa[5] = sB.y; e_sa[6] = sB.z; e_sa[7] = sB.w;
+          }
+        }
+        ws_acc_read4<R>(e_r[0], e_r[1], e_r[2], e_r[3]);
+      } else if constexpr (S == 1) {
+        ws_acc_read4<R + 4>(e_r[4], e_r[5], e_r[6], e_r[7]);
+        if constexpr (N == 0) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) e_bs[i] = SCALED ? e_ba[i] * e_sa[i] : e_ba[i];
+        }
+      } else if constexpr (S == 2) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e_v[i] = SCALED ? fmaf(e_r[i], e_sa[i], e_bs[i]) : e_r[i] + e_bs[i];
+        if constexpr (leaky) {   // max(v, 0.01 v) as bare v_max_f32 (the arithmetic of conv_bf16_epi_groups.inc's lean order), ONE statement
+          typedef float f32x2_t __attribute__((ext_vector_type(2)));
+          float sv[8];
+#pragma unroll
+          for (int i = 0; i < 8; i += 2) {
+            const f32x2_t t = (f32x2_t){e_v[i], e_v[i + 1]} * (f32x2_t){LEAKY_SLOPE, LEAKY_SLOPE};
+            sv[i] = t.x;
+            sv[i + 1] = t.y;
+          }
+          asm("v_max_f32 %0, %0, %8\n\tv_max_f32 %1, %1, %9\n\tv_max_f32 %2, %2, %10\n\tv_max_f32 %3, %3, %11\n\t"
+              "v_max_f32 %4, %4, %12\n\tv_max_f32 %5, %5, %13\n\tv_max_f32 %6, %6, %14\n\tv_max_f32 %7, %7, %15"
+              : "+v"(e_v[0]), "+v"(e_v[1]), "+v"(e_v[2]), "+v"(e_v[3]), "+v"(e_v[4]), "+v"(e_v[5]), "+v"(e_v[6]), "+v"(e_v[7])
+              : "v"(sv[0]), "v"(sv[1]), "v"(sv[2]), "v"(sv[3]), "v"(sv[4]), "v"(sv[5]), "v"(sv[6]), "v"(sv[7]));
+        }
+        if constexpr (write_signs) {   // byte = sum of (v[i] > 0) << i: compare into vcc, add-with-carry shifts it in (values 7 down to 0)
+          unsigned mA = 0;
+#define WS_SGN(I) "v_cmp_lt_f32_e32 vcc, 0, %" #I "\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t"
+          asm(WS_SGN(8) WS_SGN(7) WS_SGN(6) WS_SGN(5) WS_SGN(4) WS_SGN(3) WS_SGN(2) "v_cmp_lt_f32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
+              : "+v"(mA)
+              : "v"(e_v[0]), "v"(e_v[1]), "v"(e_v[2]), "v"(e_v[3]), "v"(e_v[4]), "v"(e_v[5]), "v"(e_v[6]), "v"(e_v[7])
+              : "vcc");
+#undef WS_SGN
+          sg[N][Q >> 2] |= mA << (8 * (Q & 3));
+        }
+      } else {
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (__bf16)e_v[i];
+        const u32x4 w = __builtin_bit_cast(u32x4, o);   // (x, y) = this lane's 4 channels of block cb, (z, w) = of block cb + 1
+        const u32x2 wa = {w.x, w.y}, wb = {w.z, w.w};
+        if constexpr (U < 8) {   // straight to the staging area: a unit is [2 channel blocks][32 pixels][16 B], 8 B per lane and block
+          unsigned char* dst = reinterpret_cast<unsigned char*>(smem4) + stg_wr + (U >> 2) * 16384 + (U & 3) * 1024;
+          *reinterpret_cast<u32x2*>(dst) = wa;
+          *reinterpret_cast<u32x2*>(dst + 512) = wb;
+        } else {
+          hA[U - 8] = wa;
+          hB[U - 8] = wb;
+        }
+      }
+    }
+  };
+  auto store_signs = [&]() {   // the 8 sign bytes of a pixel (this lane's half of the 128 channels) go out together
+    if constexpr (write_signs) {
+      const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)(p.signs + (size_t)b_e * plane * 16), (short)0, plane * 16, 0x00020000);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const int vs = vo_e[n] < 0 ? (int)OOB : (vo_e[n] >> 4) * 8;
+        const u32x2 tsg = {sg[n][0], sg[n][1]};
+        __builtin_amdgcn_raw_buffer_store_b64(tsg, rs_s, vs, 0, 0);
+        sg[n][0] = 0u;
+        sg[n][1] = 0u;
+      }
+    }
+  };
+
+  // one tap-major 16-channel chunk (every chunk of a tile but the first and the last): 9 K steps of 8 MFMAs.  P = parity of the chunk
+  // (weight buffer AND operand set of step 0); STAGE: steps 0..7 hand the parked units over (the tile's second chunk)
+  auto chunk = [&](auto stage_tag, auto p_tag) {
+    constexpr bool STAGE = decltype(stage_tag)::value;
     constexpr int P = decltype(p_tag)::value;
-    constexpr bool LAST = decltype(last_tag)::value;
     const unsigned pa = a_b0 + P * WS_WB;
     const unsigned ibn = ibo == WS_I0 + 2 * WS_IB ? (unsigned)WS_I0 : ibo + WS_IB;   // the next chunk's input buffer
     auto one = [&](auto s_tag) {
@@ -514,23 +676,69 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if constexpr (S < 8) {
         constexpr int T1 = S + 1, KY1 = T1 / 3, KX1 = T1 % 3;
         const unsigned rowo = (unsigned)KY1 * lw16 + ibo;
-        ws_sa<FIRST && S == 0, T1, KX1>(Ac[0], Ac[1], Bc[0], Bc[1], An[0], An[1], An[2], An[3], Bn[0], Bn[1], pa, pbr[0] + rowo, pbr[1] + rowo);
-        constexpr bool STAGE = STC == 1;
+        ws_sa<false, T1, KX1>(Ac[0], Ac[1], Bc[0], Bc[1], An[0], An[1], An[2], An[3], Bn[0], Bn[1], pa, pbr[0] + rowo, pbr[1] + rowo);
         constexpr int HI = STAGE ? S : 0;
-        ws_sb<FIRST && S == 0, STAGE, (S >> 2) * 16384 + (S & 3) * 1024>(Ac[2], Ac[3], Bc[0], Bc[1], An[0], An[1], An[2], An[3], Bn[0], Bn[1], stg_wr, hA[HI],
-                                                                       hB[HI]);
+        ws_sb<false, STAGE, (S >> 2) * 16384 + (S & 3) * 1024>(Ac[2], Ac[3], Bc[0], Bc[1], An[0], An[1], An[2], An[3], Bn[0], Bn[1], stg_wr, hA[HI], hB[HI]);
       } else {
         [[maybe_unused]] const unsigned long long tx0 = WS_STAMP();
         ws_x8(Ac[0], Bc[0], Bc[1]);
         t_x8 += WS_STAMP() - tx0;
-        if constexpr (LAST) {
-          ws_y8_last(Ac[1], Ac[2], Ac[3], Bc[0], Bc[1]);
-        } else {
-          ws_y8(Ac[1], Ac[2], Ac[3], Bc[0], Bc[1], An[0], An[1], An[2], An[3], Bn[0], Bn[1], a_b0 + (1 - P) * WS_WB, pbr[0] + ibn, pbr[1] + ibn);
-        }
+        ws_y8(Ac[1], Ac[2], Ac[3], Bc[0], Bc[1], An[0], An[1], An[2], An[3], Bn[0], Bn[1], a_b0 + (1 - P) * WS_WB, pbr[0] + ibn, pbr[1] + ibn);
       }
     };
     ws_static_for(one, std::make_integer_sequence<int, 9>{});
+    ibo = ibn;
+  };
+  // a GROUP-MAJOR chunk: the 9 taps of accumulator rows 0, 1 (group 0), then those of rows 2, 3 (group 1), one MFMA per statement
+  // with a slice of the epilogue behind each.  FIRST = true: the tile's first chunk (weight buffer 0; both groups start from
+  // zero; group 0's MFMAs carry the epilogue of the PREVIOUS tile's group 1, whose registers group 1's first MFMAs then
+  // overwrite).  FIRST = false: the tile's last chunk (weight buffer 1; group 1's MFMAs carry the epilogue of THIS tile's group 0).
+  // Operand set of step s (0..17): set 1 when s is even.
+  auto gm_chunk = [&](auto first_tag) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    constexpr int P = FIRST ? 0 : 1;
+    const unsigned pa = a_b0 + P * WS_WB;
+    const unsigned ibn = ibo == WS_I0 + 2 * WS_IB ? (unsigned)WS_I0 : ibo + WS_IB;
+    auto one = [&](auto s_tag) {
+      constexpr int S = decltype(s_tag)::value, G = S / 9, TAP = S % 9;
+      constexpr bool ODD = (S & 1) != 0;   // operand set of this step: 1 when even
+      u32x4(&Ac)[4] = ODD ? A0 : A1;
+      u32x4(&Bc)[2] = ODD ? B0 : B1;
+      u32x4(&An)[4] = ODD ? A1 : A0;
+      u32x4(&Bn)[2] = ODD ? B1 : B0;
+      constexpr bool ZERO = FIRST && TAP == 0;
+      constexpr bool EPI = FIRST ? G == 0 : G == 1;   // this group's MFMAs carry the other group's epilogue
+      constexpr int EG = FIRST ? 1 : 0;
+      auto slice = [&](auto m_tag) {
+        if constexpr (EPI) epi(WsIC<EG>{}, WsIC<TAP * 4 + decltype(m_tag)::value>{});
+      };
+      if constexpr (S < 17) {
+        constexpr int GN = (S + 1) / 9, T1 = (S + 1) % 9, KY1 = T1 / 3, KX1 = T1 % 3;   // the next step: group, tap
+        const unsigned rowo = (unsigned)KY1 * lw16 + ibo;
+        ws_g1<4 * G + 0, ZERO, 2 * GN, T1, KX1>(Ac[0], Bc[0], An[0], Bn[0], pa, pbr[0] + rowo);
+        slice(WsIC<0>{});
+        ws_g1<4 * G + 1, ZERO, 2 * GN + 1, T1, KX1>(Ac[0], Bc[1], An[1], Bn[1], pa, pbr[1] + rowo);
+        slice(WsIC<1>{});
+        ws_g0<4 * G + 2, ZERO>(Ac[1], Bc[0]);
+        slice(WsIC<2>{});
+        ws_gw<4 * G + 3, ZERO>(Ac[1], Bc[1], An[0], An[1], Bn[0], Bn[1]);
+        slice(WsIC<3>{});
+      } else {   // the chunk's last step: the barrier behind its second MFMA (every slice is through: 32 < 4 * 8)
+        ws_g0<4, false>(Ac[0], Bc[0]);
+        [[maybe_unused]] const unsigned long long tx0 = WS_STAMP();
+        ws_g0<5, false, true>(Ac[0], Bc[1]);
+        t_x8 += WS_STAMP() - tx0;
+        if constexpr (FIRST) {   // ... then the six operand quads of the next (tap-major, weight buffer 1) chunk's step 0
+          const unsigned pan = a_b0 + WS_WB;
+          ws_g3<6, 0, false>(Ac[1], Bc[0], An[0], An[1], Bn[0], pan, pbr[0] + ibn, An[0], An[1], Bn[0]);
+          ws_g3<7, 2, true>(Ac[1], Bc[1], An[2], An[3], Bn[1], pan, pbr[1] + ibn, An[0], An[1], Bn[0]);
+        } else {
+          ws_g0<6, false>(Ac[1], Bc[0]);
+          ws_g0<7, false>(Ac[1], Bc[1]);
+        }
+      }
+    };
+    ws_static_for(one, std::make_integer_sequence<int, 18>{});
     ibo = ibn;
   };
   using TT = std::true_type;
@@ -538,127 +746,42 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   for (;;) {
     [[maybe_unused]] const unsigned long long tc0 = WS_STAMP();
-    chunk(TT{}, WsIC<0>{}, WsIC<0>{}, FT{});
-    chunk(FT{}, WsIC<0>{}, WsIC<1>{}, FT{});
-    chunk(FT{}, WsIC<1>{}, WsIC<0>{}, FT{});   // period 2: the parked units go to the staging area
-    if (nck == 4) {
-      chunk(FT{}, WsIC<0>{}, WsIC<1>{}, TT{});
-    } else {
-      chunk(FT{}, WsIC<0>{}, WsIC<1>{}, FT{});
-      for (int c = 4; c + 2 < nck; c += 2) {
-        chunk(FT{}, WsIC<0>{}, WsIC<0>{}, FT{});
-        chunk(FT{}, WsIC<0>{}, WsIC<1>{}, FT{});
-      }
-      chunk(FT{}, WsIC<0>{}, WsIC<0>{}, FT{});
-      chunk(FT{}, WsIC<0>{}, WsIC<1>{}, TT{});
+    epar = tpar ^ 1;
+    gm_chunk(TT{});                 // chunk 0; group 1 of the previous tile leaves its accumulators -> hA / hB
+    store_signs();                  // (the previous tile's sign map is complete)
+    t_gmf += WS_STAMP() - tc0;
+    epar = tpar;                    // from here on the epilogue in progress is this tile's
+    vo_e[0] = vo[0]; vo_e[1] = vo[1]; b_e = T.b;
+    [[maybe_unused]] const unsigned long long tq0 = WS_STAMP();
+    chunk(TT{}, WsIC<1>{});         // chunk 1: the parked units go to the staging area
+    [[maybe_unused]] const unsigned long long tq1 = WS_STAMP();
+    chunk(FT{}, WsIC<0>{});
+    t_c1 += tq1 - tq0;
+    t_c2 += WS_STAMP() - tq1;
+    for (int c = 3; c + 1 < nck; c += 2) {
+      chunk(FT{}, WsIC<1>{});
+      chunk(FT{}, WsIC<0>{});
     }
+    [[maybe_unused]] const unsigned long long tl0 = WS_STAMP();
+    gm_chunk(FT{});                 // chunk nck - 1; group 0 of this tile -> staging area
     [[maybe_unused]] const unsigned long long ts0 = WS_STAMP();
+    t_gml += ts0 - tl0;
     t_chunks += ts0 - tc0;
-    // ---- seam: the accumulators of T -> parked bf16 units (every unit of the previous tile has been handed over)
-    {
-      const float* eb = ldsf + WS_EB / 4;
-      const float* es = ldsf + WS_ES / 4 + tpar * 128;
-      unsigned sg[2][2] = {{0u, 0u}, {0u, 0u}};
-      auto group = [&](auto q_tag) {
-        constexpr int Q = decltype(q_tag)::value, MB = Q >> 1, GP = Q & 1;
-        const int cl = MB * 32 + 16 * GP + 4 * half;   // local channel of group A; group B = cl + 8
-        const float4 bA = *reinterpret_cast<const float4*>(eb + cl), bB = *reinterpret_cast<const float4*>(eb + cl + 8);
-        const float ba[8] = {bA.x, bA.y, bA.z, bA.w, bB.x, bB.y, bB.z, bB.w};
-        float sa[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, bs[8];
-        if constexpr (SCALED) {
-          const float4 sA = *reinterpret_cast<const float4*>(es + cl), sB = *reinterpret_cast<const float4*>(es + cl + 8);
-          sa[0] = sA.x; sa[1] = sA.y; sa[2] = sA.z; sa[3] = sA.w; sa[4] = sB.x; sa[5] = sB.y; sa[6] = sB.z; sa[7] = sB.w;
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) bs[i] = SCALED ? ba[i] * sa[i] : ba[i];
-        float v[2][8];
-        auto rd = [&](auto n_tag) {   // fma(acc, scale, bias * scale); without a channel scale acc + bias -- the same bits (fma(a, 1, b) = round(a + b))
-          constexpr int N = decltype(n_tag)::value, R = (MB * 2 + N) * 16 + 8 * GP;
-          float r8[8];
-          ws_acc_read8<R>(r8);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) v[N][i] = SCALED ? fmaf(r8[i], sa[i], bs[i]) : r8[i] + bs[i];
-        };
-        // (modes 0 / 1: both pixel groups' reads up front -- two independent chains for the scheduler; the scaled modes keep the
-        //  channel scale and the sign bytes live and have no registers for that)
-        rd(WsIC<0>{});
-        if constexpr (MODE < 2) rd(WsIC<1>{});
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-          if constexpr (MODE >= 2) {
-            if (n == 1) {
-              __builtin_amdgcn_sched_barrier(0);
-              rd(WsIC<1>{});
-            }
-          }
-          if (leaky) {   // max(v, 0.01 v) as bare v_max_f32 (the arithmetic of conv_bf16_epi_groups.inc's lean order); ONE statement:
-            // hipcc pads every asm statement with a wait state, and the seam is bound by instruction issue
-            typedef float f32x2_t __attribute__((ext_vector_type(2)));
-            float sv[8];
-#pragma unroll
-            for (int i = 0; i < 8; i += 2) {
-              const f32x2_t t = (f32x2_t){v[n][i], v[n][i + 1]} * (f32x2_t){LEAKY_SLOPE, LEAKY_SLOPE};
-              sv[i] = t.x;
-              sv[i + 1] = t.y;
-            }
-            asm("v_max_f32 %0, %0, %8\n\tv_max_f32 %1, %1, %9\n\tv_max_f32 %2, %2, %10\n\tv_max_f32 %3, %3, %11\n\t"
-                "v_max_f32 %4, %4, %12\n\tv_max_f32 %5, %5, %13\n\tv_max_f32 %6, %6, %14\n\tv_max_f32 %7, %7, %15"
-                : "+v"(v[n][0]), "+v"(v[n][1]), "+v"(v[n][2]), "+v"(v[n][3]), "+v"(v[n][4]), "+v"(v[n][5]), "+v"(v[n][6]), "+v"(v[n][7])
-                : "v"(sv[0]), "v"(sv[1]), "v"(sv[2]), "v"(sv[3]), "v"(sv[4]), "v"(sv[5]), "v"(sv[6]), "v"(sv[7]));
-          }
-          if (write_signs) {   // byte = sum of (v[i] > 0) << i: compare into vcc, add-with-carry shifts it in (values 7 down to 0)
-            unsigned mA = 0;
-#define WS_SGN(I) "v_cmp_lt_f32_e32 vcc, 0, %" #I "\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t"
-            asm(WS_SGN(8) WS_SGN(7) WS_SGN(6) WS_SGN(5) WS_SGN(4) WS_SGN(3) WS_SGN(2) "v_cmp_lt_f32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
-                : "+v"(mA)
-                : "v"(v[n][0]), "v"(v[n][1]), "v"(v[n][2]), "v"(v[n][3]), "v"(v[n][4]), "v"(v[n][5]), "v"(v[n][6]), "v"(v[n][7])
-                : "vcc");
-#undef WS_SGN
-            sg[n][Q >> 2] |= mA << (8 * (Q & 3));
-          }
-          bf16x8 o;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) o[i] = (__bf16)v[n][i];
-          const u32x4 w = __builtin_bit_cast(u32x4, o);   // (x, y) = this lane's 4 channels of block cb, (z, w) = of block cb + 1
-          const u32x2 wa = {w.x, w.y}, wb = {w.z, w.w};
-          const int U = Q * 2 + n;   // (compile-time after unrolling)
-          if (U < 8) {   // straight to the staging area: the unit's layout is [2 channel blocks][32 pixels][16 B], 8 B per lane and block
-            unsigned char* dst = reinterpret_cast<unsigned char*>(smem4) + stg_wr + (U >> 2) * 16384 + (U & 3) * 1024;
-            *reinterpret_cast<u32x2*>(dst) = wa;
-            *reinterpret_cast<u32x2*>(dst + 512) = wb;
-          } else {
-            hA[U - 8] = wa;
-            hB[U - 8] = wb;
-          }
-        }
-        // (no hoisting of the next group's loads / reads into this one: with every group in flight at once the seam needs more than
-        //  the 128 arch VGPRs and hipcc would park the overflow in AGPRs -- the accumulators, which it does not know are live)
-        __builtin_amdgcn_sched_barrier(0);
-      };
-      if (!WS_DBG(2)) ws_static_for(group, std::make_integer_sequence<int, 8>{});
-      if (write_signs) {   // the 8 sign bytes of a pixel (this lane's half of the 128 channels) go out together
-        const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)(p.signs + (size_t)T.b * plane * 16), (short)0, plane * 16, 0x00020000);
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-          const int vs = vo[n] < 0 ? (int)OOB : (vo[n] >> 4) * 8;
-          const u32x2 tsg = {sg[n][0], sg[n][1]};
-          __builtin_amdgcn_raw_buffer_store_b64(tsg, rs_s, vs, 0, 0);
-        }
-      }
-    }
     unsigned kn = k_ord + 1;
     const bool has_next = find_tile(kn, T);
     k_ord = kn;
-    t_seam += WS_STAMP() - ts0;
     if (!has_next) break;
     decode_pix(T, pbr, vo, lw16);
     tpar ^= 1;
-    ws_prefetch(A0[0], A0[1], A0[2], A0[3], B0[0], B0[1], a_b0, pbr[0] + ibo, pbr[1] + ibo);   // (the last period's barrier: chunk 0 has landed)
+    ws_prefetch4(A1[0], A1[1], B1[0], B1[1], a_b0, pbr[0] + ibo, pbr[1] + ibo);   // (the last period's barrier: chunk 0 has landed)
+    t_seam += WS_STAMP() - ts0;
   }
-  // ---- the last tile's output: staged half (written by the seam), then the parked half
+  // ---- the last tile: group 1's epilogue on its own, then the parked half's hand-over
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // (the last MFMAs' results are in the accumulator file)
+  ws_static_for([&](auto i_tag) { epi(WsIC<1>{}, i_tag); }, std::make_integer_sequence<int, 32>{});
+  store_signs();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_s_barrier();   // (the loaders have read the staged half)
+  __builtin_amdgcn_s_barrier();   // (the loaders have read the staged half of the last tile)
   {
     // (the staging address is re-derived from v_mbcnt: live across the tile loop it costs a register the 256-register
     //  instantiations do not have)
@@ -676,7 +799,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #ifdef YOGO_DIAG
   if (p.stamps && tw == 0 && lane == 0) {
     unsigned long long* d = p.stamps + (size_t)blockIdx.x * 16;
-    d[0] = t_start; d[1] = __builtin_amdgcn_s_memtime(); d[2] = t_chunks; d[3] = t_seam; d[5] = k_ord; d[6] = t_x8;
+    d[0] = t_start; d[1] = __builtin_amdgcn_s_memtime(); d[2] = t_chunks; d[3] = t_seam; d[5] = k_ord; d[6] = t_x8; d[10] = t_gmf; d[11] = t_gml; d[12] = t_c1; d[13] = t_c2;
   }
 #endif
 }
@@ -731,10 +854,9 @@ int launch_conv_bf16_ws(const ConvWsParams& p, hipStream_t stream) {
   static int n_cu = 0;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_ws_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_ws_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_ws_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_ws_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES);
+#define WS_ATTR(M) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_ws_kernel<M>), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES);
+    WS_ATTR(0) WS_ATTR(1) WS_ATTR(3) WS_ATTR(4) WS_ATTR(5) WS_ATTR(7)
+#undef WS_ATTR
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
@@ -746,11 +868,14 @@ int launch_conv_bf16_ws(const ConvWsParams& p, hipStream_t stream) {
   int grid = min(p.ntiles, n_cu);
   if (grid >= 8) grid &= ~7;
   const bool leaky = p.act == ACT_LEAKY, sc = p.chan_scale != nullptr, sg = p.signs != nullptr;
-  const int mode = (!sc && !sg) ? (leaky ? 1 : 0) : ((sc && sg && leaky) ? 2 : 3);
-  if (mode == 0) hipLaunchKernelGGL(conv_bf16_ws_kernel<0>, dim3(grid), dim3(512), WS_LDS_BYTES, stream, p);
-  else if (mode == 1) hipLaunchKernelGGL(conv_bf16_ws_kernel<1>, dim3(grid), dim3(512), WS_LDS_BYTES, stream, p);
-  else if (mode == 2) hipLaunchKernelGGL(conv_bf16_ws_kernel<2>, dim3(grid), dim3(512), WS_LDS_BYTES, stream, p);
-  else hipLaunchKernelGGL(conv_bf16_ws_kernel<3>, dim3(grid), dim3(512), WS_LDS_BYTES, stream, p);
+  if (sg && !leaky) {
+    yogo_set_error("conv_bf16_ws: a sign map goes with LeakyReLU");
+    return YOGO_ERR_ARG;
+  }
+  const int mode = (leaky ? 1 : 0) | (sg ? 2 : 0) | (sc ? 4 : 0);
+#define WS_LAUNCH(M) case M: hipLaunchKernelGGL(conv_bf16_ws_kernel<M>, dim3(grid), dim3(512), WS_LDS_BYTES, stream, p); break;
+  switch (mode) { WS_LAUNCH(0) WS_LAUNCH(1) WS_LAUNCH(3) WS_LAUNCH(4) WS_LAUNCH(5) WS_LAUNCH(7) }
+#undef WS_LAUNCH
   if (yogo_launch_log_enabled())
     yogo_launch_log("conv_bf16_ws_kernel<%d> | Kb=%d in=%dx%d ncb=%d TW=%d tiles_per_band=%d nchunk=%d ntiles=%d grid=%d lds=%d act=%d signs=%d scale=%d", mode, p.Kb, p.IH,
                     p.IW, p.ncb, p.TW, p.tiles_per_band, p.nchunk, p.ntiles, grid, WS_LDS_BYTES, p.act, p.signs != nullptr, p.chan_scale != nullptr);
