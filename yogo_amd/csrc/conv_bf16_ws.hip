@@ -129,22 +129,24 @@ __device__ __forceinline__ void ws_sb(const u32x4& a2, const u32x4& a3, const u3
   : [an0] "+v"(an0), [an1] "+v"(an1), [an2] "+v"(an2), [an3] "+v"(an3), [bn0] "+v"(bn0), [bn1] "+v"(bn1)                  \
   : [a2] "v"(a2), [a3] "v"(a3), [b0] "v"(b0), [b1] "v"(b1), [stg] "v"(stg), [sda] "v"(sda), [sdb] "v"(sdb), [soff] "n"(SOFF) \
   : "memory", WS_ACC_CLOBBER
-#define WS_SB_BODY(M, ST) M(4, a2, b0) ST M(5, a2, b1) M(6, a3, b0) M(7, a3, b1) "s_waitcnt lgkmcnt(0)"
+// (LDS operations retire in order: with the staging write behind the six reads, lgkmcnt(1) retires the reads and leaves the write --
+//  ~150 cycles until it is acknowledged -- in flight; the chunk's barrier statement waits for it)
+#define WS_SB_BODY(M, ST, W) M(4, a2, b0) ST M(5, a2, b1) M(6, a3, b0) M(7, a3, b1) "s_waitcnt lgkmcnt(" W ")"
 // (a parked unit is un-swapped: this lane's 8 bytes of channel block cb go to the lower 512 B of the unit, those of cb + 1 above)
-#define WS_STW "ds_write_b64 %[stg], %[sda] offset:%[soff]\n\tds_write_b64 %[stg], %[sdb] offset:%[soff]+512\n\t"
+#define WS_STW "ds_write2st64_b64 %[stg], %[sda], %[sdb] offset0:%[soff]/512 offset1:%[soff]/512+1\n\t"
   if constexpr (ZERO) {
-    if constexpr (STAGE) asm volatile(WS_SB_BODY(WS_MFMA0, WS_STW) WS_SB_OPS);
-    else asm volatile(WS_SB_BODY(WS_MFMA0, "") WS_SB_OPS);
+    if constexpr (STAGE) asm volatile(WS_SB_BODY(WS_MFMA0, WS_STW, "1") WS_SB_OPS);
+    else asm volatile(WS_SB_BODY(WS_MFMA0, "", "0") WS_SB_OPS);
   } else {
-    if constexpr (STAGE) asm volatile(WS_SB_BODY(WS_MFMA, WS_STW) WS_SB_OPS);
-    else asm volatile(WS_SB_BODY(WS_MFMA, "") WS_SB_OPS);
+    if constexpr (STAGE) asm volatile(WS_SB_BODY(WS_MFMA, WS_STW, "1") WS_SB_OPS);
+    else asm volatile(WS_SB_BODY(WS_MFMA, "", "0") WS_SB_OPS);
   }
 #undef WS_SB_BODY
 #undef WS_SB_OPS
 }
 // step 8, first part: row mb = 0, then the chunk's barrier (the loaders arrive with the next chunk landed)
 __device__ __forceinline__ void ws_x8(const u32x4& a0, const u32x4& b0, const u32x4& b1) {
-  asm volatile(WS_MFMA(0, a0, b0) WS_MFMA(1, a0, b1) "s_barrier" : : [a0] "v"(a0), [b0] "v"(b0), [b1] "v"(b1) : "memory", WS_ACC_CLOBBER);
+  asm volatile(WS_MFMA(0, a0, b0) WS_MFMA(1, a0, b1) "s_waitcnt lgkmcnt(0)\n\ts_barrier" : : [a0] "v"(a0), [b0] "v"(b0), [b1] "v"(b1) : "memory", WS_ACC_CLOBBER);
 }
 // step 8, second part: rows mb = 1..3 with the operand reads of the next chunk's step 0 (the other buffer) up front
 __device__ __forceinline__ void ws_y8(const u32x4& a1, const u32x4& a2,
@@ -195,7 +197,7 @@ template <int TILE, bool ZERO, bool BARRIER = false>
 __device__ __forceinline__ void ws_g0(const u32x4& a, const u32x4& b) {
 #define WS_G0_OPS : : [a] "v"(a), [b] "v"(b), [tl] "n"(TILE) : "memory", WS_ACC_CLOBBER
   if constexpr (ZERO) asm volatile("v_mfma_f32_32x32x16_bf16 a[16*%[tl]:16*%[tl]+15], %[a], %[b], 0" WS_G0_OPS);
-  else if constexpr (BARRIER) asm volatile("v_mfma_f32_32x32x16_bf16 a[16*%[tl]:16*%[tl]+15], %[a], %[b], a[16*%[tl]:16*%[tl]+15]\n\ts_barrier" WS_G0_OPS);
+  else if constexpr (BARRIER) asm volatile("v_mfma_f32_32x32x16_bf16 a[16*%[tl]:16*%[tl]+15], %[a], %[b], a[16*%[tl]:16*%[tl]+15]\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" WS_G0_OPS);
   else asm volatile("v_mfma_f32_32x32x16_bf16 a[16*%[tl]:16*%[tl]+15], %[a], %[b], a[16*%[tl]:16*%[tl]+15]" WS_G0_OPS);
 #undef WS_G0_OPS
 }
@@ -267,6 +269,9 @@ template <int N> using WsIC = std::integral_constant<int, N>;
 // forward of the training step; 4 / 5 / 3: the other combinations a ModelDefn can ask for.  The epilogue is bound by
 // vector-instruction issue, so what a launch does not need is compiled out -- and a variant that kept every run-time flag's
 // operands live did not fit the 128 arch VGPRs.
+#ifndef WS_ROT
+#define WS_ROT 0   // 1: the epilogue slices run one gap late (measured: no difference)
+#endif
 #ifndef WS_PRIO_COMPUTE
 #define WS_PRIO_COMPUTE 3
 #endif
@@ -605,14 +610,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int i = 0; i < 8; ++i) e_v[i] = SCALED ? fmaf(e_r[i], e_sa[i], e_bs[i]) : e_r[i] + e_bs[i];
         if constexpr (leaky) {   // max(v, 0.01 v) as bare v_max_f32 (the arithmetic of conv_bf16_epi_groups.inc's lean order), ONE statement
-          typedef float f32x2_t __attribute__((ext_vector_type(2)));
+          // (single-issue multiplies, not v_pk_mul_f32: beside MFMAs a packed fp32 instruction costs ~11 cycles more than the two
+          //  it replaces -- MI355X_MICROARCH.md "price of one filler beside MFMAs"; the file is built with -fno-slp-vectorize)
           float sv[8];
 #pragma unroll
-          for (int i = 0; i < 8; i += 2) {
-            const f32x2_t t = (f32x2_t){e_v[i], e_v[i + 1]} * (f32x2_t){LEAKY_SLOPE, LEAKY_SLOPE};
-            sv[i] = t.x;
-            sv[i + 1] = t.y;
-          }
+          for (int i = 0; i < 8; ++i) sv[i] = e_v[i] * LEAKY_SLOPE;
           asm("v_max_f32 %0, %0, %8\n\tv_max_f32 %1, %1, %9\n\tv_max_f32 %2, %2, %10\n\tv_max_f32 %3, %3, %11\n\t"
               "v_max_f32 %4, %4, %12\n\tv_max_f32 %5, %5, %13\n\tv_max_f32 %6, %6, %14\n\tv_max_f32 %7, %7, %15"
               : "+v"(e_v[0]), "+v"(e_v[1]), "+v"(e_v[2]), "+v"(e_v[3]), "+v"(e_v[4]), "+v"(e_v[5]), "+v"(e_v[6]), "+v"(e_v[7])
@@ -709,8 +711,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       constexpr bool ZERO = FIRST && TAP == 0;
       constexpr bool EPI = FIRST ? G == 0 : G == 1;   // this group's MFMAs carry the other group's epilogue
       constexpr int EG = FIRST ? 1 : 0;
+      // (slice i runs in gap i + 1: the hand-over slice of a unit -- an LDS write -- then sits behind the FIRST statement of the next
+      //  step, three MFMAs in front of that step's lgkmcnt(0), and the bias loads behind its second)
       auto slice = [&](auto m_tag) {
-        if constexpr (EPI) epi(WsIC<EG>{}, WsIC<TAP * 4 + decltype(m_tag)::value>{});
+        constexpr int I = TAP * 4 + decltype(m_tag)::value - WS_ROT;
+        if constexpr (EPI && I >= 0) epi(WsIC<EG>{}, WsIC<I>{});
       };
       if constexpr (S < 17) {
         constexpr int GN = (S + 1) / 9, T1 = (S + 1) % 9, KY1 = T1 / 3, KX1 = T1 % 3;   // the next step: group, tap
@@ -723,8 +728,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         slice(WsIC<2>{});
         ws_gw<4 * G + 3, ZERO>(Ac[1], Bc[1], An[0], An[1], Bn[0], Bn[1]);
         slice(WsIC<3>{});
-      } else {   // the chunk's last step: the barrier behind its second MFMA (every slice is through: 32 < 4 * 8)
+      } else {   // the chunk's last step: the last slice (31, in gap 32) behind its first MFMA, the barrier behind the second
         ws_g0<4, false>(Ac[0], Bc[0]);
+        slice(WsIC<0>{});
         [[maybe_unused]] const unsigned long long tx0 = WS_STAMP();
         ws_g0<5, false, true>(Ac[0], Bc[1]);
         t_x8 += WS_STAMP() - tx0;
