@@ -269,9 +269,6 @@ template <int N> using WsIC = std::integral_constant<int, N>;
 // forward of the training step; 4 / 5 / 3: the other combinations a ModelDefn can ask for.  The epilogue is bound by
 // vector-instruction issue, so what a launch does not need is compiled out -- and a variant that kept every run-time flag's
 // operands live did not fit the 128 arch VGPRs.
-#ifndef WS_ROT
-#define WS_ROT 0   // 1: the epilogue slices run one gap late (measured: no difference)
-#endif
 #ifndef WS_PRIO_COMPUTE
 #define WS_PRIO_COMPUTE 3
 #endif
@@ -583,11 +580,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   unsigned sg[2][2] = {{0u, 0u}, {0u, 0u}};   // sign bytes of the tile in the epilogue: [pixel group][dword]
   int vo_e[2] = {(int)OOB, (int)OOB};          // ... its output offsets / image (the sign map goes out when group 1 is through)
   int b_e = 0;
-  auto epi = [&](auto grp_tag, auto i_tag) {
-    constexpr int GRP = decltype(grp_tag)::value, I = decltype(i_tag)::value;
-    if constexpr (I < 32) {
-      constexpr int UL = I >> 2, S = I & 3, U = GRP * 8 + UL, Q = U >> 1, N = U & 1, MB = Q >> 1, GP = Q & 1, R = (MB * 2 + N) * 16 + 8 * GP;
-      if constexpr (S == 0) {
+  // stage 0: the channel group's bias / scale from LDS (needed by a unit with N == 0 only) | 1, 2: four accumulator reads each | 3: the
+  // arithmetic | 4: bf16 + hand-over
+  auto epi = [&](auto grp_tag, auto ul_tag, auto stg_tag) {
+    constexpr int GRP = decltype(grp_tag)::value, UL = decltype(ul_tag)::value, STG = decltype(stg_tag)::value;
+    if constexpr (UL >= 0 && UL < 8) {
+      constexpr int U = GRP * 8 + UL, Q = U >> 1, N = U & 1, MB = Q >> 1, GP = Q & 1, R = (MB * 2 + N) * 16 + 8 * GP;
+      if constexpr (STG == 0) {
         if constexpr (N == 0) {
           const float* eb = ldsf + WS_EB / 4;
           const int cl = MB * 32 + 16 * GP + 4 * half;   // local channel of group A; group B = cl + 8
@@ -599,14 +598,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             e_sa[0] = sA.x; e_sa[1] = sA.y; e_sa[2] = sA.z; e_sa[3] = sA.w; e_sa[4] = sB.x; e_sa[5] = sB.y; e_sa[6] = sB.z; e_sa[7] = sB.w;
           }
         }
+      } else if constexpr (STG == 1) {
         ws_acc_read4<R>(e_r[0], e_r[1], e_r[2], e_r[3]);
-      } else if constexpr (S == 1) {
+      } else if constexpr (STG == 2) {
         ws_acc_read4<R + 4>(e_r[4], e_r[5], e_r[6], e_r[7]);
-        if constexpr (N == 0) {
+      } else if constexpr (STG == 3) {
+        if constexpr (N == 0) {   // (the first use of the LDS loads of stage 0)
 #pragma unroll
           for (int i = 0; i < 8; ++i) e_bs[i] = SCALED ? e_ba[i] * e_sa[i] : e_ba[i];
         }
-      } else if constexpr (S == 2) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) e_v[i] = SCALED ? fmaf(e_r[i], e_sa[i], e_bs[i]) : e_r[i] + e_bs[i];
         if constexpr (leaky) {   // max(v, 0.01 v) as bare v_max_f32 (the arithmetic of conv_bf16_epi_groups.inc's lean order), ONE statement
@@ -711,11 +711,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       constexpr bool ZERO = FIRST && TAP == 0;
       constexpr bool EPI = FIRST ? G == 0 : G == 1;   // this group's MFMAs carry the other group's epilogue
       constexpr int EG = FIRST ? 1 : 0;
-      // (slice i runs in gap i + 1: the hand-over slice of a unit -- an LDS write -- then sits behind the FIRST statement of the next
-      //  step, three MFMAs in front of that step's lgkmcnt(0), and the bias loads behind its second)
+      // The epilogue of unit TAP (0..7) of the other group, one stage per gap.  hipcc's own s_waitcnt for an LDS load of the
+      // epilogue counts only ITS operations: behind this step's operand reads it would also wait for THEM (an LDS round trip
+      // with the matrix pipe running dry).  So everything that touches LDS sits behind the step's LAST statement, whose
+      // lgkmcnt(0) has just drained the queue: the first use of the bias / scale (stage 3), their loads for the next channel
+      // group, and -- one step later, behind the first statement -- the hand-over write.
       auto slice = [&](auto m_tag) {
-        constexpr int I = TAP * 4 + decltype(m_tag)::value - WS_ROT;
-        if constexpr (EPI && I >= 0) epi(WsIC<EG>{}, WsIC<I>{});
+        constexpr int M = decltype(m_tag)::value;
+        if constexpr (EPI) {
+          if constexpr (M == 0) {
+            if constexpr (TAP == 0) epi(WsIC<EG>{}, WsIC<0>{}, WsIC<0>{});
+            else epi(WsIC<EG>{}, WsIC<TAP - 1>{}, WsIC<4>{});
+          } else if constexpr (M == 1) {
+            epi(WsIC<EG>{}, WsIC<TAP>{}, WsIC<1>{});
+          } else if constexpr (M == 2) {
+            epi(WsIC<EG>{}, WsIC<TAP>{}, WsIC<2>{});
+          } else {
+            epi(WsIC<EG>{}, WsIC<TAP>{}, WsIC<3>{});
+            epi(WsIC<EG>{}, WsIC<TAP + 1>{}, WsIC<0>{});
+          }
+        }
       };
       if constexpr (S < 17) {
         constexpr int GN = (S + 1) / 9, T1 = (S + 1) % 9, KY1 = T1 / 3, KX1 = T1 % 3;   // the next step: group, tap
@@ -784,7 +799,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   // ---- the last tile: group 1's epilogue on its own, then the parked half's hand-over
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // (the last MFMAs' results are in the accumulator file)
-  ws_static_for([&](auto i_tag) { epi(WsIC<1>{}, i_tag); }, std::make_integer_sequence<int, 32>{});
+  ws_static_for([&](auto u_tag) {
+    epi(WsIC<1>{}, u_tag, WsIC<0>{}); epi(WsIC<1>{}, u_tag, WsIC<1>{}); epi(WsIC<1>{}, u_tag, WsIC<2>{}); epi(WsIC<1>{}, u_tag, WsIC<3>{});
+    epi(WsIC<1>{}, u_tag, WsIC<4>{});
+  }, std::make_integer_sequence<int, 8>{});
   store_signs();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();   // (the loaders have read the staged half of the last tile)
