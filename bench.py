@@ -9,7 +9,7 @@
 One JSON line on rank 0.  A "step" is one optimisation step over one per-GPU batch resident in HBM (weak scaling:
 per-GPU batch fixed, the images are sharded over ranks, one RCCL all-reduce of the flat gradient per step).
 `roofline` is measured live with HIP events (torch.cuda.Event on the stream the kernels are launched on) around every
-launch of the dominant kernel -- conv_bf16_kernel<4,2,8,false,10,false,0,true,false> (the stride-1 bf16 convolutions with 128 GEMM rows, ping-pong main loop) by
+launch of the dominant kernel -- conv_bf16_ws_kernel (the stride-1 bf16 convolutions with 128 output channels: persistent, wavefront-specialised) by
 default, conv_igemm_f32_kernel<4,2> under --dtype f32;
 `cpu_baseline` times the CPU oracle (oracle/yogo_oracle.py: the reference's algorithm on torch CPU ops) on a bounded
 sample of the same workload -- a reported baseline, never the target.
@@ -149,6 +149,7 @@ def inference_extras(model, dev, B: int = 256):
             def e2e():
                 format_preds_batched(model.forward_raw(x))   # decode inside the threshold + NMS kernel's loads
             ms_e2e = _timed_gpu(e2e)
+            fire = float((model(x)[:, 4] > 0.5).float().mean())   # share of the grid cells above the objectness threshold on THIS network
         dense = synthetic_dense_predictions(B, model.Sx, model.Sy, NUM_CLASSES, device=dev)
         ms_nd = _timed_gpu(lambda: format_preds_batched(dense), reps=2)
         real = synthetic_predictions(B, model.Sx, model.Sy, NUM_CLASSES, K=100, device=dev)
@@ -169,6 +170,9 @@ def inference_extras(model, dev, B: int = 256):
     out["forward_decode_fp32_images_per_s"] = round(64 / ms32 * 1e3, 1)
     out["forward_decode_bf16_images_per_s"] = round(B / ms16 * 1e3, 1)
     out["end_to_end_bf16_forward_decode_nms_images_per_s"] = round(B / ms_e2e * 1e3, 1)
+    out["end_to_end_network"] = (f"the network of this run after its training steps on synthetic labels: {fire:.3f} of the grid cells fire (objectness > 0.5) "
+                                 "-- between the 'realistic' (100 objects, ~0.008) and the 'dense' (0.93) post-process workloads below; a random-init "
+                                 "network is the dense case (13.5 ms of NMS per batch, profiles/r03_infer_kernel_stats.txt)")
     out["threshold_nms_dense_images_per_s"] = round(B / ms_nd * 1e3, 1)
     out["threshold_nms_realistic_images_per_s"] = round(B / ms_nr * 1e3, 1)
     out["fused_decode_threshold_nms_realistic_images_per_s"] = round(B / ms_fr * 1e3, 1)
@@ -394,16 +398,19 @@ def main():
             except Exception:
                 tj = {}
         if args.dtype == "bf16":
-            # dominant kernel: conv_bf16_kernel<4,2,8,false,10,false,0,true,false> = every stride-1 convolution with 128 GEMM rows (forward
+            # dominant kernel: conv_bf16_ws_kernel = every stride-1 convolution with 128 output channels (forward
             # of layers 3/5/6, data gradient of layers 5/6).  Algorithmic FLOPs per launch: 2*B*Cout*Cin*k*k*OH*OW.
             sel = [e for e in prof if e[0] in ("fwd", "dgrad") and e[2] == 34]
             ms = ms_of(sel)
             fl = sum(e[3] for e in sel)
             achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            traffic = next((v.get("hbm_bytes_per_launch") for k, v in tj.items() if k.startswith("conv_bf16_kernel<4,2,8,false,10,false,0,true")), None)
+            # (the kernel has one instantiation per epilogue: <0> for layers 5 / 6, <7> for layer 3 -- weight their launches)
+            tw = [(v.get("hbm_bytes_per_launch"), v.get("launches_fetch", 0)) for k, v in tj.items() if k.startswith("conv_bf16_ws_kernel")]
+            tw = [(a, n) for a, n in tw if a is not None and n]
+            traffic = round(sum(a * n for a, n in tw) / sum(n for _, n in tw), 1) if tw else None
             allc = [e for e in prof_all if e[0] in ("fwd", "dgrad") and e[2] in (30, 34)]
-            roof = {"bound": "mfma", "kernel": "conv_bf16_kernel<4,2,8,false,10,false,0,true,false> (stride-1 bf16 convolutions with 128 GEMM rows: "
-                                               "forward of layers 3/5/6, data gradient of layers 5/6)",
+            roof = {"bound": "mfma", "kernel": "conv_bf16_ws_kernel<0|7> (persistent wavefront-specialised stride-1 bf16 convolutions with 128 output "
+                                               "channels: forward of layers 3/5/6, data gradient of layers 5/6)",
                     "achieved": round(achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                     "calls_timed": len(sel), "avg_call_ms": round(ms / max(1, len(sel)), 4),

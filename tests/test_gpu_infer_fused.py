@@ -134,3 +134,65 @@ def test_nms_degenerate_boxes_bit_exact_vs_oracle():
             assert k == want.shape[0], (kw, b, k, want.shape[0])
             assert torch.equal(cells[b, :k], wcells), (kw, b)
             assert torch.equal(rows[b, :k].view(torch.int32), want.view(torch.int32)), (kw, b)
+
+
+def test_configs4_batch_256_inference_plan_and_results():
+    """BASELINE configs[4] at its real size: `yogo infer`'s path at batch 256 (bf16 eval forward at 772x1032 -> YOGO.forward_raw -> the
+    fused decode + threshold + NMS launch, yogo/infer.py:300-386) on 128 copies of two images.  (i) the launch log holds every
+    convolution / post-process kernel of the committed rocprofv3 summary of this path (profiles/r*_infer_kernel_stats.txt): the
+    batch-256 plan the bench measures is the plan tested here; (ii) the copies agree with each other bit for bit; (iii) the rows
+    and cells of the two images are the CPU algorithm's (oracle format_preds) on the decoded tensors of the same run -- index
+    for index, bit for bit; (iv) the decoded tensor is within the bf16 inference bound of the fp32 CPU oracle's forward."""
+    import glob
+    import os
+    import re
+
+    from yogo_amd import _hip
+    from yogo_amd.model import YOGO
+    from yogo_amd.utils import format_preds_batched
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    torch.manual_seed(7)
+    m = YOGO((772, 1032), 0.0425, 0.0555, 7, inference=True).cuda().eval()
+    for k, v in m.state_dict().items():   # trained-like running statistics keep the eval-mode activations finite (as bench.py's CPU leg)
+        if k.endswith("running_var"):
+            v.fill_(5000.0)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    x2 = O.synthetic_images(2, 772, 1032, seed=95)
+    x = x2.cuda().repeat(128, 1, 1, 1)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        _hip.launch_log(True)
+        raw = m.forward_raw(x)
+        rows, cells, counts = format_preds_batched(raw, obj_thresh=0.5, iou_thresh=0.5)
+        torch.cuda.synchronize()
+        log = _hip.read_launch_log()
+        _hip.launch_log(False)
+        dec = raw.decoded()
+    # (i) the kernel set of the committed profile of this path
+    launched = {re.sub(r"\s+", "", ln.split("|")[0]) for ln in log}
+    profs = sorted(glob.glob(os.path.join(root, "profiles", "r*_infer_kernel_stats.txt")))
+    assert profs
+    want = set()
+    for ln in open(profs[-1]):
+        if ln.startswith("# rocprofv3") and "post" in ln:
+            break   # (the second table is the post-process alone on synthetic predictions)
+        mm = re.search(r"((?:conv_bf16_kernel|conv_bf16_ws_kernel|nms_batched_kernel)<[^>]*>)", ln)
+        if mm and "nms_batched_kernel<false>" not in mm.group(1):   # (the profile also times the two-pass form)
+            want.add(re.sub(r"\s+", "", mm.group(1)))
+    assert want and not (want - launched), (sorted(want - launched), sorted(launched))
+    # (ii) replication
+    n = counts.cpu().tolist()
+    assert n[0::2] == [n[0]] * 128 and n[1::2] == [n[1]] * 128
+    for b in (2, 3, 254, 255):
+        assert torch.equal(rows[b, :n[b]].view(torch.int32), rows[b & 1, :n[b & 1]].view(torch.int32)) and torch.equal(cells[b, :n[b]], cells[b & 1, :n[b & 1]])
+    assert torch.equal(dec[254:256].view(torch.int32), dec[0:2].view(torch.int32))
+    # (iii) the CPU algorithm on the same decoded tensors
+    assert n[0] > 0 and n[1] > 0
+    for b in (0, 1):
+        ref = O.format_preds(dec[b].cpu(), obj_thresh=0.5, iou_thresh=0.5)
+        assert ref.shape[0] == n[b]
+        assert torch.equal(ref.view(torch.int32), rows[b, :n[b]].cpu().view(torch.int32))
+    # (iv) the forward itself against the fp32 oracle (the bound of test_gpu_bf16.py's inference tests: 3e-2 of the output range)
+    want_out = O.yogo_forward(x2, sd, O.arch("base_model", 7), 0.0425, 0.0555, inference=True)
+    err = (dec[0:2].cpu() - want_out).abs().max().item()
+    assert err <= 3e-2 * float(want_out.abs().max()), err

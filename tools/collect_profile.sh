@@ -4,7 +4,7 @@
 #   and the same for the inference path (tools/infer_profile.py)                           ->  gpurun_out/<tag>/infer_{e2e,post,fetch,write}
 # then `python tools/summarize_prof.py gpurun_out/<tag> <tag>` (locally) writes profiles/<tag>_*.txt and profiles/traffic.json.
 set -uo pipefail
-TAG="${1:-r03}"
+TAG="${1:-r04}"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT="gpurun_out/$TAG"
 mkdir -p "$OUT"

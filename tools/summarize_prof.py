@@ -51,12 +51,13 @@ for k, v in traffic.items():
     key = k.replace("void ", "").replace(", ", ",")
     out[key] = v
 json.dump(out, open("profiles/traffic.json", "w"), indent=1, sort_keys=True)
-top = sorted(out.items(), key=lambda kv: -kv[1].get("hbm_bytes_per_launch", 0))[:12]
+# every kernel that moves more than 1 MB per launch (round 3's table was cut at 12 rows and lost the dominant kernel)
+top = [kv for kv in sorted(out.items(), key=lambda kv: -kv[1].get("hbm_bytes_per_launch", 0)) if kv[1].get("hbm_bytes_per_launch", 0) > 1e6]
 with open(f"profiles/{tag}_hbm_traffic.txt", "w") as f:
     f.write(f"# rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-inference  ({tag})\n")
     f.write("# bytes per launch; FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md HBM section)\n")
     for k, v in top:
-        f.write(f"{k:60s} fetch {v.get('fetch_bytes_per_launch',0)/1e6:10.1f} MB  write {v.get('write_bytes_per_launch',0)/1e6:10.1f} MB  n={v.get('launches_fetch')}\n")
+        f.write(f"{k:70s} fetch {v.get('fetch_bytes_per_launch',0)/1e6:10.1f} MB  write {v.get('write_bytes_per_launch',0)/1e6:10.1f} MB  n={v.get('launches_fetch')}\n")
 # ---- matrix-core utilisation ------------------------------------------------------------------------------------------
 mf = one("mfma/*counter_collection.csv") or one("mfma/*/*counter_collection.csv")
 if mf:
@@ -179,7 +180,7 @@ if itraffic:
         f.write("# bytes per launch at batch 256; FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md HBM section); algorithmic: 154 MB read of the\n")
         f.write("# [256, 12, 97, 129] fp32 head output per pass (+ 154 MB written by the separate decode)\n")
         for k, v in sorted(itraffic.items(), key=lambda kv: -(kv[1].get("fetch", 0) + kv[1].get("write", 0)))[:10]:
-            f.write(f"{k:60s} fetch {v.get('fetch',0)/1e6:10.1f} MB  write {v.get('write',0)/1e6:10.1f} MB  n={v.get('n')}\n")
+            f.write(f"{k:70s} fetch {v.get('fetch',0)/1e6:10.1f} MB  write {v.get('write',0)/1e6:10.1f} MB  n={v.get('n')}\n")
     print(open(f"profiles/{tag}_infer_hbm_traffic.txt").read())
     json.dump(itraffic, open("profiles/traffic_infer.json", "w"), indent=1, sort_keys=True)
 print(open(f"profiles/{tag}_kernel_stats.txt").read()[:3200])
