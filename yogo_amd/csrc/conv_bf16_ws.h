@@ -17,7 +17,9 @@
 #define WS_STG (WS_I0 + 3 * WS_IB)    // output staging: [2 regions][4 wavefronts][4 units][64 lanes] x 16 B = 32 KB
 #define WS_EB (WS_STG + 32768)        // [128] fp32 bias
 #define WS_ES (WS_EB + 512)           // [2][128] fp32 channel scale (by tile parity)
-#define WS_LDS_BYTES (WS_ES + 1024)   // 157 184
+#define WS_MB (WS_ES + 1024)           // mailbox loader -> compute: [4 wavefronts][64 lanes] x 16 B (operand row addresses, output offsets of the NEXT tile)
+#define WS_MBS (WS_MB + 4096)         // ... and its scalars: {there is a next tile, staged row pitch in bytes, image}
+#define WS_LDS_BYTES (WS_MBS + 16)    // 161 296
 
 struct ConvWsParams {
   const void* in;     // bf16 NCHW8c [B][Kb][IH][IW] units

@@ -509,6 +509,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             rs_out_n = ws_rsrc(reinterpret_cast<unsigned char*>(p.out) + (size_t)Tn.b * obytes, obytes);
           }
         }
+        // the NEXT tile's geometry for the partner compute wavefront (same lanes, same pixels): written in period 1 -- the compute
+        // wavefront read the previous message at its tile seam, in front of this tile's period 0 -- and read at the next seam
+        if (c == 1) {
+          unsigned char* mb = reinterpret_cast<unsigned char*>(smem4);
+          *reinterpret_cast<u32x4*>(mb + WS_MB + (tw * 64 + lane) * 16) = u32x4{pbr_[0], pbr_[1], (unsigned)vo_n[0], (unsigned)vo_n[1]};
+          if (tw == 0 && lane == 0) *reinterpret_cast<u32x4*>(mb + WS_MBS) = u32x4{has_next ? 1u : 0u, lw16_, (unsigned)Tn.b, 0u};
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (written before this period's barrier; read two or more barriers later)
+        }
         [[maybe_unused]] const unsigned long long tw1 = WS_STAMP();
         // vector-memory operations retire in order: everything but this period's input request (4) and stores (4) has to be done
         if (dr && req) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -788,11 +796,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     [[maybe_unused]] const unsigned long long ts0 = WS_STAMP();
     t_gml += ts0 - tl0;
     t_chunks += ts0 - tc0;
-    unsigned kn = k_ord + 1;
-    const bool has_next = find_tile(kn, T);
-    k_ord = kn;
+    // the next tile: looked up and decoded by the partner loader wavefront (mailbox, written in period 1 of this tile)
+    const u32x4 mbs = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(smem4) + WS_MBS);
+    const u32x4 mbl = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(smem4) + WS_MB + (tw * 64 + lane) * 16);
+    const bool has_next = __builtin_amdgcn_readfirstlane((int)mbs.x) != 0;
+    ++k_ord;
     if (!has_next) break;
-    decode_pix(T, pbr, vo, lw16);
+    lw16 = (unsigned)__builtin_amdgcn_readfirstlane((int)mbs.y);
+    T.b = __builtin_amdgcn_readfirstlane((int)mbs.z);
+    pbr[0] = mbl.x; pbr[1] = mbl.y; vo[0] = (int)mbl.z; vo[1] = (int)mbl.w;
     tpar ^= 1;
     ws_prefetch4(A1[0], A1[1], B1[0], B1[1], a_b0, pbr[0] + ibo, pbr[1] + ibo);   // (the last period's barrier: chunk 0 has landed)
     t_seam += WS_STAMP() - ts0;
