@@ -22,7 +22,7 @@ if __name__ == "__main__":
     dbgs = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0, 1, 2, 3, 4]
     lib = H.lib()
     lib.yogo_diag_conv_bf16.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t]
-    st = torch.zeros(256 * 16, dtype=torch.int64, device="cuda")
+    st = torch.zeros(512 * 16, dtype=torch.int64, device="cuda")
     for w in which:
         for dbg in dbgs:
             lib.yogo_diag_conv_bf16(dbg, 0, None, 0)
@@ -31,7 +31,8 @@ if __name__ == "__main__":
             lib.yogo_diag_conv_bf16(dbg, 0, st.data_ptr(), st.numel() * 8)
             BC.bench(w[:-1], B, *BC.LAYERS[w[:-1]], w[-1], reps=1)
             torch.cuda.synchronize()
-            h = st.view(256, 16).cpu().double()
+            hh = st.view(512, 16).cpu().double()
+            h, lp = hh[:256], hh[256:]
             h = h[h[:, 1] != 0]
             if h.numel() == 0:
                 print("  (no stamps)")
@@ -40,4 +41,5 @@ if __name__ == "__main__":
             nt = h[:, 5]
             print(f"  {w} dbg={dbg}: wgs={h.shape[0]} tiles/wg={nt.mean():.1f} life={life.mean():.0f} (max {life.max():.0f}) | compute per tile: life {(life / nt).mean():.0f} "
                   f"chunks {(h[:, 2] / nt).mean():.0f} (first {(h[:, 10] / nt).mean():.0f}, c1 {(h[:, 12] / nt).mean():.0f}, c2 {(h[:, 13] / nt).mean():.0f}, last {(h[:, 11] / nt).mean():.0f}) seam {(h[:, 3] / nt).mean():.0f} x8 {(h[:, 6] / nt).mean():.0f} | loader per tile: work {(h[:, 8] / nt).mean():.0f} "
-                  f"wait+barrier {(h[:, 9] / nt).mean():.0f}")
+                  f"wait+barrier {(h[:, 9] / nt).mean():.0f}; loader work in periods 0..3: " + " ".join(f"{(lp[:h.shape[0], k] / nt).mean():.0f}" for k in range(4))
+                  + "; their vmcnt waits: " + " ".join(f"{(lp[:h.shape[0], 4 + k] / nt).mean():.0f}" for k in range(4)))

@@ -26,7 +26,8 @@ if [[ "${1:-}" == "variant" ]]; then
   exit 0
 fi
 mkdir -p "$OUT" "$OBJ"
-COMMON=(-O3 --offload-arch=gfx950 -fPIC -std=c++17 -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -I"$HERE" -I"$HERE/../../include" "${DEFS[@]}")
+# (EXTRA_DEFS="-DNAME=VALUE ...": extra macros for an experiment, e.g. a diagnostic build of an ablation)
+COMMON=(-O3 --offload-arch=gfx950 -fPIC -std=c++17 -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -I"$HERE" -I"$HERE/../../include" "${DEFS[@]}" ${EXTRA_DEFS:-})
 pids=()
 for f in "$HERE"/*.hip; do
   base="$(basename "$f" .hip)"

@@ -1404,8 +1404,8 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
     q.B = B; q.Kb = bf_kb_of(K); q.IH = IH; q.IW = IW; q.act = act;
 #ifdef YOGO_DIAG
     q.dbg = g_diag_dbg;
-    q.stamps = (g_diag_stamps != nullptr && g_diag_stamps_bytes >= 256 * 128) ? g_diag_stamps : nullptr;
-    if (q.stamps) (void)hipMemsetAsync(g_diag_stamps, 0, 256 * 128, stream);
+    q.stamps = (g_diag_stamps != nullptr && g_diag_stamps_bytes >= 512 * 128) ? g_diag_stamps : nullptr;
+    if (q.stamps) (void)hipMemsetAsync(g_diag_stamps, 0, 512 * 128, stream);
 #endif
     if (conv_bf16_ws_plan(&q)) return launch_conv_bf16_ws(q, stream);
   }

@@ -238,6 +238,10 @@ __device__ __forceinline__ void ws_prefetch4(u32x4& an0, u32x4& an1, u32x4& bn0,
 // four consecutive accumulator registers -> VGPRs (see ws_acc_read8: the statement clobbers every accumulator register)
 template <int R>
 __device__ __forceinline__ void ws_acc_read4(float& r0, float& r1, float& r2, float& r3) {
+#if defined(WS_ABL) && (WS_ABL & 64)
+  asm volatile("v_mov_b32 %0, 1.0\n\tv_mov_b32 %1, 1.0\n\tv_mov_b32 %2, 1.0\n\tv_mov_b32 %3, 1.0" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3) : "n"(R) : WS_ACC_CLOBBER);
+  return;
+#endif
   asm volatile("v_accvgpr_read_b32 %0, a[%4]\n\tv_accvgpr_read_b32 %1, a[%4+1]\n\tv_accvgpr_read_b32 %2, a[%4+2]\n\tv_accvgpr_read_b32 %3, a[%4+3]"
                : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)
                : "n"(R)
@@ -252,6 +256,13 @@ __device__ __forceinline__ void ws_prefetch(u32x4& an0, u32x4& an1, u32x4& an2, 
                : "memory");
 }
 
+// compile-time ablations (build.sh variant TAG conv_bf16_ws -DWS_ABL=bits; timings only, the results are wrong): 8 = the loaders do
+// not decode the next tile (its input then comes out of L2: the clock rises), 16 = no epilogue in the gaps of the
+// group-major chunks, 32 = the slot decode twice, 64 = plain moves instead of accumulator reads
+#ifndef WS_ABL
+#define WS_ABL 0
+#endif
+#define WS_ABLATE(BIT) ((WS_ABL & (BIT)) != 0)
 #ifdef YOGO_DIAG
 #define WS_DBG(BIT) (p.dbg & (BIT))
 #define WS_STAMP() __builtin_amdgcn_s_memtime()
@@ -457,7 +468,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     req_w(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // (#1) chunks 0 (and the input of chunk 1) of the first tile have landed
-    [[maybe_unused]] unsigned long long t_wait = 0, t_work = 0;
+    [[maybe_unused]] unsigned long long t_wait = 0, t_work = 0, t_wp[4] = {0, 0, 0, 0}, t_wv[4] = {0, 0, 0, 0};
     bool has_next = true;
     int ib2 = 2;   // ring slot of the next input request (the chunk two periods ahead)
     // the NEXT tile is looked up and decoded in period 0, behind that period's requests and stores: its ~1.5 k cycles of scalar
@@ -502,8 +513,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           unsigned kn = k_ord + 1;
           has_next = find_tile(kn, Tn);
           k_ord = kn;
-          if (has_next) {
+          if (has_next && WS_ABLATE(8)) {
+#pragma unroll
+            for (int i = 0; i < WS_NI; ++i) voff_n[i] = voff[i];
+          } else if (has_next) {
             decode_slots(Tn, voff_n);
+            if constexpr (WS_ABLATE(32)) {
+              TileS T2 = Tn;
+              asm volatile("" : "+s"(T2.p0), "+s"(T2.p1), "+s"(T2.bw));
+              int v2[WS_NI];
+              decode_slots(T2, v2);
+#pragma unroll
+              for (int i = 0; i < WS_NI; ++i) asm volatile("" : : "v"(v2[i]));
+            }
             decode_pix(Tn, pbr_, vo_n, lw16_);
             rs_in_n = ws_rsrc(reinterpret_cast<const unsigned char*>(p.in) + (size_t)Tn.b * ibytes, ibytes);
             rs_out_n = ws_rsrc(reinterpret_cast<unsigned char*>(p.out) + (size_t)Tn.b * obytes, obytes);
@@ -522,9 +544,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (dr && req) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (dr || req) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        [[maybe_unused]] const unsigned long long tw2 = WS_STAMP();
         __builtin_amdgcn_s_barrier();
         t_work += tw1 - tw0;
         t_wait += WS_STAMP() - tw1;
+#ifdef YOGO_DIAG
+        if (c < 4) { t_wp[c] += tw1 - tw0; t_wv[c] += tw2 - tw1; }
+#endif
       }
       // the tile that was computed becomes the one whose output is handed over
 #pragma unroll
@@ -550,6 +576,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (p.stamps && ttid == 0) {
       unsigned long long* d = p.stamps + (size_t)blockIdx.x * 16;
       d[8] = t_work; d[9] = t_wait;
+      unsigned long long* e = p.stamps + (size_t)(gridDim.x + blockIdx.x) * 16;   // second table: the loaders' work / memory waits in periods 0..3
+      e[0] = t_wp[0]; e[1] = t_wp[1]; e[2] = t_wp[2]; e[3] = t_wp[3];
+      e[4] = t_wv[0]; e[5] = t_wv[1]; e[6] = t_wv[2]; e[7] = t_wv[3];
     }
 #endif
     return;
@@ -726,6 +755,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       // group, and -- one step later, behind the first statement -- the hand-over write.
       auto slice = [&](auto m_tag) {
         constexpr int M = decltype(m_tag)::value;
+        if constexpr (WS_ABLATE(16)) return;
         if constexpr (EPI) {
           if constexpr (M == 0) {
             if constexpr (TAP == 0) epi(WsIC<EG>{}, WsIC<0>{}, WsIC<0>{});
