@@ -250,6 +250,24 @@ int yogo_conv_first_bn_wgrad_finalize_xg(const float* sums, const float* gram, c
                                          const float* gamma, const float* w_oihw, float* dw, float* dgamma, float* dbeta, int B,
                                          int Cin, int Cout, int IH, int IW, int stride, int training, float clip,
                                          yogo_stream_t stream);
+/* The same pair of sweeps WITHOUT the layer's conv output z in memory (ABI 5).  What the backward pass needs of z is (a) the sign of
+ * the BatchNorm output for the LeakyReLU derivative and (b) sum g * xhat, which is linear in z = W . patch and follows from the
+ * weight-gradient sums themselves.  yogo_conv_first_mfma_signs = yogo_conv_first_mfma that also writes (a) as a bit map, signs =
+ * [B][OH*OW][2] bytes (byte h of a pixel: bit i = channel 4h + i, bit 4 + i = channel 8 + 4h + i; z may then be NULL);
+ * yogo_conv_first_bn_wgrad_bf16_xs reads it in place of z (_xs_supported: uint8 one-channel image, stride 2, even sizes, Cout 8 or
+ * 16, ACT_NONE / ACT_LEAKY, no conv bias); yogo_conv_first_bn_wgrad_finalize_xs derives (b); w_oihw there = the bf16-rounded weights
+ * the forward pass multiplied with.  Replaces the same reference lines as the _xg pair (model_defns.py:34-35 under autograd). */
+int yogo_conv_first_mfma_signs(const void* in, const float* w, const float* bias, void* z, void* y, void* signs, const float* mean,
+                               const float* invstd, const float* gamma, const float* beta, int B, int Cout, int IH, int IW, int act,
+                               yogo_stream_t stream);
+int yogo_conv_first_bn_wgrad_xs_supported(int in_dtype, int Cin, int Cout, int IH, int IW, int stride, int act);
+int yogo_conv_first_bn_wgrad_bf16_xs(const void* in, int in_dtype, const void* g, const void* signs, const float* mean,
+                                     const float* invstd, const float* gamma, const float* beta, float* part, int B, int Cin,
+                                     int Cout, int IH, int IW, int stride, int act, yogo_stream_t stream);
+int yogo_conv_first_bn_wgrad_finalize_xs(const float* sums, const float* gram, const float* mean, const float* invstd,
+                                         const float* gamma, const float* w_oihw, float* dw, float* dgamma, float* dbeta, int B,
+                                         int Cin, int Cout, int IH, int IW, int stride, int training, float clip,
+                                         yogo_stream_t stream);
 
 /* ---- data-parallel exchange over RCCL / xGMI (replaces torch DDP: init_process_group("nccl") + DistributedDataParallel,
  * yogo/train.py:155-159; gradient all-reduce overlapped with backward, buffers broadcast from rank 0).  One process per GPU.

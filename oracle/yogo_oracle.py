@@ -711,6 +711,8 @@ def bf16_block_forward(i: int, x_in: torch.Tensor, sd: Dict[str, torch.Tensor], 
         sh = torch.addcmul(beta, -mean, sc)
         y = _rb(_act(z * sc[None, :, None, None] + sh[None, :, None, None], act))
         S.update(z=z, mean=mean, invstd=invstd, gamma=gamma, beta=beta, y=y, mean64=mean64, var64=var64, count=cnt)
+        if i == 0:
+            S["a"] = a   # the unrounded convolution (layer 0 of the engine may keep no z: bf16_block_backward(l0_no_z=True))
     elif i == n - 1:
         S.update(y=a)   # fp32 head
     else:
@@ -738,8 +740,36 @@ def bf16_head_gradient(raw: torch.Tensor, sd: Dict[str, torch.Tensor], label: to
     return loss.detach(), comps, _rb(g), g
 
 
+# Layer 0 of the engine keeps no conv output when its fused backward sweep can do without (engine._L0_NO_Z: one-channel uint8 image
+# on the matrix cores, 8 or 16 output channels, BatchNorm, no conv bias, no activation or LeakyReLU): bf16_train_step follows.
+L0_NO_Z = True
+
+
+def l0_keeps_no_z(spec: list, l0_mfma: bool) -> bool:
+    co, k, s, hb, hbn, act, dp = spec[0]
+    return bool(L0_NO_Z and l0_mfma and hbn and not hb and act in (None, "leaky") and co in (8, 16))
+
+
+def l0_sign_map(S: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """what yogo_conv_first_mfma_signs writes beside y: uint8 [B][OH*OW*2]; byte h of a pixel: bit i = (BatchNorm output of channel
+    4h + i > 0), bit 4 + i = (... of channel 8 + 4h + i > 0); the BatchNorm output = z * sc + sh of the ROUNDED z (what y is made of)."""
+    z, mean, invstd, gamma, beta = S["z"], S["mean"], S["invstd"], S["gamma"], S["beta"]
+    sc = invstd * gamma
+    sh = torch.addcmul(beta, -mean, sc)
+    pos = (z * sc[None, :, None, None] + sh[None, :, None, None]) > 0
+    B, co, OH, OW = pos.shape
+    full = torch.zeros(B, 16, OH * OW, dtype=torch.int32)
+    full[:, :co] = pos.reshape(B, co, -1).to(torch.int32)
+    out = torch.zeros(B, OH * OW, 2, dtype=torch.int32)
+    for h in range(2):
+        for i in range(4):
+            out[:, :, h] |= full[:, 4 * h + i] << i
+            out[:, :, h] |= full[:, 8 + 4 * h + i] << (4 + i)
+    return out.to(torch.uint8).reshape(B, OH * OW * 2)
+
+
 def bf16_block_backward(i: int, g: torch.Tensor, S: Dict[str, torch.Tensor], Sp: Optional[Dict[str, torch.Tensor]], spec: list,
-                        l0_mfma: bool, dz_given: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+                        l0_mfma: bool, dz_given: Optional[torch.Tensor] = None, l0_no_z: bool = False) -> Dict[str, torch.Tensor]:
     """block i of the bf16-storage backward from ``g`` = gradient w.r.t. the block's output (bf16-valued): returns a dict with
     ``dW``, optionally ``db``, ``dgamma``, ``dbeta``, ``dz`` (the bf16 BatchNorm-backward output) and ``dx`` (the bf16 gradient
     w.r.t. the previous block's output, with that block's activation derivative and dropout mask applied when it has no
@@ -754,7 +784,16 @@ def bf16_block_backward(i: int, g: torch.Tensor, S: Dict[str, torch.Tensor], Sp:
         # LeakyReLU activation): dz never exists; dW = c1 (A1 - S1/N P - S2/N A2)
         z, mean, invstd, gamma, beta = S["z"], S["mean"], S["invstd"], S["gamma"], S["beta"]
         xh = (z - mean[None, :, None, None]) * invstd[None, :, None, None]
-        yb = torch.addcmul(beta[None, :, None, None], gamma[None, :, None, None], xh)
+        if l0_no_z:
+            # the engine kept the SIGN MAP of the BatchNorm output instead of z (conv_first_mfma_kernel: r = z * sc + sh of the rounded
+            # z, the value y is made of) and derives sum gb * xhat from the weight-gradient sums, i.e. from the UNROUNDED convolution
+            # (conv_first_bn_wgrad_pk_kernel<true> + finalize, derive_s2): xhat of `a`, not of bf16(a)
+            sc = invstd * gamma
+            sh = torch.addcmul(beta, -mean, sc)
+            yb = z * sc[None, :, None, None] + sh[None, :, None, None]
+            xh = (S["a"].to(f64) - mean.to(f64)[None, :, None, None]) * invstd.to(f64)[None, :, None, None]
+        else:
+            yb = torch.addcmul(beta[None, :, None, None], gamma[None, :, None, None], xh)
         gb = g * _act_bwd_factor(yb, act)
         S1 = gb.to(f64).sum(dim=(0, 2, 3))
         S2 = (gb.to(f64) * xh.to(f64)).sum(dim=(0, 2, 3))
@@ -854,7 +893,7 @@ def bf16_train_step(
         pre = conv_prefix(spec, i)
         if taps is not None:
             taps[f"g{i}"] = g
-        r = bf16_block_backward(i, g, saved[i], saved[i - 1] if i > 0 else None, spec, l0_mfma)
+        r = bf16_block_backward(i, g, saved[i], saved[i - 1] if i > 0 else None, spec, l0_mfma, l0_no_z=(i == 0 and l0_keeps_no_z(spec, l0_mfma)))
         grads[pre + "weight"] = fin(r["dW"])
         if "db" in r:
             grads[pre + "bias"] = fin(r["db"])

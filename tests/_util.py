@@ -142,8 +142,17 @@ def teacher_forced_bf16_step_check(O, tr, model, x, lab, spec, sd0, what):
         mask = Sv.mask.cpu() if Sv.mask is not None else None
         S = O.bf16_block_forward(i, x_in, sd0, spec, l0_mfma, mask)
         if hbn:
-            hz = from8c_cpu(Sv.z, co)
-            assert_bf16_tensor_matches(hz, S["z"], f"L{i} z = bf16(conv)")
+            if Sv.z is None:   # layer 0 keeps the sign map of its BatchNorm output instead of z (engine._L0_NO_Z): its z is an EXACT fp32
+                assert i == 0 and Sv.signs0 is not None   # sum (bf16 weights x 8-bit pixels), so the oracle's bf16(conv) IS the kernel's
+                hz = S["z"]
+                Ss = O.bf16_block_forward(i, x_in, sd0, spec, l0_mfma, mask, z_given=hz, stats_given=(Sv.mean.cpu(), Sv.invstd.cpu()))
+                want = O.l0_sign_map(Ss)
+                nflip = int(((Sv.signs0.cpu().view(want.shape) ^ want).to(torch.int32).bitwise_and(0xFF) != 0).sum())
+                print(f"   L0 sign map: {nflip} of {want.numel()} bytes differ from sign(z * sc + sh)")
+                assert nflip <= 1e-5 * want.numel() + 1, ("L0 sign map", nflip)   # (an fma against a multiply and an add, next to zero)
+            else:
+                hz = from8c_cpu(Sv.z, co)
+                assert_bf16_tensor_matches(hz, S["z"], f"L{i} z = bf16(conv)")
             # statistics: of the stored z (layer 0 on the direct / matrix-core kernels: of the unrounded convolution)
             St = S if i == 0 else O.bf16_block_forward(i, x_in, sd0, spec, l0_mfma, mask, z_given=hz)
             torch.testing.assert_close(Sv.mean.cpu(), St["mean"], rtol=1e-5, atol=1e-5 * float(St["mean"].abs().max()) + 1e-7)
@@ -189,7 +198,8 @@ def teacher_forced_bf16_step_check(O, tr, model, x, lab, spec, sd0, what):
         g_in = from8c_cpu(tc[("g", i)], co)
         hdz = from8c_cpu(tc[("dz", i)], co) if ("dz", i) in tc else None
         # (the weight / bias / data gradients of a BatchNorm block are formed from the step's OWN dz, which is checked first)
-        r = O.bf16_block_backward(i, g_in, rec[i], rec[i - 1] if i > 0 else None, spec, l0_mfma, dz_given=hdz)
+        r = O.bf16_block_backward(i, g_in, rec[i], rec[i - 1] if i > 0 else None, spec, l0_mfma, dz_given=hdz,
+                                  l0_no_z=(i == 0 and saved[0].z is None and getattr(saved[0], "signs0", None) is not None))
         pre = O.conv_prefix(spec, i)
         if "dz" in r:
             assert hdz is not None, (what, i, "the step recorded no BatchNorm-backward output")

@@ -115,8 +115,10 @@ def _mock_step(name, H, W, C=5, B=2):
     saved = []
     for i, S in enumerate(taps["saved"]):
         last = i == n - 1
+        no_z = i == 0 and O.l0_keeps_no_z(spec, O.l0_on_matrix_cores(spec, x))   # (the engine then keeps the sign map instead of z)
         saved.append(_Obj(x_in=x if i == 0 else _to8c(S["x"]), y=S["y"] if last else _to8c(S["y"]),
-                          z=_to8c(S["z"]) if S["bn"] else None, mean=S.get("mean"), invstd=S.get("invstd"), mask=None,
+                          z=_to8c(S["z"]) if S["bn"] and not no_z else None, signs0=O.l0_sign_map(S) if no_z else None,
+                          mean=S.get("mean"), invstd=S.get("invstd"), mask=None,
                           pre=_to8c(S["pre"]) if S.get("pre") is not None else None))
     trace = {"saved": saved, "raw": taps[f"y{n - 1}"]}
     for i in range(n):

@@ -411,6 +411,55 @@ def test_fused_layer0_backward_matches_separate_passes():
             assert torch.equal(a, b_), n
 
 
+def test_layer0_backward_without_conv_output_matches_with_it():
+    """engine._L0_NO_Z: the forward pass keeps the SIGN MAP of layer 0's BatchNorm output instead of its conv output z (1/16 of the
+    bytes, yogo_conv_first_mfma_signs) and the fused backward sweep takes the LeakyReLU derivative from it and derives sum g * xhat
+    from its own weight-gradient sums (yogo_conv_first_bn_wgrad_bf16_xs / _finalize_xs).  Against the sweep that reads z: y and every
+    gradient behind layer 0 are bit-identical; layer 0's own gradients differ by what z's bf16 rounding (2^-9 of |z|, and |z| is a few
+    sigma) puts into sum g * xhat on the path that reads z -- measured 1e-3 .. 4e-3 (conv weight) and 3e-3 .. 1e-2
+    (BatchNorm weight; the larger on the 65 x 35 map) of the tensor's max; stated: 3e-2.  (The path without z is the one the
+    teacher-forced checks pin against the oracle, at 5e-4: tests/_util.py, oracle.bf16_block_backward(l0_no_z=True).)"""
+    from yogo_amd import engine as E
+    from yogo_amd.model import YOGO
+    from yogo_amd.train import HipTrainer
+    from yogo_amd.yogo_loss import YOGOLoss
+
+    for Himg, Wimg, B in ((96, 128, 4), (130, 70, 3)):
+        x = O.synthetic_images(B, Himg, Wimg, seed=43).cuda()
+        out = {}
+        old = E._L0_NO_Z
+        try:
+            for no_z in (False, True):
+                E._L0_NO_Z = no_z
+                torch.manual_seed(6)
+                model = YOGO((Himg, Wimg), 0.0425, 0.0555, 7, clip_value=1e9).cuda()
+                model.train()
+                lab = O.synthetic_labels(B, model.Sx, model.Sy, K=6, num_classes=7, seed=44).cuda()
+                tr = HipTrainer(model, YOGOLoss().cuda(), total_steps=5, half=True)
+                tr.trace = {}
+                tr.step(x, lab)
+                S0 = tr.trace["saved"][0]
+                assert (S0.z is None) == no_z and (S0.signs0 is not None) == no_z
+                names = [n for n, _ in model.named_parameters()]
+                sizes = [p.numel() for p in model.parameters()]
+                out[no_z] = (tr.flat.grad.clone().cpu(), S0.y.clone().cpu(), names, sizes)
+        finally:
+            E._L0_NO_Z = old
+        g0, y0, names, sizes = out[False]
+        g1, y1 = out[True][:2]
+        assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+        off = 0
+        for n, sz in zip(names, sizes):
+            a, b_ = g1[off:off + sz], g0[off:off + sz]
+            off += sz
+            if n.startswith("model.0."):
+                d = float((a - b_).abs().max())
+                print(f"   {n:20s} max|d|/max|g| {d / float(b_.abs().max()):.2e}")
+                assert d < 3e-2 * float(b_.abs().max()) + 1e-7, (n, d, float(b_.abs().max()))
+            else:
+                assert torch.equal(a, b_), n
+
+
 def test_bf16_dropout_masks():
     """Dropout2d in the bf16 training path: all layers' channel masks come from one rand call; every layer keeps its own p,
     the survivors are scaled by 1 / (1 - p), dropped channels are zero in the block output."""

@@ -359,6 +359,7 @@ struct ConvFirstBnWgradParams {
   const void* in;
   const cf_u32x4* g;   // gradient w.r.t. the block output, bf16 NCHW8c [B][Mb][OH][OW]
   const cf_u32x4* z;   // saved conv output (pre-BatchNorm), same layout
+  const unsigned short* signs;   // ... or (conv_first_bn_wgrad_pk_kernel<true>) the sign map of the BatchNorm output, yogo_conv_first_mfma_signs
   const float *mean, *invstd, *gamma, *beta;
   float* part;
   int B, Cin, Cout, Mb, IH, IW, OH, OW, stride, act;
@@ -570,7 +571,13 @@ __global__ __launch_bounds__(CF_THREADS, GRAM ? 3 : 2) void conv_first_bn_wgrad_
 // channels -- (z, g) unpacked from the bf16 pairs of the unit, xh, the activation factor, gb, S1, S2 -- and
 // A1[c..c+1][j] += gb[c..c+1] * patch_j is one packed FMA with the patch value broadcast.  Same arithmetic per element, same
 // summation order, so the sums are bit-identical to conv_first_bn_wgrad_kernel's.
+//
+// SIGNS = true: no z at all.  z enters the sweep twice: through the sign of the BatchNorm output (LeakyReLU derivative) -- the forward
+// pass wrote that as one bit per value -- and through S2 = sum gb * xh, which is LINEAR in z = W . patch:
+//   sum gb * z = sum_j W[c][j] * A1[c][j]   =>   S2 = invstd * (W[c] . A1[c] - mean * S1)      (the finalize kernel, derive_s2)
+// so the layer's conv output is neither written by the forward pass nor read here (0.82 GB each way at 128 x 772 x 1032).
 typedef float cf_f32x2 __attribute__((ext_vector_type(2)));
+template <bool SIGNS>
 __global__ __launch_bounds__(CF_THREADS, 3) void conv_first_bn_wgrad_pk_kernel(const ConvFirstBnWgradParams p) {
   constexpr int NJ = 9, PER = 2 * NJ + 2, COC = 8, NP = COC / 2;
   __shared__ float red[4][COC * PER];
@@ -615,23 +622,39 @@ __global__ __launch_bounds__(CF_THREADS, 3) void conv_first_bn_wgrad_pk_kernel(c
       }
       const size_t u = ((size_t)b * p.Mb + (co0 >> 3)) * npix + pc;
       cf_u32x4 gw = p.g[u];
-      const cf_u32x4 zw = p.z[u];
+      cf_u32x4 zw = {0u, 0u, 0u, 0u};
+      unsigned sgn = 0;
+      if constexpr (SIGNS) {
+        // the pixel's 16 bits: channel c < 4 or >= 12 at bit c, 4..7 at c + 4, 8..11 at c - 4 (two bytes in the forward kernel's lane order)
+        if (leaky) sgn = (unsigned)p.signs[(size_t)b * npix + pc] >> (co0 ? 4 : 0);
+      } else {
+        zw = p.z[u];
+      }
       if (!ok) gw = cf_u32x4{0u, 0u, 0u, 0u};   // a pixel beyond the tail contributes gb = 0 to every sum
       const unsigned gws[4] = {gw.x, gw.y, gw.z, gw.w}, zws[4] = {zw.x, zw.y, zw.z, zw.w};
 #pragma unroll
       for (int q = 0; q < NP; ++q) {
         // the two bf16 of a dword, widened: low half << 16, high half masked
         const cf_f32x2 gv = {__builtin_bit_cast(float, gws[q] << 16), __builtin_bit_cast(float, gws[q] & 0xFFFF0000u)};
-        const cf_f32x2 zv = {__builtin_bit_cast(float, zws[q] << 16), __builtin_bit_cast(float, zws[q] & 0xFFFF0000u)};
-        const cf_f32x2 xh = (zv - mu[q]) * is[q];
         cf_f32x2 gb = gv;
-        if (leaky) {
-          const cf_f32x2 yb = __builtin_elementwise_fma(ga[q], xh, be[q]);
-          const cf_f32x2 f = {yb.x > 0.f ? 1.f : LEAKY_SLOPE, yb.y > 0.f ? 1.f : LEAKY_SLOPE};
-          gb = gv * f;
+        if constexpr (SIGNS) {
+          if (leaky) {
+            const int pos = q < 2 ? 2 * q : 8 + 2 * (q - 2);   // (a constant of the unrolled loop)
+            const cf_f32x2 f = {(sgn >> pos) & 1u ? 1.f : LEAKY_SLOPE, (sgn >> (pos + 1)) & 1u ? 1.f : LEAKY_SLOPE};
+            gb = gv * f;
+          }
+          s1[q] += gb;
+        } else {
+          const cf_f32x2 zv = {__builtin_bit_cast(float, zws[q] << 16), __builtin_bit_cast(float, zws[q] & 0xFFFF0000u)};
+          const cf_f32x2 xh = (zv - mu[q]) * is[q];
+          if (leaky) {
+            const cf_f32x2 yb = __builtin_elementwise_fma(ga[q], xh, be[q]);
+            const cf_f32x2 f = {yb.x > 0.f ? 1.f : LEAKY_SLOPE, yb.y > 0.f ? 1.f : LEAKY_SLOPE};
+            gb = gv * f;
+          }
+          s1[q] += gb;
+          s2[q] = __builtin_elementwise_fma(gb, xh, s2[q]);
         }
-        s1[q] += gb;
-        s2[q] = __builtin_elementwise_fma(gb, xh, s2[q]);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) a1[q][j] = __builtin_elementwise_fma(gb, cf_f32x2{x[j], x[j]}, a1[q][j]);
       }
@@ -669,14 +692,20 @@ __global__ void conv_first_bn_wgrad_finalize_kernel(const float* __restrict__ su
                                                     const float* __restrict__ w, float* __restrict__ dw,
                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int Cout, int NJ,
                                                     float inv_count, int training, int gram, float clip,
-                                                    const float* __restrict__ ext_pg) {
+                                                    const float* __restrict__ ext_pg, int derive_s2) {
   const int PER = 2 * NJ + 2;
   const float* pg = ext_pg != nullptr ? ext_pg : sums + Cout * PER;  // P[NJ] then G[NJ][NJ]
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= Cout * (NJ + 2)) return;
   const int c = e / (NJ + 2), j = e - c * (NJ + 2);
   const float* sc = sums + c * PER;
-  const float S1 = sc[2 * NJ], S2 = sc[2 * NJ + 1];
+  const float S1 = sc[2 * NJ];
+  float S2 = sc[2 * NJ + 1];
+  if (derive_s2) {   // the sweep saw no z: sum gb * xh = invstd * (sum_j W[c][j] * A1[c][j] - mean * S1)   (z = W . patch, no conv bias)
+    float t = 0.f;
+    for (int k = 0; k < NJ; ++k) t = fmaf(w[c * NJ + k], sc[k], t);
+    S2 = invstd[c] * (t - mean[c] * S1);
+  }
   float v;
   if (j < NJ) {
     const float c1 = gamma[c] * invstd[c];
@@ -824,13 +853,13 @@ extern "C" int yogo_conv_first_bn_wgrad_cols(int Cin, int Cout, int* cols) {
 
 // part: rows (yogo_conv_first_wgrad_rows) x cols floats.  Follow with yogo_partials_reduce(part, rows, cols, 0, sums) and
 // yogo_conv_first_bn_wgrad_finalize.
-static int conv_first_bn_wgrad_impl(const void* in, int in_dtype, const void* g, const void* z, const float* mean,
+static int conv_first_bn_wgrad_impl(const void* in, int in_dtype, const void* g, const void* z, const void* signs, const float* mean,
                                     const float* invstd, const float* gamma, const float* beta, float* part, int B, int Cin, int Cout,
                                     int IH, int IW, int stride, int act, int ext_gram, hipStream_t stream);
 extern "C" int yogo_conv_first_bn_wgrad_bf16(const void* in, int in_dtype, const void* g, const void* z, const float* mean,
                                              const float* invstd, const float* gamma, const float* beta, float* part, int B,
                                              int Cin, int Cout, int IH, int IW, int stride, int act, hipStream_t stream) {
-  return conv_first_bn_wgrad_impl(in, in_dtype, g, z, mean, invstd, gamma, beta, part, B, Cin, Cout, IH, IW, stride, act, 0, stream);
+  return conv_first_bn_wgrad_impl(in, in_dtype, g, z, nullptr, mean, invstd, gamma, beta, part, B, Cin, Cout, IH, IW, stride, act, 0, stream);
 }
 // the same when the caller holds P and G of this batch already (yogo_conv_first_gram in the forward pass): no Gram pass;
 // finish with yogo_conv_first_bn_wgrad_finalize_xg
@@ -838,24 +867,45 @@ extern "C" int yogo_conv_first_bn_wgrad_bf16_xg(const void* in, int in_dtype, co
                                                 const float* invstd, const float* gamma, const float* beta, float* part, int B,
                                                 int Cin, int Cout, int IH, int IW, int stride, int act, hipStream_t stream) {
   YOGO_CHECK_ARG(Cin == 1, "conv_first_bn_wgrad_bf16_xg: one input channel only");
-  return conv_first_bn_wgrad_impl(in, in_dtype, g, z, mean, invstd, gamma, beta, part, B, Cin, Cout, IH, IW, stride, act, 1, stream);
+  return conv_first_bn_wgrad_impl(in, in_dtype, g, z, nullptr, mean, invstd, gamma, beta, part, B, Cin, Cout, IH, IW, stride, act, 1, stream);
 }
-static int conv_first_bn_wgrad_impl(const void* in, int in_dtype, const void* g, const void* z, const float* mean,
+extern "C" int yogo_conv_first_mfma_supported(int in_dtype, int Cin, int Cout, int IH, int IW, int stride);   // conv_first_mfma.hip
+// 1 when the sweep can run WITHOUT the saved conv output: from the sign map of yogo_conv_first_mfma_signs (uint8 one-channel image,
+// stride 2, even sizes, Cout = 8 or 16, no activation or LeakyReLU, no conv bias, caller-held Gram matrix)
+static bool conv_first_fast_shape(int in_dtype, int Cin, int IH, int IW, int stride) {
+  return in_dtype == 0 && Cin == 1 && stride == 2 && IH % 2 == 0 && IW % 2 == 0 && (long long)IH * IW < (1ll << 31);
+}
+extern "C" int yogo_conv_first_bn_wgrad_xs_supported(int in_dtype, int Cin, int Cout, int IH, int IW, int stride, int act) {
+  return conv_first_fast_shape(in_dtype, Cin, IH, IW, stride) && (Cout == 8 || Cout == 16) && (act == ACT_NONE || act == ACT_LEAKY) &&
+         yogo_conv_first_mfma_supported(in_dtype, Cin, Cout, IH, IW, stride);
+}
+// yogo_conv_first_bn_wgrad_bf16_xg without z: signs = the sign map of the forward pass (may be NULL when act is ACT_NONE); the S2
+// column of the partial rows stays zero -- finish with yogo_conv_first_bn_wgrad_finalize_xs, which derives it (see the kernel)
+extern "C" int yogo_conv_first_bn_wgrad_bf16_xs(const void* in, int in_dtype, const void* g, const void* signs, const float* mean,
+                                                const float* invstd, const float* gamma, const float* beta, float* part, int B,
+                                                int Cin, int Cout, int IH, int IW, int stride, int act, hipStream_t stream) {
+  YOGO_CHECK_ARG(yogo_conv_first_bn_wgrad_xs_supported(in_dtype, Cin, Cout, IH, IW, stride, act), "conv_first_bn_wgrad_bf16_xs: unsupported shape");
+  YOGO_CHECK_ARG(signs != nullptr || act == ACT_NONE, "conv_first_bn_wgrad_bf16_xs: LeakyReLU needs the sign map");
+  return conv_first_bn_wgrad_impl(in, in_dtype, g, nullptr, signs != nullptr ? signs : g, mean, invstd, gamma, beta, part, B, Cin, Cout, IH, IW, stride, act, 1, stream);
+}
+static int conv_first_bn_wgrad_impl(const void* in, int in_dtype, const void* g, const void* z, const void* signs, const float* mean,
                                     const float* invstd, const float* gamma, const float* beta, float* part, int B, int Cin, int Cout,
                                     int IH, int IW, int stride, int act, int ext_gram, hipStream_t stream) {
-  YOGO_CHECK_ARG(in && g && z && mean && invstd && gamma && beta && part, "conv_first_bn_wgrad_bf16: null pointer");
+  YOGO_CHECK_ARG(in && g && (z || signs) && mean && invstd && gamma && beta && part, "conv_first_bn_wgrad_bf16: null pointer");
   YOGO_CHECK_ARG((Cin == 1 || Cin == 3) && Cout > 0 && (stride == 1 || stride == 2) && (in_dtype == 0 || in_dtype == 1),
                  "conv_first_bn_wgrad_bf16: unsupported shape");
   ConvFirstBnWgradParams p{};
-  p.in = in; p.g = reinterpret_cast<const cf_u32x4*>(g); p.z = reinterpret_cast<const cf_u32x4*>(z);
+  p.in = in; p.g = reinterpret_cast<const cf_u32x4*>(g); p.z = reinterpret_cast<const cf_u32x4*>(z); p.signs = reinterpret_cast<const unsigned short*>(signs);
   p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta; p.part = part;
   p.B = B; p.Cin = Cin; p.Cout = Cout; p.Mb = ((Cout + 15) / 16) * 2; p.IH = IH; p.IW = IW; p.stride = stride; p.act = act;
   p.OH = (IH - 1) / stride + 1; p.OW = (IW - 1) / stride + 1; p.ext_gram = ext_gram;
   if (B == 0) return YOGO_OK;
   dim3 grid(first_wgrad_tiles(p.OH, p.OW), B);
-  const bool fast = in_dtype == 0 && Cin == 1 && stride == 2 && IH % 2 == 0 && IW % 2 == 0 && (long long)IH * IW < (1ll << 31);
-  if (fast && ext_gram && Cout % 8 == 0 && (act == ACT_NONE || act == ACT_LEAKY))
-    hipLaunchKernelGGL(conv_first_bn_wgrad_pk_kernel, grid, dim3(CF_THREADS), 0, stream, p);
+  const bool fast = conv_first_fast_shape(in_dtype, Cin, IH, IW, stride);
+  if (z == nullptr)   // (yogo_conv_first_bn_wgrad_bf16_xs checked the shape)
+    hipLaunchKernelGGL(conv_first_bn_wgrad_pk_kernel<true>, grid, dim3(CF_THREADS), 0, stream, p);
+  else if (fast && ext_gram && Cout % 8 == 0 && (act == ACT_NONE || act == ACT_LEAKY))
+    hipLaunchKernelGGL(conv_first_bn_wgrad_pk_kernel<false>, grid, dim3(CF_THREADS), 0, stream, p);
   else if (fast)
     hipLaunchKernelGGL((conv_first_bn_wgrad_kernel<uint8_t, 1, 8, true, true>), grid, dim3(CF_THREADS), 0, stream, p);
   else if (in_dtype == 0 && Cin == 1) hipLaunchKernelGGL((conv_first_bn_wgrad_kernel<uint8_t, 1, 8, true>), grid, dim3(CF_THREADS), 0, stream, p);
@@ -868,13 +918,14 @@ static int conv_first_bn_wgrad_impl(const void* in, int in_dtype, const void* g,
 
 static int conv_first_bn_wgrad_finalize_impl(const float* sums, const float* ext_pg, const float* mean, const float* invstd,
                                              const float* gamma, const float* w_oihw, float* dw, float* dgamma, float* dbeta, int B,
-                                             int Cin, int Cout, int IH, int IW, int stride, int training, float clip, hipStream_t stream);
+                                             int Cin, int Cout, int IH, int IW, int stride, int training, float clip, int derive_s2,
+                                             hipStream_t stream);
 extern "C" int yogo_conv_first_bn_wgrad_finalize(const float* sums, const float* mean, const float* invstd, const float* gamma,
                                                  const float* w_oihw, float* dw, float* dgamma, float* dbeta, int B, int Cin,
                                                  int Cout, int IH, int IW, int stride, int training, float clip,
                                                  hipStream_t stream) {
   return conv_first_bn_wgrad_finalize_impl(sums, nullptr, mean, invstd, gamma, w_oihw, dw, dgamma, dbeta, B, Cin, Cout, IH, IW, stride,
-                                           training, clip, stream);
+                                           training, clip, 0, stream);
 }
 // gram: float[90] = P[9] then G[9][9] of the batch (yogo_conv_first_gram)
 extern "C" int yogo_conv_first_bn_wgrad_finalize_xg(const float* sums, const float* gram, const float* mean, const float* invstd,
@@ -883,16 +934,27 @@ extern "C" int yogo_conv_first_bn_wgrad_finalize_xg(const float* sums, const flo
                                                     hipStream_t stream) {
   YOGO_CHECK_ARG(gram != nullptr && Cin == 1, "conv_first_bn_wgrad_finalize_xg: bad arguments");
   return conv_first_bn_wgrad_finalize_impl(sums, gram, mean, invstd, gamma, w_oihw, dw, dgamma, dbeta, B, Cin, Cout, IH, IW, stride,
-                                           training, clip, stream);
+                                           training, clip, 0, stream);
+}
+// ... behind yogo_conv_first_bn_wgrad_bf16_xs: S2 = sum gb * xh is derived from A1 and S1; w_oihw = the weights the FORWARD pass
+// multiplied with (rounded to bf16)
+extern "C" int yogo_conv_first_bn_wgrad_finalize_xs(const float* sums, const float* gram, const float* mean, const float* invstd,
+                                                    const float* gamma, const float* w_oihw, float* dw, float* dgamma, float* dbeta,
+                                                    int B, int Cin, int Cout, int IH, int IW, int stride, int training, float clip,
+                                                    hipStream_t stream) {
+  YOGO_CHECK_ARG(gram != nullptr && Cin == 1, "conv_first_bn_wgrad_finalize_xs: bad arguments");
+  return conv_first_bn_wgrad_finalize_impl(sums, gram, mean, invstd, gamma, w_oihw, dw, dgamma, dbeta, B, Cin, Cout, IH, IW, stride,
+                                           training, clip, 1, stream);
 }
 static int conv_first_bn_wgrad_finalize_impl(const float* sums, const float* ext_pg, const float* mean, const float* invstd,
                                              const float* gamma, const float* w_oihw, float* dw, float* dgamma, float* dbeta, int B,
-                                             int Cin, int Cout, int IH, int IW, int stride, int training, float clip, hipStream_t stream) {
+                                             int Cin, int Cout, int IH, int IW, int stride, int training, float clip, int derive_s2,
+                                             hipStream_t stream) {
   YOGO_CHECK_ARG(sums && mean && invstd && gamma && w_oihw && dw && dgamma && dbeta, "conv_first_bn_wgrad_finalize: null pointer");
   const int OH = (IH - 1) / stride + 1, OW = (IW - 1) / stride + 1, NJ = Cin * 9;
   const int n = Cout * (NJ + 2);
   hipLaunchKernelGGL(conv_first_bn_wgrad_finalize_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, sums, mean, invstd, gamma,
-                     w_oihw, dw, dgamma, dbeta, Cout, NJ, 1.0f / ((float)B * (float)OH * (float)OW), training, Cin == 1 ? 1 : 0, clip, ext_pg);
+                     w_oihw, dw, dgamma, dbeta, Cout, NJ, 1.0f / ((float)B * (float)OH * (float)OW), training, Cin == 1 ? 1 : 0, clip, ext_pg, derive_s2);
   YOGO_CHECK_LAUNCH("conv_first_bn_wgrad_finalize");
   return YOGO_OK;
 }

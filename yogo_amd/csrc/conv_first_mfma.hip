@@ -26,6 +26,7 @@ struct ConvFirstMfmaParams {
   const float* bias;        // optional [Cout]
   cfm_u32x4* z;             // optional: conv output, bf16 NCHW8c [B][2][OH*OW] units
   cfm_u32x4* y;             // optional: act(BatchNorm(z)), same layout
+  unsigned char* signs;     // optional (with y): [B][OH*OW][2] bytes, bit = (BatchNorm output > 0) -- see yogo_conv_first_mfma_signs
   const float* mean;        // for y: [Cout] each
   const float* invstd;
   const float* gamma;
@@ -178,6 +179,13 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const ConvFirstMfm
         float r[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) r[i] = fmaf((float)o[i], sc[i], sh[i]);
+        if (p.signs != nullptr) {  // what the backward pass needs of the pre-activation: one byte per lane (its 8 channels of the pixel)
+          unsigned m = 0;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) m |= (r[i] > 0.f ? 1u : 0u) << i;
+          const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)(p.signs + (size_t)b * 2 * npix), (short)0, 2 * npix, 0x00020000);
+          __builtin_amdgcn_raw_buffer_store_b8((unsigned char)m, rs_s, valid ? 2 * pix + half : (int)OOB, 0, 0);
+        }
         if (p.act == ACT_LEAKY) {  // (uniform branches around whole blocks)
 #pragma unroll
           for (int i = 0; i < 8; ++i) r[i] = fmaxf(r[i], LEAKY_SLOPE * r[i]);
@@ -421,16 +429,33 @@ extern "C" int yogo_conv_first_mfma_stats_rows(int B, int IH, int IW, int* rows)
 //   stats_part: partial (sum, sumsq) of conv + bias (fp32, before rounding) -> yogo_bn_finalize(part, rows, 16, ...)
 //   z: conv + bias in bf16 NCHW8c;  y: act((z - mean) * invstd * gamma + beta) in bf16 NCHW8c (needs mean/invstd/gamma/beta);
 //   without y the activation goes onto z (inference with BatchNorm folded into w and bias): z = act(conv + bias)
+static int conv_first_mfma_impl(const void* in, const float* w, const float* bias, void* z, void* y, void* signs, const float* mean,
+                               const float* invstd, const float* gamma, const float* beta, float* stats_part, int B, int Cout,
+                               int IH, int IW, int act, hipStream_t stream);
 extern "C" int yogo_conv_first_mfma(const void* in, const float* w, const float* bias, void* z, void* y, const float* mean,
                                     const float* invstd, const float* gamma, const float* beta, float* stats_part, int B, int Cout,
                                     int IH, int IW, int act, hipStream_t stream) {
+  return conv_first_mfma_impl(in, w, bias, z, y, nullptr, mean, invstd, gamma, beta, stats_part, B, Cout, IH, IW, act, stream);
+}
+// the same with the SIGN MAP of the BatchNorm output beside y: signs = [B][OH*OW][2] bytes; byte h of a pixel, bit i = (pre-activation
+// of channel 4h + i > 0), bit 4 + i = (... of channel 8 + 4h + i > 0) -- the lane order of the kernel, one byte store per lane.  It is
+// all the layer-0 backward pass needs of z (yogo_conv_first_bn_wgrad_bf16_xs): with it z (16x the bytes) need not be written at all.
+extern "C" int yogo_conv_first_mfma_signs(const void* in, const float* w, const float* bias, void* z, void* y, void* signs,
+                                          const float* mean, const float* invstd, const float* gamma, const float* beta, int B, int Cout,
+                                          int IH, int IW, int act, hipStream_t stream) {
+  YOGO_CHECK_ARG(y && signs, "conv_first_mfma_signs: the sign map goes with y");
+  return conv_first_mfma_impl(in, w, bias, z, y, signs, mean, invstd, gamma, beta, nullptr, B, Cout, IH, IW, act, stream);
+}
+static int conv_first_mfma_impl(const void* in, const float* w, const float* bias, void* z, void* y, void* signs, const float* mean,
+                               const float* invstd, const float* gamma, const float* beta, float* stats_part, int B, int Cout,
+                               int IH, int IW, int act, hipStream_t stream) {
   YOGO_CHECK_ARG(in && w && (z || y || stats_part), "conv_first_mfma: null pointer");
   YOGO_CHECK_ARG(yogo_conv_first_mfma_supported(0, 1, Cout, IH, IW, 2) && B >= 0, "conv_first_mfma: unsupported shape %dx%d Cout=%d", IH, IW, Cout);
   YOGO_CHECK_ARG(y == nullptr || (mean && invstd && gamma && beta), "conv_first_mfma: y needs mean / invstd / gamma / beta");
   if (B == 0) return YOGO_OK;
   ConvFirstMfmaParams p{};
   p.in = reinterpret_cast<const unsigned char*>(in); p.w = w; p.bias = bias;
-  p.z = reinterpret_cast<cfm_u32x4*>(z); p.y = reinterpret_cast<cfm_u32x4*>(y);
+  p.z = reinterpret_cast<cfm_u32x4*>(z); p.y = reinterpret_cast<cfm_u32x4*>(y); p.signs = reinterpret_cast<unsigned char*>(signs);
   p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta; p.stats_part = stats_part;
   p.B = B; p.Cout = Cout; p.IH = IH; p.IW = IW; p.OH = IH / 2; p.OW = IW / 2; p.act = act;
   p.gpi = cdiv(p.OH * p.OW, 32); p.total = B * p.gpi;

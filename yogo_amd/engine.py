@@ -60,6 +60,7 @@ class Saved:
     z: Optional[torch.Tensor] = None       # conv output of a BN block
     pre: Optional[torch.Tensor] = None     # pre-activation (SiLU blocks)
     signs: Optional[torch.Tensor] = None   # sign map of y (LeakyReLU blocks without BatchNorm, bf16 path)
+    signs0: Optional[torch.Tensor] = None  # layer 0 on the matrix cores: sign map of its BatchNorm output -- kept INSTEAD of z
     w_used: Optional[torch.Tensor] = None  # layer 0 on the matrix cores: the bf16-rounded weights the forward multiplied with
     gram: Optional[torch.Tensor] = None    # layer 0: float[90] patch sums P and Gram matrix G of the batch (reused by backward)
     mask: Optional[torch.Tensor] = None    # Dropout2d channel mask, already scaled
@@ -365,6 +366,7 @@ _FUSE_LAYER0_BWD = True     # BatchNorm backward + activation derivative + first
 _LEAKY_SIGNS = True         # LeakyReLU blocks without BatchNorm hand the next data gradient a 1-bit sign map, not the bf16 output
 _L0_MFMA = True             # layer 0 (uint8 image, 1 -> <=16 channels, stride 2, BatchNorm) on the matrix cores
 _L0_GRAM = True             # ... with the batch statistics from the exact integer patch Gram matrix (backward reuses it)
+_L0_NO_Z = True             # ... and without its conv output in memory: sign map + derived sums (yogo_conv_first_*_xs)
 _PACK_MULTI = True          # all weight packings of a step in one launch
 _BN_STATS_PASS = True       # BatchNorm statistics of layers > 0 by a sweep over the stored bf16 output (not the conv epilogue)
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
@@ -484,8 +486,7 @@ def forward_bf16_train(eng: Engine, x: torch.Tensor) -> Tuple[torch.Tensor, List
             gamma = _f32(bn.weight.detach()) if bn.weight is not None else torch.ones(L.cout, device=dev)
             beta = _f32(bn.bias.detach()) if bn.bias is not None else torch.zeros(L.cout, device=dev)
             w32 = _f32(L.conv.weight.detach())
-            out8 = torch.empty(B, _blocks(L.cout), OH, OW, 8, dtype=torch.bfloat16, device=dev)
-            y = torch.empty_like(out8)
+            y = torch.empty(B, _blocks(L.cout), OH, OW, 8, dtype=torch.bfloat16, device=dev)
             if bn_train and _L0_GRAM:   # sweep 1: exact integer patch sums -> statistics of all channels (and backward's G)
                 rows = _hip.query_ints("yogo_conv_first_gram_rows", 1, B, H, W)[0]
                 gpart = torch.empty(rows * 54, dtype=torch.int32, device=dev)
@@ -518,8 +519,17 @@ def forward_bf16_train(eng: Engine, x: torch.Tensor) -> Tuple[torch.Tensor, List
                 invstd = torch.empty(L.cout, dtype=torch.float32, device=dev)
                 _hip.call("yogo_bn_invstd", bn.running_var, float(bn.eps), invstd, L.cout, st)
                 mean = bn.running_mean
-            # sweep 2: the convolution again, z (saved for backward) and y = act(BatchNorm(z)) written together
-            _hip.call("yogo_conv_first_mfma", cur, w32, bias, out8, y, mean, invstd, gamma, beta, None, B, L.cout, H, W, L.act, st)
+            # sweep 2: the convolution again, y = act(BatchNorm(z)) and what backward needs of z: its sign map when the fused backward
+            # sweep can take that (it derives everything else from its own sums), else z itself
+            no_z = (_L0_NO_Z and _FUSE_LAYER0_BWD and S.gram is not None and L.conv.bias is None
+                    and _hip.lib().yogo_conv_first_bn_wgrad_xs_supported(0, L.cin, L.cout, H, W, L.s, L.act))
+            if no_z:
+                out8 = None
+                S.signs0 = torch.empty(B, OH * OW * 2, dtype=torch.uint8, device=dev)
+                _hip.call("yogo_conv_first_mfma_signs", cur, w32, bias, None, y, S.signs0, mean, invstd, gamma, beta, B, L.cout, H, W, L.act, st)
+            else:
+                out8 = torch.empty_like(y)
+                _hip.call("yogo_conv_first_mfma", cur, w32, bias, out8, y, mean, invstd, gamma, beta, None, B, L.cout, H, W, L.act, st)
             S.mean, S.invstd, S.bn_train, S.z, S.y = mean, invstd, bn_train, out8, y
             S.w_used = w32.to(torch.bfloat16).to(torch.float32)
             cur = y
@@ -681,9 +691,10 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
             wst = _hip.stream_ptr()
             xdt = 0 if S.x_in.dtype == torch.uint8 else 1
             if fuse0:
-                keep.append(S.z)
-                xg = "_xg" if S.gram is not None else ""
-                _hip.call("yogo_conv_first_bn_wgrad_bf16" + xg, S.x_in, xdt, g, S.z, S.mean, S.invstd, gamma, beta, part, B, L.cin, L.cout,
+                xg = "_xs" if S.signs0 is not None else "_xg" if S.gram is not None else ""
+                zs = S.signs0 if S.signs0 is not None else S.z
+                keep.append(zs)
+                _hip.call("yogo_conv_first_bn_wgrad_bf16" + xg, S.x_in, xdt, g, zs, S.mean, S.invstd, gamma, beta, part, B, L.cin, L.cout,
                           IH, IW, L.s, L.act, wst)
                 _hip.call("yogo_partials_reduce", part, rows, cols, 0.0, sums, wst)
                 _hip.call("yogo_conv_first_bn_wgrad_finalize" + xg, sums, *((S.gram,) if S.gram is not None else ()), S.mean, S.invstd, gamma,
