@@ -227,8 +227,14 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
   const int gx = gridDim.x, gy = gridDim.y;
   const int b = udivm((int)widx, gx * gy, p.m_gxy);
   const int rem_ = (int)widx - b * gx * gy;
-  const int by = udivm(rem_, gx, p.m_gx);
-  const int bx = rem_ - by * gx;
+  // stride-2 data gradient with <= 64 rows: the two row parities of a tile are NEIGHBOURS in the walk -- they stage the same gradient
+  // tile, and 195 tiles apart (parity-major) the second fetch no longer finds it in the XCD's L2 (FETCH 2.2x the tensor).  Layer 2's data
+  // gradient -6 % in the same-box A/B (gpurun_out/r4_abpair.log); the 128-row tile (layer 4, not bound by memory) loses 4 % and keeps
+  // the parity-major order.
+  constexpr bool PAIR = S2D && MW < 4;
+  const int mb_ = udivm(PAIR ? (rem_ >> 1) : rem_, gx, p.m_gx);
+  const int by = PAIR ? 2 * mb_ + (rem_ & 1) : mb_;
+  const int bx = (PAIR ? (rem_ >> 1) : rem_) - mb_ * gx;
   const int py = S2D ? (by & 1) : 0;
   const int m0 = (S2D ? (by >> 1) : by) * BM;
   // S2D tiles the quad grid of this row parity; everything else tiles the output
