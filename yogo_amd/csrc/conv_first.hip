@@ -364,6 +364,7 @@ struct ConvFirstBnWgradParams {
   float* part;
   int B, Cin, Cout, Mb, IH, IW, OH, OW, stride, act;
   int ext_gram;  // GRAM kernels: the caller already has P and G of this batch (yogo_conv_first_gram) -- skip that pass
+  unsigned m_ow; // conv_first_bn_wgrad_pk_kernel: ceil(2^32 / OW) when pixel / OW may be taken as a multiply-high (OH * OW * OW < 2^32), else 0
 };
 
 // GRAM (Cin = 1): z is the bias-free convolution of the patches, so A2[c][j] = invstd_c * (sum_j' W[c][j'] G[j'][j] - mean_c P[j])
@@ -607,7 +608,10 @@ __global__ __launch_bounds__(CF_THREADS, 3) void conv_first_bn_wgrad_pk_kernel(c
       const int pix = pbase + k * CF_THREADS + tid;
       const bool ok = pix < npix;
       const int pc = ok ? pix : 0;
-      const int oy = pc / p.OW, ox = pc - oy * p.OW;
+      // (one multiply-high where it is exact.  Measured on this sweep and dropped, round 4: one 2-byte-aligned dword per patch row in
+      //  place of the two 16-bit loads -- 356 -> 611 us, misaligned dwords are slow; the loads of pixel k + 1 issued before the
+      //  arithmetic of pixel k -- 356 -> 426 us)
+      const int oy = p.m_ow ? (int)__umulhi((unsigned)pc, p.m_ow) : pc / p.OW, ox = pc - oy * p.OW;
       float x[NJ];
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
@@ -899,6 +903,7 @@ static int conv_first_bn_wgrad_impl(const void* in, int in_dtype, const void* g,
   p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta; p.part = part;
   p.B = B; p.Cin = Cin; p.Cout = Cout; p.Mb = ((Cout + 15) / 16) * 2; p.IH = IH; p.IW = IW; p.stride = stride; p.act = act;
   p.OH = (IH - 1) / stride + 1; p.OW = (IW - 1) / stride + 1; p.ext_gram = ext_gram;
+  p.m_ow = ((long long)p.OH * p.OW * p.OW < (1ll << 32) && p.OW > 1) ? (unsigned)(((1ull << 32) + (unsigned)p.OW - 1ull) / (unsigned)p.OW) : 0u;
   if (B == 0) return YOGO_OK;
   dim3 grid(first_wgrad_tiles(p.OH, p.OW), B);
   const bool fast = conv_first_fast_shape(in_dtype, Cin, IH, IW, stride);

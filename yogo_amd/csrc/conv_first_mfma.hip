@@ -180,9 +180,13 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const ConvFirstMfm
 #pragma unroll
         for (int i = 0; i < 8; ++i) r[i] = fmaf((float)o[i], sc[i], sh[i]);
         if (p.signs != nullptr) {  // what the backward pass needs of the pre-activation: one byte per lane (its 8 channels of the pixel)
-          unsigned m = 0;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) m |= (r[i] > 0.f ? 1u : 0u) << i;
+          unsigned m = 0;   // bit i = (r[i] > 0): compare into vcc, add-with-carry shifts it in (values 7 down to 0) -- 2 instructions per value
+#define CFM_SGN(I) "v_cmp_lt_f32_e32 vcc, 0, %" #I "\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t"
+          asm(CFM_SGN(8) CFM_SGN(7) CFM_SGN(6) CFM_SGN(5) CFM_SGN(4) CFM_SGN(3) CFM_SGN(2) "v_cmp_lt_f32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
+              : "+v"(m)
+              : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(r[4]), "v"(r[5]), "v"(r[6]), "v"(r[7])
+              : "vcc");
+#undef CFM_SGN
           const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)(p.signs + (size_t)b * 2 * npix), (short)0, 2 * npix, 0x00020000);
           __builtin_amdgcn_raw_buffer_store_b8((unsigned char)m, rs_s, valid ? 2 * pix + half : (int)OOB, 0, 0);
         }
