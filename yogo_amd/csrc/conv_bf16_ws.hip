@@ -258,7 +258,8 @@ __device__ __forceinline__ void ws_prefetch(u32x4& an0, u32x4& an1, u32x4& an2, 
 
 // compile-time ablations (build.sh variant TAG conv_bf16_ws -DWS_ABL=bits; timings only, the results are wrong): 8 = the loaders do
 // not decode the next tile (its input then comes out of L2: the clock rises), 16 = no epilogue in the gaps of the
-// group-major chunks, 32 = the slot decode twice, 64 = plain moves instead of accumulator reads
+// group-major chunks, 32 = the slot decode twice, 64 = plain moves instead of accumulator reads, 128 = chunk 1 does not stage the parked units
+// (0.3 k of layer 5's 22 k cycles per tile)
 #ifndef WS_ABL
 #define WS_ABL 0
 #endif
@@ -812,7 +813,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     epar = tpar;                    // from here on the epilogue in progress is this tile's
     vo_e[0] = vo[0]; vo_e[1] = vo[1]; b_e = T.b;
     [[maybe_unused]] const unsigned long long tq0 = WS_STAMP();
-    chunk(TT{}, WsIC<1>{});         // chunk 1: the parked units go to the staging area
+    chunk(std::integral_constant<bool, !WS_ABLATE(128)>{}, WsIC<1>{});         // chunk 1: the parked units go to the staging area (ablation 128: they do not)
     [[maybe_unused]] const unsigned long long tq1 = WS_STAMP();
     chunk(FT{}, WsIC<0>{});
     t_c1 += tq1 - tq0;
