@@ -233,6 +233,15 @@ def test_layer0_on_matrix_cores(B, IH, IW, Cout, use_bias):
     y2 = torch.full_like(z, float("nan"))
     h.call("yogo_bn_apply_act_bf16", z, y2, mean.cuda(), invstd.cuda(), 0, 1e-5, gamma.cuda(), beta.cuda(), B, Cout, OH * OW, 1, st)
     assert torch.equal(y.view(torch.int16), y2.view(torch.int16))
+    # the variant with the sign map of the BatchNorm output (ABI 5): same y with or without z; a pixel's two bytes hold, in the kernel's
+    # lane order, the bits (z * sc + sh > 0) of the ROUNDED z -- the value y is made of -- and padding channels read "not positive"
+    y3 = torch.full_like(z, float("nan"))
+    sg = torch.full((B, OH * OW * 2), 0xAA, dtype=torch.uint8, device="cuda")
+    h.call("yogo_conv_first_mfma_signs", xc, wc, bc, None, y3, sg, mean.cuda(), invstd.cuda(), gamma.cuda(), beta.cuda(), B, Cout, IH, IW, 1, st)
+    assert torch.equal(y.view(torch.int16), y3.view(torch.int16))
+    want = O.l0_sign_map(dict(z=from8c(z, Cout).float().cpu(), mean=mean, invstd=invstd, gamma=gamma, beta=beta))
+    nflip = int((sg.cpu() != want).sum())
+    assert nflip <= 1e-5 * want.numel() + 1, (nflip, want.numel())   # (an fma against a multiply and an add, next to zero)
     # and the direct kernel with the same (rounded) weights agrees to the output rounding
     z_old = torch.full_like(z, float("nan"))
     h.call("yogo_conv_first_fwd_train_bf16", xc, 0, bf(w).cuda(), bc, z_old, None, None, B, 1, Cout, IH, IW, 2, 0, st)
