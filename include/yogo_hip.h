@@ -191,6 +191,15 @@ int yogo_conv2d_wgrad_bf16in(const void* x, const void* g, float* dw, float* db,
 int yogo_conv2d_wgrad_bf16_workspace_bytes(int B, int Cin, int Cout, int IH, int IW, int ksize, int stride, size_t* bytes);
 int yogo_conv2d_wgrad_bf16(const void* x, const void* g, float* dw, float* db, void* workspace, int B, int Cin, int Cout,
                            int IH, int IW, int ksize, int stride, float clip, yogo_stream_t stream);
+/* ... with the split-K reduction deferred (ABI 5): recorded in `queue` and run by yogo_wgrad_reduce_flush together with every other
+ * recorded one -- one launch for the weight gradients of a whole backward pass (the per-layer launches are ~21 us each, mostly launch and
+ * tail latency).  dw / db / workspace stay valid until the flush; results are bit-identical to yogo_conv2d_wgrad_bf16.  A queue holds up
+ * to 16 reductions (a 17th flushes first) and belongs to one host thread. */
+int yogo_wgrad_reduce_queue_create(void** queue_out);
+int yogo_wgrad_reduce_queue_destroy(void* queue);
+int yogo_wgrad_reduce_flush(void* queue, yogo_stream_t stream);
+int yogo_conv2d_wgrad_bf16_deferred(const void* x, const void* g, float* dw, float* db, void* workspace, int B, int Cin, int Cout, int IH,
+                                    int IW, int ks, int stride, float clip, void* queue, yogo_stream_t stream);
 int yogo_conv_first_fwd_bf16(const void* in, int in_dtype, const float* w, const float* bias, void* out, int B, int Cin,
                              int Cout, int IH, int IW, int stride, int act, yogo_stream_t stream);
 int yogo_conv_first_fwd_train_bf16(const void* in, int in_dtype, const float* w, const float* bias, void* out_bf16,

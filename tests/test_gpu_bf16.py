@@ -469,6 +469,34 @@ def test_layer0_backward_without_conv_output_matches_with_it():
                 assert torch.equal(a, b_), n
 
 
+def test_deferred_weight_gradient_reductions_are_bit_identical():
+    """engine._WGRAD_DEFER_REDUCE: the split-K reductions of all weight gradients in one launch behind the last layer
+    (yogo_conv2d_wgrad_bf16_deferred + yogo_wgrad_reduce_flush) against one launch per layer: the same bits in every gradient."""
+    from yogo_amd import engine as E
+    from yogo_amd.model import YOGO
+    from yogo_amd.train import HipTrainer
+    from yogo_amd.yogo_loss import YOGOLoss
+
+    for Himg, Wimg, B in ((96, 128, 4), (193, 258, 3)):
+        x = O.synthetic_images(B, Himg, Wimg, seed=45).cuda()
+        out = {}
+        old = E._WGRAD_DEFER_REDUCE
+        try:
+            for defer in (False, True):
+                E._WGRAD_DEFER_REDUCE = defer
+                torch.manual_seed(7)
+                model = YOGO((Himg, Wimg), 0.0425, 0.0555, 7, clip_value=1.0).cuda()
+                model.train()
+                lab = O.synthetic_labels(B, model.Sx, model.Sy, K=6, num_classes=7, seed=46).cuda()
+                tr = HipTrainer(model, YOGOLoss().cuda(), total_steps=5, half=True)
+                tr.step(x, lab)
+                out[defer] = tr.flat.grad.clone().cpu()
+        finally:
+            E._WGRAD_DEFER_REDUCE = old
+        assert torch.isfinite(out[True]).all() and float(out[True].abs().max()) > 0
+        assert torch.equal(out[False], out[True])
+
+
 def test_bf16_dropout_masks():
     """Dropout2d in the bf16 training path: all layers' channel masks come from one rand call; every layer keeps its own p,
     the survivors are scaled by 1 / (1 - p), dropped channels are zero in the block output."""

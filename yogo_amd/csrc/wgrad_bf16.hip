@@ -488,6 +488,8 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
 }
 
 // defined in wgrad_f32.hip (the fixed-order slab reduction is shared)
+extern "C" int yogo_internal_wgrad_reduce_q(void* queue, const float* slab, int nslab, int T, int M, int N, int Mpad, int Npad, float clip, float* dw,
+                                            const float* bias_part, int nbias, float* db, hipStream_t stream);
 extern "C" int yogo_internal_wgrad_reduce(const float* slab, int nslab, int T, int M, int N, int Mpad, int Npad, float clip, float* dw,
                                           const float* bias_part, int nbias, float* db, hipStream_t stream);
 
@@ -605,8 +607,22 @@ extern "C" int yogo_conv2d_wgrad_bf16_workspace_bytes(int B, int Cin, int Cout, 
 }
 
 // fp32 dw (OIHW) / db from bf16 NCHW8c x and g on the bf16 matrix cores (fp32 accumulation); clamped to +-clip when clip > 0
+static int conv2d_wgrad_bf16_impl(const void* x, const void* g, float* dw, float* db, void* workspace, int B, int Cin, int Cout, int IH, int IW,
+                                 int ks, int stride, float clip, void* queue, hipStream_t stream);
 extern "C" int yogo_conv2d_wgrad_bf16(const void* x, const void* g, float* dw, float* db, void* workspace, int B, int Cin, int Cout,
                                       int IH, int IW, int ks, int stride, float clip, hipStream_t stream) {
+  return conv2d_wgrad_bf16_impl(x, g, dw, db, workspace, B, Cin, Cout, IH, IW, ks, stride, clip, nullptr, stream);
+}
+// the same with the split-K reduction DEFERRED: it is recorded in `queue` (yogo_wgrad_reduce_queue_create) and runs, together with
+// every other recorded one, when yogo_wgrad_reduce_flush(queue, stream) is called -- one launch for the weight gradients of a
+// whole backward pass instead of one per layer.  dw / db / workspace must stay valid until then; same bits as the immediate form.
+extern "C" int yogo_conv2d_wgrad_bf16_deferred(const void* x, const void* g, float* dw, float* db, void* workspace, int B, int Cin, int Cout,
+                                               int IH, int IW, int ks, int stride, float clip, void* queue, hipStream_t stream) {
+  YOGO_CHECK_ARG(queue != nullptr, "conv2d_wgrad_bf16_deferred: null queue");
+  return conv2d_wgrad_bf16_impl(x, g, dw, db, workspace, B, Cin, Cout, IH, IW, ks, stride, clip, queue, stream);
+}
+static int conv2d_wgrad_bf16_impl(const void* x, const void* g, float* dw, float* db, void* workspace, int B, int Cin, int Cout, int IH, int IW,
+                                 int ks, int stride, float clip, void* queue, hipStream_t stream) {
   YOGO_CHECK_ARG(x && g && dw && workspace, "conv2d_wgrad_bf16: null pointer");
   YOGO_CHECK_ARG(B > 0 && Cin > 0 && Cout > 0 && IH > 0 && IW > 0 && (ks == 1 || ks == 3) && (stride == 1 || stride == 2) &&
                      !(ks == 1 && stride != 1), "conv2d_wgrad_bf16: bad shape");
@@ -658,5 +674,5 @@ extern "C" int yogo_conv2d_wgrad_bf16(const void* x, const void* g, float* dw, f
   }
   YOGO_CHECK_LAUNCH("conv2d_wgrad_bf16");
   const int nbias = wb_bias_rows(pl, T);
-  return yogo_internal_wgrad_reduce(p.slab, pl.nsplit * pl.KS, T, Cout, Cin, pl.Mpad, pl.Npad, clip, dw, p.bias_part, nbias, db, stream);
+  return yogo_internal_wgrad_reduce_q(queue, p.slab, pl.nsplit * pl.KS, T, Cout, Cin, pl.Mpad, pl.Npad, clip, dw, p.bias_part, nbias, db, stream);
 }

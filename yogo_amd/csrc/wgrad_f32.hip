@@ -296,18 +296,18 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
 // NWAVE = 16 (many slabs): sixteen wavefronts share the slabs of a workgroup's 256 elements -- a lane's chain of dependent
 // 8-load batches is what the kernel waits for (24 us per launch, seven launches per step, with a quarter of the CUs busy), and it
 // is a quarter as long.
-template <int NWAVE>
-__global__ __launch_bounds__(64 * NWAVE) void wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, int T, int M, int N,
-                                                                  int Mpad, int Npad, float clip, float* __restrict__ dw,
-                                                                  const float* __restrict__ bias_part, int nbias,
-                                                                  float* __restrict__ db) {
-  __shared__ double sh[NWAVE][256];
+// (the body: workgroup `bid` of one reduction; NWAVE of the launch's wavefronts take part -- the multi-layer launch below runs 16 and
+//  gives a reduction with few slabs the 4 its own launch would have, so that its fixed summation order is the same)
+template <int MAXW>
+__device__ __forceinline__ void wgrad_reduce_body(double (&sh)[MAXW][256], int bid, int NWAVE, const float* __restrict__ slab, int nslab, int T, int M,
+                                                  int N, int Mpad, int Npad, float clip, float* __restrict__ dw, const float* __restrict__ bias_part,
+                                                  int nbias, float* __restrict__ db) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t stride = (size_t)T * Mpad * Npad;  // Npad is a multiple of 32, Mpad*Npad of 1024
   const int nw = (int)((stride + 255) / 256);
-  if ((int)blockIdx.x < nw) {
-    const size_t e0 = (size_t)blockIdx.x * 256 + lane * 4;
-    const bool in = e0 < stride;  // stride is a multiple of 4
+  if (bid < nw) {
+    const size_t e0 = (size_t)bid * 256 + lane * 4;
+    const bool in = e0 < stride && wave < NWAVE;  // stride is a multiple of 4
     const int per = (nslab + NWAVE - 1) / NWAVE;
     const int k0 = wave * per, k1 = min(nslab, k0 + per);
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(64 * NWAVE) void wgrad_reduce_kernel(const float* _
     }
     sh[wave][lane * 4 + 0] = s0; sh[wave][lane * 4 + 1] = s1; sh[wave][lane * 4 + 2] = s2; sh[wave][lane * 4 + 3] = s3;
     __syncthreads();
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t e = (size_t)bid * 256 + threadIdx.x;
     if (threadIdx.x < 256 && e < stride) {
       const int n = (int)(e % Npad);
       const int m = (int)((e / Npad) % Mpad);
@@ -339,7 +339,6 @@ __global__ __launch_bounds__(64 * NWAVE) void wgrad_reduce_kernel(const float* _
       if (m < M && n < N) {
         const int i = threadIdx.x;
         double acc = 0.0;   // (fixed order, wavefront 0 first)
-#pragma unroll
         for (int w = 0; w < NWAVE; ++w) acc += sh[w][i];
         float v = (float)acc;
         if (clip > 0.f) v = fminf(fmaxf(v, -clip), clip);
@@ -351,7 +350,7 @@ __global__ __launch_bounds__(64 * NWAVE) void wgrad_reduce_kernel(const float* _
     // fixed-order combine
     double* shb = &sh[0][0];  // [16 parts][16 channels]
     const int c = threadIdx.x & 15, part = threadIdx.x >> 4;
-    const int e = ((int)blockIdx.x - nw) * 16 + c;
+    const int e = (bid - nw) * 16 + c;
     double s = 0.0;
     if (threadIdx.x < 256) {
       if (e < M)
@@ -369,8 +368,83 @@ __global__ __launch_bounds__(64 * NWAVE) void wgrad_reduce_kernel(const float* _
     }
   }
 }
+template <int NWAVE>
+__global__ __launch_bounds__(64 * NWAVE) void wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, int T, int M, int N,
+                                                                  int Mpad, int Npad, float clip, float* __restrict__ dw,
+                                                                  const float* __restrict__ bias_part, int nbias,
+                                                                  float* __restrict__ db) {
+  __shared__ double sh[NWAVE][256];
+  wgrad_reduce_body<NWAVE>(sh, (int)blockIdx.x, NWAVE, slab, nslab, T, M, N, Mpad, Npad, clip, dw, bias_part, nbias, db);
+}
+
+// ---- the split-K reductions of SEVERAL weight gradients in one launch (a training step: one per convolution, ~21 us each of
+// which most is launch + tail latency of a quarter-filled chip, seven launches per step)
+#define WRQ_MAX 16
+struct WgradReduceDesc {
+  const float* slab; float* dw; const float* bias_part; float* db;
+  int nslab, T, M, N, Mpad, Npad, nbias, nwave, first_block;
+  float clip;
+};
+struct WgradReduceMulti {
+  WgradReduceDesc d[WRQ_MAX];
+  int n;
+};
+__global__ __launch_bounds__(1024) void wgrad_reduce_multi_kernel(const WgradReduceMulti q) {
+  __shared__ double sh[16][256];
+  int i = 0;   // (uniform) the reduction this workgroup belongs to
+  while (i + 1 < q.n && (int)blockIdx.x >= q.d[i + 1].first_block) ++i;
+  const WgradReduceDesc& r = q.d[i];
+  wgrad_reduce_body<16>(sh, (int)blockIdx.x - r.first_block, r.nwave, r.slab, r.nslab, r.T, r.M, r.N, r.Mpad, r.Npad, r.clip, r.dw, r.bias_part,
+                        r.nbias, r.db);
+}
+struct WgradReduceQueue {
+  WgradReduceMulti m;
+  int blocks;
+};
 
 // slab reduction shared with wgrad_bf16.hip (kernels cannot be launched across translation units without RDC)
+extern "C" int yogo_internal_wgrad_reduce(const float* slab, int nslab, int T, int M, int N, int Mpad, int Npad, float clip, float* dw,
+                                          const float* bias_part, int nbias, float* db, hipStream_t stream);
+static int wgrad_reduce_flush(WgradReduceQueue* q, hipStream_t stream) {
+  if (q->m.n == 0) return YOGO_OK;
+  hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(q->blocks), dim3(1024), 0, stream, q->m);
+  q->m.n = 0;
+  q->blocks = 0;
+  YOGO_CHECK_LAUNCH("wgrad_reduce_multi");
+  return YOGO_OK;
+}
+// queue != NULL: the reduction is only recorded (yogo_wgrad_reduce_flush launches everything recorded in one kernel)
+extern "C" int yogo_internal_wgrad_reduce_q(void* queue, const float* slab, int nslab, int T, int M, int N, int Mpad, int Npad, float clip, float* dw,
+                                            const float* bias_part, int nbias, float* db, hipStream_t stream) {
+  if (queue == nullptr) return yogo_internal_wgrad_reduce(slab, nslab, T, M, N, Mpad, Npad, clip, dw, bias_part, nbias, db, stream);
+  WgradReduceQueue* q = reinterpret_cast<WgradReduceQueue*>(queue);
+  if (q->m.n == WRQ_MAX)
+    if (int e = wgrad_reduce_flush(q, stream)) return e;
+  WgradReduceDesc& r = q->m.d[q->m.n++];
+  r.slab = slab; r.dw = dw; r.bias_part = db ? bias_part : nullptr; r.db = db;
+  r.nslab = nslab; r.T = T; r.M = M; r.N = N; r.Mpad = Mpad; r.Npad = Npad; r.nbias = nbias; r.clip = clip;
+  r.nwave = nslab >= 64 ? 16 : 4;   // (as yogo_internal_wgrad_reduce picks its kernel: same summation order, same bits)
+  r.first_block = q->blocks;
+  q->blocks += (int)(((size_t)T * Mpad * Npad + 255) / 256) + (db ? cdiv(M, 16) : 0);
+  return YOGO_OK;
+}
+extern "C" int yogo_wgrad_reduce_queue_create(void** queue_out) {
+  YOGO_CHECK_ARG(queue_out != nullptr, "wgrad_reduce_queue_create: null pointer");
+  WgradReduceQueue* q = new WgradReduceQueue();
+  q->m.n = 0;
+  q->blocks = 0;
+  *queue_out = q;
+  return YOGO_OK;
+}
+extern "C" int yogo_wgrad_reduce_flush(void* queue, hipStream_t stream) {
+  YOGO_CHECK_ARG(queue != nullptr, "wgrad_reduce_flush: null queue");
+  return wgrad_reduce_flush(reinterpret_cast<WgradReduceQueue*>(queue), stream);
+}
+extern "C" int yogo_wgrad_reduce_queue_destroy(void* queue) {
+  delete reinterpret_cast<WgradReduceQueue*>(queue);
+  return YOGO_OK;
+}
+
 extern "C" int yogo_internal_wgrad_reduce(const float* slab, int nslab, int T, int M, int N, int Mpad, int Npad, float clip, float* dw,
                                           const float* bias_part, int nbias, float* db, hipStream_t stream) {
   const int nw = (int)(((size_t)T * Mpad * Npad + 255) / 256);

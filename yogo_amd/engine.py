@@ -366,6 +366,7 @@ _FUSE_LAYER0_BWD = True     # BatchNorm backward + activation derivative + first
 _LEAKY_SIGNS = True         # LeakyReLU blocks without BatchNorm hand the next data gradient a 1-bit sign map, not the bf16 output
 _L0_MFMA = True             # layer 0 (uint8 image, 1 -> <=16 channels, stride 2, BatchNorm) on the matrix cores
 _L0_GRAM = True             # ... with the batch statistics from the exact integer patch Gram matrix (backward reuses it)
+_WGRAD_DEFER_REDUCE = True  # the per-layer split-K reductions of the weight gradients in one launch at the end of the backward pass
 _L0_NO_Z = True             # ... and without its conv output in memory: sign map + derived sums (yogo_conv_first_*_xs)
 _PACK_MULTI = True          # all weight packings of a step in one launch
 _BN_STATS_PASS = True       # BatchNorm statistics of layers > 0 by a sweep over the stored bf16 output (not the conv epilogue)
@@ -618,6 +619,9 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
         return torch.empty(param.shape, dtype=torch.float32, device=dev)
 
     keep: list = []   # tensors in use on the weight-gradient stream
+    # the split-K reductions of the weight gradients: deferred to ONE launch behind the last layer -- unless a per-layer hook wants
+    # each layer's gradients as soon as the layer is through
+    wq = _wgrad_queue() if (_WGRAD_DEFER_REDUCE and on_layer is None) else None
     if graw.dtype == torch.bfloat16 and graw.ndim == 5:   # already NCHW8c (yogo_decode_bwd_bf16)
         g = graw
         B = g.shape[0]
@@ -712,7 +716,9 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
             else:
                 eng._tick("wgrad", i, 2.0 * B * L.cout * L.cin * L.k * L.k * OH * OW, mw=30,
                           nbytes=B * 2 * 8 * (_blocks(L.cout) * OH * OW + _blocks(L.cin) * IH * IW))
-                if _WGRAD_BF16_MFMA:
+                if _WGRAD_BF16_MFMA and wq is not None:   # the split-K reduction waits for the flush behind the last layer
+                    _hip.call("yogo_conv2d_wgrad_bf16_deferred", S.x_in, g, dw, db, ws, B, L.cin, L.cout, IH, IW, L.k, L.s, clip, wq, wst)
+                elif _WGRAD_BF16_MFMA:
                     _hip.call("yogo_conv2d_wgrad_bf16", S.x_in, g, dw, db, ws, B, L.cin, L.cout, IH, IW, L.k, L.s, clip, wst)
                 else:   # exact fp32 MFMA on the widened bf16 inputs
                     _hip.call("yogo_conv2d_wgrad_bf16in", S.x_in, g, dw, db, ws, B, L.cin, L.cout, IH, IW, L.k, L.s, clip, wst)
@@ -745,11 +751,28 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
                 _hip.call("yogo_conv2d_dgrad_bf16", g, pk, dx, act_ref, ref_act, Sp.mask, B, L.cin, L.cout, IH, IW, L.k, L.s, st)
             eng._tock()
             g = dx
+    if wq is not None:   # every layer's split-K reduction in ONE launch (they are ~21 us each, mostly launch and tail latency)
+        with torch.cuda.stream(_side_stream(dev) if _WGRAD_SIDE_STREAM else torch.cuda.current_stream()):
+            _hip.call("yogo_wgrad_reduce_flush", wq, _hip.stream_ptr())
     if _WGRAD_SIDE_STREAM:
         torch.cuda.current_stream().wait_stream(_side_stream(dev))
     keep.clear()
     bb = eng.backbone_ref()
     return [grads.get(id(p)) for p in bb.parameters()]
+
+
+_WGRAD_QUEUE = None
+
+
+def _wgrad_queue() -> int:
+    """the process's queue of deferred weight-gradient reductions (yogo_wgrad_reduce_queue_create; one host thread drives a GPU)"""
+    global _WGRAD_QUEUE
+    if _WGRAD_QUEUE is None:
+        import ctypes
+        h = ctypes.c_void_p(0)
+        _hip.call("yogo_wgrad_reduce_queue_create", ctypes.addressof(h))
+        _WGRAD_QUEUE = int(h.value)
+    return _WGRAD_QUEUE
 
 
 _ENGINES: "weakref.WeakKeyDictionary[nn.Module, Engine]" = weakref.WeakKeyDictionary()
