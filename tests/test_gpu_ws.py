@@ -68,6 +68,10 @@ CASES = [
     ("fwd_signs", 5, 128, 3, 3),        # one pixel group in use
     ("fwd_plain", 40, 128, 97, 129),    # 1 000 tiles: every workgroup walks several tiles, image changes at the seams
     ("fwd_signs", 24, 64, 193, 258),
+    ("dgrad", 2, 256, 20, 22),          # 16 chunks per tile
+    ("fwd_leaky", 1, 128, 300, 3),      # tall and three pixels wide: one band of width 3
+    ("fwd_plain", 1, 64, 3, 1000),      # three rows: every tile holds the whole height
+    ("dgrad_mask", 7, 128, 50, 131),    # widths one past a multiple of the band width
 ]
 
 
