@@ -365,6 +365,7 @@ struct ConvFirstBnWgradParams {
   int B, Cin, Cout, Mb, IH, IW, OH, OW, stride, act;
   int ext_gram;  // GRAM kernels: the caller already has P and G of this batch (yogo_conv_first_gram) -- skip that pass
   unsigned m_ow; // conv_first_bn_wgrad_pk_kernel: ceil(2^32 / OW) when pixel / OW may be taken as a multiply-high (OH * OW * OW < 2^32), else 0
+  unsigned m_ow2; // conv_first_bn_wgrad_pk2_kernel: ceil(2^32 / (OW / 2))
 };
 
 // GRAM (Cin = 1): z is the bias-free convolution of the patches, so A2[c][j] = invstd_c * (sum_j' W[c][j'] G[j'][j] - mean_c P[j])
@@ -690,6 +691,106 @@ __global__ __launch_bounds__(CF_THREADS, 3) void conv_first_bn_wgrad_pk_kernel(c
   }
 }
 
+// The sign-map sweep with TWO horizontally adjacent output pixels per lane and step (output width even).  The sweep above issues 8
+// vector-memory instructions per pixel and pass (six 16-bit image loads, the gradient unit, the sign word) and waits on the CU's
+// vector-memory path for most of its time (wait_any 0.55, issuing 0.29: profiles/r04_mfma_util.txt).  A pixel pair (2m, 2m + 1) reads
+// image columns 4m - 1 .. 4m + 3 of three rows: two ALIGNED dwords per row, [4m - 4, 4m) for its last byte and [4m, 4m + 4) -- 6 + 2 + 1
+// instructions per pair instead of 16.  Same arithmetic per element; a lane's pixels enter its sums in another order than above
+// (the sums agree to fp32 rounding, not bit for bit).
+__global__ __launch_bounds__(CF_THREADS, 3) void conv_first_bn_wgrad_pk2_kernel(const ConvFirstBnWgradParams p) {
+  constexpr int NJ = 9, PER = 2 * NJ + 2, COC = 8, NP = COC / 2;
+  __shared__ float red[4][COC * PER];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y;
+  const int npix = p.OH * p.OW, npair = npix >> 1, ow2 = p.OW >> 1;
+  const int qbase = blockIdx.x * (CF_THREADS * CFW_PPT / 2);
+  const int ncol = p.Cout * PER + NJ + NJ * NJ;
+  const unsigned char* ib = reinterpret_cast<const unsigned char*>(p.in) + (size_t)b * p.IH * p.IW;
+  const unsigned* sgp = reinterpret_cast<const unsigned*>(p.signs) + (size_t)b * npair;
+  float* prow = p.part + (size_t)(b * gridDim.x + blockIdx.x) * ncol;
+  for (int e = tid; e < NJ + NJ * NJ; e += CF_THREADS) prow[p.Cout * PER + e] = 0.f;   // P / G: the finalize reads the caller's
+  const bool leaky = p.act == ACT_LEAKY;   // (uniform)
+  for (int co0 = 0; co0 < p.Cout; co0 += COC) {
+    cf_f32x2 a1[NP][NJ], s1[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      s1[q] = cf_f32x2{0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) a1[q][j] = cf_f32x2{0.f, 0.f};
+    }
+    for (int k = 0; k < CFW_PPT / 2; ++k) {
+      const int pr = qbase + k * CF_THREADS + tid;
+      const bool ok = pr < npair;
+      const int pc = ok ? pr : 0;
+      const int oy = (int)__umulhi((unsigned)pc, p.m_ow2), m = pc - oy * ow2;   // pixel pair (oy, 2m), (oy, 2m + 1)
+      float x[2][NJ];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int iy = 2 * oy + kh - 1;  // <= IH - 1 (even sizes)
+        const bool rok = ok && iy >= 0;
+        const int o_ = rok ? iy * p.IW + 4 * m : 0;   // bytes o_ - 1 .. o_ + 3
+        const unsigned wb = *reinterpret_cast<const unsigned*>(ib + o_);
+        unsigned wa = *reinterpret_cast<const unsigned*>(ib + ((rok && m > 0) ? o_ - 4 : o_));
+        wa = (rok && m > 0) ? wa >> 24 : 0u;   // column 4m - 1 (zero padding in the first column)
+        const unsigned w = rok ? wb : 0u;
+        x[0][kh * 3 + 0] = (float)wa;
+        x[0][kh * 3 + 1] = (float)(w & 0xFFu);
+        x[0][kh * 3 + 2] = (float)((w >> 8) & 0xFFu);
+        x[1][kh * 3 + 0] = (float)((w >> 8) & 0xFFu);
+        x[1][kh * 3 + 1] = (float)((w >> 16) & 0xFFu);
+        x[1][kh * 3 + 2] = (float)(w >> 24);
+      }
+      const size_t u = ((size_t)b * p.Mb + (co0 >> 3)) * npix + 2 * (size_t)pc;
+      cf_u32x4 gw[2] = {p.g[u], p.g[u + 1]};
+      // a pixel's 16 sign bits: channel c < 4 or >= 12 at bit c, 4..7 at c + 4, 8..11 at c - 4; the pair's two words are one dword
+      unsigned sg2 = leaky ? sgp[pc] >> (co0 ? 4 : 0) : 0u;
+      if (!ok) gw[0] = gw[1] = cf_u32x4{0u, 0u, 0u, 0u};   // a pair beyond the tail contributes gb = 0 to every sum
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const unsigned gws[4] = {gw[e].x, gw[e].y, gw[e].z, gw[e].w};
+        const unsigned sgn = e ? sg2 >> 16 : sg2;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          const cf_f32x2 gv = {__builtin_bit_cast(float, gws[q] << 16), __builtin_bit_cast(float, gws[q] & 0xFFFF0000u)};
+          cf_f32x2 gb = gv;
+          if (leaky) {
+            const int pos = q < 2 ? 2 * q : 8 + 2 * (q - 2);   // (a constant of the unrolled loop)
+            const cf_f32x2 f = {(sgn >> pos) & 1u ? 1.f : LEAKY_SLOPE, (sgn >> (pos + 1)) & 1u ? 1.f : LEAKY_SLOPE};
+            gb = gv * f;
+          }
+          s1[q] += gb;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) a1[q][j] = __builtin_elementwise_fma(gb, cf_f32x2{x[e][j], x[e][j]}, a1[q][j]);
+        }
+      }
+    }
+    // cross-lane sums (DPP), then the four wavefronts through LDS -- the column layout of conv_first_bn_wgrad_kernel
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = 2 * q + h;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const float v1 = wave_sum(h ? a1[q][j].y : a1[q][j].x);
+          if (lane == 0) red[wave][c * PER + j] = v1;
+        }
+        const float t1 = wave_sum(h ? s1[q].y : s1[q].x);
+        if (lane == 0) {
+          red[wave][c * PER + 2 * NJ] = t1;
+          red[wave][c * PER + 2 * NJ + 1] = 0.f;   // (S2: derived by the finalize kernel)
+        }
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < COC * PER; e += CF_THREADS) {
+      const int c = e / PER, kk = e - c * PER;
+      if (!(kk >= NJ && kk < 2 * NJ)) prow[(co0 + c) * PER + kk] = red[0][e] + red[1][e] + red[2][e] + red[3][e];   // (the A2 columns come from the Gram matrix)
+    }
+    __syncthreads();
+  }
+}
+
 // sums [Cout*(2*NJ+2) + NJ (+ NJ*NJ)] -> dW (OIHW), dgamma, dbeta, each clamped to +-clip when clip > 0
 __global__ void conv_first_bn_wgrad_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ mean,
                                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
@@ -874,6 +975,11 @@ extern "C" int yogo_conv_first_bn_wgrad_bf16_xg(const void* in, int in_dtype, co
   return conv_first_bn_wgrad_impl(in, in_dtype, g, z, nullptr, mean, invstd, gamma, beta, part, B, Cin, Cout, IH, IW, stride, act, 1, stream);
 }
 extern "C" int yogo_conv_first_mfma_supported(int in_dtype, int Cin, int Cout, int IH, int IW, int stride);   // conv_first_mfma.hip
+static bool g_cf_pairs = true;   // the sign-map sweep takes two pixels per lane where the output width is even (A/B switch)
+extern "C" int yogo_conv_first_bn_wgrad_pairs(int on) {
+  g_cf_pairs = on != 0;
+  return YOGO_OK;
+}
 // 1 when the sweep can run WITHOUT the saved conv output: from the sign map of yogo_conv_first_mfma_signs (uint8 one-channel image,
 // stride 2, even sizes, Cout = 8 or 16, no activation or LeakyReLU, no conv bias, caller-held Gram matrix)
 static bool conv_first_fast_shape(int in_dtype, int Cin, int IH, int IW, int stride) {
@@ -907,7 +1013,10 @@ static int conv_first_bn_wgrad_impl(const void* in, int in_dtype, const void* g,
   if (B == 0) return YOGO_OK;
   dim3 grid(first_wgrad_tiles(p.OH, p.OW), B);
   const bool fast = conv_first_fast_shape(in_dtype, Cin, IH, IW, stride);
-  if (z == nullptr)   // (yogo_conv_first_bn_wgrad_bf16_xs checked the shape)
+  p.m_ow2 = p.OW >= 4 ? (unsigned)(((1ull << 32) + (unsigned)(p.OW / 2) - 1ull) / (unsigned)(p.OW / 2)) : 0u;
+  if (z == nullptr && p.OW % 2 == 0 && p.OW >= 4 && p.m_ow != 0 && g_cf_pairs)   // (yogo_conv_first_bn_wgrad_bf16_xs checked the shape)
+    hipLaunchKernelGGL(conv_first_bn_wgrad_pk2_kernel, grid, dim3(CF_THREADS), 0, stream, p);
+  else if (z == nullptr)
     hipLaunchKernelGGL(conv_first_bn_wgrad_pk_kernel<true>, grid, dim3(CF_THREADS), 0, stream, p);
   else if (fast && ext_gram && Cout % 8 == 0 && (act == ACT_NONE || act == ACT_LEAKY))
     hipLaunchKernelGGL(conv_first_bn_wgrad_pk_kernel<false>, grid, dim3(CF_THREADS), 0, stream, p);
