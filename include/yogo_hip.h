@@ -272,6 +272,7 @@ int yogo_conv_first_mfma_signs(const void* in, const float* w, const float* bias
 int yogo_conv_first_bn_wgrad_xs_supported(int in_dtype, int Cin, int Cout, int IH, int IW, int stride, int act);
 /* plan switch (tests / A-B tools): the _xs sweep with two adjacent pixels per lane (default, even output widths) or one */
 int yogo_conv_first_bn_wgrad_pairs(int on);
+int yogo_conv_first_mfma_pairs(int on);   /* ... and the forward sweep that writes y */
 int yogo_conv_first_bn_wgrad_bf16_xs(const void* in, int in_dtype, const void* g, const void* signs, const float* mean,
                                      const float* invstd, const float* gamma, const float* beta, float* part, int B, int Cin,
                                      int Cout, int IH, int IW, int stride, int act, yogo_stream_t stream);

@@ -229,6 +229,141 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const ConvFirstMfm
   }
 }
 
+// The training sweep (y, optionally z and the sign map; no statistics) with TWO horizontally adjacent output pixels per lane and step
+// (output width even): a wavefront takes 64 consecutive pixels as two MFMAs -- the even and the odd ones.  The kernel above issues 4
+// 16-bit image loads, a 16-byte store and a byte store per lane and 32 pixels and waits on the CU's vector-memory path; a pixel pair
+// (2m, 2m + 1) reads image columns 4m - 1 .. 4m + 3: two ALIGNED dwords per row, and its sign bytes leave as one dword per pair.
+// Same arithmetic per element: bit-identical outputs.
+__global__ __launch_bounds__(256) void conv_first_mfma2_kernel(const ConvFirstMfmaParams p) {
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  const int wave_g = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = gridDim.x * 4;
+  const int npix = p.OH * p.OW;
+  constexpr unsigned OOB = 0x80000000u;
+  cfm_bf16x8 wa;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int slot = 8 * half + j, ky = slot >> 2, kx = slot & 3;
+    const bool ok = ky < 3 && kx < 3 && l31 < p.Cout;
+    wa[j] = (__bf16)(ok ? p.w[l31 * 9 + min(ky, 2) * 3 + min(kx, 2)] : 0.f);
+  }
+  float bs[8], sc[8], sh[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int ch = (i < 4 ? 0 : 8) + 4 * half + (i & 3);
+    const bool ok = ch < p.Cout;
+    bs[i] = (ok && p.bias != nullptr) ? p.bias[ch] : 0.f;
+    sc[i] = sh[i] = 0.f;
+    if (ok) {
+      sc[i] = p.invstd[ch] * p.gamma[ch];
+      sh[i] = fmaf(-p.mean[ch], sc[i], p.beta[ch]);
+    }
+  }
+  const int gpi2 = (npix + 63) >> 6, total2 = p.B * gpi2;
+  int nb = wave_g / gpi2, ngi = wave_g - nb * gpi2;
+  unsigned n_a0 = 0, n_b0 = 0, n_a1 = 0, n_b1 = 0;
+  int n_pix = 0;
+#define CFM2_FETCH()                                                                                                   \
+  {                                                                                                                    \
+    n_pix = ngi * 64 + 2 * l31;                                                                                        \
+    const bool valid_ = n_pix < npix && nb < p.B;                                                                      \
+    const int pc_ = valid_ ? n_pix : npix - 2;                                                                         \
+    const int oy_ = (int)__umulhi((unsigned)pc_, p.m_ow), ox_ = pc_ - oy_ * p.OW;                                      \
+    const int r0_ = 2 * oy_ - 1 + 2 * half;                                                                            \
+    const auto rs_ = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (size_t)min(nb, p.B - 1) * p.IH * p.IW), (short)0, \
+                                                       p.IH * p.IW, 0x00020000);                                       \
+    const int o0_ = r0_ * p.IW + 2 * ox_; /* columns 4m .. 4m + 3 of the row; 4m - 4 .. 4m - 1 for the left neighbour */ \
+    const bool ok0_ = valid_ && r0_ >= 0, ok1_ = valid_ && half == 0;                                                  \
+    n_a0 = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs_, (ok0_ && ox_ > 0) ? o0_ - 4 : (int)OOB, 0, 0);          \
+    n_b0 = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs_, ok0_ ? o0_ : (int)OOB, 0, 0);                           \
+    n_a1 = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs_, (ok1_ && ox_ > 0) ? o0_ + p.IW - 4 : (int)OOB, 0, 0);   \
+    n_b1 = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs_, ok1_ ? o0_ + p.IW : (int)OOB, 0, 0);                    \
+  }
+  CFM2_FETCH()
+  for (int g = wave_g; g < total2; g += nwaves) {  // g is uniform over the wavefront
+    const int b = nb, pix = n_pix;
+    const bool valid = pix < npix;
+    const unsigned a0 = n_a0, b0 = n_b0, a1 = n_a1, b1 = n_b1;
+    ngi += nwaves;
+    while (ngi >= gpi2) {
+      ngi -= gpi2;
+      ++nb;
+    }
+    CFM2_FETCH()
+    unsigned sgn2 = 0;   // this lane's sign bytes of the pair: pixel 2m in bits 0..7, pixel 2m + 1 in bits 16..23
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      // bytes 1, 2, 3 of a word = kernel columns 0, 1, 2: pixel 2m reads (4m - 1, 4m, 4m + 1), pixel 2m + 1 (4m + 1, 4m + 2, 4m + 3)
+      const unsigned w0 = e ? b0 : (((a0 >> 24) << 8) | (b0 << 16));
+      const unsigned w1 = e ? b1 : (((a1 >> 24) << 8) | (b1 << 16));
+      unsigned bx, by, bz, bw_;
+      cfm_bytes_to_bf16(w0, bx, by);
+      cfm_bytes_to_bf16(w1, bz, bw_);
+      const cfm_u32x4 bw = {bx, by, bz, bw_};
+      cfm_f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, __builtin_bit_cast(cfm_bf16x8, bw), acc, 0, 0, 0);
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = acc[i];
+      if (p.bias != nullptr) {  // (uniform)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += bs[i];
+      }
+      cfm_bf16x8 o;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = (__bf16)v[i];
+      const int vo = valid ? (half * npix + pix + e) * 16 : (int)OOB;
+      if (p.z != nullptr) {
+        const cfm_u32x4 w4 = __builtin_bit_cast(cfm_u32x4, o);
+        const auto r0s = __builtin_amdgcn_permlane32_swap(w4.x, w4.z, false, false);
+        const auto r1s = __builtin_amdgcn_permlane32_swap(w4.y, w4.w, false, false);
+        const cfm_u32x4 st = {r0s[0], r1s[0], r0s[1], r1s[1]};
+        const auto rs_z = __builtin_amdgcn_make_buffer_rsrc((void*)(p.z + (size_t)b * 2 * npix), (short)0, 2 * npix * 16, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(st, rs_z, vo, 0, 0);
+      }
+      float r[8];   // BatchNorm + activation of the ROUNDED z, as yogo_bn_apply_act_bf16 computes it from the stored tensor
+#pragma unroll
+      for (int i = 0; i < 8; ++i) r[i] = fmaf((float)o[i], sc[i], sh[i]);
+      if (p.signs != nullptr) {
+        unsigned m = 0;
+#define CFM_SGN(I) "v_cmp_lt_f32_e32 vcc, 0, %" #I "\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t"
+        asm(CFM_SGN(8) CFM_SGN(7) CFM_SGN(6) CFM_SGN(5) CFM_SGN(4) CFM_SGN(3) CFM_SGN(2) "v_cmp_lt_f32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
+            : "+v"(m)
+            : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(r[4]), "v"(r[5]), "v"(r[6]), "v"(r[7])
+            : "vcc");
+#undef CFM_SGN
+        sgn2 |= m << (16 * e);
+      }
+      if (p.act == ACT_LEAKY) {  // (uniform branches around whole blocks)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = fmaxf(r[i], LEAKY_SLOPE * r[i]);
+      } else if (p.act == ACT_SILU) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = act_fwd(r[i], ACT_SILU);
+      }
+      cfm_bf16x8 yo;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) yo[i] = (__bf16)r[i];
+      const cfm_u32x4 w4 = __builtin_bit_cast(cfm_u32x4, yo);
+      const auto r0s = __builtin_amdgcn_permlane32_swap(w4.x, w4.z, false, false);
+      const auto r1s = __builtin_amdgcn_permlane32_swap(w4.y, w4.w, false, false);
+      const cfm_u32x4 st = {r0s[0], r1s[0], r0s[1], r1s[1]};
+      const auto rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (size_t)b * 2 * npix), (short)0, 2 * npix * 16, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b128(st, rs_y, vo, 0, 0);
+    }
+    if (p.signs != nullptr) {
+      // a pixel's two bytes are (half 0, half 1): the partner lane's pair comes over the crossbar, the lower half-wave stores the pair's
+      // four bytes as one dword
+      const unsigned other = (unsigned)__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, (int)sgn2);
+      const unsigned word = (sgn2 & 0xFFu) | ((other & 0xFFu) << 8) | ((sgn2 & 0xFF0000u)) | ((other & 0xFF0000u) << 8);
+      const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)(p.signs + (size_t)b * 2 * npix), (short)0, 2 * npix, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b32(word, rs_s, (valid && half == 0) ? 2 * pix : (int)OOB, 0, 0);
+    }
+  }
+#undef CFM2_FETCH
+}
+
 // ---- batch statistics without the convolution: P = sum patch (9), G = sum patch (x) patch (9 x 9) --------------------------
 // z_c = w_c . patch + b_c is linear in the patch, so  sum z_c = w_c . P + N b_c  and  sum (z_c - b_c)^2 = w_c^T G w_c:  the
 // statistics of ALL channels follow from 54 channel-independent sums over the uint8 image.  They are accumulated as INTEGERS
@@ -433,6 +568,11 @@ extern "C" int yogo_conv_first_mfma_stats_rows(int B, int IH, int IW, int* rows)
 //   stats_part: partial (sum, sumsq) of conv + bias (fp32, before rounding) -> yogo_bn_finalize(part, rows, 16, ...)
 //   z: conv + bias in bf16 NCHW8c;  y: act((z - mean) * invstd * gamma + beta) in bf16 NCHW8c (needs mean/invstd/gamma/beta);
 //   without y the activation goes onto z (inference with BatchNorm folded into w and bias): z = act(conv + bias)
+static bool g_cfm_pairs = true;   // (A/B switch, with yogo_conv_first_bn_wgrad_pairs)
+extern "C" int yogo_conv_first_mfma_pairs(int on) {
+  g_cfm_pairs = on != 0;
+  return YOGO_OK;
+}
 static int conv_first_mfma_impl(const void* in, const float* w, const float* bias, void* z, void* y, void* signs, const float* mean,
                                const float* invstd, const float* gamma, const float* beta, float* stats_part, int B, int Cout,
                                int IH, int IW, int act, hipStream_t stream);
@@ -465,7 +605,11 @@ static int conv_first_mfma_impl(const void* in, const float* w, const float* bia
   p.gpi = cdiv(p.OH * p.OW, 32); p.total = B * p.gpi;
   p.m_ow = cfm_magic(p.OW);
   YOGO_CHECK_ARG((long long)p.total * 32 < (1ll << 31) && (long long)p.OH * p.OW * p.OW < (1ll << 32), "conv_first_mfma: batch / image too large");
-  hipLaunchKernelGGL(conv_first_mfma_kernel, dim3(cfm_grid(p.total)), dim3(256), 0, stream, p);
+  // the training sweep (y [+ z] [+ sign map], no statistics) at an even output width: two pixels per lane
+  if (g_cfm_pairs && y != nullptr && stats_part == nullptr && p.OW % 2 == 0 && p.OW >= 4)
+    hipLaunchKernelGGL(conv_first_mfma2_kernel, dim3(cfm_grid(B * cdiv(p.OH * p.OW, 64))), dim3(256), 0, stream, p);
+  else
+    hipLaunchKernelGGL(conv_first_mfma_kernel, dim3(cfm_grid(p.total)), dim3(256), 0, stream, p);
   YOGO_CHECK_LAUNCH("conv_first_mfma");
   return YOGO_OK;
 }
