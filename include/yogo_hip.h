@@ -197,6 +197,7 @@ int yogo_conv2d_wgrad_bf16(const void* x, const void* g, float* dw, float* db, v
  * to 16 reductions (a 17th flushes first) and belongs to one host thread. */
 int yogo_wgrad_reduce_queue_create(void** queue_out);
 int yogo_wgrad_reduce_queue_destroy(void* queue);
+int yogo_wgrad_reduce_queue_reset(void* queue);   /* forget the recorded reductions without running them */
 int yogo_wgrad_reduce_flush(void* queue, yogo_stream_t stream);
 int yogo_conv2d_wgrad_bf16_deferred(const void* x, const void* g, float* dw, float* db, void* workspace, int B, int Cin, int Cout, int IH,
                                     int IW, int ks, int stride, float clip, void* queue, yogo_stream_t stream);

@@ -436,6 +436,14 @@ extern "C" int yogo_wgrad_reduce_queue_create(void** queue_out) {
   *queue_out = q;
   return YOGO_OK;
 }
+// forget whatever is recorded (a backward pass that failed half way leaves reductions whose buffers are gone)
+extern "C" int yogo_wgrad_reduce_queue_reset(void* queue) {
+  YOGO_CHECK_ARG(queue != nullptr, "wgrad_reduce_queue_reset: null queue");
+  WgradReduceQueue* q = reinterpret_cast<WgradReduceQueue*>(queue);
+  q->m.n = 0;
+  q->blocks = 0;
+  return YOGO_OK;
+}
 extern "C" int yogo_wgrad_reduce_flush(void* queue, hipStream_t stream) {
   YOGO_CHECK_ARG(queue != nullptr, "wgrad_reduce_flush: null queue");
   return wgrad_reduce_flush(reinterpret_cast<WgradReduceQueue*>(queue), stream);

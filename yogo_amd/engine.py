@@ -622,6 +622,8 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
     # the split-K reductions of the weight gradients: deferred to ONE launch behind the last layer -- unless a per-layer hook wants
     # each layer's gradients as soon as the layer is through
     wq = _wgrad_queue() if (_WGRAD_DEFER_REDUCE and on_layer is None) else None
+    if wq is not None:
+        _hip.call("yogo_wgrad_reduce_queue_reset", wq)   # (a pass that raised half way must not leave its reductions behind)
     if graw.dtype == torch.bfloat16 and graw.ndim == 5:   # already NCHW8c (yogo_decode_bwd_bf16)
         g = graw
         B = g.shape[0]
