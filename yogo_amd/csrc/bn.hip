@@ -21,7 +21,20 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   const int c = blockIdx.x * 8 + cl;
   double s = 0.0, q = 0.0;
   if (c < C) {
-    for (int r = slice; r < rows; r += 32) {
+    // (eight loads in flight, added in the same order: the chain of dependent load -> add steps was what the 24 us of this
+    //  16-workgroup kernel were)
+    int r = slice;
+    for (; r + 7 * 32 < rows; r += 8 * 32) {
+      float2 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float2*>(part + ((size_t)(r + j * 32) * row_stride + c) * 2);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        s += (double)v[j].x;
+        q += (double)v[j].y;
+      }
+    }
+    for (; r < rows; r += 32) {
       const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)r * row_stride + c) * 2);
       s += (double)v.x;
       q += (double)v.y;
@@ -187,7 +200,15 @@ __global__ __launch_bounds__(256) void partials_reduce_kernel(const float* __res
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= N) return;
   double s = 0.0;
-  for (int r = 0; r < rows; ++r) s += (double)part[(size_t)r * N + j];
+  int r = 0;   // (eight loads in flight, added in the same order)
+  for (; r + 8 <= rows; r += 8) {
+    float v8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v8[k] = part[(size_t)(r + k) * N + j];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += (double)v8[k];
+  }
+  for (; r < rows; ++r) s += (double)part[(size_t)r * N + j];
   float v = (float)s;
   if (clip > 0.f) v = fminf(fmaxf(v, -clip), clip);
   out[j] = v;
@@ -285,7 +306,15 @@ __global__ __launch_bounds__(256) void partials_fold_kernel(float* __restrict__ 
   const int s = blockIdx.y;
   if (j >= N) return;
   double acc = 0.0;
-  for (int r = s; r < rows; r += S) acc += (double)part[(size_t)r * N + j];
+  int r = s;   // (eight loads in flight, added in the same order)
+  for (; r + 7 * S < rows; r += 8 * S) {
+    float v8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v8[k] = part[(size_t)(r + k * S) * N + j];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += (double)v8[k];
+  }
+  for (; r < rows; r += S) acc += (double)part[(size_t)r * N + j];
   part[(size_t)s * N + j] = (float)acc;
 }
 
