@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void conv_first_mfma2_kernel(const ConvFirstMf
     const bool ok = ch < p.Cout;
     bs[i] = (ok && p.bias != nullptr) ? p.bias[ch] : 0.f;
     sc[i] = sh[i] = 0.f;
-    if (ok) {
+    if (ok && p.y != nullptr) {
       sc[i] = p.invstd[ch] * p.gamma[ch];
       sh[i] = fmaf(-p.mean[ch], sc[i], p.beta[ch]);
     }
@@ -310,6 +310,15 @@ __global__ __launch_bounds__(256) void conv_first_mfma2_kernel(const ConvFirstMf
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] += bs[i];
       }
+      if (p.y == nullptr && p.act != ACT_NONE) {  // inference (BatchNorm folded into w / bias): z = act(conv + bias)
+        if (p.act == ACT_LEAKY) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], LEAKY_SLOPE * v[i]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = act_fwd(v[i], ACT_SILU);
+        }
+      }
       cfm_bf16x8 o;
 #pragma unroll
       for (int i = 0; i < 8; ++i) o[i] = (__bf16)v[i];
@@ -322,6 +331,7 @@ __global__ __launch_bounds__(256) void conv_first_mfma2_kernel(const ConvFirstMf
         const auto rs_z = __builtin_amdgcn_make_buffer_rsrc((void*)(p.z + (size_t)b * 2 * npix), (short)0, 2 * npix * 16, 0x00020000);
         __builtin_amdgcn_raw_buffer_store_b128(st, rs_z, vo, 0, 0);
       }
+      if (p.y == nullptr) continue;   // (uniform)
       float r[8];   // BatchNorm + activation of the ROUNDED z, as yogo_bn_apply_act_bf16 computes it from the stored tensor
 #pragma unroll
       for (int i = 0; i < 8; ++i) r[i] = fmaf((float)o[i], sc[i], sh[i]);
@@ -605,8 +615,8 @@ static int conv_first_mfma_impl(const void* in, const float* w, const float* bia
   p.gpi = cdiv(p.OH * p.OW, 32); p.total = B * p.gpi;
   p.m_ow = cfm_magic(p.OW);
   YOGO_CHECK_ARG((long long)p.total * 32 < (1ll << 31) && (long long)p.OH * p.OW * p.OW < (1ll << 32), "conv_first_mfma: batch / image too large");
-  // the training sweep (y [+ z] [+ sign map], no statistics) at an even output width: two pixels per lane
-  if (g_cfm_pairs && y != nullptr && stats_part == nullptr && p.OW % 2 == 0 && p.OW >= 4)
+  // the sweeps that write tensors (training: y [+ z] [+ sign map]; inference: z = act(conv + bias)) at an even output width: two pixels per lane
+  if (g_cfm_pairs && (y != nullptr || z != nullptr) && stats_part == nullptr && p.OW % 2 == 0 && p.OW >= 4)
     hipLaunchKernelGGL(conv_first_mfma2_kernel, dim3(cfm_grid(B * cdiv(p.OH * p.OW, 64))), dim3(256), 0, stream, p);
   else
     hipLaunchKernelGGL(conv_first_mfma_kernel, dim3(cfm_grid(p.total)), dim3(256), 0, stream, p);
