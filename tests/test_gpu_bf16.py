@@ -197,6 +197,56 @@ def test_wgrad_bf16_workspace_is_large_enough(case):
     assert float((db.cpu() - b.grad).abs().max()) < 1e-4 * float(b.grad.abs().max()), case
 
 
+def test_deferred_wgrad_reductions_through_the_c_abi():
+    """yogo_conv2d_wgrad_bf16_deferred + yogo_wgrad_reduce_flush against yogo_conv2d_wgrad_bf16, 20 reductions of six shapes in one
+    queue (a queue holds 16: the 17th flushes the first sixteen), with and without bias gradient and clamp: the same bits; a reset
+    queue runs nothing."""
+    import ctypes
+    h = H()
+    st = h.stream_ptr()
+    qh = ctypes.c_void_p(0)
+    h.call("yogo_wgrad_reduce_queue_create", ctypes.addressof(qh))
+    q = int(qh.value)
+    try:
+        shapes = [(1, 128, 32, 9, 12, 3, 1), (2, 128, 24, 11, 20, 3, 1), (1, 128, 128, 9, 17, 3, 1), (2, 16, 32, 9, 12, 3, 1),
+                  (1, 128, 12, 7, 11, 1, 1), (2, 32, 64, 18, 22, 3, 2)]
+        g = torch.Generator().manual_seed(77)
+        jobs = []
+        for j in range(20):
+            B, Cin, Cout, IH, IW, k, s = shapes[j % len(shapes)]
+            pad = 1 if k == 3 else 0
+            OH, OW = (IH + 2 * pad - k) // s + 1, (IW + 2 * pad - k) // s + 1
+            x8 = to8c(bf(torch.randn(B, Cin, IH, IW, generator=g)))
+            g8 = to8c(bf(torch.randn(B, Cout, OH, OW, generator=g)))
+            nbytes = h.query_size("yogo_conv2d_wgrad_bf16_workspace_bytes", B, Cin, Cout, IH, IW, k, s)
+            clip = 0.0 if j % 3 else 0.05
+            want_db = j % 2 == 0
+            ref = (torch.full((Cout, Cin, k, k), float("nan"), device="cuda"), torch.full((Cout,), float("nan"), device="cuda") if want_db else None)
+            got = (torch.full_like(ref[0], float("nan")), torch.full_like(ref[1], float("nan")) if want_db else None)
+            ws0 = torch.empty(nbytes // 4, device="cuda")
+            ws1 = torch.empty(nbytes // 4, device="cuda")
+            h.call("yogo_conv2d_wgrad_bf16", x8, g8, ref[0], ref[1], ws0, B, Cin, Cout, IH, IW, k, s, clip, st)
+            h.call("yogo_conv2d_wgrad_bf16_deferred", x8, g8, got[0], got[1], ws1, B, Cin, Cout, IH, IW, k, s, clip, q, st)
+            jobs.append((ref, got, ws1, x8, g8))
+        torch.cuda.synchronize()
+        assert not bool(torch.isnan(jobs[0][1][0]).any())      # the first sixteen ran when the seventeenth was recorded
+        assert bool(torch.isnan(jobs[19][1][0]).all())         # the last four wait for the flush
+        h.call("yogo_wgrad_reduce_flush", q, st)
+        torch.cuda.synchronize()
+        for ref, got, *_ in jobs:
+            assert torch.equal(ref[0], got[0]) and (ref[1] is None or torch.equal(ref[1], got[1]))
+        # recorded, then forgotten: nothing is written
+        B, Cin, Cout, IH, IW, k, s = shapes[0]
+        dwx = torch.full((Cout, Cin, k, k), float("nan"), device="cuda")
+        h.call("yogo_conv2d_wgrad_bf16_deferred", jobs[0][3], jobs[0][4], dwx, None, jobs[0][2], B, Cin, Cout, IH, IW, k, s, 0.0, q, st)
+        h.call("yogo_wgrad_reduce_queue_reset", q)
+        h.call("yogo_wgrad_reduce_flush", q, st)
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(dwx).all())
+    finally:
+        h.call("yogo_wgrad_reduce_queue_destroy", q)
+
+
 @pytest.mark.parametrize("B,IH,IW,Cout,use_bias", [(3, 20, 24, 16, False), (2, 36, 70, 7, True), (2, 772, 1032, 16, False)])
 def test_layer0_on_matrix_cores(B, IH, IW, Cout, use_bias):
     """yogo_conv_first_mfma: uint8 image -> conv (bf16-rounded weights, exact bf16 inputs, fp32 accumulation) + BatchNorm sums,
