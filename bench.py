@@ -409,7 +409,7 @@ def main():
             tw = [(a, n) for a, n in tw if a is not None and n]
             traffic = round(sum(a * n for a, n in tw) / sum(n for _, n in tw), 1) if tw else None
             allc = [e for e in prof_all if e[0] in ("fwd", "dgrad") and e[2] in (30, 34)]
-            roof = {"bound": "mfma", "kernel": "conv_bf16_ws_kernel<0|7> (persistent wavefront-specialised stride-1 bf16 convolutions with 128 output "
+            roof = {"bound": "mfma", "kernel": "conv_bf16_ws_kernel<0|3|7> (persistent wavefront-specialised stride-1 bf16 convolutions with 128 output "
                                                "channels: forward of layers 3/5/6, data gradient of layers 5/6)",
                     "achieved": round(achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
