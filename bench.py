@@ -333,7 +333,8 @@ def main():
     # breakdown of every convolution launch comes from a few untimed steps after it
     dominant_tag = 34 if args.dtype == "bf16" else 4
     trainer.engine.prof = []
-    trainer.engine.prof_only = {dominant_tag}
+    # (tag 35: the stride-2 128 -> 128 forward, the one launch of north_star's K5-K8 forward set that is not the dominant kernel)
+    trainer.engine.prof_only = {dominant_tag, 35} if args.dtype == "bf16" else {dominant_tag}
     # per step: host time to ENQUEUE the step (perf_counter around trainer.step, no sync) and one HIP event pair on the launch
     # stream -- whether the timed region was GPU-bound or waiting for the host shows in the record itself
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -366,6 +367,21 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+    # how many ranks the GRADIENT transport actually joins: a ones-vector summed through the trainer's own exchange (the same
+    # exchange_begin / exchange_end the step uses: torch.distributed "nccl" = RCCL, or librccl through the C ABI under --comm rccl)
+    transport = "none (one rank)"
+    rccl_ranks = 1
+    if world > 1:
+        keep = trainer.flat.grad[:64].clone()
+        trainer.flat.grad[:64].fill_(1.0)
+        trainer.exchange_begin(0, 64)
+        trainer.exchange_end()
+        torch.cuda.synchronize()
+        joined = int(round(float(trainer.flat.grad[:64].min().item())))
+        trainer.flat.grad[:64].copy_(keep)
+        is_rccl = args.comm == "rccl" or args.backend == "nccl"
+        transport = ("librccl via yogo_comm_*" if args.comm == "rccl" else f"torch.distributed {args.backend}") + f": ones-vector all-reduce summed to {joined}"
+        rccl_ranks = joined if is_rccl else 0
 
     if rank == 0:
         # ---- roofline of the dominant kernel, from the in-loop HIP events ---------------------------------------
@@ -433,6 +449,23 @@ def main():
                     "traffic_source": "profiles/traffic.json (committed rocprofv3 --pmc passes), not measured in this run",
                     "calls_timed": len(sel), "avg_call_ms": round(ms / max(1, len(sel)), 4)}
         value = world * B * args.steps / dt
+        rec_ns = None
+        if args.dtype == "bf16":
+            # what north_star names: ">= 70 % of gfx950 MFMA peak on the 3x3 conv GEMM" on the forward of the 64->128 / 128->128 3x3
+            # layers (SURVEY.md K5-K8 = yogo/model_defns.py:49-65, layers 3..6 here), stride-2 layer 4 included -- Sigma FLOPs / Sigma
+            # HIP-event time over those launches of the timed region
+            ns = [e for e in prof if e[0] == "fwd" and 3 <= e[1] <= 6]
+            ns_ms = ms_of(ns)
+            ns_tf = sum(e[3] for e in ns) / max(ns_ms, 1e-9) / 1e9
+            per = {}
+            for e in ns:
+                a = per.setdefault(e[1], [0.0, 0.0])
+                a[0] += e[4].elapsed_time(e[5])
+                a[1] += e[3]
+            rec_ns = {"bound": "mfma", "kernels": "forward of layers 3-6 (K5-K8: conv 64->128 s1, 128->128 s2, 128->128 s1 x 2)",
+                      "achieved": round(ns_tf, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ns_tf / BF16_MFMA_PEAK_TFLOPS, 4),
+                      "calls_timed": len(ns), "ms_per_step": round(ns_ms / max(1, args.steps), 4),
+                      "per_layer_tflops": {str(k): round(v[1] / max(v[0], 1e-9) / 1e9, 1) for k, v in sorted(per.items())}}
         rec = {
             "metric": "training images/sec (772x1032 gray)", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
@@ -441,11 +474,13 @@ def main():
                                    "7 classes" + ("" if args.dtype == "bf16" else " -- run at fp32 storage+arithmetic"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}"},
             "roofline": roof,
+            "roofline_north_star_fwd": rec_ns,
             "host_enqueue_ms_per_step": round(1e3 * _median(enq), 3),
             "host_enqueue_ms_per_step_max": round(1e3 * max(enq), 3),
             "gpu_ms_per_step_events": round(_median(gpu_step_ms), 3),
             "gpu_ms_per_step_events_min_max": [round(min(gpu_step_ms), 3), round(max(gpu_step_ms), 3)],
-            "rccl_ranks": (world if (world > 1 and args.backend == "nccl") else (1 if world == 1 else 0)),
+            "rccl_ranks": rccl_ranks,
+            "gradient_transport": transport,
             "step_tflops": round(value * TRAIN_GFLOP_PER_IMG / 1e3, 2),
             "conv_breakdown": by_kind,
             "loss": round(loss_rec["loss"], 4),

@@ -147,11 +147,13 @@ int yogo_conv_bf16_packed_bytes(int Cin, int Cout, int ksize, int mode, size_t* 
 int yogo_conv_bf16_pack(const float* w_oihw, const float* scale, void* packed, int Cin, int Cout, int ksize, int mode,
                         yogo_stream_t stream);
 int yogo_conv2d_fwd_bf16_stats_shape(int B, int Cin, int Cout, int IH, int IW, int ksize, int stride, int* rows, int* mpad);
-/* Plan switch (no counterpart in the reference; cuDNN picks its algorithm behind torch.backends.cudnn.benchmark,
- * yogo/train.py:36).  on = 1 (default): the stride-1 3x3 bf16 convolutions with 128 output channels and 64 / 128 / ... input
- * channels (forward of yogo/model_defns.py:49-65's 128-channel blocks and their data gradients) run on the persistent
- * 4-wavefront kernel (conv_bf16_p4_kernel); on = 0: on the tiled 8-wavefront kernel.  Results are bit-identical. */
-int yogo_conv_bf16_persistent(int on);
+/* Plan (no counterpart in the reference; cuDNN picks its algorithm behind torch.backends.cudnn.benchmark, yogo/train.py:36): the 3x3
+ * bf16 convolutions with 128 GEMM rows and 64 / 128 / ... contraction channels (forward of yogo/model_defns.py:49-65's 128-channel
+ * blocks and their data gradients) run on the persistent wavefront-specialised kernels (conv_bf16_ws_kernel; 8 wavefronts per CU: 4
+ * compute, 4 load / store), everything else on the tiled conv_bf16_kernel.  The two families agree bit for bit where the tiled plan
+ * also steps the contraction in 16-channel chunks (every shape of the training step), within one bf16 ulp otherwise.  The library has
+ * no run-time plan switch and no mutable global state besides its lazily-loaded module handles and the launch log: the A/B switches
+ * used by tests/ and tools/ (yogo_hook_*) exist only in libyogo_hip_hooks.so (build.sh, -DYOGO_TEST_HOOKS), which the package never loads. */
 /* y = chan_scale * act(conv(x) + bias); out: bf16 NCHW8c, or fp32 NCHW when out_f32 != NULL (the head);
  * stats_part (optional): BatchNorm partial (sum, sumsq) of the fp32 pre-activation */
 int yogo_conv2d_fwd_bf16(const void* in, const void* packed, const float* bias, void* out, float* out_f32,
@@ -194,7 +196,8 @@ int yogo_conv2d_wgrad_bf16(const void* x, const void* g, float* dw, float* db, v
 /* ... with the split-K reduction deferred (ABI 5): recorded in `queue` and run by yogo_wgrad_reduce_flush together with every other
  * recorded one -- one launch for the weight gradients of a whole backward pass (the per-layer launches are ~21 us each, mostly launch and
  * tail latency).  dw / db / workspace stay valid until the flush; results are bit-identical to yogo_conv2d_wgrad_bf16.  A queue holds up
- * to 16 reductions (a 17th flushes first) and belongs to one host thread. */
+ * to 16 reductions (a 17th flushes first, on the stream of the call that records it) and belongs to one host thread AND one stream:
+ * record and flush a queue on the same stream. */
 int yogo_wgrad_reduce_queue_create(void** queue_out);
 int yogo_wgrad_reduce_queue_destroy(void* queue);
 int yogo_wgrad_reduce_queue_reset(void* queue);   /* forget the recorded reductions without running them */
@@ -271,9 +274,7 @@ int yogo_conv_first_mfma_signs(const void* in, const float* w, const float* bias
                                const float* invstd, const float* gamma, const float* beta, int B, int Cout, int IH, int IW, int act,
                                yogo_stream_t stream);
 int yogo_conv_first_bn_wgrad_xs_supported(int in_dtype, int Cin, int Cout, int IH, int IW, int stride, int act);
-/* plan switch (tests / A-B tools): the _xs sweep with two adjacent pixels per lane (default, even output widths) or one */
-int yogo_conv_first_bn_wgrad_pairs(int on);
-int yogo_conv_first_mfma_pairs(int on);   /* ... and the forward sweep that writes y */
+/* (both sweeps take two adjacent pixels per lane where the output width is even, one otherwise) */
 int yogo_conv_first_bn_wgrad_bf16_xs(const void* in, int in_dtype, const void* g, const void* signs, const float* mean,
                                      const float* invstd, const float* gamma, const float* beta, float* part, int B, int Cin,
                                      int Cout, int IH, int IW, int stride, int act, yogo_stream_t stream);

@@ -213,3 +213,36 @@ def teacher_forced_bf16_step_check(O, tr, model, x, lab, spec, sd0, what):
             check_grad(f"model.{i}.1.bias", r["dbeta"], rt)
         if i > 0:
             assert_bf16_tensor_matches(from8c_cpu(tc[("g", i - 1)], spec[i - 1][0]), r["dx"], f"L{i - 1} g = bf16(data gradient of L{i})")
+
+
+# ---- the test-hooks library ------------------------------------------------------------------------------------------------------
+# libyogo_hip_hooks.so (yogo_amd/csrc/build.sh) = the product's objects with the three files that own a plan choice recompiled under
+# -DYOGO_TEST_HOOKS: the same kernels plus yogo_hook_conv_bf16_persistent / yogo_hook_conv_first_mfma_pairs /
+# yogo_hook_conv_first_bn_wgrad_pairs.  The product library has no such switch (no mutable global state); A/B and bit-identity tests
+# bind the hooks library in place of the product's for their duration.
+import contextlib
+
+
+@contextlib.contextmanager
+def hooks_library():
+    import ctypes
+    import os
+
+    from yogo_amd import _hip
+
+    path = os.path.join(os.path.dirname(_hip.LIB_PATH), "libyogo_hip_hooks.so")
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} missing: run `bash yogo_amd/csrc/build.sh` (it builds the product and the hooks library)")
+    _hip.lib()
+    L = _hip.bind(path, _hip.prototypes())
+    for name in ("yogo_hook_conv_bf16_persistent", "yogo_hook_conv_first_mfma_pairs", "yogo_hook_conv_first_bn_wgrad_pairs"):
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_int]
+    prev = _hip._lib
+    _hip._lib = L
+    try:
+        yield L
+    finally:
+        for name in ("yogo_hook_conv_bf16_persistent", "yogo_hook_conv_first_mfma_pairs", "yogo_hook_conv_first_bn_wgrad_pairs"):
+            getattr(L, name)(1)
+        _hip._lib = prev

@@ -34,13 +34,18 @@ def main():
     xs = O.synthetic_images(world * Bper, Himg, Wimg, seed=5)
     labs = O.synthetic_labels(world * Bper, model.Sx, model.Sy, K=5, num_classes=C, seed=6)
     x, lab = xs[rank * Bper:(rank + 1) * Bper].cuda(), labs[rank * Bper:(rank + 1) * Bper].cuda()
+    from yogo_amd import _hip
+
+    _hip.launch_log(True)
     tr.step(x, lab)
     torch.cuda.synchronize()
+    log = _hip.read_launch_log()
+    _hip.launch_log(False)
     sd1 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     tr.broadcast_buffers()     # what the Trainer does in front of validation: rank 0's BatchNorm statistics everywhere
     torch.cuda.synchronize()
     torch.save({"sd0": sd0, "grad_sum": tr.flat.grad.cpu(), "flat": tr.flat.flat.cpu(), "loss": tr.loss_components(),
-                "sd1": sd1, "sd2": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, "split_off": tr.split_off},
+                "sd1": sd1, "sd2": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, "split_off": tr.split_off, "launch_log": log},
                os.path.join(outdir, f"rank{rank}.pt"))
     dist.barrier()
     tr.close()

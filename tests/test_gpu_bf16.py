@@ -293,13 +293,14 @@ def test_layer0_on_matrix_cores(B, IH, IW, Cout, use_bias):
     nflip = int((sg.cpu() != want).sum())
     assert nflip <= 1e-5 * want.numel() + 1, (nflip, want.numel())   # (an fma against a multiply and an add, next to zero)
     # the two-pixels-per-lane form of the sweep (even output widths; the default) against the one-pixel form: the same bits
-    h.call("yogo_conv_first_mfma_pairs", 0)
-    try:
+    from _util import hooks_library
+
+    with hooks_library():   # (the product library has no plan switch: the one-pixel form runs in the test-hooks build of the same objects)
+        h.call("yogo_hook_conv_first_mfma_pairs", 0)
         z1, y1 = torch.full_like(z, float("nan")), torch.full_like(z, float("nan"))
         sg1 = torch.full_like(sg, 0x55)
         h.call("yogo_conv_first_mfma_signs", xc, wc, bc, z1, y1, sg1, mean.cuda(), invstd.cuda(), gamma.cuda(), beta.cuda(), B, Cout, IH, IW, 1, st)
-    finally:
-        h.call("yogo_conv_first_mfma_pairs", 1)
+        torch.cuda.synchronize()
     assert torch.equal(z1.view(torch.int16), z.view(torch.int16)) and torch.equal(y1.view(torch.int16), y.view(torch.int16))
     assert torch.equal(sg1, sg)
     # and the direct kernel with the same (rounded) weights agrees to the output rounding

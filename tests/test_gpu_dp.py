@@ -40,6 +40,14 @@ def test_two_ranks_on_one_card(tmp_path, half):
         assert torch.equal(res[0]["sd0"][k], res[1]["sd0"][k]), k
     assert torch.equal(res[0]["flat"], res[1]["flat"]) and torch.equal(res[0]["grad_sum"], res[1]["grad_sum"])
     assert 0 < res[0]["split_off"] < res[0]["flat"].numel()
+    if half:
+        # the world > 1 step is the step the bench measures: the split-K reductions of the weight gradients stay deferred under the
+        # overlap hook -- one multi-reduce launch in front of the tail part's all-reduce, one behind the last layer, none per layer
+        for r in range(world):
+            names = [ln.split("|")[0].strip() for ln in res[r]["launch_log"]]
+            multi = [n for n in names if n.startswith("wgrad_reduce_multi_kernel")]
+            single = [n for n in names if n.startswith("wgrad_reduce_kernel")]
+            assert len(multi) == 2 and not single, (r, multi, single)
     # BatchNorm statistics stay per rank (the reference has no SyncBN): different shards -> different running means
     assert not torch.equal(res[0]["sd1"]["model.0.1.running_mean"], res[1]["sd1"]["model.0.1.running_mean"])
     # ... until the Trainer is about to evaluate: HipTrainer.broadcast_buffers hands every rank rank 0's statistics (DDP's

@@ -15,6 +15,17 @@ def _blocks(c):
 
 
 def _run(persistent, kind, B, Cin, H, W, seed):
+    """persistent: the PRODUCT library (libyogo_hip.so, which has no plan switch); tiled: the test-hooks library -- the same objects
+    plus yogo_hook_conv_bf16_persistent (tests/_util.py:hooks_library)"""
+    import contextlib
+
+    from _util import hooks_library
+
+    with (contextlib.nullcontext() if persistent else hooks_library()):
+        return _run_in(persistent, kind, B, Cin, H, W, seed)
+
+
+def _run_in(persistent, kind, B, Cin, H, W, seed):
     from yogo_amd import _hip as Hh
 
     Cout = 128
@@ -25,7 +36,8 @@ def _run(persistent, kind, B, Cin, H, W, seed):
     y8 = torch.full((B, _blocks(Cout), H, W, 8), 7.0, device="cuda").to(torch.bfloat16)   # poisoned: every unit must be written
     bias = torch.randn(Cout, device="cuda", generator=g)
     msk = (torch.rand(B, Cout, device="cuda", generator=g) > 0.2).float() / 0.8
-    Hh.call("yogo_conv_bf16_persistent", 1 if persistent else 0)
+    if not persistent:
+        Hh.call("yogo_hook_conv_bf16_persistent", 0)
     try:
         Hh.launch_log(True)
         sg = None
@@ -52,7 +64,6 @@ def _run(persistent, kind, B, Cin, H, W, seed):
         log = Hh.read_launch_log()
     finally:
         Hh.launch_log(False)
-        Hh.call("yogo_conv_bf16_persistent", 1)
     return y8, sg, log
 
 
@@ -106,3 +117,49 @@ def test_persistent_kernel_repeats_itself():
     for _ in range(3):
         b, sb, _ = _run(True, "fwd_signs", 16, 128, 97, 129, seed=5)
         assert torch.equal(a.view(torch.int16), b.view(torch.int16)) and torch.equal(sa, sb)
+
+
+@pytest.mark.parametrize("mode,B,Cin,H,W", [(4, 2, 128, 23, 37), (5, 2, 64, 19, 45), (4, 1, 96, 40, 41), (5, 3, 128, 9, 11)])
+def test_scaled_modes_against_cpu_fp32(mode, B, Cin, H, W):
+    """conv_bf16_ws_kernel<4> (channel scale, no activation: the data gradient into a Dropout2d block) and <5> (LeakyReLU + channel
+    scale, no sign map: an eval-style forward with a mask) are never launched by base_model's training step, so beside the
+    bit-identity with the tiled kernel they get an independent reference here: a CPU fp32 convolution of the same bf16-rounded
+    operands (yogo/model_defns.py:49-65's blocks: conv + bias -> LeakyReLU -> Dropout2d scale), one bf16 rounding of the output."""
+    import torch.nn.functional as F
+
+    from yogo_amd import _hip as Hh
+
+    st = Hh.stream_ptr()
+    g = torch.Generator().manual_seed(100 + mode + H)
+    w = (torch.randn(128, Cin, 3, 3, generator=g) * 0.05).to(torch.bfloat16).float()
+    x = torch.randn(B, Cin, H, W, generator=g).to(torch.bfloat16).float()
+    bias = torch.randn(128, generator=g)
+    msk = (torch.rand(B, 128, generator=g) > 0.2).float() / 0.8
+    x8 = torch.empty(B, _blocks(Cin), H, W, 8, dtype=torch.bfloat16, device="cuda")
+    Hh.call("yogo_nchw_f32_to_bf16_8c", x.cuda(), x8, B, Cin, H * W, st)
+    y8 = torch.full((B, 16, H, W, 8), 7.0, device="cuda").to(torch.bfloat16)
+    Hh.launch_log(True)
+    try:
+        if mode == 5:
+            packed = torch.empty(Hh.query_size("yogo_conv_bf16_packed_bytes", Cin, 128, 3, 0), dtype=torch.uint8, device="cuda")
+            Hh.call("yogo_conv_bf16_pack", w.cuda(), None, packed, Cin, 128, 3, 0, st)
+            Hh.call("yogo_conv2d_fwd_bf16", x8, packed, bias.cuda(), y8, None, msk.cuda(), None, B, Cin, 128, H, W, 3, 1, 1, st)
+            want = F.leaky_relu(F.conv2d(x.double(), w.double(), bias.double(), padding=1), 0.01) * msk.double()[:, :, None, None]
+        else:
+            # data gradient of a forward conv 128 -> Cin: dy has Cin channels, dx 128; dx = conv_transpose(dy, wf) * mask
+            wf = (torch.randn(Cin, 128, 3, 3, generator=g) * 0.05).to(torch.bfloat16).float()
+            packed = torch.empty(Hh.query_size("yogo_conv_bf16_packed_bytes", 128, Cin, 3, 1), dtype=torch.uint8, device="cuda")
+            Hh.call("yogo_conv_bf16_pack", wf.cuda(), None, packed, 128, Cin, 3, 1, st)
+            Hh.call("yogo_conv2d_dgrad_bf16", x8, packed, y8, None, 0, msk.cuda(), B, 128, Cin, H, W, 3, 1, st)
+            want = F.conv_transpose2d(x.double(), wf.double(), padding=1) * msk.double()[:, :, None, None]
+        torch.cuda.synchronize()
+        log = Hh.read_launch_log()
+    finally:
+        Hh.launch_log(False)
+    assert any(ln.startswith(f"conv_bf16_ws_kernel<{mode}>") for ln in log), log
+    got = torch.empty(B, 128, H, W, device="cuda")
+    Hh.call("yogo_bf16_8c_to_nchw_f32", y8, got, B, 128, H * W, st)
+    got = got.cpu().double()
+    # one bf16 rounding of an fp32-accumulated value: |d| <= 2^-8 |want| (+ fp32 accumulation noise of a K = 9 Cin contraction)
+    tol = 2.0 ** -8 * want.abs() + 2e-5 * float(want.abs().max())
+    assert bool(((got - want).abs() <= tol).all()), float(((got - want).abs() - tol).max())

@@ -1,4 +1,4 @@
-"""In-process A/B of the persistent wavefront-specialised kernel against the tiled 8-wavefront kernel (yogo_conv_bf16_persistent 1 / 0):
+"""In-process A/B of the persistent wavefront-specialised kernel against the tiled 8-wavefront kernel (yogo_hook_conv_bf16_persistent 1 / 0 in libyogo_hip_hooks.so -- the product library has no plan switch):
 the launches of the training step the persistent kernel takes, alternating, one device, one process.
     python tools/ab_ws.py [rounds] [B] [which]"""
 import collections
@@ -12,6 +12,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from yogo_amd import _hip as H
+H.LIB_PATH = os.path.join(ROOT, "yogo_amd", "lib", "libyogo_hip_hooks.so")   # the product's objects + the yogo_hook_* switches
+import ctypes
+_f = H.lib().yogo_hook_conv_bf16_persistent
+_f.restype, _f.argtypes = ctypes.c_int, [ctypes.c_int]
 import bench_conv_bf16 as BC
 
 if __name__ == "__main__":
@@ -24,7 +28,7 @@ if __name__ == "__main__":
     res = collections.defaultdict(list)
     for r in range(rounds + 1):
         for mode in (0, 1):
-            H.call("yogo_conv_bf16_persistent", mode)
+            H.call("yogo_hook_conv_bf16_persistent", mode)
             for w in which:
                 kind = w[-1]
                 buf = io.StringIO()
@@ -33,7 +37,7 @@ if __name__ == "__main__":
                 m = re.search(r": ([\d.]+) ms", buf.getvalue())
                 if r > 0 and m:
                     res[(w, mode)].append(float(m.group(1)))
-    H.call("yogo_conv_bf16_persistent", 1)
+    H.call("yogo_hook_conv_bf16_persistent", 1)
     print("kernel        tiled (ms)                         persistent (ms)")
     for w in which:
         a, b = res[(w, 0)], res[(w, 1)]

@@ -60,13 +60,19 @@ def lib() -> ctypes.CDLL:
             f"yogo_amd: HIP extension not built ({LIB_PATH} missing). Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `bash yogo_amd/csrc/build.sh`. There is no CPU fallback."
         )
-    L = ctypes.CDLL(LIB_PATH)
     _protos = parse_header()
-    for name, (ret, args) in _protos.items():
-        fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+    _lib = bind(LIB_PATH, _protos)
+    return _lib
+
+
+def bind(path: str, protos: Dict[str, Tuple[str, List[str]]]) -> ctypes.CDLL:
+    """dlopen `path` and give every prototype of the header its argument types (AttributeError if the library does not export a
+    declared symbol)"""
+    L = ctypes.CDLL(path)
+    for name, (ret, args) in protos.items():
+        fn = getattr(L, name)
         fn.restype = ctypes.c_char_p if "char" in ret else ctypes.c_int
         fn.argtypes = [ctypes.c_void_p if a == "ptr" else _CTYPES[a] for a in args]
-    _lib = L
     return L
 
 

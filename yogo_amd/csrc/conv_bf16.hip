@@ -1330,9 +1330,16 @@ static bool g_bf_rowdma = true;
 // (diagnostic build: yogo_diag_conv_bf16_rowdma(0) keeps the per-lane slot staging of the lean 4-wavefront tiles)
 static bool g_bf_lean4 = true; // (diagnostic build: yogo_diag_conv_bf16_lean4(0) selects the generic step loop of the 4-wavefront tiles)
 static bool g_bf_ring = true; // (diagnostic build: yogo_diag_conv_bf16_ring(0) selects the two-buffer loop of the stride-2 data gradient)
-static bool g_bf_ws = true;   // the persistent wavefront-specialised kernel (conv_bf16_ws.hip) takes the launches it is eligible for
-// Plan switch (A/B runs and the bit-identity tests of the two kernels): 0 = every launch goes to conv_bf16_kernel
-extern "C" int yogo_conv_bf16_persistent(int on) { g_bf_ws = on != 0; return YOGO_OK; }
+// the persistent wavefront-specialised kernels (conv_bf16_ws.hip, conv_bf16_ws2.hip) take the launches they are eligible for.  The
+// product has NO run-time plan switch (no mutable global state in the library): the switch below exists in the test-hooks build
+// (build.sh: libyogo_hip_hooks.so, -DYOGO_TEST_HOOKS; loaded by tests/ and tools/ only) and in the diagnostic build.
+#if defined(YOGO_TEST_HOOKS) || defined(YOGO_DIAG)
+static bool g_bf_ws = true;
+// 0 = every launch goes to the tiled conv_bf16_kernel (A/B runs and the bit-identity tests of the two kernel families)
+extern "C" int yogo_hook_conv_bf16_persistent(int on) { g_bf_ws = on != 0; return YOGO_OK; }
+#else
+static constexpr bool g_bf_ws = true;
+#endif
 static bool g_bf_pp = true;   // (diagnostic build: yogo_diag_conv_bf16_pp(0) selects the interleaved main loop for A/B runs)
 #ifdef YOGO_DIAG
 extern "C" int yogo_diag_conv_bf16_pp(int on) { g_bf_pp = on != 0; return YOGO_OK; }
@@ -1404,7 +1411,8 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
   const int T = ks * ks, pad = ks == 3 ? 1 : 0;
   // stride-1 3x3 convolutions with 128 output channels and the lean epilogue: the persistent wavefront-specialised kernel
   if (in != nullptr && g_bf_ws && !s2d && a == 1 && ks == 3 && out_f32 == nullptr && out_pre == nullptr && act_ref == nullptr && !signs_read &&
-      stats_part == nullptr && (act == ACT_NONE || act == ACT_LEAKY) && conv_bf16_ws_eligible(K, M, IH, IW, B)) {
+      stats_part == nullptr && (act == ACT_NONE || act == ACT_LEAKY) && !(signs != nullptr && act != ACT_LEAKY) &&
+      conv_bf16_ws_eligible(K, M, IH, IW, B)) {
     ConvWsParams q{};
     q.in = in; q.wp = packed; q.bias = bias; q.out = out; q.signs = reinterpret_cast<unsigned char*>(signs); q.chan_scale = chan_scale;
     q.B = B; q.Kb = bf_kb_of(K); q.IH = IH; q.IW = IW; q.act = act;

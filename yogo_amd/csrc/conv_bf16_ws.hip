@@ -23,6 +23,7 @@
 //     One barrier per chunk orders everything: DMA landed (loaders wait vmcnt first), staging written (compute waits
 //     lgkmcnt), staging read, buffers free.
 #include "conv_bf16_ws.h"
+#include <mutex>
 #include <type_traits>
 #include <utility>
 
@@ -918,17 +919,31 @@ bool conv_bf16_ws_plan(ConvWsParams* p) {
 }
 
 int launch_conv_bf16_ws(const ConvWsParams& p, hipStream_t stream) {
-  static int n_cu = 0;
-  static bool attr_set = false;
-  if (!attr_set) {
-#define WS_ATTR(M) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_ws_kernel<M>), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES);
-    WS_ATTR(0) WS_ATTR(1) WS_ATTR(3) WS_ATTR(4) WS_ATTR(5) WS_ATTR(7)
+  // per device, once: the dynamic-LDS attribute of every instantiation and the CU count (a second device in the process, or a
+  // first call from two host threads, must not see another device's state)
+  static std::mutex mu;
+  static int n_cu_of[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+    yogo_set_error("conv_bf16_ws: hipGetDevice failed");
+    return YOGO_ERR_HIP;
+  }
+  int n_cu;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (n_cu_of[dev] == 0) {
+      hipError_t e = hipSuccess;
+#define WS_ATTR(M) if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_ws_kernel<M>), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES);
+      WS_ATTR(0) WS_ATTR(1) WS_ATTR(3) WS_ATTR(4) WS_ATTR(5) WS_ATTR(7)
 #undef WS_ATTR
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
-    attr_set = true;
+      if (e != hipSuccess) {
+        yogo_set_error("conv_bf16_ws: hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) failed: %s", WS_LDS_BYTES, hipGetErrorString(e));
+        return YOGO_ERR_HIP;
+      }
+      hipDeviceProp_t prop;
+      n_cu_of[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    n_cu = n_cu_of[dev];
   }
   if (p.ntiles <= 0) return YOGO_OK;
   // one persistent workgroup per CU; a multiple of 8 so that a workgroup's tiles stay inside one XCD's run

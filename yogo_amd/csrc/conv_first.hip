@@ -807,9 +807,10 @@ __global__ void conv_first_bn_wgrad_finalize_kernel(const float* __restrict__ su
   const float S1 = sc[2 * NJ];
   float S2 = sc[2 * NJ + 1];
   if (derive_s2) {   // the sweep saw no z: sum gb * xh = invstd * (sum_j W[c][j] * A1[c][j] - mean * S1)   (z = W . patch, no conv bias)
-    float t = 0.f;
-    for (int k = 0; k < NJ; ++k) t = fmaf(w[c * NJ + k], sc[k], t);
-    S2 = invstd[c] * (t - mean[c] * S1);
+    // (in double: for a uint8 image W . A1 and mean * S1 are both ~ pixel mean x |W| x S1 and cancel down to the covariance part)
+    double t = 0.0;
+    for (int k = 0; k < NJ; ++k) t = fma((double)w[c * NJ + k], (double)sc[k], t);
+    S2 = (float)((double)invstd[c] * (t - (double)mean[c] * (double)S1));
   }
   float v;
   if (j < NJ) {
@@ -975,11 +976,16 @@ extern "C" int yogo_conv_first_bn_wgrad_bf16_xg(const void* in, int in_dtype, co
   return conv_first_bn_wgrad_impl(in, in_dtype, g, z, nullptr, mean, invstd, gamma, beta, part, B, Cin, Cout, IH, IW, stride, act, 1, stream);
 }
 extern "C" int yogo_conv_first_mfma_supported(int in_dtype, int Cin, int Cout, int IH, int IW, int stride);   // conv_first_mfma.hip
-static bool g_cf_pairs = true;   // the sign-map sweep takes two pixels per lane where the output width is even (A/B switch)
-extern "C" int yogo_conv_first_bn_wgrad_pairs(int on) {
+// the sign-map sweep takes two pixels per lane where the output width is even; a switch only in the test-hooks / diagnostic builds
+#if defined(YOGO_TEST_HOOKS) || defined(YOGO_DIAG)
+static bool g_cf_pairs = true;
+extern "C" int yogo_hook_conv_first_bn_wgrad_pairs(int on) {
   g_cf_pairs = on != 0;
   return YOGO_OK;
 }
+#else
+static constexpr bool g_cf_pairs = true;
+#endif
 // 1 when the sweep can run WITHOUT the saved conv output: from the sign map of yogo_conv_first_mfma_signs (uint8 one-channel image,
 // stride 2, even sizes, Cout = 8 or 16, no activation or LeakyReLU, no conv bias, caller-held Gram matrix)
 static bool conv_first_fast_shape(int in_dtype, int Cin, int IH, int IW, int stride) {

@@ -578,11 +578,16 @@ extern "C" int yogo_conv_first_mfma_stats_rows(int B, int IH, int IW, int* rows)
 //   stats_part: partial (sum, sumsq) of conv + bias (fp32, before rounding) -> yogo_bn_finalize(part, rows, 16, ...)
 //   z: conv + bias in bf16 NCHW8c;  y: act((z - mean) * invstd * gamma + beta) in bf16 NCHW8c (needs mean/invstd/gamma/beta);
 //   without y the activation goes onto z (inference with BatchNorm folded into w and bias): z = act(conv + bias)
-static bool g_cfm_pairs = true;   // (A/B switch, with yogo_conv_first_bn_wgrad_pairs)
-extern "C" int yogo_conv_first_mfma_pairs(int on) {
+// two pixels per lane where the output width is even; a switch only in the test-hooks / diagnostic builds (see conv_bf16.hip)
+#if defined(YOGO_TEST_HOOKS) || defined(YOGO_DIAG)
+static bool g_cfm_pairs = true;
+extern "C" int yogo_hook_conv_first_mfma_pairs(int on) {
   g_cfm_pairs = on != 0;
   return YOGO_OK;
 }
+#else
+static constexpr bool g_cfm_pairs = true;
+#endif
 static int conv_first_mfma_impl(const void* in, const float* w, const float* bias, void* z, void* y, void* signs, const float* mean,
                                const float* invstd, const float* gamma, const float* beta, float* stats_part, int B, int Cout,
                                int IH, int IW, int act, hipStream_t stream);

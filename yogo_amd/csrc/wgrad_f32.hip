@@ -408,6 +408,7 @@ extern "C" int yogo_internal_wgrad_reduce(const float* slab, int nslab, int T, i
 static int wgrad_reduce_flush(WgradReduceQueue* q, hipStream_t stream) {
   if (q->m.n == 0) return YOGO_OK;
   hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(q->blocks), dim3(1024), 0, stream, q->m);
+  if (yogo_launch_log_enabled()) yogo_launch_log("wgrad_reduce_multi_kernel | reductions=%d blocks=%d", q->m.n, q->blocks);
   q->m.n = 0;
   q->blocks = 0;
   YOGO_CHECK_LAUNCH("wgrad_reduce_multi");
@@ -462,6 +463,7 @@ extern "C" int yogo_internal_wgrad_reduce(const float* slab, int nslab, int T, i
   else
     hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(nw + (db ? cdiv(M, 16) : 0)), dim3(256), 0, stream, slab, nslab, T, M, N, Mpad, Npad,
                        clip, dw, bias_part, nbias, db);
+  if (yogo_launch_log_enabled()) yogo_launch_log("wgrad_reduce_kernel<%d> | nslab=%d T=%d M=%d N=%d", nslab >= 64 ? 16 : 4, nslab, T, M, N);
   YOGO_CHECK_LAUNCH("wgrad_reduce");
   return YOGO_OK;
 }

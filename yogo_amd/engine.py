@@ -559,7 +559,7 @@ def forward_bf16_train(eng: Engine, x: torch.Tensor) -> Tuple[torch.Tensor, List
             # algorithmic bytes: input + output once at storage precision (bf16 NCHW8c, channels padded to 16; fp32 head)
             nbytes = B * (_blocks(L.cin) * 8 * H * W * 2 + (L.cout * OH * OW * 4 if last else _blocks(L.cout) * 8 * OH * OW * 2))
             # mw tags the kernel variant for bench.py: 34 = conv_bf16_kernel<4,2,8,...> (128 output channels, stride 1)
-            eng._tick("fwd", i, 2.0 * B * L.cout * L.cin * L.k * L.k * OH * OW, mw=34 if (L.cout > 64 and L.s == 1) else 30, nbytes=nbytes)
+            eng._tick("fwd", i, 2.0 * B * L.cout * L.cin * L.k * L.k * OH * OW, mw=34 if (L.cout > 64 and L.s == 1) else (35 if (L.cout > 64 and L.cin > 64 and L.k == 3) else 30), nbytes=nbytes)
             if silu_pre:
                 S.pre = torch.empty_like(out8)
                 _hip.call("yogo_conv2d_fwd_bf16_pre", cur, pk, bias, out8, S.pre, mask, B, L.cin, L.cout, H, W, L.k, L.s, fused_act, st)
@@ -606,8 +606,12 @@ def forward_bf16_train(eng: Engine, x: torch.Tensor) -> Tuple[torch.Tensor, List
 
 def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
                         grad_out: Optional[Dict[int, torch.Tensor]] = None, on_layer=None,
-                        trace: Optional[dict] = None) -> List[Optional[torch.Tensor]]:
-    """``trace`` (tests / probes only): a dict that receives clones of the activation gradients as they exist between the
+                        trace: Optional[dict] = None, flush_layers=None) -> List[Optional[torch.Tensor]]:
+    """``on_layer(i)`` is called once every gradient kernel of layer i has been enqueued.  With ``flush_layers`` (layer indices) the
+    hook only needs COMPLETE parameter gradients at those layers: the split-K reductions stay deferred and are flushed in front of
+    the hook there (and behind the last layer) -- two launches for the data-parallel trainer's two-part exchange instead of one
+    reduction per layer, the same bits.  Without it a hook gets every layer's gradients reduced as soon as the layer is through.
+    ``trace`` (tests / probes only): a dict that receives clones of the activation gradients as they exist between the
     kernels -- ("g", i): gradient w.r.t. block i's output, ("dz", i): BatchNorm-backward output of block i -- so that every
     kernel of a real step can be checked against the oracle given its ACTUAL inputs (tests/_util.py, teacher-forced check)."""
     st, dev, clip = _hip.stream_ptr(), graw.device, float(eng.clip)
@@ -621,7 +625,8 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
     keep: list = []   # tensors in use on the weight-gradient stream
     # the split-K reductions of the weight gradients: deferred to ONE launch behind the last layer -- unless a per-layer hook wants
     # each layer's gradients as soon as the layer is through
-    wq = _wgrad_queue() if (_WGRAD_DEFER_REDUCE and on_layer is None) else None
+    wq = _wgrad_queue() if (_WGRAD_DEFER_REDUCE and (on_layer is None or flush_layers is not None)) else None
+    flush_at = frozenset(flush_layers) if flush_layers is not None else frozenset()
     if wq is not None:
         _hip.call("yogo_wgrad_reduce_queue_reset", wq)   # (a pass that raised half way must not leave its reductions behind)
     if graw.dtype == torch.bfloat16 and graw.ndim == 5:   # already NCHW8c (yogo_decode_bwd_bf16)
@@ -729,6 +734,9 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
             grads[id(L.conv.bias)] = db
         grads[id(L.conv.weight)] = dw
         if on_layer is not None:
+            if wq is not None and i in flush_at:   # the hook takes the gradients of layers >= i: their reductions run now, as one launch
+                with torch.cuda.stream(wstream):
+                    _hip.call("yogo_wgrad_reduce_flush", wq, _hip.stream_ptr())
             if wstream is not main:
                 main.wait_stream(wstream)   # the weight gradient of this layer is part of what the hook hands over
             on_layer(i)

@@ -334,6 +334,8 @@ class HipTrainer:
             ws = torch.empty(_hip.query_size("yogo_loss_workspace_bytes", B, Sy, Sx) // 4, dtype=torch.float32, device=raw.device)
             lab = labels if (labels.dtype == torch.float32 and labels.is_contiguous()) else labels.contiguous().float()
             hook = self._on_layer_done if self.world > 1 else None
+            # the hook needs complete gradients at split_layer only: the deferred split-K reductions are flushed there and at the end
+            flush = (self.split_layer,) if hook is not None else None
             fused = self.half and not m.inference and _FUSED_DECODE_LOSS
             if fused:
                 # ---- decode + loss forward/backward + decode backward in one pass over the cells (bit-identical to the three calls
@@ -341,7 +343,7 @@ class HipTrainer:
                 g8 = torch.empty(B, ((P + 15) // 16) * 2, Sy, Sx, 8, dtype=torch.bfloat16, device=raw.device)
                 _hip.call("yogo_decode_loss_bwd_bf16", raw, lab, m._Cxs, m._Cys, g8, out, ws, B, P, Sy, Sx, aw, ah, wm, hm,
                           float(L.no_obj_weight), float(L.iou_weight), float(L.classify_weight), float(L.label_smoothing), st)
-                backward_bf16_train(eng, saved, g8, grad_out=self.flat.grad_views, on_layer=hook, trace=self.trace)
+                backward_bf16_train(eng, saved, g8, grad_out=self.flat.grad_views, on_layer=hook, trace=self.trace, flush_layers=flush)
             else:
                 pred = torch.empty_like(raw)
                 _hip.call("yogo_decode_fwd", raw, pred, m._Cxs, m._Cys, B, P, Sy, Sx, aw, ah, wm, hm, int(bool(m.inference)), st)
@@ -355,7 +357,7 @@ class HipTrainer:
             elif self.half:   # the head's gradient goes straight to bf16 NCHW8c
                 g8 = torch.empty(B, ((P + 15) // 16) * 2, Sy, Sx, 8, dtype=torch.bfloat16, device=raw.device)
                 _hip.call("yogo_decode_bwd_bf16", raw, pred, gpred, g8, B, P, Sy, Sx, int(bool(m.inference)), st)
-                backward_bf16_train(eng, saved, g8, grad_out=self.flat.grad_views, on_layer=hook, trace=self.trace)
+                backward_bf16_train(eng, saved, g8, grad_out=self.flat.grad_views, on_layer=hook, trace=self.trace, flush_layers=flush)
             else:
                 graw = torch.empty_like(raw)
                 _hip.call("yogo_decode_bwd", raw, pred, gpred, graw, B, P, Sy, Sx, int(bool(m.inference)), st)
