@@ -15,6 +15,7 @@
 // kernel is built around few, wide memory operations rather than around MFMA issue.
 #include "common.h"
 #include "conv_bf16_ws.h"
+#include "conv_bf16_ws2.h"
 #include <type_traits>
 #include <utility>
 #include <cstdlib>
@@ -1422,6 +1423,21 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
     if (q.stamps) (void)hipMemsetAsync(g_diag_stamps, 0, 512 * 128, stream);
 #endif
     if (conv_bf16_ws_plan(&q)) return launch_conv_bf16_ws(q, stream);
+  }
+  // stride-2 3x3 data gradient into 128 channels (scale / LeakyReLU-sign-map epilogue): the persistent wavefront-specialised kernel
+  // that stages the gradient tile once for both row parities (conv_bf16_ws2.hip)
+  if (in != nullptr && g_bf_ws && s2d && ks == 3 && out_f32 == nullptr && out_pre == nullptr && act_ref == nullptr && bias == nullptr &&
+      stats_part == nullptr && act == ACT_NONE && (!signs_read || (signs != nullptr && ref_act == ACT_LEAKY)) && (signs_read || signs == nullptr) &&
+      conv_bf16_ws2_eligible(K, M, OH, OW, B)) {
+    ConvWs2Params q{};
+    q.in = in; q.wp = packed; q.out = out; q.signs = signs_read ? reinterpret_cast<const unsigned char*>(signs) : nullptr; q.chan_scale = chan_scale;
+    q.B = B; q.Kb = bf_kb_of(K); q.IH = IH; q.IW = IW; q.OH = OH; q.OW = OW;
+#ifdef YOGO_DIAG
+    q.dbg = g_diag_dbg;
+    q.stamps = (g_diag_stamps != nullptr && g_diag_stamps_bytes >= 512 * 128) ? g_diag_stamps : nullptr;
+    if (q.stamps) (void)hipMemsetAsync(g_diag_stamps, 0, 512 * 128, stream);
+#endif
+    if (conv_bf16_ws2_plan(&q)) return launch_conv_bf16_ws2(q, stream);
   }
   const int MW = bf_pick_mw(M);
   const bool small_n = s2d || a == 2;  // two accumulator sets / four-fold input tile: half the pixel groups per wavefront
