@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from yogo_amd import _hip as H
 
-H.LIB_PATH = os.path.join(ROOT, "yogo_amd", "lib", "libyogo_hip_diag.so")
+H.LIB_PATH = os.environ.get("YOGO_DIAG_LIB", os.path.join(ROOT, "yogo_amd", "lib", "libyogo_hip_diag.so"))   # (an ablation build: YOGO_DIAG_LIB=...)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import bench_conv_bf16 as BC   # noqa: E402
 

@@ -17,19 +17,21 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 # item 4): outside those statements the compiler must not spill, use scratch, move through v_accvgpr_*, or give an AGPR to any
 # operand (gfx950 lets the allocator use AV-class registers for DS / VMEM data).  audit_ws FILE.s STRICT(1|0)
 audit_ws() {
-  local S="$1" strict="$2" bad spill
+  local S="$1" strict="$2" bad scr spill
   [[ -f "$S" ]] || return 0
-  bad=$(awk '/;;#ASMSTART/{a=1} /;;#ASMEND/{a=0} { if (!a && $0 !~ /^[ \t]*[;.]/ && ($0 ~ /v_accvgpr_|scratch_/ || $0 ~ /[ ,\[]a[0-9]+([ ,\]:]|$)/ || $0 ~ /[ ,]a\[[0-9]+:[0-9]+\]/)) n++ } END { print n+0 }' "$S")
+  bad=$(awk '/;;#ASMSTART/{a=1} /;;#ASMEND/{a=0} { if (!a && $0 !~ /^[ \t]*[;.]/ && ($0 ~ /v_accvgpr_/ || $0 ~ /[ ,\[]a[0-9]+([ ,\]:]|$)/ || $0 ~ /[ ,]a\[[0-9]+:[0-9]+\]/)) n++ } END { print n+0 }' "$S")
+  scr=$(awk '/;;#ASMSTART/{a=1} /;;#ASMEND/{a=0} { if (!a && $0 !~ /^[ \t]*[;.]/ && $0 ~ /scratch_/) n++ } END { print n+0 }' "$S")
   spill=$(grep -E "\.vgpr_spill_count:|\.private_segment_fixed_size:" "$S" | awk '{ s += $2 } END { print s+0 }')
-  if [[ "$bad" != 0 || "$spill" != 0 ]]; then
-    echo "$(basename "$S") audit FAILED: $bad compiler accumulator / AGPR-operand / scratch instructions outside the asm statements, spill / scratch total $spill" >&2
-    [[ "$strict" == 1 ]] && return 1
+  if [[ "$bad" != 0 || "$scr" != 0 || "$spill" != 0 ]]; then
+    echo "$(basename "$S") audit: $bad compiler accumulator / AGPR-operand instructions outside the asm statements, $scr scratch instructions, spill / scratch total $spill" >&2
+    [[ "$strict" == 1 && ( "$bad" != 0 || "$WS_SPILL_OK" != 1 ) ]] && { echo "audit FAILED" >&2; return 1; }
   else
     echo "$(basename "$S" -hip-amdgcn-amd-amdhsa-gfx950.s) audit ok (no compiler v_accvgpr_* / AGPR operands / scratch outside the asm statements, no spills)"
   fi
   return 0
 }
 WS_FILES="conv_bf16_ws conv_bf16_ws2"
+WS_SPILL_OK="${WS_SPILL_OK:-0}"   # (experiments: WS_SPILL_OK=1 turns a spill into a warning)
 # variant TAG FILE [-DNAME=VALUE ...]: libyogo_hip_TAG.so = the product objects with FILE.hip recompiled under the given macros
 # (in-process A/B of a compile-time choice: tools/ab_variants.py loads several such libraries side by side).  Build the product first.
 if [[ "${1:-}" == "variant" ]]; then

@@ -80,6 +80,21 @@ __device__ __forceinline__ void w2_dma6(i32x4 rs, unsigned lds, int voff, unsign
                : "memory", "scc");
 }
 #undef W2_PN
+__device__ __forceinline__ void w2_dma1(i32x4 rs, unsigned lds, int voff, unsigned soff) {
+  rs = w2_u4(rs); lds = w2_u(lds); soff = w2_u(soff);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds" ::"v"(voff), "s"(lds), "s"(rs), "s"(soff) : "memory");
+}
+// four pieces, contiguous in memory and in LDS (a 4 KB weight group)
+__device__ __forceinline__ void w2_dma4c(i32x4 rs, unsigned lds, int voff, unsigned soff) {
+  unsigned so;
+  rs = w2_u4(rs); lds = w2_u(lds); soff = w2_u(soff);
+#define W2_PC "s_add_u32 m0, m0, 1024\n\ts_add_u32 %0, %0, 1024\n\tbuffer_load_dwordx4 %1, %2, %0 offen lds\n\t"
+  asm volatile("s_mov_b32 m0, %3\n\ts_mov_b32 %0, %4\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %0 offen lds\n\t" W2_PC W2_PC W2_PC
+               : "=&s"(so)
+               : "v"(voff), "s"(rs), "s"(lds), "s"(soff)
+               : "memory", "scc");
+#undef W2_PC
+}
 // 64 lanes x 4 bytes -> LDS bytes [lds, lds + 256)
 __device__ __forceinline__ void w2_dma_dword(i32x4 rs, unsigned lds, int voff, unsigned soff) {
   rs = w2_u4(rs); lds = w2_u(lds); soff = w2_u(soff);
@@ -94,8 +109,9 @@ __device__ __forceinline__ void w2_vmwait() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 #ifdef YOGO_DIAG
-#define W2_VMWAIT(N) do { const unsigned long long v0__ = __builtin_amdgcn_s_memtime(); w2_vmwait<N>(); t_vm += __builtin_amdgcn_s_memtime() - v0__; } while (0)
-#define W2_LBARRIER() do { const unsigned long long v0__ = __builtin_amdgcn_s_memtime(); w2_barrier(); t_lb += __builtin_amdgcn_s_memtime() - v0__; } while (0)
+// (the loaders' stamps only with diagnostic bit 64: an s_memtime is a scalar-memory round trip, four of them per period are not free)
+#define W2_VMWAIT(N) do { if (W2_DBG(64)) { const unsigned long long v0__ = __builtin_amdgcn_s_memtime(); w2_vmwait<N>(); t_vm += __builtin_amdgcn_s_memtime() - v0__; } else w2_vmwait<N>(); } while (0)
+#define W2_LBARRIER() do { if (W2_DBG(64)) { const unsigned long long v0__ = __builtin_amdgcn_s_memtime(); w2_barrier(); t_lb += __builtin_amdgcn_s_memtime() - v0__; } else w2_barrier(); } while (0)
 #else
 #define W2_VMWAIT(N) w2_vmwait<N>()
 #define W2_LBARRIER() w2_barrier()
@@ -118,6 +134,142 @@ struct W2Step { int g, sh, px; };
 __device__ constexpr W2Step kW2StepsA[3] = {{0, 0, 0}, {1, 0, 1}, {2, 1, 1}};
 __device__ constexpr W2Step kW2StepsB[6] = {{0, 0, 0}, {2, 0, 1}, {3, 1, 1}, {1, 2, 0}, {4, 2, 1}, {5, 3, 1}};
 __device__ constexpr W2Step w2_step(bool pass_b, int s) { return pass_b ? kW2StepsB[s < 6 ? s : 5] : kW2StepsA[s < 3 ? s : 2]; }
+
+
+// ---- the asm statements of a compute wavefront's K steps --------------------------------------------------------------------
+// The eight 32x32 accumulator tiles are a[0:127], OWNED BY THE ASM STATEMENTS (named literally, listed as clobbers: see
+// conv_bf16_ws.hip -- as "+v" operands hipcc copies the 16-register tuples around every statement and spills 400-600 registers;
+// build.sh audits that no compiler-generated instruction touches an AGPR).  Tile of (px, mb, n) = 4 px + 2 mb + n.
+#define W2_ACC_CLOBBER "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95","a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127"
+// A K step = one tap x 16 channels for one column parity PX: 4 MFMAs (row blocks 0, 1 x pixel groups 0, 1) on tiles 4 PX .. 4 PX + 3.
+// Operands are requested TWO steps ahead: under the load of this kernel (LDS-DMA of 32 KB per period beside 80 KB of operand reads)
+// an LDS read takes 200+ cycles, a step's MFMAs 128 -- with the reads of step s + 1 behind the MFMAs of step s every step stalled
+// ~100 cycles (1 330 instead of 768 cycles per period: gpurun_out/r5_ws2_st5.log; hipcc's own schedule of the loop ran the same).
+// Per period of six steps:   step 0: reads of step 2 | 1: of step 3 | 2: of steps 4, 5 | 3: none, then lgkmcnt(0) + the period's
+// BARRIER (every read of the period's buffers is in registers) | 4: the next period's steps 0, 1 | 5: none, then lgkmcnt(0).
+// (compile-time ablations for timing runs, results wrong: W2_ABL bit 0 = no MFMAs, 1 = no operand reads, 2 = no weight DMA, 3 = no epilogue arithmetic / staging)
+#ifndef W2_ABL
+#define W2_ABL 0
+#endif
+#if W2_ABL & 1
+#define W2_MF(K, A, B) "s_nop 0\n\t"
+#define W2_MF0(K, A, B) "s_nop 0\n\t"
+#else
+#define W2_MF(K, A, B) "v_mfma_f32_32x32x16_bf16 a[16*(%[tb]+" #K "):16*(%[tb]+" #K ")+15], %[" #A "], %[" #B "], a[16*(%[tb]+" #K "):16*(%[tb]+" #K ")+15]\n\t"
+#define W2_MF0(K, A, B) "v_mfma_f32_32x32x16_bf16 a[16*(%[tb]+" #K "):16*(%[tb]+" #K ")+15], %[" #A "], %[" #B "], 0\n\t"
+#endif
+#if W2_ABL & 2
+#define W2_RDA(D0, D1, P, O) "s_nop 0\n\t"
+#define W2_RDB "s_nop 0\n\t"
+#else
+#define W2_RDA(D0, D1, P, O) "ds_read_b128 %[" #D0 "], %[" #P "] offset:%[" #O "]\n\tds_read_b128 %[" #D1 "], %[" #P "] offset:%[" #O "]+512\n\t"
+#define W2_RDB "ds_read_b128 %[bn0], %[pb0] offset:%[bo]\n\tds_read_b128 %[bn1], %[pb1] offset:%[bo]\n\t"
+#endif
+#define W2_OPS_IN [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1), [tb] "n"(4 * PX)
+// MFMAs + one weight group (AOFF) and one pair of pixel quads (pb0 / pb1 + BIMM); ends when all but these four reads are done
+template <int PX, bool ZERO, int AOFF, int BIMM>
+__device__ __forceinline__ void w2_k_ab(const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1, u32x4& an0, u32x4& an1, u32x4& bn0, u32x4& bn1,
+                                        unsigned pa, unsigned pb0, unsigned pb1) {
+  if constexpr (ZERO)
+    asm volatile(W2_MF0(0, a0, b0) W2_RDA(an0, an1, pa, ao) W2_MF0(1, a0, b1) W2_RDB W2_MF0(2, a1, b0) W2_MF0(3, a1, b1) "s_waitcnt lgkmcnt(4)"
+                 : [an0] "=&v"(an0), [an1] "=&v"(an1), [bn0] "=&v"(bn0), [bn1] "=&v"(bn1)
+                 : W2_OPS_IN, [pa] "v"(pa), [pb0] "v"(pb0), [pb1] "v"(pb1), [ao] "n"(AOFF), [bo] "n"(BIMM)
+                 : "memory", W2_ACC_CLOBBER);
+  else
+    asm volatile(W2_MF(0, a0, b0) W2_RDA(an0, an1, pa, ao) W2_MF(1, a0, b1) W2_RDB W2_MF(2, a1, b0) W2_MF(3, a1, b1) "s_waitcnt lgkmcnt(4)"
+                 : [an0] "=&v"(an0), [an1] "=&v"(an1), [bn0] "=&v"(bn0), [bn1] "=&v"(bn1)
+                 : W2_OPS_IN, [pa] "v"(pa), [pb0] "v"(pb0), [pb1] "v"(pb1), [ao] "n"(AOFF), [bo] "n"(BIMM)
+                 : "memory", W2_ACC_CLOBBER);
+}
+// MFMAs + two weight groups (AOFF, AOFF2) and one pair of pixel quads; WAIT6: ends when all but these six reads are done (step 2),
+// else without a wait (step 4: the operands of step 5 landed in front of the barrier)
+template <int PX, bool WAIT6, int AOFF, int AOFF2, int BIMM>
+__device__ __forceinline__ void w2_k_aab(const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1, u32x4& an0, u32x4& an1, u32x4& am0, u32x4& am1,
+                                         u32x4& bn0, u32x4& bn1, unsigned pa, unsigned pb0, unsigned pb1) {
+  if constexpr (WAIT6)
+    asm volatile(W2_MF(0, a0, b0) W2_RDA(an0, an1, pa, ao) W2_MF(1, a0, b1) W2_RDA(am0, am1, pa, ao2) W2_MF(2, a1, b0) W2_RDB W2_MF(3, a1, b1) "s_waitcnt lgkmcnt(6)"
+                 : [an0] "=&v"(an0), [an1] "=&v"(an1), [am0] "=&v"(am0), [am1] "=&v"(am1), [bn0] "=&v"(bn0), [bn1] "=&v"(bn1)
+                 : W2_OPS_IN, [pa] "v"(pa), [pb0] "v"(pb0), [pb1] "v"(pb1), [ao] "n"(AOFF), [ao2] "n"(AOFF2), [bo] "n"(BIMM)
+                 : "memory", W2_ACC_CLOBBER);
+  else
+    asm volatile(W2_MF(0, a0, b0) W2_RDA(an0, an1, pa, ao) W2_MF(1, a0, b1) W2_RDA(am0, am1, pa, ao2) W2_MF(2, a1, b0) W2_RDB W2_MF(3, a1, b1)
+                 : [an0] "=&v"(an0), [an1] "=&v"(an1), [am0] "=&v"(am0), [am1] "=&v"(am1), [bn0] "=&v"(bn0), [bn1] "=&v"(bn1)
+                 : W2_OPS_IN, [pa] "v"(pa), [pb0] "v"(pb0), [pb1] "v"(pb1), [ao] "n"(AOFF), [ao2] "n"(AOFF2), [bo] "n"(BIMM)
+                 : "memory", W2_ACC_CLOBBER);
+}
+// MFMAs without reads.  TAIL 0: nothing (step 4 of a pass's last period); 1: lgkmcnt(0) + s_barrier (step 3); 2: lgkmcnt(0) (step 5); 3: the wait
+// states between an MFMA and a read of its result (step 5 of a pass's last period; hipcc does not look inside asm statements)
+template <int PX, int TAIL>
+__device__ __forceinline__ void w2_k_0(const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1, u32x4& x0, u32x4& x1, u32x4& x2, u32x4& x3, u32x4& x4,
+                                       u32x4& x5) {
+  // (x0 .. x5: the registers the retired reads wrote -- named "+v" so that their uses stay behind this statement)
+#define W2_K0_OUT [x0] "+v"(x0), [x1] "+v"(x1), [x2] "+v"(x2), [x3] "+v"(x3), [x4] "+v"(x4), [x5] "+v"(x5)
+  if constexpr (TAIL == 1)
+    asm volatile(W2_MF(0, a0, b0) W2_MF(1, a0, b1) W2_MF(2, a1, b0) W2_MF(3, a1, b1) "s_waitcnt lgkmcnt(0)\n\ts_barrier" : W2_K0_OUT : W2_OPS_IN : "memory", W2_ACC_CLOBBER);
+  else if constexpr (TAIL == 2)
+    asm volatile(W2_MF(0, a0, b0) W2_MF(1, a0, b1) W2_MF(2, a1, b0) W2_MF(3, a1, b1) "s_waitcnt lgkmcnt(0)" : W2_K0_OUT : W2_OPS_IN : "memory", W2_ACC_CLOBBER);
+  else if constexpr (TAIL == 3)
+    asm volatile(W2_MF(0, a0, b0) W2_MF(1, a0, b1) W2_MF(2, a1, b0) W2_MF(3, a1, b1) "s_nop 15\n\ts_nop 15" : W2_K0_OUT : W2_OPS_IN : "memory", W2_ACC_CLOBBER);
+  else
+    asm volatile(W2_MF(0, a0, b0) W2_MF(1, a0, b1) W2_MF(2, a1, b0) W2_MF(3, a1, b1) : W2_K0_OUT : W2_OPS_IN : "memory", W2_ACC_CLOBBER);
+#undef W2_K0_OUT
+}
+// the operands of a pass's steps 0 and 1 (weight groups 0 and AOFF2, pixel quads of the first slot)
+template <int AOFF2>
+__device__ __forceinline__ void w2_kfirst(u32x4& an0, u32x4& an1, u32x4& am0, u32x4& am1, u32x4& bn0, u32x4& bn1, unsigned pa, unsigned pb0, unsigned pb1) {
+  asm volatile("ds_read_b128 %[an0], %[pa]\n\tds_read_b128 %[an1], %[pa] offset:512\n\tds_read_b128 %[bn0], %[pb0]\n\tds_read_b128 %[bn1], %[pb1]\n\t"
+               "ds_read_b128 %[am0], %[pa] offset:%[ao2]\n\tds_read_b128 %[am1], %[pa] offset:%[ao2]+512\n\ts_waitcnt lgkmcnt(0)"
+               : [an0] "=&v"(an0), [an1] "=&v"(an1), [am0] "=&v"(am0), [am1] "=&v"(am1), [bn0] "=&v"(bn0), [bn1] "=&v"(bn1)
+               : [pa] "v"(pa), [pb0] "v"(pb0), [pb1] "v"(pb1), [ao2] "n"(AOFF2)
+               : "memory");
+}
+// eight consecutive accumulator registers -> VGPRs in ONE statement; it clobbers every accumulator register, so hipcc cannot keep a
+// value of its own in an AGPR across any part of the epilogue (conv_bf16_ws.hip: ws_acc_read8)
+template <int R>
+__device__ __forceinline__ void w2_acc_read8(float (&r)[8]) {
+  asm volatile(
+      "v_accvgpr_read_b32 %0, a[%8]\n\tv_accvgpr_read_b32 %1, a[%8+1]\n\tv_accvgpr_read_b32 %2, a[%8+2]\n\tv_accvgpr_read_b32 %3, a[%8+3]\n\t"
+      "v_accvgpr_read_b32 %4, a[%8+4]\n\tv_accvgpr_read_b32 %5, a[%8+5]\n\tv_accvgpr_read_b32 %6, a[%8+6]\n\tv_accvgpr_read_b32 %7, a[%8+7]"
+      : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]), "=v"(r[4]), "=v"(r[5]), "=v"(r[6]), "=v"(r[7])
+      : "n"(R)
+      : W2_ACC_CLOBBER);
+}
+// the six K steps of a period (pass A: two 16-channel chunks x slices 0 1 2; pass B: one chunk x slices 3 .. 8 ordered by dy shift):
+// weight group, dy row (0: a, 1: a + 1) and byte offset of the pixel quads, column parity.  Steps 0, 2, 3, 5 need new pixel quads.
+__device__ constexpr int w2_grp(bool pb, int s) { return pb ? (s == 0 ? 0 : s == 1 ? 2 : s == 2 ? 3 : s == 3 ? 1 : s) : s; }
+__device__ constexpr int w2_brow(bool pb, int s) { return pb && s >= 3 ? 1 : 0; }
+__device__ constexpr int w2_bimm(bool pb, int s) { return ((s == 2 || s == 5) ? 16 : 0) + ((!pb && s >= 3) ? W2_DYS : 0); }
+__device__ constexpr bool w2_newb(int s) { return s == 0 || s == 2 || s == 3 || s == 5; }
+__device__ constexpr int w2_bset(int s) { return s < 2 ? 0 : (s == 2 ? 1 : (s < 5 ? 2 : 3)); }   // pixel-quad sets: steps 0 1 | 2 | 3 4 | 5
+__device__ constexpr int w2_aset(int par, int s) { return (s + 2 * par) & 3; }             // weight-quad sets, by period parity
+
+// ---- the store wavefront's AGPR quarter buffers: 16 staged units (unit u = 4 cw + 2 n + e, LDS bytes cw * 4096 + n * 2048 + e * 512
+// from the lane's base) <-> a[BASE + 4 u : BASE + 4 u + 3]
+#define W2_RDU(U) "ds_read_b128 a[%[b]+4*" #U ":%[b]+4*" #U "+3], %[ad] offset:(" #U "/4)*4096+((" #U "/2)%%2)*2048+(" #U "%%2)*512\n\t"
+template <int BASE>
+__device__ __forceinline__ void w2_rd16_a(unsigned addr) {
+  asm volatile(W2_RDU(0) W2_RDU(1) W2_RDU(2) W2_RDU(3) W2_RDU(4) W2_RDU(5) W2_RDU(6) W2_RDU(7) W2_RDU(8) W2_RDU(9) W2_RDU(10) W2_RDU(11) W2_RDU(12) W2_RDU(13)
+               W2_RDU(14) W2_RDU(15)
+               :
+               : [ad] "v"(addr), [b] "n"(BASE)
+               : "memory", W2_ACC_CLOBBER);
+}
+#undef W2_RDU
+// units 8 H .. 8 H + 7 (compute wavefronts 2 H, 2 H + 1) -> 8 stores: pixel-group offsets vo[s], s = 2 (cw & 1) + n; scalar offsets so0
+// (channel block of e = 0) and so0 + dso (e = 1)
+template <int BASE, int H>
+__device__ __forceinline__ void w2_st8_a(const int (&vo)[4], i32x4 rs, unsigned so0, unsigned dso) {
+  rs = w2_u4(rs);
+  so0 = w2_u(so0);
+  const unsigned so1 = w2_u(so0 + dso);
+#define W2_STU(J, V, S) "buffer_store_dwordx4 a[%[b]+4*(8*%[h]+" #J "):%[b]+4*(8*%[h]+" #J ")+3], %[" #V "], %[rs], %[" #S "] offen\n\t"
+  asm volatile("s_nop 4\n\t" W2_STU(0, v0, s0) W2_STU(1, v0, s1) W2_STU(2, v1, s0) W2_STU(3, v1, s1) W2_STU(4, v2, s0) W2_STU(5, v2, s1) W2_STU(6, v3, s0)
+               W2_STU(7, v3, s1)
+               :
+               : [v0] "v"(vo[0]), [v1] "v"(vo[1]), [v2] "v"(vo[2]), [v3] "v"(vo[3]), [rs] "s"(rs), [s0] "s"(so0), [s1] "s"(so1), [b] "n"(BASE), [h] "n"(H)
+               : "memory");
+#undef W2_STU
+}
 
 #ifdef YOGO_DIAG
 #define W2_DBG(BIT) (p.dbg & (BIT))
@@ -172,140 +324,151 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   unsigned k_ord = 0;
   TileS T{};
   if (!find_tile(k_ord, T)) return;
+#ifdef YOGO_DIAG
+  if (W2_DBG(32)) {   // experiment: the workgroups of a CU group start an eighth of a tile apart (are the CUs' store bursts in phase?)
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long dt = (unsigned long long)((blockIdx.x >> 3) & 7u) * 4000ull;
+    while (__builtin_amdgcn_s_memtime() - t0 < dt) __builtin_amdgcn_s_sleep(8);
+  }
+#endif
   if (p.chan_scale == nullptr && tid < 128) reinterpret_cast<float*>(lds + W2_ES)[tid] = 1.f;
   __syncthreads();
 
-  if (team == 1) {
+  if (team == 1 && tw < 3) {
     // =====================================================================================================================
-    // LOADERS
+    // LOAD wavefronts (3): the weight slices of the next period, the next tile's dy and (wavefront 2) the small inputs of the
+    // epilogues -- the sign bytes of a pass, the channel scale of the tile's image.  They issue no stores: vector-memory
+    // operations retire in order, and a load that waits behind a store's acknowledgement holds the period's barrier.
     // =====================================================================================================================
     const int lane = w2_lane();
     const int q31 = lane & 31, hp = lane >> 5;
-    const int ttid = tw * 64 + lane;
     const int rowb = IW * 16, kcb = IH * IW * 16;
-    const unsigned ibytes = (unsigned)p.Kb * kcb, obytes = 16u * plane16, wbytes = 9u * p.Kb * 2048u;
+    const unsigned ibytes = (unsigned)p.Kb * kcb, wbytes = 9u * p.Kb * 2048u;
     const unsigned wstep = (unsigned)p.Kb * 2048u;   // bytes between the slices of the packed weights
     const i32x4 rs_w = w2_rsrc(p.wp, wbytes);
     const int lane16 = W2_DBG(4) ? (int)OOB : lane * 16;
     const bool has_scale = p.chan_scale != nullptr;
     const i32x4 rs_sc = w2_rsrc(p.chan_scale, has_scale ? (unsigned)p.B * 512u : 0u);
-
-    // per-tile lane geometry: the dy element this lane stages (position ttid of the [rows_in][lw] image of a channel block), the
-    // output offsets of the quads it stores (lane = (column parity hp, quad q31) of pixel group n), and the sign-map offsets it
-    // fetches for its partner compute wavefront (lane = (half-wave hp, quad q31))
-    struct LaneGeo { int dyoff; int vo[2][2]; int vs[2][2][2]; };
-    auto decode = [&](const TileS& t, LaneGeo& g) __attribute__((always_inline)) {
+    [[maybe_unused]] unsigned long long t_vm = 0, t_lb = 0;
+    // dy element of position q * 64 + lane of the [rows_in][lw] image of a channel block, q = 0..3
+    auto decode = [&](const TileS& t, int (&dyoff)[4]) __attribute__((always_inline)) {
       const unsigned m_bw = t.lastband ? p.m_bwl : p.m_bw;
       const int bw = t.bw;
       const int i_lo = w2_udivm1(t.p0, bw, m_bw), i_hi = w2_udivm1(t.p1 - 1, bw, m_bw);
       const int rows_in = i_hi - i_lo + 2;
       const int lw = bw + 1;
       const unsigned inv_lw = t.lastband ? p.m_lwl : p.m_lw;   // (lw >= 2)
-      const int r_ = w2_udivm(ttid, inv_lw), x_ = ttid - r_ * lw;
-      const int iy = i_lo + r_, ix = t.j0 + x_;
-      g.dyoff = (r_ < rows_in && iy < IH && ix < IW && !W2_DBG(4)) ? iy * rowb + ix * 16 : (int)OOB;
 #pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        const int pp = t.p0 + (nh * 2 + n) * 32 + q31;
+      for (int q = 0; q < 4; ++q) {
+        const int pos = q * 64 + lane;
+        const int r_ = w2_udivm(pos, inv_lw), x_ = pos - r_ * lw;
+        const int iy = i_lo + r_, ix = t.j0 + x_;
+        dyoff[q] = (r_ < rows_in && iy < IH && ix < IW && !W2_DBG(4)) ? iy * rowb + ix * 16 : (int)OOB;
+      }
+    };
+    // sign-map offsets of the tile's four 32-quad groups s (compute wavefront cw owns groups 2 (cw & 1) + n): lane = (half-wave hp,
+    // quad q31); + 4 bytes for the upper 64 channels
+    auto decode_vs = [&](const TileS& t, int (&vs)[2][4][2]) __attribute__((always_inline)) {
+      const unsigned m_bw = t.lastband ? p.m_bwl : p.m_bw;
+      const int bw = t.bw;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int pp = t.p0 + s * 32 + q31;
         const bool pv = pp < t.p1;
         const int pc = pv ? pp : (t.p1 - 1);
         const int i = w2_udivm1(pc, bw, m_bw), j = pc - i * bw;
         const int pix = 2 * i * OW + 2 * (t.j0 + j);
         const bool vx = 2 * (t.j0 + j) + 1 < OW, vy = 2 * i + 1 < OH;
 #pragma unroll
-        for (int py = 0; py < 2; ++py) {
-          const bool okr = pv && (py == 0 || vy);
-          g.vo[py][n] = (okr && (hp == 0 || vx) && !W2_DBG(1)) ? (pix + py * OW + hp) * 16 : (int)OOB;
+        for (int py = 0; py < 2; ++py)
 #pragma unroll
           for (int px = 0; px < 2; ++px)
-            g.vs[py][n][px] = (okr && (px == 0 || vx)) ? (hp * plane + pix + py * OW + px) * 8 + mh * 4 : (int)OOB;
-        }
+            vs[py][s][px] = (pv && (py == 0 || vy) && (px == 0 || vx)) ? (hp * plane + pix + py * OW + px) * 8 : (int)OOB;
       }
     };
     auto rs_in_of = [&](int b) __attribute__((always_inline)) { return w2_rsrc(reinterpret_cast<const unsigned char*>(p.in) + (size_t)b * ibytes, ibytes); };
-    auto rs_out_of = [&](int b) __attribute__((always_inline)) { return w2_rsrc(reinterpret_cast<unsigned char*>(p.out) + (size_t)b * obytes, obytes); };
     auto rs_sg_of = [&](int b) __attribute__((always_inline)) { return w2_rsrc(SIGNS ? p.signs + (size_t)b * plane16 : nullptr, SIGNS ? (unsigned)plane16 : 0u); };
-    // requests ----------------------------------------------------------------------------------------------------------
-    // weights of a pass-A period (chunks 2 k, 2 k + 1: groups cc * 3 + slice) / a pass-B period (chunk c: slices 3 .. 8) -> buffer wb
+    // weight groups 2 tw, 2 tw + 1 of a period (4 KB each, contiguous in memory and in LDS).  Pass A, period k: group cc * 3 + t =
+    // slice t of chunk 2 k + cc; pass B, chunk c: group g = slice 3 + g
     auto req_wA = [&](int k, int wb) __attribute__((always_inline)) {
-      w2_dma3(rs_w, (unsigned)(wb * W2_WB + tw * 1024), lane16, (unsigned)((4 * k) * 2048 + tw * 1024), wstep);
-      w2_dma3(rs_w, (unsigned)(wb * W2_WB + 3 * 4096 + tw * 1024), lane16, (unsigned)((4 * k + 2) * 2048 + tw * 1024), wstep);
-    };
-    auto req_wB = [&](int c, int wb) __attribute__((always_inline)) {
-      w2_dma6(rs_w, (unsigned)(wb * W2_WB + tw * 1024), lane16, (unsigned)(3u * wstep + (unsigned)((2 * c) * 2048 + tw * 1024)), wstep);
-    };
-    // 16-channel chunk c of the dy tile described by (rs, dyoff) -> slot c (this wavefront's 64 positions of both channel blocks)
-    auto req_dy = [&](i32x4 rs, int dyoff, int c) __attribute__((always_inline)) {
-      w2_dma2(rs, (unsigned)(W2_DY + c * W2_DYS + tw * 1024), dyoff, (unsigned)(2 * c) * (unsigned)kcb, (unsigned)kcb);
-    };
-    auto req_signs = [&](i32x4 rs, const int (&vs)[2][2]) {
-      if constexpr (SIGNS) {
+      if constexpr ((W2_ABL & 4) != 0) return;
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-          for (int px = 0; px < 2; ++px) w2_dma_dword(rs, (unsigned)(W2_SG + (tw * 4 + n * 2 + px) * 256), vs[n][px], 0u);
+      for (int u = 0; u < 2; ++u) {
+        const int g = 2 * tw + u, cc = g >= 3 ? 1 : 0, t = g - 3 * cc;
+        w2_dma4c(rs_w, (unsigned)(wb * W2_WB + g * 4096), lane16, (unsigned)t * wstep + (unsigned)((4 * k + 2 * cc) * 2048));
       }
     };
-    auto req_scale = [&](int b) __attribute__((always_inline)) {   // [128] floats: two 256-byte pieces, loaders 2 / 3 repeat those of 0 / 1 (the same counts in every wavefront)
-      if (has_scale) w2_dma_dword(rs_sc, (unsigned)(W2_ES + (tw & 1) * 256), lane * 4, (unsigned)((b * 128 + (tw & 1) * 64) * 4));
+    auto req_wB = [&](int c, int wb) __attribute__((always_inline)) {
+      if constexpr ((W2_ABL & 4) != 0) return;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int g = 2 * tw + u;
+        w2_dma4c(rs_w, (unsigned)(wb * W2_WB + g * 4096), lane16, (unsigned)(3 + g) * wstep + (unsigned)((2 * c) * 2048));
+      }
     };
-    // the staged quarter (mb, gp) of this wavefront's partner: 4 units (n, px) of 1 KB in slot `sl` -> 4 stores, each one channel
-    // block of 32 quads x both column parities (lanes 0-31: px 0, lanes 32-63: px 1)
-    auto store_quarter = [&](int sl, int quarter, const int (&vo)[2], i32x4 rs_o) {
-      const unsigned char* base = lds + W2_STG + sl * W2_SLOT + (tw * 4 + hp) * 1024 + q31 * 16;
-      u32x4 d[4];
+    // 16-channel chunk c of a dy tile -> slot c: 8 pieces (channel block, position quarter); wavefront 0 takes pieces 0-2, 1: 3-5, 2: 6-7
+    const int j_lo = tw * 3, nd = tw < 2 ? 3 : 2;
+    auto req_dy = [&](i32x4 rs, const int (&dyoff)[4], int c) __attribute__((always_inline)) {
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) d[n * 2 + e] = *reinterpret_cast<const u32x4*>(base + n * 2048 + e * 512);
-      const int cb0 = mh * 8 + quarter * 2;   // channel block of e = 0 (quarter = mb * 2 + gp)
-#pragma unroll
-      for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) w2_store16(d[n * 2 + e], vo[n], rs_o, (unsigned)(cb0 + e) * (unsigned)plane16);
+      for (int u = 0; u < 3; ++u) {
+        if (u < nd) {   // (uniform)
+          const int j = j_lo + u, q = j & 3, kb = j >> 2;
+          const int vo = q == 0 ? dyoff[0] : (q == 1 ? dyoff[1] : (q == 2 ? dyoff[2] : dyoff[3]));
+          w2_dma1(rs, (unsigned)(W2_DY + c * W2_DYS + j * 1024), vo, (unsigned)(2 * c + kb) * (unsigned)kcb);
+        }
+      }
     };
-
-    [[maybe_unused]] unsigned long long t_vm = 0, t_lb = 0;
-    LaneGeo gc{}, gn{};
-    decode(T, gc);
-    i32x4 rs_in = rs_in_of(T.b), rs_out = rs_out_of(T.b), rs_sg = rs_sg_of(T.b);
-    // first tile: everything of its first period
-    for (int c = 0; c < nck; ++c) req_dy(rs_in, gc.dyoff, c);
+    // the 16 sign dwords of a pass: compute wavefront cw's (n, px) -> [cw][n][px][64 lanes]; its channels' bytes are the 4 at + 4 (cw >> 1)
+    auto req_signs = [&](i32x4 rs, const int (&vs)[4][2]) __attribute__((always_inline)) {
+      if constexpr (SIGNS) {
+#pragma unroll
+        for (int cw = 0; cw < 4; ++cw)
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int px = 0; px < 2; ++px)
+              w2_dma_dword(rs, (unsigned)(W2_SG + (cw * 4 + n * 2 + px) * 256), vs[(cw & 1) * 2 + n][px], (unsigned)((cw >> 1) * 4));
+      }
+    };
+    auto req_scale = [&](int b) __attribute__((always_inline)) {   // [128] floats: two 256-byte pieces
+      if (has_scale) {
+        w2_dma_dword(rs_sc, (unsigned)W2_ES, lane * 4, (unsigned)(b * 512));
+        w2_dma_dword(rs_sc, (unsigned)(W2_ES + 256), lane * 4, (unsigned)(b * 512 + 256));
+      }
+    };
+    const bool small = tw == 2;   // (uniform) this wavefront also fetches the epilogues' small inputs
+    int dyo[4], dyo_n[4] = {(int)OOB, (int)OOB, (int)OOB, (int)OOB};
+    int vs[2][4][2], vs_n[2][4][2];
+    decode(T, dyo);
+    if (small) decode_vs(T, vs);
+    i32x4 rs_in_n = rs_in_of(T.b);
+    for (int c = 0; c < nck; ++c) req_dy(rs_in_n, dyo, c);
     req_wA(0, 0);
-    req_signs(rs_sg, gc.vs[0]);
+    if (small) {
+      req_signs(rs_sg_of(T.b), vs[0]);
+      req_scale(T.b);
+    }
     W2_VMWAIT(0);
     W2_LBARRIER();   // (#1)
     int wpar = 0;           // weight buffer of the MFMA period being computed
-    bool pend = false;      // a staged quarter of the previous epilogue is waiting in slot 1 (its last quarter)
-    int vo_pend[2] = {(int)OOB, (int)OOB};
-    i32x4 rs_pend = rs_out;
     bool has_next = true;
     TileS Tn{};
-    i32x4 rs_in_n = rs_in;
     for (;;) {
-      // ---------------- pass A: np periods of 32 channels
-      for (int k = 0; k < np; ++k) {
+      for (int k = 0; k < np; ++k) {           // pass A
         if (k + 1 < np) req_wA(k + 1, wpar ^ 1);
         else req_wB(0, wpar ^ 1);
-        if (k == 0) {
-          const bool hadp = pend;
-          if (pend) {   // the last quarter of the previous tile's pass B
-            store_quarter(1, 3, vo_pend, rs_pend);
-            pend = false;
-          }
-          req_scale(T.b);   // (the channel scale is read by the epilogue quarters only: free since the previous tile's last one)
-          // the next tile: looked up and decoded here, behind this period's requests
+        if (k == 0) {   // the next tile: looked up and decoded behind this period's requests
+          // (the channel scale is read by the epilogue quarters only: free since the previous tile's last one; it may stay in flight)
+          if (small) req_scale(T.b);
           unsigned kn = k_ord + 1;
           has_next = find_tile(kn, Tn);
           k_ord = kn;
           if (has_next) {
-            decode(Tn, gn);
+            decode(Tn, dyo_n);
+            if (small) decode_vs(Tn, vs_n);
             rs_in_n = rs_in_of(Tn.b);
           }
-          // (vector-memory operations retire in order: everything but what was issued behind the weights has to be done)
-          if (hadp && has_scale) W2_VMWAIT(5);
-          else if (hadp) W2_VMWAIT(4);
-          else if (has_scale) W2_VMWAIT(1);
+          if (small && has_scale) W2_VMWAIT(2);
           else W2_VMWAIT(0);
         } else {
           W2_VMWAIT(0);
@@ -313,56 +476,239 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         W2_LBARRIER();
         wpar ^= 1;
       }
-      // ---------------- epilogue A: 4 quarters
-      for (int e = 0; e < 4; ++e) {
-        if (e >= 1) store_quarter((e - 1) & 1, e - 1, gc.vo[0], rs_out);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the staging reads are in registers before the slot is written again)
-        W2_LBARRIER();
-      }
-      // ---------------- pass B: nck periods of 16 channels
-      for (int c = 0; c < nck; ++c) {
+      for (int e = 0; e < 4; ++e) W2_LBARRIER();   // epilogue A
+      for (int c = 0; c < nck; ++c) {          // pass B
         if (c + 1 < nck) req_wB(c + 1, wpar ^ 1);
         else if (has_next) req_wA(0, wpar ^ 1);
-        if (c == 0) {
-          store_quarter(1, 3, gc.vo[0], rs_out);
-          req_signs(rs_sg, gc.vs[1]);
-          if constexpr (SIGNS) W2_VMWAIT(8);
-          else W2_VMWAIT(4);
-        } else if (has_next) {
-          req_dy(rs_in_n, gn.dyoff, c - 1);
-          W2_VMWAIT(2);
+        if (c == 0) {   // pass B's sign bytes (pass A's were read in front of its first quarter); they may stay in flight
+          if (small && SIGNS) {
+            req_signs(rs_sg_of(T.b), vs[1]);
+            W2_VMWAIT(16);
+          } else {
+            W2_VMWAIT(0);
+          }
+        } else if (has_next) {   // slot c - 1 is free: the next tile's chunk (it may stay in flight)
+          req_dy(rs_in_n, dyo_n, c - 1);
+          if (tw < 2) W2_VMWAIT(3);
+          else W2_VMWAIT(2);
         } else {
           W2_VMWAIT(0);
         }
         W2_LBARRIER();
         wpar ^= 1;
       }
-      // ---------------- epilogue B
-      for (int e = 0; e < 4; ++e) {
-        if (e == 0 && has_next) req_dy(rs_in_n, gn.dyoff, nck - 1);
-        if (e >= 1) store_quarter((e - 1) & 1, e - 1, gc.vo[1], rs_out);
-        if (e == 3 && has_next) req_signs(rs_sg_of(Tn.b), gn.vs[0]);   // (the sign area is free: pass B's bytes were read in front of quarter 0)
+      for (int e = 0; e < 4; ++e) {            // epilogue B
+        if (e == 0 && has_next) req_dy(rs_in_n, dyo_n, nck - 1);
+        if (e == 1 && has_next && small) req_signs(rs_sg_of(Tn.b), vs_n[0]);   // (pass B's bytes were read in front of quarter 0)
+        if (e == 3) W2_VMWAIT(0);   // (everything of the next tile's first period has landed)
+        W2_LBARRIER();
+      }
+      if (!has_next) break;
+      T = Tn;
+      if (small) {
+#pragma unroll
+        for (int a_ = 0; a_ < 2; ++a_)
+#pragma unroll
+          for (int b_ = 0; b_ < 4; ++b_)
+#pragma unroll
+            for (int c_ = 0; c_ < 2; ++c_) vs[a_][b_][c_] = vs_n[a_][b_][c_];
+      }
+    }
+#ifdef YOGO_DIAG
+    if (p.stamps && tw == 0 && lane == 0) {
+      unsigned long long* d = p.stamps + (size_t)blockIdx.x * 16;
+      d[10] = t_vm; d[11] = t_lb;
+    }
+#endif
+    return;
+  }
+  if (team == 1) {
+    // =====================================================================================================================
+    // STORE wavefront: the output.  The compute wavefronts stage a quarter of a pass (16 units of 1 KB) per epilogue period; this
+    // wavefront moves every staged quarter into REGISTERS in the following period (the slot is free again) and issues the stores at
+    // an even pace -- 8 per period -- over the periods that follow.  Why: the output is 128 KB per tile, ~80 % of what a CU's share
+    // of the chip's write bandwidth moves in a tile's time (tools/probes/store_rate.hip: 10.5 B/cycle/CU at saturation, one store
+    // wavefront per CU reaches it).  Issued in bursts behind the epilogues the stores back up in the CU's memory pipeline, the weight
+    // loads queue behind them and the MFMA passes wait (first forms of this kernel: the dy-load + store skeleton alone took 0.63 ms);
+    // and a store wavefront that must finish 16 stores inside an epilogue period holds that period's barrier.  It issues no loads and
+    // never waits for a store.  Register FIFO: three quarter buffers -- a[0:63], a[64:127] (this role's AGPRs hold data, not
+    // accumulators) and 16 VGPR quads; the schedule below is static (K = 128: 4 + 4 + 8 + 4 periods per tile).
+    // =====================================================================================================================
+    const int lane = w2_lane();
+    const int q31 = lane & 31, hp = lane >> 5;
+    const unsigned obytes = 16u * plane16;
+    [[maybe_unused]] unsigned long long t_vm = 0, t_lb = 0;
+    [[maybe_unused]] unsigned dbg_run = 0;
+    // output offsets of the tile's four 32-quad groups s: lane = (column parity hp, quad q31)
+    auto decode = [&](const TileS& t, int (&vo)[2][4]) __attribute__((always_inline)) {
+      const unsigned m_bw = t.lastband ? p.m_bwl : p.m_bw;
+      const int bw = t.bw;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int pp = t.p0 + s * 32 + q31;
+        const bool pv = pp < t.p1;
+        const int pc = pv ? pp : (t.p1 - 1);
+        const int i = w2_udivm1(pc, bw, m_bw), j = pc - i * bw;
+        const int pix = 2 * i * OW + 2 * (t.j0 + j);
+        const bool vx = 2 * (t.j0 + j) + 1 < OW, vy = 2 * i + 1 < OH;
+#pragma unroll
+        for (int py = 0; py < 2; ++py) vo[py][s] = (pv && (py == 0 || vy) && (hp == 0 || vx) && !W2_DBG(1)) ? (pix + py * OW + hp) * 16 : (int)OOB;
+      }
+    };
+    auto rs_out_of = [&](int b) __attribute__((always_inline)) { return w2_rsrc(reinterpret_cast<unsigned char*>(p.out) + (size_t)b * obytes, obytes); };
+    // staged unit u = 4 cw + 2 n + e of a quarter (mb, gp): compute wavefront cw's pixel group n, channel block e of the pair; a lane
+    // reads the column parity hp's 16 bytes of quad q31 -> one store covers 32 quads x both column parities of ONE channel block
+    const unsigned stg_rd = (unsigned)(W2_STG + hp * 1024 + q31 * 16);
+    // ... immediately (any K): 16 reads, 16 stores
+    auto store_quarter = [&](int sl, int quarter, const int (&vo)[4], i32x4 rs_o) __attribute__((always_inline)) {
+      const unsigned char* base = lds + stg_rd + sl * W2_SLOT;
+#pragma unroll
+      for (int cw = 0; cw < 4; ++cw) {
+        u32x4 d[4];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) d[n * 2 + e] = *reinterpret_cast<const u32x4*>(base + cw * 4096 + n * 2048 + e * 512);
+        const int cb0 = (cw >> 1) * 8 + quarter * 2;   // channel block of e = 0 (quarter = mb * 2 + gp)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) w2_store16(d[n * 2 + e], vo[(cw & 1) * 2 + n], rs_o, (unsigned)(cb0 + e) * (unsigned)plane16);
+      }
+    };
+    int vo[2][4], vo_n[2][4];
+    decode(T, vo);
+    i32x4 rs_out = rs_out_of(T.b);
+    W2_LBARRIER();   // (#1)
+    bool has_next = true;
+    TileS Tn{};
+    int vo_prev[4] = {(int)OOB, (int)OOB, (int)OOB, (int)OOB};   // pass B of the previous tile (its stores run into this tile's first periods)
+    i32x4 rs_prev = rs_out;
+    auto next_tile = [&]() __attribute__((always_inline)) {
+      unsigned kn = k_ord + 1;
+      has_next = find_tile(kn, Tn);
+      k_ord = kn;
+      if (has_next) decode(Tn, vo_n);
+    };
+    auto advance = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) vo_prev[s] = vo[1][s];
+      rs_prev = rs_out;
+      if (has_next) {
+        T = Tn;
+#pragma unroll
+        for (int a_ = 0; a_ < 2; ++a_)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) vo[a_][s] = vo_n[a_][s];
+        rs_out = rs_out_of(T.b);
+      }
+    };
+    if (nck == 8) {
+      // ---- the paced form.  Quarter buffers: QB0 = a[0:63], QB1 = a[64:127], QB2 = q2[16].  Per tile (periods t = 0..19: P0-3, EA0-3,
+      //      Q0-7, EB0-3), stores in front of reads inside a period:
+      //        read  (slot -> QB):  t5 A0->0, t6 A1->1, t7 A2->2, t8 A3->0, t17 B0->1, t18 B1->2, t19 B2->0, t0' B3->1
+      //        store (8 units):     t6 A0a, t7 A0b, t8 A1a, t9 A1b, t10 A2a, t11 A2b, t12 A3a, t13 A3b,
+      //                             t18 B0a, t19 B0b, t0' B1a, t1' B1b, t2' B2a, t3' B2b, t4' B3a, t5' B3b
+      //      (every quarter is read one period after it was staged and is out of its buffer before the buffer's next read)
+      u32x4 q2[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) q2[u] = u32x4{0u, 0u, 0u, 0u};
+      const unsigned rd0 = stg_rd, rd1 = stg_rd + W2_SLOT;
+      auto rd_q2 = [&](unsigned addr) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) q2[u] = *reinterpret_cast<const u32x4*>(lds + addr + (u >> 2) * 4096 + ((u >> 1) & 1) * 2048 + (u & 1) * 512);
+      };
+      auto st_q2 = [&](auto h_tag, int quarter, const int (&vv)[4], i32x4 rs_o) __attribute__((always_inline)) {
+        constexpr int Hh = decltype(h_tag)::value;
+#pragma unroll
+        for (int u = 8 * Hh; u < 8 * Hh + 8; ++u) {
+          const int cw = u >> 2, n = (u >> 1) & 1, e = u & 1;
+          w2_store16(q2[u], vv[(cw & 1) * 2 + n], rs_o, (unsigned)((cw >> 1) * 8 + quarter * 2 + e) * (unsigned)plane16);
+        }
+      };
+      auto lb = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (this period's staging reads are in registers before the slot is written again)
+        W2_LBARRIER();
+      };
+      using H0 = W2IC<0>;
+      using H1 = W2IC<1>;
+      for (;;) {
+        // t0 (P0)
+        st_q2(H0{}, 1, vo_prev, rs_prev);            // B1a
+        w2_rd16_a<64>(rd1);                          // B3 -> QB1
+        next_tile();
+        lb();
+        st_q2(H1{}, 1, vo_prev, rs_prev); lb();      // t1: B1b
+        w2_st8_a<0, 0>(vo_prev, rs_prev, (unsigned)(0 * 8 + 2 * 2) * (unsigned)plane16, (unsigned)plane16); lb();   // t2: B2a
+        w2_st8_a<0, 1>(vo_prev, rs_prev, (unsigned)(1 * 8 + 2 * 2) * (unsigned)plane16, (unsigned)plane16); lb();   // t3: B2b
+        w2_st8_a<64, 0>(vo_prev, rs_prev, (unsigned)(0 * 8 + 3 * 2) * (unsigned)plane16, (unsigned)plane16); lb();  // t4 (EA0): B3a
+        w2_st8_a<64, 1>(vo_prev, rs_prev, (unsigned)(1 * 8 + 3 * 2) * (unsigned)plane16, (unsigned)plane16);        // t5 (EA1): B3b
+        w2_rd16_a<0>(rd0); lb();                                                                                     //           A0 -> QB0
+        w2_st8_a<0, 0>(vo[0], rs_out, (unsigned)(0 * 8 + 0 * 2) * (unsigned)plane16, (unsigned)plane16);            // t6 (EA2): A0a
+        w2_rd16_a<64>(rd1); lb();                                                                                    //           A1 -> QB1
+        w2_st8_a<0, 1>(vo[0], rs_out, (unsigned)(1 * 8 + 0 * 2) * (unsigned)plane16, (unsigned)plane16);            // t7 (EA3): A0b
+        rd_q2(rd0); lb();                                                                                            //           A2 -> QB2
+        w2_st8_a<64, 0>(vo[0], rs_out, (unsigned)(0 * 8 + 1 * 2) * (unsigned)plane16, (unsigned)plane16);           // t8 (Q0): A1a
+        w2_rd16_a<0>(rd1); lb();                                                                                     //          A3 -> QB0
+        w2_st8_a<64, 1>(vo[0], rs_out, (unsigned)(1 * 8 + 1 * 2) * (unsigned)plane16, (unsigned)plane16); lb();     // t9: A1b
+        st_q2(H0{}, 2, vo[0], rs_out); lb();                                                                         // t10: A2a
+        st_q2(H1{}, 2, vo[0], rs_out); lb();                                                                         // t11: A2b
+        w2_st8_a<0, 0>(vo[0], rs_out, (unsigned)(0 * 8 + 3 * 2) * (unsigned)plane16, (unsigned)plane16); lb();      // t12: A3a
+        w2_st8_a<0, 1>(vo[0], rs_out, (unsigned)(1 * 8 + 3 * 2) * (unsigned)plane16, (unsigned)plane16); lb();      // t13: A3b
+        lb();                                                                                                        // t14
+        lb();                                                                                                        // t15
+        lb();                                                                                                        // t16 (EB0)
+        w2_rd16_a<64>(rd0); lb();                                                                                    // t17 (EB1): B0 -> QB1
+        w2_st8_a<64, 0>(vo[1], rs_out, (unsigned)(0 * 8 + 0 * 2) * (unsigned)plane16, (unsigned)plane16);           // t18 (EB2): B0a
+        rd_q2(rd1); lb();                                                                                            //            B1 -> QB2
+        w2_st8_a<64, 1>(vo[1], rs_out, (unsigned)(1 * 8 + 0 * 2) * (unsigned)plane16, (unsigned)plane16);           // t19 (EB3): B0b
+        w2_rd16_a<0>(rd0); lb();                                                                                     //            B2 -> QB0
+        advance();
+        if (!has_next) break;
+      }
+      // the last tile's pass B: B1 (QB2), B2 (QB0) and B3 (slot 1)
+      st_q2(H0{}, 1, vo_prev, rs_prev);
+      st_q2(H1{}, 1, vo_prev, rs_prev);
+      w2_rd16_a<64>(rd1);
+      w2_st8_a<0, 0>(vo_prev, rs_prev, (unsigned)(0 * 8 + 2 * 2) * (unsigned)plane16, (unsigned)plane16);
+      w2_st8_a<0, 1>(vo_prev, rs_prev, (unsigned)(1 * 8 + 2 * 2) * (unsigned)plane16, (unsigned)plane16);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      w2_st8_a<64, 0>(vo_prev, rs_prev, (unsigned)(0 * 8 + 3 * 2) * (unsigned)plane16, (unsigned)plane16);
+      w2_st8_a<64, 1>(vo_prev, rs_prev, (unsigned)(1 * 8 + 3 * 2) * (unsigned)plane16, (unsigned)plane16);
+      return;
+    }
+    // ---- any other K: every staged quarter goes out in the period after its staging
+    bool pend = false;
+    for (;;) {
+      for (int k = 0; k < np; ++k) {           // pass A
+        if (k == 0) {
+          if (pend) store_quarter(1, 3, vo_prev, rs_prev);
+          pend = false;
+          next_tile();
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (e == 3) W2_VMWAIT(0);   // (everything of the next tile's first period has landed; its P0 weights were waited for in the last B period)
+        W2_LBARRIER();
+      }
+      for (int e = 0; e < 4; ++e) {            // epilogue A
+        if (e >= 1) store_quarter((e - 1) & 1, e - 1, vo[0], rs_out);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the staging reads are in registers before the slot is written again)
+        W2_LBARRIER();
+      }
+      for (int c = 0; c < nck; ++c) {          // pass B
+        if (c == 0) store_quarter(1, 3, vo[0], rs_out);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        W2_LBARRIER();
+      }
+      for (int e = 0; e < 4; ++e) {            // epilogue B
+        if (e >= 1) store_quarter((e - 1) & 1, e - 1, vo[1], rs_out);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         W2_LBARRIER();
       }
       pend = true;
-      vo_pend[0] = gc.vo[1][0]; vo_pend[1] = gc.vo[1][1];
-      rs_pend = rs_out;
+      advance();
       if (!has_next) break;
-      T = Tn;
-      gc = gn;
-      rs_in = rs_in_n;
-      rs_out = rs_out_of(T.b);
-      rs_sg = rs_sg_of(T.b);
     }
-    store_quarter(1, 3, vo_pend, rs_pend);
-#ifdef YOGO_DIAG
-    if (p.stamps && ttid == 0) {
-      unsigned long long* d = p.stamps + (size_t)blockIdx.x * 16;
-      d[10] = t_vm; d[11] = t_lb; d[12] = __builtin_amdgcn_s_memtime();
-    }
-#endif
+    store_quarter(1, 3, vo_prev, rs_prev);
     return;
   }
 
@@ -387,47 +733,82 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   };
   decode_pix(T);
-  f32x16 acc[2][2][2];   // [px][mb][n]
-  auto acc_zero = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[a][b][c][r] = 0.f;
+  // the operand sets of the K steps: weight quads of step s of a period of parity PAR in A[w2_aset(PAR, s)], pixel quads in B[w2_bset(s)]
+  u32x4 A[4][2], B[4][2];
+  unsigned pb0[2], pb1[2];   // this lane's pixel-quad addresses in the period's first dy slot: row a, row a + 1
+  // one period = six K steps.  FIRST: the pass's first period (the accumulators start from zero); LASTP: its last (no operands
+  // of a next period; the MFMA -> vector-ALU wait states).  pa / pan: this lane's weight unit in this / the next period's buffer
+  auto period = [&](auto pb_tag, auto first_tag, auto last_tag, auto par_tag, unsigned pa, unsigned pan) __attribute__((always_inline)) {
+    constexpr bool PB = decltype(pb_tag)::value, FIRST = decltype(first_tag)::value, LASTP = decltype(last_tag)::value;
+    constexpr int PAR = decltype(par_tag)::value;
+    constexpr int NSL = PB ? W2_DYS : 2 * W2_DYS;   // bytes from this period's first dy slot to the next period's
+#define W2_A(S) A[w2_aset(PAR, S)]
+#define W2_B(S) B[w2_bset(S)]
+#define W2_PX(S) ((S) % 3 == 0 ? 0 : 1)
+#define W2_PB(S, N) (w2_brow(PB, S) ? pb1[N] : pb0[N])
+    // step 0: reads of step 2
+    w2_k_ab<W2_PX(0), FIRST, w2_grp(PB, 2) * 4096, w2_bimm(PB, 2)>(W2_A(0)[0], W2_A(0)[1], W2_B(0)[0], W2_B(0)[1], W2_A(2)[0], W2_A(2)[1], W2_B(2)[0], W2_B(2)[1], pa,
+                                                                  W2_PB(2, 0), W2_PB(2, 1));
+    // step 1: reads of step 3
+    w2_k_ab<W2_PX(1), FIRST, w2_grp(PB, 3) * 4096, w2_bimm(PB, 3)>(W2_A(1)[0], W2_A(1)[1], W2_B(1)[0], W2_B(1)[1], W2_A(3)[0], W2_A(3)[1], W2_B(3)[0], W2_B(3)[1], pa,
+                                                                  W2_PB(3, 0), W2_PB(3, 1));
+    // step 2: reads of steps 4 and 5
+    w2_k_aab<W2_PX(2), true, w2_grp(PB, 4) * 4096, w2_grp(PB, 5) * 4096, w2_bimm(PB, 5)>(W2_A(2)[0], W2_A(2)[1], W2_B(2)[0], W2_B(2)[1], W2_A(4)[0], W2_A(4)[1], W2_A(5)[0],
+                                                                                        W2_A(5)[1], W2_B(5)[0], W2_B(5)[1], pa, W2_PB(5, 0), W2_PB(5, 1));
+    // step 3: everything of this period is in registers -> the period's barrier
+    w2_k_0<W2_PX(3), 1>(W2_A(3)[0], W2_A(3)[1], W2_B(3)[0], W2_B(3)[1], W2_A(4)[0], W2_A(4)[1], W2_A(5)[0], W2_A(5)[1], W2_B(5)[0], W2_B(5)[1]);
+    if constexpr (!LASTP) {
+      // step 4: the next period's steps 0 and 1 (its parity is the other one: their weight quads go to the sets of this period's steps 2, 3)
+      w2_k_aab<W2_PX(4), false, 0, w2_grp(PB, 1) * 4096, NSL>(W2_A(4)[0], W2_A(4)[1], W2_B(4)[0], W2_B(4)[1], W2_A(2)[0], W2_A(2)[1], W2_A(3)[0], W2_A(3)[1], W2_B(0)[0],
+                                                              W2_B(0)[1], pan, pb0[0], pb0[1]);
+      w2_k_0<W2_PX(5), 2>(W2_A(5)[0], W2_A(5)[1], W2_B(5)[0], W2_B(5)[1], W2_A(2)[0], W2_A(2)[1], W2_A(3)[0], W2_A(3)[1], W2_B(0)[0], W2_B(0)[1]);
+    } else {
+      w2_k_0<W2_PX(4), 0>(W2_A(4)[0], W2_A(4)[1], W2_B(4)[0], W2_B(4)[1], W2_A(2)[0], W2_A(2)[1], W2_A(3)[0], W2_A(3)[1], W2_B(0)[0], W2_B(0)[1]);
+      w2_k_0<W2_PX(5), 3>(W2_A(5)[0], W2_A(5)[1], W2_B(5)[0], W2_B(5)[1], W2_A(2)[0], W2_A(2)[1], W2_A(3)[0], W2_A(3)[1], W2_B(0)[0], W2_B(0)[1]);
+    }
+#undef W2_A
+#undef W2_B
+#undef W2_PX
+#undef W2_PB
   };
-  // one 16-channel chunk: weight groups at wbase (this lane's unit of row block 0), dy slot at dbase; NS steps of 4 MFMAs
-  auto run16 = [&](auto passb_tag, unsigned wbase, unsigned dbase) __attribute__((always_inline)) {
-    constexpr bool PB = decltype(passb_tag)::value;
-    constexpr int NS = PB ? 6 : 3;
-    u32x4 Bv[2];
-    w2_static_for([&](auto s_tag) __attribute__((always_inline)) {
-      constexpr int S = decltype(s_tag)::value;
-      constexpr W2Step st = w2_step(PB, S);
-      constexpr int prev_sh = S == 0 ? -1 : w2_step(PB, S > 0 ? S - 1 : 0).sh;
-      if constexpr (st.sh != prev_sh) {
-        const unsigned so = (unsigned)((st.sh & 1) * 16) + ((st.sh & 2) ? lw16 : 0u);
+  // a pass: `nper` periods from dy slot 0 on; the weight buffer alternates (wpar)
+  auto run_pass = [&](auto pb_tag, int nper, int& wpar) __attribute__((always_inline)) {
+    constexpr bool PB = decltype(pb_tag)::value;
+    using TT = std::true_type;
+    using FT = std::false_type;
 #pragma unroll
-        for (int n = 0; n < 2; ++n) Bv[n] = *reinterpret_cast<const u32x4*>(lds + dbase + pbr[n] + so);
+    for (int n = 0; n < 2; ++n) {
+      pb0[n] = (unsigned)W2_DY + pbr[n];
+      pb1[n] = pb0[n] + lw16;
+    }
+    w2_kfirst<w2_grp(PB, 1) * 4096>(A[0][0], A[0][1], A[1][0], A[1][1], B[0][0], B[0][1], (unsigned)(wpar * W2_WB) + a_b0, pb0[0], pb0[1]);
+    for (int k = 0; k < nper; ++k) {
+      const unsigned pa = (unsigned)(wpar * W2_WB) + a_b0, pan = (unsigned)((wpar ^ 1) * W2_WB) + a_b0;
+      const bool last = k == nper - 1;   // (uniform)
+      if (k == 0) {
+        if (last) period(pb_tag, TT{}, TT{}, W2IC<0>{}, pa, pan);
+        else period(pb_tag, TT{}, FT{}, W2IC<0>{}, pa, pan);
+      } else if (k & 1) {
+        if (last) period(pb_tag, FT{}, TT{}, W2IC<1>{}, pa, pan);
+        else period(pb_tag, FT{}, FT{}, W2IC<1>{}, pa, pan);
+      } else {
+        if (last) period(pb_tag, FT{}, TT{}, W2IC<0>{}, pa, pan);
+        else period(pb_tag, FT{}, FT{}, W2IC<0>{}, pa, pan);
       }
-      u32x4 Av[2];
+      wpar ^= 1;
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb) Av[mb] = *reinterpret_cast<const u32x4*>(lds + wbase + st.g * 4096 + mb * 512);
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-          acc[st.px][mb][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Av[mb]), __builtin_bit_cast(bf16x8, Bv[n]),
-                                                                      acc[st.px][mb][n], 0, 0, 0);
-    }, std::make_integer_sequence<int, NS>{});
+      for (int n = 0; n < 2; ++n) {
+        pb0[n] += PB ? W2_DYS : 2 * W2_DYS;
+        pb1[n] += PB ? W2_DYS : 2 * W2_DYS;
+      }
+    }
   };
   // a quarter of a pass's epilogue: channel group (mb, gp) of the 8 accumulator tiles -> staging slot `sl` (4 units of 1 KB)
   [[maybe_unused]] unsigned long long t_bw = 0, t_ebw = 0;   // (diagnostic build) ticks inside the barrier statements of the MFMA periods / the epilogue quarters
   unsigned sg[2][2] = {{0u, 0u}, {0u, 0u}};   // this lane's sign bytes of the pass: [n][px], byte mb * 2 + gp
   auto epi_quarter = [&](auto q_tag, int sl) __attribute__((always_inline)) {
     constexpr int Q = decltype(q_tag)::value, MB = Q >> 1, GP = Q & 1;
+    if constexpr ((W2_ABL & 8) != 0) return;
     const float* es = reinterpret_cast<const float*>(lds + W2_ES) + mh * 64 + MB * 32 + 16 * GP + 4 * half;
     const float4 sA = *reinterpret_cast<const float4*>(es), sB = *reinterpret_cast<const float4*>(es + 8);
     const float sa[8] = {sA.x, sA.y, sA.z, sA.w, sB.x, sB.y, sB.z, sB.w};
@@ -437,7 +818,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     unsigned char* dst0 = lds + stg_wr + sl * W2_SLOT;
     w2_static_for([&](auto u_tag) __attribute__((always_inline)) {   // the quarter's four units (n, px)
       constexpr int n = decltype(u_tag)::value >> 1, px = decltype(u_tag)::value & 1;
-      float v[8];
+      float v[8], r[8];
+      w2_acc_read8<16 * (4 * px + 2 * MB + n) + 8 * GP>(r);
       if constexpr (SIGNS) {
         const unsigned m = sg[n][px] >> (8 * Q);
 #pragma unroll
@@ -445,15 +827,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           const int t = (int)(m << (31 - i)) >> 31;   // bit i spread over the word (v_bfe_i32) selects scale or 0.01 * scale (v_bfi_b32)
           unsigned f;
           asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(f) : "v"(t), "v"(sa[i]), "v"(sl_[i]));
-          v[i] = acc[px][MB][n][8 * GP + i] * __builtin_bit_cast(float, f);
+          v[i] = r[i] * __builtin_bit_cast(float, f);
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = fmaf(acc[px][MB][n][8 * GP + i], sa[i], 0.f * sa[i]);   // (conv_bf16_epi_groups.inc: fma(acc, scale, bias * scale), bias = 0)
+        for (int i = 0; i < 8; ++i) v[i] = fmaf(r[i], sa[i], 0.f * sa[i]);   // (conv_bf16_epi_groups.inc: fma(acc, scale, bias * scale), bias = 0)
       }
       if (W2_DBG(2)) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = acc[px][MB][n][8 * GP + i];
+        for (int i = 0; i < 8; ++i) v[i] = r[i];
       }
       bf16x8 o;
 #pragma unroll
@@ -488,27 +870,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   [[maybe_unused]] unsigned long long t_a = 0, t_ea = 0, t_b = 0, t_eb = 0;
   for (;;) {
     [[maybe_unused]] const unsigned long long s0 = W2_STAMP();
-    acc_zero();
-    for (int k = 0; k < np; ++k) {
-      const unsigned wb = (unsigned)(wpar * W2_WB) + a_b0;
-      run16(std::false_type{}, wb, (unsigned)(W2_DY + (2 * k) * W2_DYS));
-      run16(std::false_type{}, wb + 3 * 4096, (unsigned)(W2_DY + (2 * k + 1) * W2_DYS));
-      [[maybe_unused]] const unsigned long long b0 = W2_STAMP();
-      w2_barrier_lgkm();
-      t_bw += W2_STAMP() - b0;
-      wpar ^= 1;
-    }
+    run_pass(std::false_type{}, np, wpar);
     [[maybe_unused]] const unsigned long long s1 = W2_STAMP();
     epilogue();
     [[maybe_unused]] const unsigned long long s2 = W2_STAMP();
-    acc_zero();
-    for (int c = 0; c < nck; ++c) {
-      run16(std::true_type{}, (unsigned)(wpar * W2_WB) + a_b0, (unsigned)(W2_DY + c * W2_DYS));
-      [[maybe_unused]] const unsigned long long b0 = W2_STAMP();
-      w2_barrier_lgkm();
-      t_bw += W2_STAMP() - b0;
-      wpar ^= 1;
-    }
+    run_pass(std::true_type{}, nck, wpar);
     [[maybe_unused]] const unsigned long long s3 = W2_STAMP();
     epilogue();
     [[maybe_unused]] const unsigned long long s4 = W2_STAMP();
