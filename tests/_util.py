@@ -218,7 +218,7 @@ def teacher_forced_bf16_step_check(O, tr, model, x, lab, spec, sd0, what):
 # ---- the test-hooks library ------------------------------------------------------------------------------------------------------
 # libyogo_hip_hooks.so (yogo_amd/csrc/build.sh) = the product's objects with the three files that own a plan choice recompiled under
 # -DYOGO_TEST_HOOKS: the same kernels plus yogo_hook_conv_bf16_persistent / yogo_hook_conv_first_mfma_pairs /
-# yogo_hook_conv_first_bn_wgrad_pairs.  The product library has no such switch (no mutable global state); A/B and bit-identity tests
+# yogo_hook_conv_first_bn_wgrad_pairs / yogo_hook_conv_bf16_ws2 (the stride-2 data-gradient member of the persistent family: off in the product).  The product library has no such switch (no mutable global state); A/B and bit-identity tests
 # bind the hooks library in place of the product's for their duration.
 import contextlib
 
@@ -235,7 +235,8 @@ def hooks_library():
         raise RuntimeError(f"{path} missing: run `bash yogo_amd/csrc/build.sh` (it builds the product and the hooks library)")
     _hip.lib()
     L = _hip.bind(path, _hip.prototypes())
-    for name in ("yogo_hook_conv_bf16_persistent", "yogo_hook_conv_first_mfma_pairs", "yogo_hook_conv_first_bn_wgrad_pairs"):
+    hooks = ("yogo_hook_conv_bf16_persistent", "yogo_hook_conv_first_mfma_pairs", "yogo_hook_conv_first_bn_wgrad_pairs", "yogo_hook_conv_bf16_ws2")
+    for name in hooks:
         fn = getattr(L, name)
         fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_int]
     prev = _hip._lib
@@ -243,6 +244,6 @@ def hooks_library():
     try:
         yield L
     finally:
-        for name in ("yogo_hook_conv_bf16_persistent", "yogo_hook_conv_first_mfma_pairs", "yogo_hook_conv_first_bn_wgrad_pairs"):
-            getattr(L, name)(1)
+        for name in hooks:   # back to the product's plan
+            getattr(L, name)(0 if name.endswith("_ws2") else 1)
         _hip._lib = prev

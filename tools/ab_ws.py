@@ -14,8 +14,9 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from yogo_amd import _hip as H
 H.LIB_PATH = os.path.join(ROOT, "yogo_amd", "lib", "libyogo_hip_hooks.so")   # the product's objects + the yogo_hook_* switches
 import ctypes
-_f = H.lib().yogo_hook_conv_bf16_persistent
-_f.restype, _f.argtypes = ctypes.c_int, [ctypes.c_int]
+for _n in ("yogo_hook_conv_bf16_persistent", "yogo_hook_conv_bf16_ws2"):
+    _f = getattr(H.lib(), _n)
+    _f.restype, _f.argtypes = ctypes.c_int, [ctypes.c_int]
 import bench_conv_bf16 as BC
 
 if __name__ == "__main__":
@@ -29,6 +30,7 @@ if __name__ == "__main__":
     for r in range(rounds + 1):
         for mode in (0, 1):
             H.call("yogo_hook_conv_bf16_persistent", mode)
+            H.call("yogo_hook_conv_bf16_ws2", mode)   # (the stride-2 data-gradient member: off in the product)
             for w in which:
                 kind = w[-1]
                 buf = io.StringIO()

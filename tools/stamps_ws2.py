@@ -40,4 +40,4 @@ if __name__ == "__main__":
             nt = h[:, 6]
             f = lambda c: (h[:, c] / nt).mean()
             print(f"  {w} dbg={dbg}: wgs={h.shape[0]} tiles/wg={nt.mean():.1f} life={life.mean():.0f} | per tile: {(life / nt).mean():.0f} = pass A {f(2):.0f} + epi A {f(3):.0f} "
-                  f"+ pass B {f(4):.0f} + epi B {f(5):.0f}; in barriers: MFMA periods {f(7):.0f}, quarters {f(8):.0f} | loader: vmcnt waits {f(10):.0f}, barriers {f(11):.0f}")
+                  f"+ pass B {f(4):.0f} + epi B {f(5):.0f}")

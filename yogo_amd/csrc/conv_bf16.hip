@@ -1338,8 +1338,13 @@ static bool g_bf_ring = true; // (diagnostic build: yogo_diag_conv_bf16_ring(0) 
 static bool g_bf_ws = true;
 // 0 = every launch goes to the tiled conv_bf16_kernel (A/B runs and the bit-identity tests of the two kernel families)
 extern "C" int yogo_hook_conv_bf16_persistent(int on) { g_bf_ws = on != 0; return YOGO_OK; }
+// The stride-2 data-gradient member (conv_bf16_ws2.hip) is built, parity-green and NOT faster than the tiled kernel: off in
+// the product, switched on by the tests / A-B tools through the hooks library
+static bool g_bf_ws2 = false;
+extern "C" int yogo_hook_conv_bf16_ws2(int on) { g_bf_ws2 = on != 0; return YOGO_OK; }
 #else
 static constexpr bool g_bf_ws = true;
+static constexpr bool g_bf_ws2 = false;
 #endif
 static bool g_bf_pp = true;   // (diagnostic build: yogo_diag_conv_bf16_pp(0) selects the interleaved main loop for A/B runs)
 #ifdef YOGO_DIAG
@@ -1426,7 +1431,7 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
   }
   // stride-2 3x3 data gradient into 128 channels (scale / LeakyReLU-sign-map epilogue): the persistent wavefront-specialised kernel
   // that stages the gradient tile once for both row parities (conv_bf16_ws2.hip)
-  if (in != nullptr && g_bf_ws && s2d && ks == 3 && out_f32 == nullptr && out_pre == nullptr && act_ref == nullptr && bias == nullptr &&
+  if (in != nullptr && g_bf_ws && g_bf_ws2 && s2d && ks == 3 && out_f32 == nullptr && out_pre == nullptr && act_ref == nullptr && bias == nullptr &&
       stats_part == nullptr && act == ACT_NONE && (!signs_read || (signs != nullptr && ref_act == ACT_LEAKY)) && (signs_read || signs == nullptr) &&
       conv_bf16_ws2_eligible(K, M, OH, OW, B)) {
     ConvWs2Params q{};

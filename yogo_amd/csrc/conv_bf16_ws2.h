@@ -3,7 +3,7 @@
 #pragma once
 #include "common.h"
 
-// 8 wavefronts per workgroup, one workgroup per CU: wavefronts 0-3 COMPUTE (one per SIMD), wavefronts 4-7 LOAD / STORE (w + 4
+// 8 wavefronts per workgroup, one workgroup per CU: wavefronts 0-3 COMPUTE and store (one per SIMD), wavefronts 4-7 LOAD (w + 4
 // shares w's SIMD).  A workgroup tile is 128 consecutive output QUADS (2x2 output pixels = one dy pixel) of a column band, all
 // 128 channels; a compute wavefront owns 64 channels x 64 quads x both column parities of ONE row parity at a time (8 accumulator
 // tiles of 32x32) and runs the tile's two row parities one after the other off ONE staged dy tile.
@@ -11,12 +11,11 @@
 #define W2_WB (6 * 4096)               // a period's weight slices: 6 groups of [2 channel blocks][128 channels] units (24 576)
 #define W2_DYS (2 * 256 * 16)          // a dy slot: one 16-channel chunk of the tile, [2 channel blocks][256 units] (8 192)
 #define W2_NSLOT 8                     // dy slots = 16-channel chunks of the contraction (K <= 128)
-#define W2_DY (2 * W2_WB)              // first dy slot
-#define W2_STG (W2_DY + W2_NSLOT * W2_DYS)   // output staging: 2 slots of [4 wavefronts][4 units][1 KB]
-#define W2_SLOT 16384
-#define W2_SG (W2_STG + 2 * W2_SLOT)   // LeakyReLU sign bytes of the pass in its epilogue: [4 wavefronts][n][px][64 lanes] dwords
-#define W2_ES (W2_SG + 4096)           // [128] fp32 channel scale of the tile's image
-#define W2_LDS_BYTES (W2_ES + 512)     // 152 064
+#define W2_NWB 3                       // weight buffers: a period's slices are requested TWO periods ahead
+#define W2_DY (W2_NWB * W2_WB)         // first dy slot
+#define W2_SG (W2_DY + W2_NSLOT * W2_DYS)   // LeakyReLU sign bytes: [pass A | pass B][4 wavefronts][n][px][64 lanes] dwords (2 x 4 KB)
+#define W2_ES (W2_SG + 2 * 4096)       // [tile parity][128] fp32 channel scale of the tile's image
+#define W2_LDS_BYTES (W2_ES + 1024)    // 148 480
 
 struct ConvWs2Params {
   const void* in;     // dy: bf16 NCHW8c [B][Kb][IH][IW] units, IH = ceil(OH / 2), IW = ceil(OW / 2)
@@ -34,7 +33,7 @@ struct ConvWs2Params {
 #endif
 };
 
-// true when the kernel takes the launch (M = 128 output channels of the gradient, K a multiple of 32 in 32 ... 128)
+// true when the kernel takes the launch (M = 128 output channels of the gradient, K = 64, 96 or 128)
 bool conv_bf16_ws2_eligible(int K, int M, int OH, int OW, int B);
 // fills the tiling part of `p`; false when no band count fits the fixed dy slot
 bool conv_bf16_ws2_plan(ConvWs2Params* p);

@@ -12,14 +12,18 @@
 //     (py = 1: 6 taps).  Slot c is refilled with the NEXT tile's chunk as soon as pass B is through with it;
 //   * wavefronts 0-3 COMPUTE (one per SIMD): 64 channels x 64 quads x both column parities = 8 accumulator tiles; per dy shift
 //     the two pixel operands are read once and serve every tap of that shift (0.83 LDS operand reads per MFMA);
-//   * wavefronts 4-7 LOAD and STORE: the weight slices of the next period (24 KB, L2 hits) by LDS-DMA into the other weight
-//     buffer, the next tile's dy, the sign bytes / channel scale of the pass whose epilogue comes next, and the output -- the
-//     compute wavefronts write finished 16-byte units to an LDS staging slot (a quarter of a pass at a time), the loaders store
-//     them with both column parities of a row in ONE instruction (64 lanes x 16 B contiguous: whole 128-byte lines, where the
-//     tiled kernel's two half-filled stores per line relied on the L2 to merge them);
-//   * one s_barrier per period orders everything (DMA landed: the loaders wait vmcnt first; staging written; buffers free).
-// Periods of a tile: pass A in 32-channel periods, its epilogue in 4 quarters, pass B in 16-channel periods, 4 quarters -- every
-// MFMA period is 24 MFMAs per compute wavefront and 24 KB of weights.
+//   * wavefronts 4-7 LOAD: the weight slices of the next period (24 KB, L2 hits) by LDS-DMA two periods ahead (three weight buffers), the next
+//     tile's dy, the sign bytes / channel scale of the epilogues.  They issue NO stores: vector-memory operations retire in order and
+//     a load behind a store's acknowledgement holds the period's barrier;
+//   * the compute wavefronts STORE their own output straight from registers at the end of each pass (the half-wave exchange and
+//     one 16-byte store per 8 values, as the tiled kernel): they issue no loads, so they never wait for a store, and four
+//     wavefronts' store queues hold a tile's output.  (Measured on the way, tools/probes/store_rate.hip + gpurun_out/r5_ws2_*: output
+//     staged through LDS and stored by the loaders -- loads stuck behind store acknowledgements, 16 k of 37 k cycles per tile in
+//     vmcnt waits; by ONE dedicated store wavefront, also paced through a 48 KB register FIFO -- the eight extra barriers per tile
+//     and the wavefront's own issue time cost what the overlap gained: all three forms ran at the tiled kernel's 0.87 ms.)
+//   * one s_barrier per MFMA period orders everything (DMA landed: the loaders wait vmcnt first; buffers free).
+// Periods of a tile: pass A in 32-channel periods, pass B in 16-channel periods -- every period is 24 MFMAs per compute wavefront
+// and 24 KB of weights.
 #include "conv_bf16_ws2.h"
 #include <mutex>
 #include <type_traits>
@@ -102,20 +106,14 @@ __device__ __forceinline__ void w2_dma_dword(i32x4 rs, unsigned lds, int voff, u
 }
 __device__ __forceinline__ void w2_store16(u32x4 data, int voff, i32x4 rs, unsigned soff) {
   rs = w2_u4(rs); soff = w2_u(soff);
-  asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen" ::"v"(data), "v"(voff), "s"(rs), "s"(soff) : "memory");
+  // (s_nop in front: the descriptor may come from v_readfirstlane; behind: a 16-byte store's data registers must not be overwritten by
+  //  the next vector instruction -- hipcc does not look inside asm statements)
+  asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(data), "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void w2_vmwait() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-#ifdef YOGO_DIAG
-// (the loaders' stamps only with diagnostic bit 64: an s_memtime is a scalar-memory round trip, four of them per period are not free)
-#define W2_VMWAIT(N) do { if (W2_DBG(64)) { const unsigned long long v0__ = __builtin_amdgcn_s_memtime(); w2_vmwait<N>(); t_vm += __builtin_amdgcn_s_memtime() - v0__; } else w2_vmwait<N>(); } while (0)
-#define W2_LBARRIER() do { if (W2_DBG(64)) { const unsigned long long v0__ = __builtin_amdgcn_s_memtime(); w2_barrier(); t_lb += __builtin_amdgcn_s_memtime() - v0__; } else w2_barrier(); } while (0)
-#else
-#define W2_VMWAIT(N) w2_vmwait<N>()
-#define W2_LBARRIER() w2_barrier()
-#endif
 // the period barrier of a compute wavefront: its LDS reads and staging writes are done, then everybody meets
 __device__ __forceinline__ void w2_barrier_lgkm() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void w2_barrier() { asm volatile("s_barrier" ::: "memory"); }
@@ -243,34 +241,6 @@ __device__ constexpr bool w2_newb(int s) { return s == 0 || s == 2 || s == 3 || 
 __device__ constexpr int w2_bset(int s) { return s < 2 ? 0 : (s == 2 ? 1 : (s < 5 ? 2 : 3)); }   // pixel-quad sets: steps 0 1 | 2 | 3 4 | 5
 __device__ constexpr int w2_aset(int par, int s) { return (s + 2 * par) & 3; }             // weight-quad sets, by period parity
 
-// ---- the store wavefront's AGPR quarter buffers: 16 staged units (unit u = 4 cw + 2 n + e, LDS bytes cw * 4096 + n * 2048 + e * 512
-// from the lane's base) <-> a[BASE + 4 u : BASE + 4 u + 3]
-#define W2_RDU(U) "ds_read_b128 a[%[b]+4*" #U ":%[b]+4*" #U "+3], %[ad] offset:(" #U "/4)*4096+((" #U "/2)%%2)*2048+(" #U "%%2)*512\n\t"
-template <int BASE>
-__device__ __forceinline__ void w2_rd16_a(unsigned addr) {
-  asm volatile(W2_RDU(0) W2_RDU(1) W2_RDU(2) W2_RDU(3) W2_RDU(4) W2_RDU(5) W2_RDU(6) W2_RDU(7) W2_RDU(8) W2_RDU(9) W2_RDU(10) W2_RDU(11) W2_RDU(12) W2_RDU(13)
-               W2_RDU(14) W2_RDU(15)
-               :
-               : [ad] "v"(addr), [b] "n"(BASE)
-               : "memory", W2_ACC_CLOBBER);
-}
-#undef W2_RDU
-// units 8 H .. 8 H + 7 (compute wavefronts 2 H, 2 H + 1) -> 8 stores: pixel-group offsets vo[s], s = 2 (cw & 1) + n; scalar offsets so0
-// (channel block of e = 0) and so0 + dso (e = 1)
-template <int BASE, int H>
-__device__ __forceinline__ void w2_st8_a(const int (&vo)[4], i32x4 rs, unsigned so0, unsigned dso) {
-  rs = w2_u4(rs);
-  so0 = w2_u(so0);
-  const unsigned so1 = w2_u(so0 + dso);
-#define W2_STU(J, V, S) "buffer_store_dwordx4 a[%[b]+4*(8*%[h]+" #J "):%[b]+4*(8*%[h]+" #J ")+3], %[" #V "], %[rs], %[" #S "] offen\n\t"
-  asm volatile("s_nop 4\n\t" W2_STU(0, v0, s0) W2_STU(1, v0, s1) W2_STU(2, v1, s0) W2_STU(3, v1, s1) W2_STU(4, v2, s0) W2_STU(5, v2, s1) W2_STU(6, v3, s0)
-               W2_STU(7, v3, s1)
-               :
-               : [v0] "v"(vo[0]), [v1] "v"(vo[1]), [v2] "v"(vo[2]), [v3] "v"(vo[3]), [rs] "s"(rs), [s0] "s"(so0), [s1] "s"(so1), [b] "n"(BASE), [h] "n"(H)
-               : "memory");
-#undef W2_STU
-}
-
 #ifdef YOGO_DIAG
 #define W2_DBG(BIT) (p.dbg & (BIT))
 #define W2_STAMP() __builtin_amdgcn_s_memtime()
@@ -331,17 +301,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     while (__builtin_amdgcn_s_memtime() - t0 < dt) __builtin_amdgcn_s_sleep(8);
   }
 #endif
-  if (p.chan_scale == nullptr && tid < 128) reinterpret_cast<float*>(lds + W2_ES)[tid] = 1.f;
+  if (p.chan_scale == nullptr && tid < 256) reinterpret_cast<float*>(lds + W2_ES)[tid] = 1.f;
   __syncthreads();
 
-  if (team == 1 && tw < 3) {
+  if (team == 1) {
     // =====================================================================================================================
-    // LOAD wavefronts (3): the weight slices of the next period, the next tile's dy and (wavefront 2) the small inputs of the
-    // epilogues -- the sign bytes of a pass, the channel scale of the tile's image.  They issue no stores: vector-memory
-    // operations retire in order, and a load that waits behind a store's acknowledgement holds the period's barrier.
+    // LOADERS (4): wavefront tw stages quarter tw of every weight group, positions tw * 64 ... of every dy channel block, and the
+    // sign bytes of its partner compute wavefront tw
     // =====================================================================================================================
     const int lane = w2_lane();
     const int q31 = lane & 31, hp = lane >> 5;
+    const int ttid = tw * 64 + lane;
     const int rowb = IW * 16, kcb = IH * IW * 16;
     const unsigned ibytes = (unsigned)p.Kb * kcb, wbytes = 9u * p.Kb * 2048u;
     const unsigned wstep = (unsigned)p.Kb * 2048u;   // bytes between the slices of the packed weights
@@ -349,31 +319,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int lane16 = W2_DBG(4) ? (int)OOB : lane * 16;
     const bool has_scale = p.chan_scale != nullptr;
     const i32x4 rs_sc = w2_rsrc(p.chan_scale, has_scale ? (unsigned)p.B * 512u : 0u);
-    [[maybe_unused]] unsigned long long t_vm = 0, t_lb = 0;
-    // dy element of position q * 64 + lane of the [rows_in][lw] image of a channel block, q = 0..3
-    auto decode = [&](const TileS& t, int (&dyoff)[4]) __attribute__((always_inline)) {
+    // per-tile lane geometry: the dy element this lane stages (position ttid of the [rows_in][lw] image of a channel block) and the
+    // sign-map offsets it fetches for its partner (lane = (half-wave hp, quad q31) of pixel group n)
+    struct LaneGeo { int dyoff; int vs[2][2][2]; };
+    auto decode = [&](const TileS& t, LaneGeo& g) __attribute__((always_inline)) {
       const unsigned m_bw = t.lastband ? p.m_bwl : p.m_bw;
       const int bw = t.bw;
       const int i_lo = w2_udivm1(t.p0, bw, m_bw), i_hi = w2_udivm1(t.p1 - 1, bw, m_bw);
       const int rows_in = i_hi - i_lo + 2;
       const int lw = bw + 1;
       const unsigned inv_lw = t.lastband ? p.m_lwl : p.m_lw;   // (lw >= 2)
+      const int r_ = w2_udivm(ttid, inv_lw), x_ = ttid - r_ * lw;
+      const int iy = i_lo + r_, ix = t.j0 + x_;
+      g.dyoff = (r_ < rows_in && iy < IH && ix < IW && !W2_DBG(4) && !W2_DBG(8)) ? iy * rowb + ix * 16 : (int)OOB;   // (diagnostic bit 8: no dy loads, weights as usual)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int pos = q * 64 + lane;
-        const int r_ = w2_udivm(pos, inv_lw), x_ = pos - r_ * lw;
-        const int iy = i_lo + r_, ix = t.j0 + x_;
-        dyoff[q] = (r_ < rows_in && iy < IH && ix < IW && !W2_DBG(4)) ? iy * rowb + ix * 16 : (int)OOB;
-      }
-    };
-    // sign-map offsets of the tile's four 32-quad groups s (compute wavefront cw owns groups 2 (cw & 1) + n): lane = (half-wave hp,
-    // quad q31); + 4 bytes for the upper 64 channels
-    auto decode_vs = [&](const TileS& t, int (&vs)[2][4][2]) __attribute__((always_inline)) {
-      const unsigned m_bw = t.lastband ? p.m_bwl : p.m_bw;
-      const int bw = t.bw;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int pp = t.p0 + s * 32 + q31;
+      for (int n = 0; n < 2; ++n) {
+        const int pp = t.p0 + (nh * 2 + n) * 32 + q31;
         const bool pv = pp < t.p1;
         const int pc = pv ? pp : (t.p1 - 1);
         const int i = w2_udivm1(pc, bw, m_bw), j = pc - i * bw;
@@ -383,332 +344,118 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int py = 0; py < 2; ++py)
 #pragma unroll
           for (int px = 0; px < 2; ++px)
-            vs[py][s][px] = (pv && (py == 0 || vy) && (px == 0 || vx)) ? (hp * plane + pix + py * OW + px) * 8 : (int)OOB;
+            g.vs[py][n][px] = (pv && (py == 0 || vy) && (px == 0 || vx)) ? (hp * plane + pix + py * OW + px) * 8 + mh * 4 : (int)OOB;
       }
     };
     auto rs_in_of = [&](int b) __attribute__((always_inline)) { return w2_rsrc(reinterpret_cast<const unsigned char*>(p.in) + (size_t)b * ibytes, ibytes); };
     auto rs_sg_of = [&](int b) __attribute__((always_inline)) { return w2_rsrc(SIGNS ? p.signs + (size_t)b * plane16 : nullptr, SIGNS ? (unsigned)plane16 : 0u); };
-    // weight groups 2 tw, 2 tw + 1 of a period (4 KB each, contiguous in memory and in LDS).  Pass A, period k: group cc * 3 + t =
-    // slice t of chunk 2 k + cc; pass B, chunk c: group g = slice 3 + g
+    // weights of a pass-A period (chunks 2 k, 2 k + 1: groups cc * 3 + slice) / a pass-B period (chunk c: slices 3 .. 8) -> buffer wb
     auto req_wA = [&](int k, int wb) __attribute__((always_inline)) {
       if constexpr ((W2_ABL & 4) != 0) return;
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int g = 2 * tw + u, cc = g >= 3 ? 1 : 0, t = g - 3 * cc;
-        w2_dma4c(rs_w, (unsigned)(wb * W2_WB + g * 4096), lane16, (unsigned)t * wstep + (unsigned)((4 * k + 2 * cc) * 2048));
-      }
+      w2_dma3(rs_w, (unsigned)(wb * W2_WB + tw * 1024), lane16, (unsigned)((4 * k) * 2048 + tw * 1024), wstep);
+      w2_dma3(rs_w, (unsigned)(wb * W2_WB + 3 * 4096 + tw * 1024), lane16, (unsigned)((4 * k + 2) * 2048 + tw * 1024), wstep);
     };
     auto req_wB = [&](int c, int wb) __attribute__((always_inline)) {
       if constexpr ((W2_ABL & 4) != 0) return;
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int g = 2 * tw + u;
-        w2_dma4c(rs_w, (unsigned)(wb * W2_WB + g * 4096), lane16, (unsigned)(3 + g) * wstep + (unsigned)((2 * c) * 2048));
-      }
+      w2_dma6(rs_w, (unsigned)(wb * W2_WB + tw * 1024), lane16, (unsigned)(3u * wstep + (unsigned)((2 * c) * 2048 + tw * 1024)), wstep);
     };
-    // 16-channel chunk c of a dy tile -> slot c: 8 pieces (channel block, position quarter); wavefront 0 takes pieces 0-2, 1: 3-5, 2: 6-7
-    const int j_lo = tw * 3, nd = tw < 2 ? 3 : 2;
-    auto req_dy = [&](i32x4 rs, const int (&dyoff)[4], int c) __attribute__((always_inline)) {
-#pragma unroll
-      for (int u = 0; u < 3; ++u) {
-        if (u < nd) {   // (uniform)
-          const int j = j_lo + u, q = j & 3, kb = j >> 2;
-          const int vo = q == 0 ? dyoff[0] : (q == 1 ? dyoff[1] : (q == 2 ? dyoff[2] : dyoff[3]));
-          w2_dma1(rs, (unsigned)(W2_DY + c * W2_DYS + j * 1024), vo, (unsigned)(2 * c + kb) * (unsigned)kcb);
-        }
-      }
+    // 16-channel chunk c of the dy tile described by (rs, dyoff) -> slot c (this wavefront's 64 positions of both channel blocks)
+    auto req_dy = [&](i32x4 rs, int dyoff, int c) __attribute__((always_inline)) {
+      w2_dma2(rs, (unsigned)(W2_DY + c * W2_DYS + tw * 1024), dyoff, (unsigned)(2 * c) * (unsigned)kcb, (unsigned)kcb);
     };
-    // the 16 sign dwords of a pass: compute wavefront cw's (n, px) -> [cw][n][px][64 lanes]; its channels' bytes are the 4 at + 4 (cw >> 1)
-    auto req_signs = [&](i32x4 rs, const int (&vs)[4][2]) __attribute__((always_inline)) {
+    auto req_signs = [&](i32x4 rs, const int (&vs)[2][2], int area) __attribute__((always_inline)) {
       if constexpr (SIGNS) {
 #pragma unroll
-        for (int cw = 0; cw < 4; ++cw)
+        for (int n = 0; n < 2; ++n)
 #pragma unroll
-          for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int px = 0; px < 2; ++px)
-              w2_dma_dword(rs, (unsigned)(W2_SG + (cw * 4 + n * 2 + px) * 256), vs[(cw & 1) * 2 + n][px], (unsigned)((cw >> 1) * 4));
+          for (int px = 0; px < 2; ++px) w2_dma_dword(rs, (unsigned)(W2_SG + area * 4096 + (tw * 4 + n * 2 + px) * 256), vs[n][px], 0u);
       }
     };
-    auto req_scale = [&](int b) __attribute__((always_inline)) {   // [128] floats: two 256-byte pieces
-      if (has_scale) {
-        w2_dma_dword(rs_sc, (unsigned)W2_ES, lane * 4, (unsigned)(b * 512));
-        w2_dma_dword(rs_sc, (unsigned)(W2_ES + 256), lane * 4, (unsigned)(b * 512 + 256));
+    auto req_scale = [&](int b, int par) __attribute__((always_inline)) {   // [128] floats: two 256-byte pieces, loaders 2 / 3 repeat those of 0 / 1
+      if (has_scale) w2_dma_dword(rs_sc, (unsigned)(W2_ES + par * 512 + (tw & 1) * 256), lane * 4, (unsigned)((b * 128 + (tw & 1) * 64) * 4));
+    };
+    LaneGeo gc{}, gn{};
+    decode(T, gc);
+    i32x4 rs_in = rs_in_of(T.b), rs_in_n = rs_in;
+    // Weight requests run TWO periods ahead of the MFMAs (three buffers): the requests of the two periods behind an epilogue are in the
+    // memory pipeline before its first store is issued
+    int wreq = 0;   // buffer of the next weight request (rotates 0, 1, 2)
+    auto req_w = [&](bool pass_b, int idx) __attribute__((always_inline)) {
+      if (pass_b) req_wB(idx, wreq);
+      else req_wA(idx, wreq);
+      wreq = wreq == W2_NWB - 1 ? 0 : wreq + 1;
+    };
+    auto vmwait_n = [&](int n) __attribute__((always_inline)) {   // (uniform) all but the n youngest vector-memory operations are done
+      switch (n) {
+        case 0: w2_vmwait<0>(); break;
+        case 1: w2_vmwait<1>(); break;
+        case 2: w2_vmwait<2>(); break;
+        case 4: w2_vmwait<4>(); break;
+        case 5: w2_vmwait<5>(); break;
+        case 6: w2_vmwait<6>(); break;
+        case 7: w2_vmwait<7>(); break;
+        case 8: w2_vmwait<8>(); break;
+        case 10: w2_vmwait<10>(); break;
+        case 11: w2_vmwait<11>(); break;
+        default: w2_vmwait<0>(); break;
       }
     };
-    const bool small = tw == 2;   // (uniform) this wavefront also fetches the epilogues' small inputs
-    int dyo[4], dyo_n[4] = {(int)OOB, (int)OOB, (int)OOB, (int)OOB};
-    int vs[2][4][2], vs_n[2][4][2];
-    decode(T, dyo);
-    if (small) decode_vs(T, vs);
-    i32x4 rs_in_n = rs_in_of(T.b);
-    for (int c = 0; c < nck; ++c) req_dy(rs_in_n, dyo, c);
-    req_wA(0, 0);
-    if (small) {
-      req_signs(rs_sg_of(T.b), vs[0]);
-      req_scale(T.b);
-    }
-    W2_VMWAIT(0);
-    W2_LBARRIER();   // (#1)
-    int wpar = 0;           // weight buffer of the MFMA period being computed
+    const int n_small = (SIGNS ? 4 : 0) + (has_scale ? 1 : 0);
+    // first tile: every chunk but the last (the first period of every tile requests that one) and the first two periods' weights
+    for (int c = 0; c + 1 < nck; ++c) req_dy(rs_in, gc.dyoff, c);
+    req_w(false, 0);
+    req_w(false, 1);   // (np >= 2)
+    w2_vmwait<0>();
+    w2_barrier();   // (#1)
+    int tpar = 0;           // channel-scale buffer of the tile
     bool has_next = true;
     TileS Tn{};
     for (;;) {
-      for (int k = 0; k < np; ++k) {           // pass A
-        if (k + 1 < np) req_wA(k + 1, wpar ^ 1);
-        else req_wB(0, wpar ^ 1);
-        if (k == 0) {   // the next tile: looked up and decoded behind this period's requests
-          // (the channel scale is read by the epilogue quarters only: free since the previous tile's last one; it may stay in flight)
-          if (small) req_scale(T.b);
+      // ---------------- pass A: np >= 2 periods of 32 channels
+      for (int k = 0; k < np; ++k) {
+        int young = 0;   // operations of this period that may stay in flight behind the barrier
+        if (k == 0) req_dy(rs_in, gc.dyoff, nck - 1);   // this tile's last dy chunk (its slot was pass B's last of the previous tile): landed with this barrier
+        if (k + 2 < np) req_w(false, k + 2);
+        else req_w(true, k + 2 - np);   // (nck >= 4)
+        young += 6;
+        if (k == 0) {
+          // what the tile's first epilogue reads: pass A's sign bytes, the channel scale of the tile's image
+          req_signs(rs_sg_of(T.b), gc.vs[0], 0);
+          req_scale(T.b, tpar);
+          young += n_small;
+          // the next tile: looked up and decoded here, behind this period's requests
           unsigned kn = k_ord + 1;
           has_next = find_tile(kn, Tn);
           k_ord = kn;
           if (has_next) {
-            decode(Tn, dyo_n);
-            if (small) decode_vs(Tn, vs_n);
+            decode(Tn, gn);
             rs_in_n = rs_in_of(Tn.b);
           }
-          if (small && has_scale) W2_VMWAIT(2);
-          else W2_VMWAIT(0);
-        } else {
-          W2_VMWAIT(0);
         }
-        W2_LBARRIER();
-        wpar ^= 1;
+        vmwait_n(young);
+        w2_barrier();
       }
-      for (int e = 0; e < 4; ++e) W2_LBARRIER();   // epilogue A
-      for (int c = 0; c < nck; ++c) {          // pass B
-        if (c + 1 < nck) req_wB(c + 1, wpar ^ 1);
-        else if (has_next) req_wA(0, wpar ^ 1);
-        if (c == 0) {   // pass B's sign bytes (pass A's were read in front of its first quarter); they may stay in flight
-          if (small && SIGNS) {
-            req_signs(rs_sg_of(T.b), vs[1]);
-            W2_VMWAIT(16);
-          } else {
-            W2_VMWAIT(0);
-          }
-        } else if (has_next) {   // slot c - 1 is free: the next tile's chunk (it may stay in flight)
-          req_dy(rs_in_n, dyo_n, c - 1);
-          if (tw < 2) W2_VMWAIT(3);
-          else W2_VMWAIT(2);
-        } else {
-          W2_VMWAIT(0);
+      // ---------------- pass B: nck periods of 16 channels
+      for (int c = 0; c < nck; ++c) {
+        int young = 0;
+        if (c + 2 < nck) { req_w(true, c + 2); young += 6; }
+        else if (has_next) { req_w(false, c + 2 - nck); young += 6; }
+        if (c == 0) {
+          req_signs(rs_sg_of(T.b), gc.vs[1], 1);   // pass B's sign bytes (their own area: the compute wavefronts may still be in pass A's epilogue)
+          young += SIGNS ? 4 : 0;
+        } else if (has_next) {
+          req_dy(rs_in_n, gn.dyoff, c - 1);   // slot c - 1 is free: the next tile's chunk
+          young += 2;
         }
-        W2_LBARRIER();
-        wpar ^= 1;
-      }
-      for (int e = 0; e < 4; ++e) {            // epilogue B
-        if (e == 0 && has_next) req_dy(rs_in_n, dyo_n, nck - 1);
-        if (e == 1 && has_next && small) req_signs(rs_sg_of(Tn.b), vs_n[0]);   // (pass B's bytes were read in front of quarter 0)
-        if (e == 3) W2_VMWAIT(0);   // (everything of the next tile's first period has landed)
-        W2_LBARRIER();
+        vmwait_n(young);
+        w2_barrier();
       }
       if (!has_next) break;
       T = Tn;
-      if (small) {
-#pragma unroll
-        for (int a_ = 0; a_ < 2; ++a_)
-#pragma unroll
-          for (int b_ = 0; b_ < 4; ++b_)
-#pragma unroll
-            for (int c_ = 0; c_ < 2; ++c_) vs[a_][b_][c_] = vs_n[a_][b_][c_];
-      }
+      gc = gn;
+      rs_in = rs_in_n;
+      tpar ^= 1;
     }
-#ifdef YOGO_DIAG
-    if (p.stamps && tw == 0 && lane == 0) {
-      unsigned long long* d = p.stamps + (size_t)blockIdx.x * 16;
-      d[10] = t_vm; d[11] = t_lb;
-    }
-#endif
-    return;
-  }
-  if (team == 1) {
-    // =====================================================================================================================
-    // STORE wavefront: the output.  The compute wavefronts stage a quarter of a pass (16 units of 1 KB) per epilogue period; this
-    // wavefront moves every staged quarter into REGISTERS in the following period (the slot is free again) and issues the stores at
-    // an even pace -- 8 per period -- over the periods that follow.  Why: the output is 128 KB per tile, ~80 % of what a CU's share
-    // of the chip's write bandwidth moves in a tile's time (tools/probes/store_rate.hip: 10.5 B/cycle/CU at saturation, one store
-    // wavefront per CU reaches it).  Issued in bursts behind the epilogues the stores back up in the CU's memory pipeline, the weight
-    // loads queue behind them and the MFMA passes wait (first forms of this kernel: the dy-load + store skeleton alone took 0.63 ms);
-    // and a store wavefront that must finish 16 stores inside an epilogue period holds that period's barrier.  It issues no loads and
-    // never waits for a store.  Register FIFO: three quarter buffers -- a[0:63], a[64:127] (this role's AGPRs hold data, not
-    // accumulators) and 16 VGPR quads; the schedule below is static (K = 128: 4 + 4 + 8 + 4 periods per tile).
-    // =====================================================================================================================
-    const int lane = w2_lane();
-    const int q31 = lane & 31, hp = lane >> 5;
-    const unsigned obytes = 16u * plane16;
-    [[maybe_unused]] unsigned long long t_vm = 0, t_lb = 0;
-    [[maybe_unused]] unsigned dbg_run = 0;
-    // output offsets of the tile's four 32-quad groups s: lane = (column parity hp, quad q31)
-    auto decode = [&](const TileS& t, int (&vo)[2][4]) __attribute__((always_inline)) {
-      const unsigned m_bw = t.lastband ? p.m_bwl : p.m_bw;
-      const int bw = t.bw;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int pp = t.p0 + s * 32 + q31;
-        const bool pv = pp < t.p1;
-        const int pc = pv ? pp : (t.p1 - 1);
-        const int i = w2_udivm1(pc, bw, m_bw), j = pc - i * bw;
-        const int pix = 2 * i * OW + 2 * (t.j0 + j);
-        const bool vx = 2 * (t.j0 + j) + 1 < OW, vy = 2 * i + 1 < OH;
-#pragma unroll
-        for (int py = 0; py < 2; ++py) vo[py][s] = (pv && (py == 0 || vy) && (hp == 0 || vx) && !W2_DBG(1)) ? (pix + py * OW + hp) * 16 : (int)OOB;
-      }
-    };
-    auto rs_out_of = [&](int b) __attribute__((always_inline)) { return w2_rsrc(reinterpret_cast<unsigned char*>(p.out) + (size_t)b * obytes, obytes); };
-    // staged unit u = 4 cw + 2 n + e of a quarter (mb, gp): compute wavefront cw's pixel group n, channel block e of the pair; a lane
-    // reads the column parity hp's 16 bytes of quad q31 -> one store covers 32 quads x both column parities of ONE channel block
-    const unsigned stg_rd = (unsigned)(W2_STG + hp * 1024 + q31 * 16);
-    // ... immediately (any K): 16 reads, 16 stores
-    auto store_quarter = [&](int sl, int quarter, const int (&vo)[4], i32x4 rs_o) __attribute__((always_inline)) {
-      const unsigned char* base = lds + stg_rd + sl * W2_SLOT;
-#pragma unroll
-      for (int cw = 0; cw < 4; ++cw) {
-        u32x4 d[4];
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-          for (int e = 0; e < 2; ++e) d[n * 2 + e] = *reinterpret_cast<const u32x4*>(base + cw * 4096 + n * 2048 + e * 512);
-        const int cb0 = (cw >> 1) * 8 + quarter * 2;   // channel block of e = 0 (quarter = mb * 2 + gp)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-          for (int e = 0; e < 2; ++e) w2_store16(d[n * 2 + e], vo[(cw & 1) * 2 + n], rs_o, (unsigned)(cb0 + e) * (unsigned)plane16);
-      }
-    };
-    int vo[2][4], vo_n[2][4];
-    decode(T, vo);
-    i32x4 rs_out = rs_out_of(T.b);
-    W2_LBARRIER();   // (#1)
-    bool has_next = true;
-    TileS Tn{};
-    int vo_prev[4] = {(int)OOB, (int)OOB, (int)OOB, (int)OOB};   // pass B of the previous tile (its stores run into this tile's first periods)
-    i32x4 rs_prev = rs_out;
-    auto next_tile = [&]() __attribute__((always_inline)) {
-      unsigned kn = k_ord + 1;
-      has_next = find_tile(kn, Tn);
-      k_ord = kn;
-      if (has_next) decode(Tn, vo_n);
-    };
-    auto advance = [&]() __attribute__((always_inline)) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) vo_prev[s] = vo[1][s];
-      rs_prev = rs_out;
-      if (has_next) {
-        T = Tn;
-#pragma unroll
-        for (int a_ = 0; a_ < 2; ++a_)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) vo[a_][s] = vo_n[a_][s];
-        rs_out = rs_out_of(T.b);
-      }
-    };
-    if (nck == 8) {
-      // ---- the paced form.  Quarter buffers: QB0 = a[0:63], QB1 = a[64:127], QB2 = q2[16].  Per tile (periods t = 0..19: P0-3, EA0-3,
-      //      Q0-7, EB0-3), stores in front of reads inside a period:
-      //        read  (slot -> QB):  t5 A0->0, t6 A1->1, t7 A2->2, t8 A3->0, t17 B0->1, t18 B1->2, t19 B2->0, t0' B3->1
-      //        store (8 units):     t6 A0a, t7 A0b, t8 A1a, t9 A1b, t10 A2a, t11 A2b, t12 A3a, t13 A3b,
-      //                             t18 B0a, t19 B0b, t0' B1a, t1' B1b, t2' B2a, t3' B2b, t4' B3a, t5' B3b
-      //      (every quarter is read one period after it was staged and is out of its buffer before the buffer's next read)
-      u32x4 q2[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) q2[u] = u32x4{0u, 0u, 0u, 0u};
-      const unsigned rd0 = stg_rd, rd1 = stg_rd + W2_SLOT;
-      auto rd_q2 = [&](unsigned addr) __attribute__((always_inline)) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) q2[u] = *reinterpret_cast<const u32x4*>(lds + addr + (u >> 2) * 4096 + ((u >> 1) & 1) * 2048 + (u & 1) * 512);
-      };
-      auto st_q2 = [&](auto h_tag, int quarter, const int (&vv)[4], i32x4 rs_o) __attribute__((always_inline)) {
-        constexpr int Hh = decltype(h_tag)::value;
-#pragma unroll
-        for (int u = 8 * Hh; u < 8 * Hh + 8; ++u) {
-          const int cw = u >> 2, n = (u >> 1) & 1, e = u & 1;
-          w2_store16(q2[u], vv[(cw & 1) * 2 + n], rs_o, (unsigned)((cw >> 1) * 8 + quarter * 2 + e) * (unsigned)plane16);
-        }
-      };
-      auto lb = [&]() __attribute__((always_inline)) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (this period's staging reads are in registers before the slot is written again)
-        W2_LBARRIER();
-      };
-      using H0 = W2IC<0>;
-      using H1 = W2IC<1>;
-      for (;;) {
-        // t0 (P0)
-        st_q2(H0{}, 1, vo_prev, rs_prev);            // B1a
-        w2_rd16_a<64>(rd1);                          // B3 -> QB1
-        next_tile();
-        lb();
-        st_q2(H1{}, 1, vo_prev, rs_prev); lb();      // t1: B1b
-        w2_st8_a<0, 0>(vo_prev, rs_prev, (unsigned)(0 * 8 + 2 * 2) * (unsigned)plane16, (unsigned)plane16); lb();   // t2: B2a
-        w2_st8_a<0, 1>(vo_prev, rs_prev, (unsigned)(1 * 8 + 2 * 2) * (unsigned)plane16, (unsigned)plane16); lb();   // t3: B2b
-        w2_st8_a<64, 0>(vo_prev, rs_prev, (unsigned)(0 * 8 + 3 * 2) * (unsigned)plane16, (unsigned)plane16); lb();  // t4 (EA0): B3a
-        w2_st8_a<64, 1>(vo_prev, rs_prev, (unsigned)(1 * 8 + 3 * 2) * (unsigned)plane16, (unsigned)plane16);        // t5 (EA1): B3b
-        w2_rd16_a<0>(rd0); lb();                                                                                     //           A0 -> QB0
-        w2_st8_a<0, 0>(vo[0], rs_out, (unsigned)(0 * 8 + 0 * 2) * (unsigned)plane16, (unsigned)plane16);            // t6 (EA2): A0a
-        w2_rd16_a<64>(rd1); lb();                                                                                    //           A1 -> QB1
-        w2_st8_a<0, 1>(vo[0], rs_out, (unsigned)(1 * 8 + 0 * 2) * (unsigned)plane16, (unsigned)plane16);            // t7 (EA3): A0b
-        rd_q2(rd0); lb();                                                                                            //           A2 -> QB2
-        w2_st8_a<64, 0>(vo[0], rs_out, (unsigned)(0 * 8 + 1 * 2) * (unsigned)plane16, (unsigned)plane16);           // t8 (Q0): A1a
-        w2_rd16_a<0>(rd1); lb();                                                                                     //          A3 -> QB0
-        w2_st8_a<64, 1>(vo[0], rs_out, (unsigned)(1 * 8 + 1 * 2) * (unsigned)plane16, (unsigned)plane16); lb();     // t9: A1b
-        st_q2(H0{}, 2, vo[0], rs_out); lb();                                                                         // t10: A2a
-        st_q2(H1{}, 2, vo[0], rs_out); lb();                                                                         // t11: A2b
-        w2_st8_a<0, 0>(vo[0], rs_out, (unsigned)(0 * 8 + 3 * 2) * (unsigned)plane16, (unsigned)plane16); lb();      // t12: A3a
-        w2_st8_a<0, 1>(vo[0], rs_out, (unsigned)(1 * 8 + 3 * 2) * (unsigned)plane16, (unsigned)plane16); lb();      // t13: A3b
-        lb();                                                                                                        // t14
-        lb();                                                                                                        // t15
-        lb();                                                                                                        // t16 (EB0)
-        w2_rd16_a<64>(rd0); lb();                                                                                    // t17 (EB1): B0 -> QB1
-        w2_st8_a<64, 0>(vo[1], rs_out, (unsigned)(0 * 8 + 0 * 2) * (unsigned)plane16, (unsigned)plane16);           // t18 (EB2): B0a
-        rd_q2(rd1); lb();                                                                                            //            B1 -> QB2
-        w2_st8_a<64, 1>(vo[1], rs_out, (unsigned)(1 * 8 + 0 * 2) * (unsigned)plane16, (unsigned)plane16);           // t19 (EB3): B0b
-        w2_rd16_a<0>(rd0); lb();                                                                                     //            B2 -> QB0
-        advance();
-        if (!has_next) break;
-      }
-      // the last tile's pass B: B1 (QB2), B2 (QB0) and B3 (slot 1)
-      st_q2(H0{}, 1, vo_prev, rs_prev);
-      st_q2(H1{}, 1, vo_prev, rs_prev);
-      w2_rd16_a<64>(rd1);
-      w2_st8_a<0, 0>(vo_prev, rs_prev, (unsigned)(0 * 8 + 2 * 2) * (unsigned)plane16, (unsigned)plane16);
-      w2_st8_a<0, 1>(vo_prev, rs_prev, (unsigned)(1 * 8 + 2 * 2) * (unsigned)plane16, (unsigned)plane16);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      w2_st8_a<64, 0>(vo_prev, rs_prev, (unsigned)(0 * 8 + 3 * 2) * (unsigned)plane16, (unsigned)plane16);
-      w2_st8_a<64, 1>(vo_prev, rs_prev, (unsigned)(1 * 8 + 3 * 2) * (unsigned)plane16, (unsigned)plane16);
-      return;
-    }
-    // ---- any other K: every staged quarter goes out in the period after its staging
-    bool pend = false;
-    for (;;) {
-      for (int k = 0; k < np; ++k) {           // pass A
-        if (k == 0) {
-          if (pend) store_quarter(1, 3, vo_prev, rs_prev);
-          pend = false;
-          next_tile();
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        W2_LBARRIER();
-      }
-      for (int e = 0; e < 4; ++e) {            // epilogue A
-        if (e >= 1) store_quarter((e - 1) & 1, e - 1, vo[0], rs_out);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the staging reads are in registers before the slot is written again)
-        W2_LBARRIER();
-      }
-      for (int c = 0; c < nck; ++c) {          // pass B
-        if (c == 0) store_quarter(1, 3, vo[0], rs_out);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        W2_LBARRIER();
-      }
-      for (int e = 0; e < 4; ++e) {            // epilogue B
-        if (e >= 1) store_quarter((e - 1) & 1, e - 1, vo[1], rs_out);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        W2_LBARRIER();
-      }
-      pend = true;
-      advance();
-      if (!has_next) break;
-    }
-    store_quarter(1, 3, vo_prev, rs_prev);
     return;
   }
 
@@ -717,8 +464,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // =======================================================================================================================
   const int lane = w2_lane(), l31 = lane & 31, half = lane >> 5;
   const unsigned a_b0 = (unsigned)(half * 128 + mh * 64 + l31) * 16u;   // weight unit [channel block half][channel] of row block mb = 0
-  const unsigned stg_wr = (unsigned)(W2_STG + tw * 4096 + l31 * 16 + half * 8);
+  const unsigned obytes = 16u * plane16;
   unsigned pbr[2], lw16;
+  int pix16[2];   // byte offset of this lane's 16-byte unit of quad (n)'s pixel (2 i, 2 j) inside the image: + half * plane16 (the upper half-wave stores the next channel block)
+  unsigned vmask = 0;   // bit n: the quad exists; bit 2 + n: its odd column exists; bit 4 + n: its odd row exists
   auto decode_pix = [&](const TileS& t) __attribute__((always_inline)) {
     const unsigned m_bw = t.lastband ? p.m_bwl : p.m_bw;
     const int bw = t.bw;
@@ -730,6 +479,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int pc = pp < t.p1 ? pp : (t.p1 - 1);
       const int i = w2_udivm1(pc, bw, m_bw), j = pc - i * bw;
       pbr[n] = (unsigned)((i - i_lo) * (bw + 1) + j) * 16u + (unsigned)half * 4096u;
+      pix16[n] = (2 * i * OW + 2 * (t.j0 + j)) * 16 + half * plane16;
+      vmask = (vmask & ~(0x15u << n)) | ((pp < t.p1 ? 1u : 0u) << n) | ((2 * (t.j0 + j) + 1 < OW ? 1u : 0u) << (2 + n)) | ((2 * i + 1 < OH ? 1u : 0u) << (4 + n));
     }
   };
   decode_pix(T);
@@ -771,8 +522,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef W2_PX
 #undef W2_PB
   };
-  // a pass: `nper` periods from dy slot 0 on; the weight buffer alternates (wpar)
-  auto run_pass = [&](auto pb_tag, int nper, int& wpar) __attribute__((always_inline)) {
+  // a pass: `nper` periods from dy slot 0 on; the weight buffer rotates (wcur)
+  auto run_pass = [&](auto pb_tag, int nper, int& wcur) __attribute__((always_inline)) {
     constexpr bool PB = decltype(pb_tag)::value;
     using TT = std::true_type;
     using FT = std::false_type;
@@ -781,9 +532,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       pb0[n] = (unsigned)W2_DY + pbr[n];
       pb1[n] = pb0[n] + lw16;
     }
-    w2_kfirst<w2_grp(PB, 1) * 4096>(A[0][0], A[0][1], A[1][0], A[1][1], B[0][0], B[0][1], (unsigned)(wpar * W2_WB) + a_b0, pb0[0], pb0[1]);
+    w2_kfirst<w2_grp(PB, 1) * 4096>(A[0][0], A[0][1], A[1][0], A[1][1], B[0][0], B[0][1], (unsigned)(wcur * W2_WB) + a_b0, pb0[0], pb0[1]);
     for (int k = 0; k < nper; ++k) {
-      const unsigned pa = (unsigned)(wpar * W2_WB) + a_b0, pan = (unsigned)((wpar ^ 1) * W2_WB) + a_b0;
+      const int wnext = wcur == W2_NWB - 1 ? 0 : wcur + 1;
+      const unsigned pa = (unsigned)(wcur * W2_WB) + a_b0, pan = (unsigned)(wnext * W2_WB) + a_b0;
       const bool last = k == nper - 1;   // (uniform)
       if (k == 0) {
         if (last) period(pb_tag, TT{}, TT{}, W2IC<0>{}, pa, pan);
@@ -795,7 +547,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (last) period(pb_tag, FT{}, TT{}, W2IC<0>{}, pa, pan);
         else period(pb_tag, FT{}, FT{}, W2IC<0>{}, pa, pan);
       }
-      wpar ^= 1;
+      wcur = wnext;
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
         pb0[n] += PB ? W2_DYS : 2 * W2_DYS;
@@ -803,80 +555,86 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     }
   };
-  // a quarter of a pass's epilogue: channel group (mb, gp) of the 8 accumulator tiles -> staging slot `sl` (4 units of 1 KB)
-  [[maybe_unused]] unsigned long long t_bw = 0, t_ebw = 0;   // (diagnostic build) ticks inside the barrier statements of the MFMA periods / the epilogue quarters
-  unsigned sg[2][2] = {{0u, 0u}, {0u, 0u}};   // this lane's sign bytes of the pass: [n][px], byte mb * 2 + gp
-  auto epi_quarter = [&](auto q_tag, int sl) __attribute__((always_inline)) {
-    constexpr int Q = decltype(q_tag)::value, MB = Q >> 1, GP = Q & 1;
+  // ---- a pass's epilogue: 8 accumulator tiles -> 16 stores.  Channel group (mb, gp) of pixel group n, column parity px: 8 values
+  //      per lane (4 channels of channel block cb, 4 of cb + 1) x scale [x LeakyReLU'(sign bit)] -> bf16; the two half-waves exchange one
+  //      8-byte group (v_permlane32_swap) so that every lane stores a whole 16-byte unit -- lanes 0-31 block cb, lanes 32-63 block cb + 1
+  //      (conv_bf16_kernel's epilogue: the same formula, the same bits).  A compute wavefront issues no loads: its stores are never waited for.
+  int tpar = 0;   // channel-scale buffer of the tile
+  auto epilogue = [&](auto py_tag, i32x4 rs_o) __attribute__((always_inline)) {
+    constexpr int PY = decltype(py_tag)::value;
     if constexpr ((W2_ABL & 8) != 0) return;
-    const float* es = reinterpret_cast<const float*>(lds + W2_ES) + mh * 64 + MB * 32 + 16 * GP + 4 * half;
-    const float4 sA = *reinterpret_cast<const float4*>(es), sB = *reinterpret_cast<const float4*>(es + 8);
-    const float sa[8] = {sA.x, sA.y, sA.z, sA.w, sB.x, sB.y, sB.z, sB.w};
-    float sl_[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) sl_[i] = LEAKY_SLOPE * sa[i];
-    unsigned char* dst0 = lds + stg_wr + sl * W2_SLOT;
-    w2_static_for([&](auto u_tag) __attribute__((always_inline)) {   // the quarter's four units (n, px)
-      constexpr int n = decltype(u_tag)::value >> 1, px = decltype(u_tag)::value & 1;
-      float v[8], r[8];
-      w2_acc_read8<16 * (4 * px + 2 * MB + n) + 8 * GP>(r);
-      if constexpr (SIGNS) {
-        const unsigned m = sg[n][px] >> (8 * Q);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int t = (int)(m << (31 - i)) >> 31;   // bit i spread over the word (v_bfe_i32) selects scale or 0.01 * scale (v_bfi_b32)
-          unsigned f;
-          asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(f) : "v"(t), "v"(sa[i]), "v"(sl_[i]));
-          v[i] = r[i] * __builtin_bit_cast(float, f);
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = fmaf(r[i], sa[i], 0.f * sa[i]);   // (conv_bf16_epi_groups.inc: fma(acc, scale, bias * scale), bias = 0)
-      }
-      if (W2_DBG(2)) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = r[i];
-      }
-      bf16x8 o;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) o[i] = (__bf16)v[i];
-      const u32x4 w = __builtin_bit_cast(u32x4, o);   // (x, y) = this lane's 4 channels of block cb, (z, w) = of block cb + 1
-      unsigned char* dst = dst0 + (n * 2 + px) * 1024;
-      *reinterpret_cast<u32x2*>(dst) = u32x2{w.x, w.y};
-      *reinterpret_cast<u32x2*>(dst + 512) = u32x2{w.z, w.w};
-    }, std::make_integer_sequence<int, 4>{});
-  };
-  auto read_signs = [&]() __attribute__((always_inline)) {
+    unsigned sg[2][2] = {{0u, 0u}, {0u, 0u}};   // this lane's sign bytes of the pass: [n][px], byte mb * 2 + gp
     if constexpr (SIGNS) {
-      const unsigned* sp = reinterpret_cast<const unsigned*>(lds + W2_SG) + tw * 256 + lane;
+      const unsigned* sp = reinterpret_cast<const unsigned*>(lds + W2_SG + PY * 4096) + tw * 256 + lane;
 #pragma unroll
       for (int n = 0; n < 2; ++n)
 #pragma unroll
         for (int px = 0; px < 2; ++px) sg[n][px] = sp[(n * 2 + px) * 64];
     }
-  };
-  auto epilogue = [&]() __attribute__((always_inline)) {
-    read_signs();
+    int vo[2][2];   // [n][px]
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int px = 0; px < 2; ++px) {
+        const bool ok = ((vmask >> n) & 1u) && (px == 0 || ((vmask >> (2 + n)) & 1u)) && (PY == 0 || ((vmask >> (4 + n)) & 1u)) && !W2_DBG(1);
+        vo[n][px] = ok ? pix16[n] + (PY * OW + px) * 16 : (int)OOB;
+      }
     w2_static_for([&](auto q_tag) __attribute__((always_inline)) {
-      epi_quarter(q_tag, decltype(q_tag)::value & 1);
-      [[maybe_unused]] const unsigned long long b0 = W2_STAMP();
-      w2_barrier_lgkm();
-      t_ebw += W2_STAMP() - b0;
+      constexpr int Q = decltype(q_tag)::value, MB = Q >> 1, GP = Q & 1;
+      const float* es = reinterpret_cast<const float*>(lds + W2_ES) + tpar * 128 + mh * 64 + MB * 32 + 16 * GP + 4 * half;
+      const float4 sA = *reinterpret_cast<const float4*>(es), sB = *reinterpret_cast<const float4*>(es + 8);
+      const float sa[8] = {sA.x, sA.y, sA.z, sA.w, sB.x, sB.y, sB.z, sB.w};
+      float sl_[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sl_[i] = LEAKY_SLOPE * sa[i];
+      const unsigned so = (unsigned)(mh * 8 + Q * 2) * (unsigned)plane16;   // channel block the lower half-wave stores
+      w2_static_for([&](auto u_tag) __attribute__((always_inline)) {   // the group's four units (n, px)
+        constexpr int n = decltype(u_tag)::value >> 1, px = decltype(u_tag)::value & 1;
+        float v[8], r[8];
+        w2_acc_read8<16 * (4 * px + 2 * MB + n) + 8 * GP>(r);
+        if constexpr (SIGNS) {
+          const unsigned m = sg[n][px] >> (8 * Q);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int t = (int)(m << (31 - i)) >> 31;   // bit i spread over the word (v_bfe_i32) selects scale or 0.01 * scale (v_bfi_b32)
+            unsigned f;
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(f) : "v"(t), "v"(sa[i]), "v"(sl_[i]));
+            v[i] = r[i] * __builtin_bit_cast(float, f);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = fmaf(r[i], sa[i], 0.f * sa[i]);   // (conv_bf16_epi_groups.inc: fma(acc, scale, bias * scale), bias = 0)
+        }
+        if (W2_DBG(2)) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = r[i];
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (__bf16)v[i];
+        const u32x4 w = __builtin_bit_cast(u32x4, o);   // (x, y) = this lane's 4 channels of block cb, (z, w) = of block cb + 1
+        // lanes 32-63 hand their block-cb group down, lanes 0-31 hand their block-(cb + 1) group up
+        const auto r0 = __builtin_amdgcn_permlane32_swap(w.x, w.z, false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(w.y, w.w, false, false);
+        const u32x4 st = {r0[0], r1[0], r0[1], r1[1]};
+        w2_store16(st, vo[n][px], rs_o, so);
+      }, std::make_integer_sequence<int, 4>{});
     }, std::make_integer_sequence<int, 4>{});
   };
 
   w2_barrier();   // (#1)
-  int wpar = 0;
+  int wcur = 0;   // weight buffer of the MFMA period being computed (rotates 0, 1, 2)
   [[maybe_unused]] unsigned long long t_a = 0, t_ea = 0, t_b = 0, t_eb = 0;
   for (;;) {
+    const i32x4 rs_o = w2_rsrc(reinterpret_cast<unsigned char*>(p.out) + (size_t)T.b * obytes, obytes);
     [[maybe_unused]] const unsigned long long s0 = W2_STAMP();
-    run_pass(std::false_type{}, np, wpar);
+    run_pass(std::false_type{}, np, wcur);
     [[maybe_unused]] const unsigned long long s1 = W2_STAMP();
-    epilogue();
+    epilogue(W2IC<0>{}, rs_o);
     [[maybe_unused]] const unsigned long long s2 = W2_STAMP();
-    run_pass(std::true_type{}, nck, wpar);
+    run_pass(std::true_type{}, nck, wcur);
     [[maybe_unused]] const unsigned long long s3 = W2_STAMP();
-    epilogue();
+    epilogue(W2IC<1>{}, rs_o);
     [[maybe_unused]] const unsigned long long s4 = W2_STAMP();
     t_a += s1 - s0; t_ea += s2 - s1; t_b += s3 - s2; t_eb += s4 - s3;
     unsigned kn = k_ord + 1;
@@ -884,11 +642,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     k_ord = kn;
     if (!has_next) break;
     decode_pix(T);
+    tpar ^= 1;
   }
 #ifdef YOGO_DIAG
   if (p.stamps && tw == 0 && lane == 0) {
     unsigned long long* d = p.stamps + (size_t)blockIdx.x * 16;
-    d[0] = t_start; d[1] = __builtin_amdgcn_s_memtime(); d[2] = t_a; d[3] = t_ea; d[4] = t_b; d[5] = t_eb; d[6] = k_ord; d[7] = t_bw; d[8] = t_ebw;
+    d[0] = t_start; d[1] = __builtin_amdgcn_s_memtime(); d[2] = t_a; d[3] = t_ea; d[4] = t_b; d[5] = t_eb; d[6] = k_ord;
   }
 #endif
 }
@@ -897,7 +656,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // host side: eligibility, tiling, launch
 // =========================================================================================================
 bool conv_bf16_ws2_eligible(int K, int M, int OH, int OW, int B) {
-  if (M != 128 || K < 32 || K > 128 || (K % 32) != 0) return false;   // nck = K / 16 even, <= 8 dy slots
+  if (M != 128 || K < 64 || K > 128 || (K % 32) != 0) return false;   // nck = K / 16 even, <= 8 dy slots, >= 2 pass-A periods
   if (OH < 2 || OW < 2 || B <= 0) return false;
   const long long IH = (OH + 1) / 2, IW = (OW + 1) / 2;
   if ((long long)(K / 8) * IH * IW * 16 >= (1ll << 31) || (long long)16 * OH * OW * 16 >= (1ll << 31)) return false;   // per-image descriptors
@@ -915,7 +674,7 @@ bool conv_bf16_ws2_plan(ConvWs2Params* p) {
     const int TW = cdiv(QW, ncb);
     if (cdiv(QW, TW) != ncb) continue;
     const int bw_min = QW - (ncb - 1) * TW;
-    auto rows_of = [&](int bw) __attribute__((always_inline)) { return min(QH, 1 + cdiv(W2_PT - 1, bw)) + 1; };
+    auto rows_of = [&](int bw) { return min(QH, 1 + cdiv(W2_PT - 1, bw)) + 1; };
     const int need = max(rows_of(TW) * (TW + 1), rows_of(bw_min) * (bw_min + 1));
     if (need > 256) continue;
     const long long tiles = (long long)(ncb - 1) * cdiv(QH * TW, W2_PT) + cdiv(QH * bw_min, W2_PT);
