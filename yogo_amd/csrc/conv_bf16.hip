@@ -1405,6 +1405,15 @@ void bf_launch_t(dim3 grid, int lds_bytes, hipStream_t stream, const ConvBf16Par
       return;
     }
   }
+  // the 4-wavefront stride-2 data gradient (layer 2): the lean-epilogue instantiation too (the same arithmetic in the same order, -1 % in
+  // the same-box A/B, gpurun_out/r5_abs2dlepi.log)
+  if constexpr (NWV == 4 && S2D && !F32 && REF != 1) {
+    const bool general = p.stats_part != nullptr || p.act == ACT_SILU || p.out_pre != nullptr || (REF == 2 && p.ref_act != ACT_LEAKY);
+    if (!general) {
+      bf_launch_one<MW, NW, NWV, S2D, PF, F32, REF, false, true>(grid, lds_bytes, stream, p, plan_txt);
+      return;
+    }
+  }
   bf_launch_one<MW, NW, NWV, S2D, PF, F32, REF, false>(grid, lds_bytes, stream, p, plan_txt);
 }
 
