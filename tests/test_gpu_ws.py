@@ -272,3 +272,93 @@ def test_persistent_stride2_dgrad_against_cpu_fp32(kind, B, K, OH, OW):
     got = got.cpu().double()
     tol = 2.0 ** -8 * want.abs() + 2e-5 * float(want.abs().max())
     assert bool(((got - want).abs() <= tol).all()), float(((got - want).abs() - tol).max())
+
+
+# ---- the stride-2 forward: conv_bf16_ws3_kernel against conv_bf16_kernel<4, 1, 8> -------------------------------------------------
+def _run_s2f(persistent, kind, B, Cin, H, W, seed):
+    """y [B][128][ceil(H/2)][ceil(W/2)] = [mask x] [LeakyReLU] (conv3x3 stride 2 (x [B][Cin][H][W]) + bias): yogo/model_defns.py:54-56"""
+    import contextlib
+
+    from _util import hooks_library
+    from yogo_amd import _hip as Hh
+
+    with (contextlib.nullcontext() if persistent else hooks_library()):
+        st = Hh.stream_ptr()
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        w = torch.randn(128, Cin, 3, 3, device="cuda", generator=g) * 0.05
+        x8 = torch.randn(B, _blocks(Cin), H, W, 8, device="cuda", generator=g).to(torch.bfloat16)
+        y8 = torch.full((B, 16, OH, OW, 8), 7.0, device="cuda").to(torch.bfloat16)   # poisoned: every unit must be written
+        bias = torch.randn(128, device="cuda", generator=g)
+        msk = (torch.rand(B, 128, device="cuda", generator=g) > 0.2).float() / 0.8
+        packed = torch.empty(Hh.query_size("yogo_conv_bf16_packed_bytes", Cin, 128, 3, 0), dtype=torch.uint8, device="cuda")
+        Hh.call("yogo_conv_bf16_pack", w, None, packed, Cin, 128, 3, 0, st)
+        if not persistent:
+            Hh.call("yogo_hook_conv_bf16_persistent", 0)
+        Hh.launch_log(True)
+        try:
+            Hh.call("yogo_conv2d_fwd_bf16", x8, packed, None if kind == "nobias" else bias, y8, None, msk if kind == "mask" else None, None, B, Cin, 128, H, W, 3, 2,
+                    1 if kind in ("leaky", "mask") else 0, st)
+            torch.cuda.synchronize()
+            log = Hh.read_launch_log()
+        finally:
+            Hh.launch_log(False)
+        return y8, log, (w, x8, bias, msk)
+
+
+S2F_CASES = [
+    # (kind, B, Cin, H, W)
+    ("nobias", 2, 128, 193, 258),     # layer 4 of base_model at 772x1032
+    ("plain", 1, 128, 20, 91),        # one band of 46 columns
+    ("leaky", 2, 64, 37, 41),         # odd sizes, 4 chunks
+    ("mask", 3, 128, 50, 66),
+    ("plain", 40, 128, 97, 129),      # every workgroup walks several tiles, image changes at the seams
+    ("leaky", 1, 96, 9, 300),         # short and wide: several bands, 6 chunks
+    ("plain", 2, 128, 300, 5),        # tall and narrow: three output columns
+    ("mask", 5, 128, 3, 3),           # two output pixels per row
+    ("plain", 3, 128, 64, 64),        # even sizes
+    ("leaky", 2, 256, 33, 95),        # 16 chunks
+]
+
+
+@pytest.mark.parametrize("kind,B,Cin,H,W", S2F_CASES)
+def test_persistent_stride2_forward_is_bit_identical_to_the_tiled_kernel(kind, B, Cin, H, W):
+    y_old, log_old, _ = _run_s2f(False, kind, B, Cin, H, W, seed=41)
+    y_new, log_new, _ = _run_s2f(True, kind, B, Cin, H, W, seed=41)
+    assert any(ln.startswith("conv_bf16_kernel<4, 1, 8, false") for ln in log_old), log_old
+    assert any(ln.startswith("conv_bf16_ws3_kernel<") for ln in log_new), log_new
+    plan = next(ln for ln in log_old if ln.startswith("conv_bf16_kernel<4, 1, 8, false"))
+    if " CKb=2 " in plan:   # the tiled kernel stepped through K in 16-channel chunks too: the same MFMA sequence per accumulator
+        assert torch.equal(y_old.view(torch.int16), y_new.view(torch.int16)), (
+            f"{(y_old.float() - y_new.float()).abs().max().item()} max abs difference, "
+            f"{(y_old.view(torch.int16) != y_new.view(torch.int16)).float().mean().item()} of the values differ")
+    else:
+        a, b = y_old.float(), y_new.float()
+        ulp = 2.0 ** -7 * torch.maximum(a.abs(), b.abs()) + 1e-6 * a.abs().max()
+        assert bool(((a - b).abs() <= ulp).all()), f"{((a - b).abs() - ulp).max().item()} beyond one bf16 step"
+        assert (a != b).float().mean().item() < 5e-3
+
+
+@pytest.mark.parametrize("kind,B,Cin,H,W", [("mask", 2, 128, 45, 53), ("plain", 1, 64, 33, 70), ("leaky", 2, 128, 18, 16)])
+def test_persistent_stride2_forward_against_cpu_fp32(kind, B, Cin, H, W):
+    """an independent reference for the new kernel: torch's CPU conv2d (float64) on the same bf16-rounded operands, one bf16 rounding of the result"""
+    import torch.nn.functional as F
+
+    from yogo_amd import _hip as Hh
+
+    y_new, log, (w, x8, bias, msk) = _run_s2f(True, kind, B, Cin, H, W, seed=43)
+    assert any(ln.startswith("conv_bf16_ws3_kernel<") for ln in log), log
+    st = Hh.stream_ptr()
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    x = torch.empty(B, Cin, H, W, device="cuda")
+    Hh.call("yogo_bf16_8c_to_nchw_f32", x8, x, B, Cin, H * W, st)
+    got = torch.empty(B, 128, OH, OW, device="cuda")
+    Hh.call("yogo_bf16_8c_to_nchw_f32", y_new, got, B, 128, OH * OW, st)
+    want = F.conv2d(x.double().cpu(), w.to(torch.bfloat16).double().cpu(), bias.double().cpu(), stride=2, padding=1)
+    if kind in ("leaky", "mask"):
+        want = F.leaky_relu(want, 0.01)
+    if kind == "mask":
+        want = want * msk.double().cpu()[:, :, None, None]
+    got = got.cpu().double()
+    tol = 2.0 ** -8 * want.abs() + 2e-5 * float(want.abs().max())
+    assert bool(((got - want).abs() <= tol).all()), float(((got - want).abs() - tol).max())

@@ -16,6 +16,7 @@
 #include "common.h"
 #include "conv_bf16_ws.h"
 #include "conv_bf16_ws2.h"
+#include "conv_bf16_ws3.h"
 #include <type_traits>
 #include <utility>
 #include <cstdlib>
@@ -1437,6 +1438,19 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
     if (q.stamps) (void)hipMemsetAsync(g_diag_stamps, 0, 512 * 128, stream);
 #endif
     if (conv_bf16_ws_plan(&q)) return launch_conv_bf16_ws(q, stream);
+  }
+  // stride-2 3x3 forward with 128 output channels and the lean epilogue: its persistent wavefront-specialised member (conv_bf16_ws3.hip)
+  if (in != nullptr && g_bf_ws && !s2d && a == 2 && ks == 3 && out_f32 == nullptr && out_pre == nullptr && act_ref == nullptr && !signs_read &&
+      signs == nullptr && stats_part == nullptr && (act == ACT_NONE || act == ACT_LEAKY) && conv_bf16_ws3_eligible(K, M, IH, IW, B)) {
+    ConvWs3Params q{};
+    q.in = in; q.wp = packed; q.bias = bias; q.out = out; q.chan_scale = chan_scale;
+    q.B = B; q.Kb = bf_kb_of(K); q.IH = IH; q.IW = IW; q.OH = OH; q.OW = OW; q.act = act;
+#ifdef YOGO_DIAG
+    q.dbg = g_diag_dbg;
+    q.stamps = (g_diag_stamps != nullptr && g_diag_stamps_bytes >= 512 * 128) ? g_diag_stamps : nullptr;
+    if (q.stamps) (void)hipMemsetAsync(g_diag_stamps, 0, 512 * 128, stream);
+#endif
+    if (conv_bf16_ws3_plan(&q)) return launch_conv_bf16_ws3(q, stream);
   }
   // stride-2 3x3 data gradient into 128 channels (scale / LeakyReLU-sign-map epilogue): the persistent wavefront-specialised kernel
   // that stages the gradient tile once for both row parities (conv_bf16_ws2.hip)
