@@ -176,7 +176,7 @@ def test_configs4_batch_256_inference_plan_and_results():
     for ln in open(profs[-1]):
         if ln.startswith("# rocprofv3") and "post" in ln:
             break   # (the second table is the post-process alone on synthetic predictions)
-        mm = re.search(r"((?:conv_bf16_kernel|conv_bf16_ws_kernel|nms_batched_kernel)<[^>]*>)", ln)
+        mm = re.search(r"((?:conv_bf16_kernel|conv_bf16_ws\d?_kernel|nms_batched_kernel)<[^>]*>)", ln)
         if mm and "nms_batched_kernel<false>" not in mm.group(1):   # (the profile also times the two-pass form)
             want.add(re.sub(r"\s+", "", mm.group(1)))
     assert want and not (want - launched), (sorted(want - launched), sorted(launched))

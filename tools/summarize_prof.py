@@ -29,6 +29,23 @@ if stats:
     for r in rows[:36]:
         name = r["Name"].replace("(anonymous namespace)::", "").split("(")[0][:70]
         lines.append(f"{name:70s} {r['Calls']:>6s} {float(r['TotalDurationNs'])/1e6:10.3f} {float(r['AverageNs'])/1e3:10.1f} {float(r['Percentage']):6.2f}")
+    # the same kernel name covers launches of different shapes (the 128-channel weight gradient: layer 3 vs layers 5 / 6; the persistent
+    # convolution <0>: forward and data gradients): average duration per (kernel, grid) from the kernel trace of the same run
+    tr = one("stats/*kernel_trace.csv") or one("stats/*/*kernel_trace.csv")
+    if tr:
+        by = defaultdict(lambda: [0.0, 0])
+        for r in csv.DictReader(open(tr)):
+            nm = r.get("Kernel_Name", "").replace("(anonymous namespace)::", "").split("(")[0]
+            if not any(t in nm for t in ("wgrad_bf16_kernel", "conv_bf16_ws")):
+                continue
+            grid = "x".join(str(r.get(k, "?")) for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z")) if "Grid_Size_X" in r else str(r.get("Grid_Size", "?"))
+            a = by[(nm, grid)]
+            a[0] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+            a[1] += 1
+        lines.append("")
+        lines.append("# by launch shape (kernel trace of the same run): kernel | grid (work-items) | calls | avg_us")
+        for (nm, grid), (t, n) in sorted(by.items()):
+            lines.append(f"{nm[:70]:70s} {grid:>16s} {n:6d} {t / n / 1e3:10.1f}")
     open(f"profiles/{tag}_kernel_stats.txt", "w").write("\n".join(lines) + "\n")
 
 traffic = {}
@@ -63,11 +80,20 @@ mf = one("mfma/*counter_collection.csv") or one("mfma/*/*counter_collection.csv"
 if mf:
     agg = defaultdict(lambda: defaultdict(float))
     nl = defaultdict(int)
+    # (the clock a kernel held = GRBM_GUI_ACTIVE / 8 XCDs / its duration in the same run's kernel trace)
+    dur = {}
+    mtr = one("mfma/*kernel_trace.csv") or one("mfma/*/*kernel_trace.csv")
+    if mtr:
+        for r in csv.DictReader(open(mtr)):
+            dur[r.get("Dispatch_Id")] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
     for r in csv.DictReader(open(mf)):
         k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
             nl[k] += 1
+            if r.get("Dispatch_Id") in dur:
+                agg[k]["__ns"] += dur[r.get("Dispatch_Id")]
+                agg[k]["__gui"] += float(r["Counter_Value"])
     rows = []
     for k, c in agg.items():
         cyc = c["GRBM_GUI_ACTIVE"] / 8.0
@@ -75,16 +101,17 @@ if mf:
             continue
         wc = max(c["SQ_WAVE_CYCLES"], 1.0)
         rows.append((c["GRBM_GUI_ACTIVE"], k, nl[k], cyc / nl[k], c["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0), c["SQ_WAIT_ANY"] / wc,
-                     c["SQ_WAIT_INST_ANY"] / wc, c["SQ_ACTIVE_INST_ANY"] / wc))
+                     c["SQ_WAIT_INST_ANY"] / wc, c["SQ_ACTIVE_INST_ANY"] / wc, (c["__gui"] / 8.0 / c["__ns"] * 1e3) if c.get("__ns") else 0.0))
     rows.sort(reverse=True)
     with open(f"profiles/{tag}_mfma_util.txt", "w") as f:
         f.write(f"# rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE "
                 f"--output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-inference  ({tag})\n")
         f.write("# mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): fraction of the kernel's cycles in which a SIMD's matrix pipe is busy;\n")
         f.write("# wait_any / wait_inst / active = shares of SQ_WAVE_CYCLES (parked at s_waitcnt or a barrier / issue stall / issuing)\n")
-        f.write(f"{'kernel':66s} {'launches':>8s} {'cycles/launch':>14s} {'mfma_busy':>10s} {'wait_any':>9s} {'wait_inst':>10s} {'active':>7s}\n")
-        for r in rows[:28]:
-            f.write(f"{r[1][:66]:66s} {r[2]:8d} {r[3]:14.0f} {r[4]:10.3f} {r[5]:9.2f} {r[6]:10.2f} {r[7]:7.2f}\n")
+        f.write("# MHz = GRBM_GUI_ACTIVE / 8 / the launch's duration in the same run's kernel trace: the shader clock the kernel held (under the counters)\n")
+        f.write(f"{'kernel':66s} {'launches':>8s} {'cycles/launch':>14s} {'mfma_busy':>10s} {'wait_any':>9s} {'wait_inst':>10s} {'active':>7s} {'MHz':>6s}\n")
+        for r in rows[:30]:
+            f.write(f"{r[1][:66]:66s} {r[2]:8d} {r[3]:14.0f} {r[4]:10.3f} {r[5]:9.2f} {r[6]:10.2f} {r[7]:7.2f} {r[8]:6.0f}\n")
     print(open(f"profiles/{tag}_mfma_util.txt").read())
 # ---- LDS conflicts and instruction mix (tools/collect_counters_extra.sh) ---------------------------------------------------------
 def per_kernel(pattern):

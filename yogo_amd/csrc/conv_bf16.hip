@@ -1441,9 +1441,9 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
   }
   // stride-2 3x3 forward with 128 output channels and the lean epilogue: its persistent wavefront-specialised member (conv_bf16_ws3.hip)
   if (in != nullptr && g_bf_ws && !s2d && a == 2 && ks == 3 && out_f32 == nullptr && out_pre == nullptr && act_ref == nullptr && !signs_read &&
-      signs == nullptr && stats_part == nullptr && (act == ACT_NONE || act == ACT_LEAKY) && conv_bf16_ws3_eligible(K, M, IH, IW, B)) {
+      stats_part == nullptr && (act == ACT_NONE || act == ACT_LEAKY) && !(signs != nullptr && act != ACT_LEAKY) && conv_bf16_ws3_eligible(K, M, IH, IW, B)) {
     ConvWs3Params q{};
-    q.in = in; q.wp = packed; q.bias = bias; q.out = out; q.chan_scale = chan_scale;
+    q.in = in; q.wp = packed; q.bias = bias; q.out = out; q.signs = reinterpret_cast<unsigned char*>(signs); q.chan_scale = chan_scale;
     q.B = B; q.Kb = bf_kb_of(K); q.IH = IH; q.IW = IW; q.OH = OH; q.OW = OW; q.act = act;
 #ifdef YOGO_DIAG
     q.dbg = g_diag_dbg;

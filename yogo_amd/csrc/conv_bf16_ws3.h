@@ -26,6 +26,7 @@ struct ConvWs3Params {
   const void* wp;     // packed weights (forward): [9][Kb][128] units
   const float* bias;  // [128] or null
   void* out;          // bf16 NCHW8c [B][16][OH][OW] units, OH = (IH - 1) / 2 + 1
+  unsigned char* signs;     // optional LeakyReLU sign map of the output (ConvBf16Params::signs)
   const float* chan_scale;  // optional [B][128]
   int B, Kb, IH, IW, OH, OW;
   int ncb, TW, tiles_per_band, gx, ntiles;

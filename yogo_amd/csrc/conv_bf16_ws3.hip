@@ -178,7 +178,7 @@ __device__ __forceinline__ void w3_static_for(F&& f, std::integer_sequence<int, 
 
 }  // namespace
 
-// MODE: bit 0 = LeakyReLU, bit 1 = channel scale (Dropout2d mask)
+// MODE: bit 0 = LeakyReLU, bit 1 = channel scale (Dropout2d mask), bit 2 = + the sign map of the output (with LeakyReLU)
 template <int MODE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_bf16_ws3_kernel(const ConvWs3Params p) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem4[];
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int OH = p.OH, OW = p.OW, IH = p.IH, IW = p.IW;
   const int plane = OH * OW, plane16 = plane * 16;
   const int nck = p.nchunk;
-  constexpr bool leaky = (MODE & 1) != 0, SCALED = (MODE & 2) != 0;
+  constexpr bool leaky = (MODE & 1) != 0, SCALED = (MODE & 2) != 0, write_signs = (MODE & 4) != 0;
 
   // ---- tile walk (as conv_bf16_ws_kernel): virtual block lin = slot + k * G, an XCD's workgroups share a contiguous run of tiles
   const unsigned NV = (unsigned)p.ntiles, G = gridDim.x, slot = blockIdx.x;
@@ -373,6 +373,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   //      the same formula, the same bits)
   auto epilogue = [&](i32x4 rs_o) __attribute__((always_inline)) {
     if constexpr ((W3_ABL & 8) != 0) return;
+    [[maybe_unused]] unsigned sg[2] = {0u, 0u};   // this lane's sign bytes of the tile: [pixel group], byte mb * 2 + gp
     w3_static_for([&](auto q_tag) __attribute__((always_inline)) {
       constexpr int Q = decltype(q_tag)::value, MB = Q >> 1, GP = Q & 1;
       const int cl = mh * 64 + MB * 32 + 16 * GP + 4 * half;   // channel of group A; group B = cl + 8
@@ -401,6 +402,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
           for (int i = 0; i < 8; ++i) asm("v_max_f32 %0, %0, %1" : "+v"(v[i]) : "v"(sv[i]));
         }
+        if constexpr (write_signs) {   // byte = sum of (v[i] > 0) << i: compare into vcc, add-with-carry shifts it in (values 7 down to 0; conv_bf16_ws.hip)
+          unsigned mA = 0;
+#define W3_SGN(I) "v_cmp_lt_f32_e32 vcc, 0, %" #I "\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t"
+          asm(W3_SGN(8) W3_SGN(7) W3_SGN(6) W3_SGN(5) W3_SGN(4) W3_SGN(3) W3_SGN(2) "v_cmp_lt_f32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
+              : "+v"(mA)
+              : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7])
+              : "vcc");
+#undef W3_SGN
+          sg[n] |= mA << (8 * Q);
+        }
         if (W3_DBG(2)) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) v[i] = r[i];
@@ -415,6 +426,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         w3_store16(st, vo[n], rs_o, so);
       }, std::make_integer_sequence<int, 2>{});
     }, std::make_integer_sequence<int, 4>{});
+    if constexpr (write_signs) {   // this wavefront's 4 sign bytes of a pixel (its 64 channels' share of the half-wave's 8) go out together
+      const i32x4 rs_s = w3_rsrc(p.signs + (size_t)T.b * plane * 16, (unsigned)plane * 16u);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const int vs = vo[n] < 0 ? (int)OOB : (vo[n] >> 1) + mh * 4;   // ((half * plane + pixel) * 8 bytes: ConvBf16Params::signs)
+        asm volatile("s_nop 4\n\tbuffer_store_dword %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(sg[n]), "v"(vs), "s"(w3_u4(rs_s)) : "memory");
+      }
+    }
   };
   // one period = the nine taps of a 16-channel chunk.  pa / pan: this lane's weight unit in this / the next period's buffer; ib / ibn: input buffers
   auto period = [&](auto first_tag, auto last_tag, unsigned pa, unsigned pan, unsigned ib, unsigned ibn) __attribute__((always_inline)) {
@@ -532,7 +551,7 @@ int launch_conv_bf16_ws3(const ConvWs3Params& p, hipStream_t stream) {
     if (n_cu_of[dev] == 0) {
       hipError_t e = hipSuccess;
 #define W3_ATTR(M) if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_ws3_kernel<M>), hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS_BYTES);
-      W3_ATTR(0) W3_ATTR(1) W3_ATTR(2) W3_ATTR(3)
+      W3_ATTR(0) W3_ATTR(1) W3_ATTR(2) W3_ATTR(3) W3_ATTR(5) W3_ATTR(7)
 #undef W3_ATTR
       if (e != hipSuccess) {
         yogo_set_error("conv_bf16_ws3: hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) failed: %s", W3_LDS_BYTES, hipGetErrorString(e));
@@ -546,13 +565,13 @@ int launch_conv_bf16_ws3(const ConvWs3Params& p, hipStream_t stream) {
   if (p.ntiles <= 0) return YOGO_OK;
   int grid = min(p.ntiles, n_cu);
   if (grid >= 8) grid &= ~7;
-  const int mode = (p.act == ACT_LEAKY ? 1 : 0) | (p.chan_scale != nullptr ? 2 : 0);
+  const int mode = (p.act == ACT_LEAKY ? 1 : 0) | (p.chan_scale != nullptr ? 2 : 0) | (p.signs != nullptr ? 4 : 0);   // (a sign map goes with LeakyReLU: the dispatch checks)
 #define W3_LAUNCH(M) case M: hipLaunchKernelGGL(conv_bf16_ws3_kernel<M>, dim3(grid), dim3(512), W3_LDS_BYTES, stream, p); break;
-  switch (mode) { W3_LAUNCH(0) W3_LAUNCH(1) W3_LAUNCH(2) W3_LAUNCH(3) }
+  switch (mode) { W3_LAUNCH(0) W3_LAUNCH(1) W3_LAUNCH(2) W3_LAUNCH(3) W3_LAUNCH(5) W3_LAUNCH(7) }
 #undef W3_LAUNCH
   if (yogo_launch_log_enabled())
-    yogo_launch_log("conv_bf16_ws3_kernel<%d> | Kb=%d in=%dx%d out=%dx%d ncb=%d TW=%d PT=%d tiles_per_band=%d nchunk=%d ntiles=%d grid=%d lds=%d act=%d scale=%d", mode, p.Kb,
-                    p.IH, p.IW, p.OH, p.OW, p.ncb, p.TW, p.PT, p.tiles_per_band, p.nchunk, p.ntiles, grid, W3_LDS_BYTES, p.act, p.chan_scale != nullptr);
+    yogo_launch_log("conv_bf16_ws3_kernel<%d> | Kb=%d in=%dx%d out=%dx%d ncb=%d TW=%d PT=%d tiles_per_band=%d nchunk=%d ntiles=%d grid=%d lds=%d act=%d scale=%d signs=%d", mode, p.Kb,
+                    p.IH, p.IW, p.OH, p.OW, p.ncb, p.TW, p.PT, p.tiles_per_band, p.nchunk, p.ntiles, grid, W3_LDS_BYTES, p.act, p.chan_scale != nullptr, p.signs != nullptr);
   YOGO_CHECK_LAUNCH("conv_bf16_ws3");
   return YOGO_OK;
 }
