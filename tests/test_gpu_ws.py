@@ -362,3 +362,96 @@ def test_persistent_stride2_forward_against_cpu_fp32(kind, B, Cin, H, W):
     got = got.cpu().double()
     tol = 2.0 ** -8 * want.abs() + 2e-5 * float(want.abs().max())
     assert bool(((got - want).abs() <= tol).all()), float(((got - want).abs() - tol).max())
+
+
+# ---- the direct stride-2 data gradient of the thin layers: conv_bf16_s2d_direct_kernel against conv_bf16_kernel<1, 2, 4, S2D> ----
+def _run_s2d_thin(direct, kind, B, K, M, OH, OW, seed):
+    """dx [B][M <= 32][OH][OW] = conv_transpose(dy [B][K][ceil(OH/2)][ceil(OW/2)]) x (LeakyReLU'(sign map) x) channel mask: autograd of
+    yogo/model_defns.py:44-46 (conv 32 -> 64, stride 2) into the LeakyReLU + Dropout2d block in front of it"""
+    import contextlib
+
+    from _util import hooks_library
+    from yogo_amd import _hip as Hh
+
+    with (contextlib.nullcontext() if direct else hooks_library()):
+        st = Hh.stream_ptr()
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        IH, IW = (OH + 1) // 2, (OW + 1) // 2
+        wf = torch.randn(K, M, 3, 3, device="cuda", generator=g) * 0.05
+        dy8 = torch.randn(B, _blocks(K), IH, IW, 8, device="cuda", generator=g).to(torch.bfloat16)
+        dx8 = torch.full((B, _blocks(M), OH, OW, 8), 7.0, device="cuda").to(torch.bfloat16)   # poisoned: every unit must be written
+        msk = (torch.rand(B, M, device="cuda", generator=g) > 0.2).float() / 0.8
+        sg = torch.randint(0, 256, (Hh.query_size("yogo_bf16_signs_bytes", B, M, OH, OW),), dtype=torch.uint8, device="cuda", generator=g)
+        packed = torch.empty(Hh.query_size("yogo_conv_bf16_packed_bytes", M, K, 3, 2), dtype=torch.uint8, device="cuda")
+        Hh.call("yogo_conv_bf16_pack", wf, None, packed, M, K, 3, 2, st)
+        if not direct:
+            Hh.call("yogo_hook_conv_bf16_direct", 0)
+        Hh.launch_log(True)
+        try:
+            if kind == "signs":
+                Hh.call("yogo_conv2d_dgrad_bf16_signs", dy8, packed, dx8, sg, msk, B, M, K, OH, OW, 3, 2, st)
+            else:
+                Hh.call("yogo_conv2d_dgrad_bf16", dy8, packed, dx8, None, 0, msk if kind == "mask" else None, B, M, K, OH, OW, 3, 2, st)
+            torch.cuda.synchronize()
+            log = Hh.read_launch_log()
+        finally:
+            Hh.launch_log(False)
+            if not direct:
+                Hh.call("yogo_hook_conv_bf16_direct", 1)
+        return dx8, log, (wf, dy8, msk, sg)
+
+
+S2D_THIN_CASES = [
+    # (kind, B, K, M, OH, OW)
+    ("signs", 2, 64, 32, 386, 516),   # layer 2 of base_model at 772x1032
+    ("signs", 1, 64, 32, 20, 22),
+    ("mask", 2, 64, 32, 37, 41),      # odd sizes: the last quad row / column has no odd member
+    ("plain", 3, 32, 32, 50, 66),     # two 16-channel steps
+    ("signs", 5, 64, 24, 33, 29),     # 24 real channels: the padding channels of the last block come out as zeros
+    ("plain", 4, 32, 16, 2, 2),       # a single quad, two channel blocks
+    ("signs", 3, 64, 32, 64, 64),
+]
+
+
+@pytest.mark.parametrize("kind,B,K,M,OH,OW", S2D_THIN_CASES)
+def test_direct_stride2_dgrad_against_the_tiled_kernel_and_cpu(kind, B, K, M, OH, OW):
+    import torch.nn.functional as F
+
+    from yogo_amd import _hip as Hh
+
+    d_old, log_old, _ = _run_s2d_thin(False, kind, B, K, M, OH, OW, seed=53)
+    d_new, log_new, (wf, dy8, msk, sg) = _run_s2d_thin(True, kind, B, K, M, OH, OW, seed=53)
+    assert any(ln.startswith("conv_bf16_kernel<") and "s2d=1" in ln for ln in log_old), log_old
+    assert any(ln.startswith("conv_bf16_s2d_direct_kernel<") for ln in log_new), log_new
+    # the direct kernel steps the contraction 16 channels at a time, the tiled plan of these shapes 32 or 64 (tap-major inside a chunk): another
+    # fp32 summation order -- the bf16 results may differ by one rounding step on a few values
+    a, b = d_old.float(), d_new.float()
+    ulp = 2.0 ** -7 * torch.maximum(a.abs(), b.abs()) + 1e-6 * a.abs().max()
+    assert bool(((a - b).abs() <= ulp).all()), f"{((a - b).abs() - ulp).max().item()} beyond one bf16 step"
+    assert (a != b).float().mean().item() < 5e-3
+    # ... and an independent reference: torch's CPU conv_transpose2d (float64) on the same bf16-rounded operands
+    if B * OH * OW <= 40000:
+        st = Hh.stream_ptr()
+        IH, IW = (OH + 1) // 2, (OW + 1) // 2
+        dy = torch.empty(B, K, IH, IW, device="cuda")
+        Hh.call("yogo_bf16_8c_to_nchw_f32", dy8, dy, B, K, IH * IW, st)
+        got = torch.empty(B, M, OH, OW, device="cuda")
+        Hh.call("yogo_bf16_8c_to_nchw_f32", d_new, got, B, M, OH * OW, st)
+        w = wf.to(torch.bfloat16).double().cpu()
+        want = F.conv_transpose2d(dy.double().cpu(), w, stride=2, padding=1, output_padding=(OH - ((IH - 1) * 2 + 1), OW - ((IW - 1) * 2 + 1)))
+        if kind == "signs":
+            s = sg.cpu().view(B, 2, OH, OW, 2).long()   # byte (h, pixel, q), bit i + 4e = (channel 16 q + 8 e + 4 h + i > 0)
+            pos = torch.zeros(B, 32, OH, OW, dtype=torch.bool)
+            for h in range(2):
+                for q in range(2):
+                    for e in range(2):
+                        for i in range(4):
+                            pos[:, 16 * q + 8 * e + 4 * h + i] = ((s[:, h, :, :, q] >> (i + 4 * e)) & 1).bool()
+            want = want * torch.where(pos[:, :M], 1.0, 0.01)
+        if kind in ("signs", "mask"):
+            want = want * msk.double().cpu()[:, :, None, None]
+        got = got.cpu().double()
+        tol = 2.0 ** -8 * want.abs() + 2e-5 * float(want.abs().max())
+        assert bool(((got - want).abs() <= tol).all()), float(((got - want).abs() - tol).max())
+        padc = d_new.float().permute(0, 1, 4, 2, 3).reshape(B, -1, OH, OW)[:, M:]
+        assert padc.numel() == 0 or float(padc.abs().max()) == 0.0

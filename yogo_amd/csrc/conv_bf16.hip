@@ -1343,10 +1343,17 @@ extern "C" int yogo_hook_conv_bf16_persistent(int on) { g_bf_ws = on != 0; retur
 // the product, switched on by the tests / A-B tools through the hooks library
 static bool g_bf_ws2 = false;
 extern "C" int yogo_hook_conv_bf16_ws2(int on) { g_bf_ws2 = on != 0; return YOGO_OK; }
+// the direct (weights-resident, no staging) kernels of the thin layers (conv_bf16_direct.hip)
+static bool g_bf_direct = true;
+extern "C" int yogo_hook_conv_bf16_direct(int on) { g_bf_direct = on != 0; return YOGO_OK; }
 #else
 static constexpr bool g_bf_ws = true;
 static constexpr bool g_bf_ws2 = false;
+static constexpr bool g_bf_direct = true;
 #endif
+bool conv_bf16_s2d_direct_eligible(int K, int M, int OH, int OW, int B);
+int launch_conv_bf16_s2d_direct(const void* in, const void* packed, void* out, const void* signs, const float* chan_scale, int B, int K, int M, int IH, int IW,
+                                int OH, int OW, hipStream_t stream);
 static bool g_bf_pp = true;   // (diagnostic build: yogo_diag_conv_bf16_pp(0) selects the interleaved main loop for A/B runs)
 #ifdef YOGO_DIAG
 extern "C" int yogo_diag_conv_bf16_pp(int on) { g_bf_pp = on != 0; return YOGO_OK; }
@@ -1452,6 +1459,11 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
 #endif
     if (conv_bf16_ws3_plan(&q)) return launch_conv_bf16_ws3(q, stream);
   }
+  // stride-2 3x3 data gradient into <= 32 channels (scale / LeakyReLU-sign-map epilogue): weights resident in LDS, operands straight from memory
+  if (in != nullptr && g_bf_direct && s2d && ks == 3 && out_f32 == nullptr && out_pre == nullptr && act_ref == nullptr && bias == nullptr &&
+      stats_part == nullptr && act == ACT_NONE && (!signs_read || (signs != nullptr && ref_act == ACT_LEAKY)) && (signs_read || signs == nullptr) &&
+      conv_bf16_s2d_direct_eligible(K, M, OH, OW, B))
+    return launch_conv_bf16_s2d_direct(in, packed, out, signs_read ? signs : nullptr, chan_scale, B, K, M, IH, IW, OH, OW, stream);
   // stride-2 3x3 data gradient into 128 channels (scale / LeakyReLU-sign-map epilogue): the persistent wavefront-specialised kernel
   // that stages the gradient tile once for both row parities (conv_bf16_ws2.hip)
   if (in != nullptr && g_bf_ws && g_bf_ws2 && s2d && ks == 3 && out_f32 == nullptr && out_pre == nullptr && act_ref == nullptr && bias == nullptr &&

@@ -1,0 +1,220 @@
+// "Direct" bf16 convolutions for the thin, memory-bound layers: the packed weights are RESIDENT in LDS (9 - 36 KB, staged once per
+// workgroup), every wavefront owns whole tiles of 32 pixels and fetches its MFMA pixel operands STRAIGHT FROM GLOBAL MEMORY into
+// registers (buffer_load_dwordx4: a lane's 16-byte unit of its pixel, shifted per tap; neighbouring taps and rows hit the CU's L1), and
+// after the one barrier behind the weight staging the wavefronts never synchronise again.
+//
+// Why (round 5): the thin layers move 2.5 GB per launch and ran at 3.2 - 4.7 TB/s as LDS-staged tiles; what they lose is
+// not arithmetic (0.1 ms of MFMAs) but the coupling of a workgroup's wavefronts -- prologue, LDS-DMA round trip, barrier, epilogue and
+// stores of a tile happen one after the other, and a load issued behind a tile's stores waits for them (the CU's vector-memory path is in
+// order).  Sixteen INDEPENDENT wavefronts per CU, each a simple load -> MFMA -> store stream over its own tiles, is the shape of the
+// kernels that do reach 5 - 6 TB/s here (the BatchNorm sweeps).
+//
+// conv_bf16_s2d_direct_kernel: the data gradient of a stride-2 3x3 convolution into <= 32 channels (layer 2 of base_model: autograd of
+// yogo/model_defns.py:44-46), decomposed by output parity as conv_bf16_kernel<.., S2D> (dx[2a+py][2b+px] receives the taps with ky = py + 1,
+// kx = px + 1 (mod 2): 1 + 2 + 2 + 4 tap-GEMMs per 2x2 output quad).  A tile = 32 consecutive quads (= dy pixels) of an image: 4 accumulator
+// tiles (py, px), per 16-channel step four pixel operands (the quad's dy pixel and its right / lower / diagonal neighbours) serve the nine
+// taps.  Epilogue as the tiled kernel: x channel scale [x LeakyReLU'(sign bit)], bf16, half-wave exchange, 16-byte stores.
+#include "common.h"
+#include <mutex>
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct ConvDirectS2dParams {
+  const u32x4* in;    // dy: bf16 NCHW8c [B][Kb][IH][IW] units
+  const u32x4* wp;    // packed weights, mode 2: [9 slices in parity-class order][Kb][32] units
+  u32x4* out;         // dx: bf16 NCHW8c [B][4][OH][OW] units
+  const unsigned char* signs;   // optional LeakyReLU sign map of the block output dx flows into ([B][2][OH][OW][2] bytes), or null
+  const float* chan_scale;      // optional [B][M]
+  int B, Kb, M, Mb, IH, IW, OH, OW;   // Mb: channel blocks of dx (2 or 4)
+  int tiles_per_img, ntiles;
+  unsigned m_iw, m_tpi;         // ceil(2^32 / d) magic numbers of IW and tiles_per_img
+};
+
+namespace {
+__device__ __forceinline__ int dd_udivm1(int n, int d, unsigned m) { return d == 1 ? n : (int)__umulhi((unsigned)n, m); }
+}  // namespace
+
+// NK: 16-channel steps of the contraction (K / 16: 2 or 4)
+template <int NK, bool SIGNS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_bf16_s2d_direct_kernel(const ConvDirectS2dParams p) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 lds_w[];   // [9][2 NK][32] units
+  constexpr int OOB = (int)0x80000000u;
+  constexpr int KB = 2 * NK;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < 9 * KB * 32; i += 256) lds_w[i] = p.wp[i];
+  __syncthreads();
+  const int IH = p.IH, IW = p.IW, OH = p.OH, OW = p.OW;
+  const int kcb = IH * IW * 16, plane = OH * OW, plane16 = plane * 16, nq = IH * IW;
+  const int nwaves = gridDim.x * 4;
+  for (int tile = blockIdx.x * 4 + wave; tile < p.ntiles; tile += nwaves) {
+    const int b = dd_udivm1(tile, p.tiles_per_img, p.m_tpi);
+    const int t = tile - b * p.tiles_per_img;
+    const int q = t * 32 + l31;
+    const bool qv = q < nq;
+    const int qc = qv ? q : nq - 1;
+    const int a = dd_udivm1(qc, IW, p.m_iw), c = qc - a * IW;
+    const bool cx = c + 1 < IW, cy = a + 1 < IH;          // the right / lower dy neighbour exists
+    const bool vx = 2 * c + 1 < OW, vy = 2 * a + 1 < OH;  // the quad's odd column / row exists
+    const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (size_t)b * KB * IH * IW), (short)0, KB * kcb, 0x00020000);
+    const auto rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (size_t)b * p.Mb * plane), (short)0, p.Mb * plane16, 0x00020000);
+    // dy operand offsets of this lane: its quad's pixel and the three neighbours, channel block `half` of a 16-channel step
+    const int v00 = (a * IW + c) * 16 + half * kcb;
+    const int vsh[4] = {v00, cx ? v00 + 16 : OOB, cy ? v00 + IW * 16 : OOB, (cx && cy) ? v00 + IW * 16 + 16 : OOB};
+    const int pix = 2 * a * OW + 2 * c;   // output pixel (2a, 2c) of the quad
+    // the epilogue's small inputs first (they are older than the operand loads: landed when the MFMAs are through)
+    unsigned sg[2][2] = {{0u, 0u}, {0u, 0u}};
+    if constexpr (SIGNS) {
+      const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)(p.signs + (size_t)b * plane * 4), (short)0, plane * 4, 0x00020000);
+#pragma unroll
+      for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+          const bool ok = qv && (px == 0 || vx) && (py == 0 || vy);
+          sg[py][px] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs_s, ok ? (half * plane + pix + py * OW + px) * 2 : OOB, 0, 0);
+        }
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+      for (int px = 0; px < 2; ++px)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[py][px][r] = 0.f;
+    u32x4 Bq[2][4];
+    auto load_step = [&](int kc, u32x4 (&dst)[4]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) dst[s] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, vsh[s], (2 * kc) * kcb, 0));
+    };
+    load_step(0, Bq[0]);
+#pragma unroll
+    for (int kc = 0; kc < NK; ++kc) {
+      if (kc + 1 < NK) load_step(kc + 1, Bq[(kc + 1) & 1]);
+      const u32x4(&Bc)[4] = Bq[kc & 1];
+      const u32x4* wk = lds_w + (2 * kc + half) * 32 + l31;   // slice s at + s * KB * 32
+      // slice -> (row parity, column parity, dy shift): 0 (0,0,0) | 1 (0,1,0) 2 (0,1,1) | 3 (1,0,0) 4 (1,0,2) | 5 (1,1,0) 6 (1,1,1) 7 (1,1,2) 8 (1,1,3)
+#define DD_MF(PY, PX, S, SH) acc[PY][PX] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wk[(S) * KB * 32]), __builtin_bit_cast(bf16x8, Bc[SH]), acc[PY][PX], 0, 0, 0);
+      // (three taps at a time between scheduling barriers: left alone, hipcc hoists all 36 weight quads of a tile and spills 150 registers)
+      __builtin_amdgcn_sched_barrier(0);
+      DD_MF(0, 0, 0, 0) DD_MF(0, 1, 1, 0) DD_MF(1, 0, 3, 0)
+      __builtin_amdgcn_sched_barrier(0);
+      DD_MF(1, 1, 5, 0) DD_MF(0, 1, 2, 1) DD_MF(1, 1, 6, 1)
+      __builtin_amdgcn_sched_barrier(0);
+      DD_MF(1, 0, 4, 2) DD_MF(1, 1, 7, 2) DD_MF(1, 1, 8, 3)
+      __builtin_amdgcn_sched_barrier(0);
+#undef DD_MF
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float sa[2][8];   // channel scale of this lane's channels: [gp][4 of block 2 gp | 4 of block 2 gp + 1]
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int ch = 16 * gp + 8 * e + 4 * half;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sa[gp][4 * e + i] = (p.chan_scale != nullptr && ch + i < p.M) ? p.chan_scale[(size_t)b * p.M + ch + i] : (ch + i < p.M ? 1.f : 0.f);
+      }
+    // ---- epilogue: (py, px, gp) -> one 16-byte store per lane: lanes 0-31 channel block 2 gp, lanes 32-63 block 2 gp + 1
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp) {
+      float sl[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sl[i] = LEAKY_SLOPE * sa[gp][i];
+#pragma unroll
+      for (int py = 0; py < 2; ++py) {
+        u32x4 un[2];   // [px]: this lane's unit of channel block 2 gp + half
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+          float v[8];
+          if constexpr (SIGNS) {
+            const unsigned m = sg[py][px] >> (8 * gp);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const int tt = (int)(m << (31 - i)) >> 31;   // bit i spread over the word selects scale or 0.01 * scale
+              unsigned f;
+              asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(f) : "v"(tt), "v"(sa[gp][i]), "v"(sl[i]));
+              v[i] = acc[py][px][8 * gp + i] * __builtin_bit_cast(float, f);
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = fmaf(acc[py][px][8 * gp + i], sa[gp][i], 0.f * sa[gp][i]);
+          }
+          bf16x8 o;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] = (__bf16)v[i];
+          const u32x4 w = __builtin_bit_cast(u32x4, o);
+          const auto r0 = __builtin_amdgcn_permlane32_swap(w.x, w.z, false, false);
+          const auto r1 = __builtin_amdgcn_permlane32_swap(w.y, w.w, false, false);
+          un[px] = u32x4{r0[0], r1[0], r0[1], r1[1]};
+        }
+        // a second exchange makes every store a CONTIGUOUS kilobyte: lanes 0-31 the even pixel, lanes 32-63 the odd pixel of ONE channel
+        // block (un[0]'s upper half-wave = (px 0, block 2 gp + 1) trades places with un[1]'s lower half-wave = (px 1, block 2 gp))
+        u32x4 se[2];   // [e]: lanes 0-31 pixel (2c), lanes 32-63 pixel (2c + 1) of channel block 2 gp + e
+        {
+          const auto x0 = __builtin_amdgcn_permlane32_swap(un[0].x, un[1].x, false, false);
+          const auto x1 = __builtin_amdgcn_permlane32_swap(un[0].y, un[1].y, false, false);
+          const auto x2 = __builtin_amdgcn_permlane32_swap(un[0].z, un[1].z, false, false);
+          const auto x3 = __builtin_amdgcn_permlane32_swap(un[0].w, un[1].w, false, false);
+          se[0] = u32x4{x0[0], x1[0], x2[0], x3[0]};
+          se[1] = u32x4{x0[1], x1[1], x2[1], x3[1]};
+        }
+        // (this lane now stores pixel px = half of its quad)
+        const bool okp = qv && (half == 0 || vx) && (py == 0 || vy);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+          __builtin_amdgcn_raw_buffer_store_b128(se[e], rs_o, (okp && 2 * gp + e < p.Mb) ? (pix + py * OW + half) * 16 + (2 * gp + e) * plane16 : OOB, 0, 0);
+      }
+    }
+  }
+}
+
+bool conv_bf16_s2d_direct_eligible(int K, int M, int OH, int OW, int B) {
+  if (M > 32 || M < 1 || (K != 32 && K != 64)) return false;
+  if (OH < 2 || OW < 2 || B <= 0) return false;
+  const long long IH = (OH + 1) / 2, IW = (OW + 1) / 2;
+  if ((long long)(K / 8) * IH * IW * 16 >= (1ll << 31) || 4ll * OH * OW * 16 >= (1ll << 31) || (long long)B * ((IH * IW + 31) / 32) >= (1ll << 31)) return false;
+  return true;
+}
+
+int launch_conv_bf16_s2d_direct(const void* in, const void* packed, void* out, const void* signs, const float* chan_scale, int B, int K, int M, int IH, int IW,
+                                int OH, int OW, hipStream_t stream) {
+  static std::mutex mu;
+  static int n_cu_of[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+    yogo_set_error("conv_bf16_s2d_direct: hipGetDevice failed");
+    return YOGO_ERR_HIP;
+  }
+  int n_cu;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (n_cu_of[dev] == 0) {
+      hipDeviceProp_t prop;
+      n_cu_of[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    n_cu = n_cu_of[dev];
+  }
+  ConvDirectS2dParams p{};
+  p.in = reinterpret_cast<const u32x4*>(in); p.wp = reinterpret_cast<const u32x4*>(packed); p.out = reinterpret_cast<u32x4*>(out);
+  p.signs = reinterpret_cast<const unsigned char*>(signs); p.chan_scale = chan_scale;
+  p.B = B; p.Kb = K / 8; p.M = M; p.Mb = ((M + 15) / 16) * 2; p.IH = IH; p.IW = IW; p.OH = OH; p.OW = OW;
+  p.tiles_per_img = cdiv(IH * IW, 32);
+  p.ntiles = B * p.tiles_per_img;
+  auto magic = [](int d) -> unsigned { return d <= 1 ? 0xFFFFFFFFu : (unsigned)(((1ull << 32) + (unsigned)d - 1ull) / (unsigned)d); };
+  p.m_iw = magic(IW); p.m_tpi = magic(p.tiles_per_img);
+  if (p.ntiles <= 0) return YOGO_OK;
+  const int lds = 9 * p.Kb * 32 * 16;           // 18 KB (K = 32) / 36 KB (K = 64): four workgroups per CU
+  const int grid = min(cdiv(p.ntiles, 4), 4 * n_cu);
+  const bool sg = signs != nullptr;
+#define DD_LAUNCH(NK, S) hipLaunchKernelGGL((conv_bf16_s2d_direct_kernel<NK, S>), dim3(grid), dim3(256), lds, stream, p)
+  if (K == 64) { if (sg) DD_LAUNCH(4, true); else DD_LAUNCH(4, false); }
+  else { if (sg) DD_LAUNCH(2, true); else DD_LAUNCH(2, false); }
+#undef DD_LAUNCH
+  if (yogo_launch_log_enabled())
+    yogo_launch_log("conv_bf16_s2d_direct_kernel<%d, %s> | K=%d M=%d dy=%dx%d dx=%dx%d tiles=%d grid=%d lds=%d signs=%d scale=%d", K / 16, sg ? "true" : "false", K, M,
+                    IH, IW, OH, OW, p.ntiles, grid, lds, sg, chan_scale != nullptr);
+  YOGO_CHECK_LAUNCH("conv_bf16_s2d_direct");
+  return YOGO_OK;
+}
