@@ -980,6 +980,15 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
     constexpr bool sign_ref = REF == 2;  // ... with the LeakyReLU sign map in place of the bf16 reference
     const int plane16 = (int)plane * 16;
     const auto rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (size_t)b * p.Mb * plane * 2), (short)0, p.Mb * plane16, 0x00020000);
+#ifndef BF_S2D_HALF_DENSE
+#define BF_S2D_HALF_DENSE 0   // (A/B variant builds: 1 = the stride-2 data gradient's units go out as they are, one half-filled store per column parity)
+#endif
+    // stride-2 data gradient: byte offset of the pixel this lane stores after the second exchange (lanes 0-31 the even, 32-63 the odd column)
+    [[maybe_unused]] int vd[NW];
+    if constexpr (S2D) {
+#pragma unroll
+      for (int n = 0; n < NW; ++n) vd[n] = ((half == 0 ? pvalid[n] : pvalid1[n]) && !BF_DBG(1)) ? (opix[n] + half) * 16 : (int)0x80000000u;
+    }
     int vo[NC][NW];  // byte offset of this lane's unit inside its image: lanes 32-63 write the next channel block
 #pragma unroll
     for (int c = 0; c < NC; ++c)
