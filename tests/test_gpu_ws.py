@@ -174,9 +174,9 @@ def _run_s2d(persistent, kind, B, K, OH, OW, seed):
     from _util import hooks_library
     from yogo_amd import _hip as Hh
 
-    # (the tiled kernel is the product's plan for this layer; conv_bf16_ws2_kernel is built, parity-green, not faster -- DESIGN.md -- and
-    #  only runs when the hooks library switches it on)
-    with (hooks_library() if persistent else contextlib.nullcontext()):
+    # (the product's plan for this layer is the direct kernel, conv_bf16_direct.hip; the tiled kernel and conv_bf16_ws2_kernel -- built,
+    #  parity-green, not faster: DESIGN.md -- both run only when the hooks library switches the plan)
+    with hooks_library():
         st = Hh.stream_ptr()
         g = torch.Generator(device="cuda").manual_seed(seed)
         IH, IW = (OH + 1) // 2, (OW + 1) // 2
@@ -188,8 +188,8 @@ def _run_s2d(persistent, kind, B, K, OH, OW, seed):
         sg = torch.randint(0, 256, (Hh.query_size("yogo_bf16_signs_bytes", B, 128, OH, OW),), dtype=torch.uint8, device="cuda", generator=g)
         packed = torch.empty(Hh.query_size("yogo_conv_bf16_packed_bytes", 128, K, 3, 2), dtype=torch.uint8, device="cuda")
         Hh.call("yogo_conv_bf16_pack", wf, None, packed, 128, K, 3, 2, st)
-        if persistent:
-            Hh.call("yogo_hook_conv_bf16_ws2", 1)
+        Hh.call("yogo_hook_conv_bf16_direct", 0)
+        Hh.call("yogo_hook_conv_bf16_ws2", 1 if persistent else 0)
         Hh.launch_log(True)
         try:
             if kind == "signs":
@@ -410,6 +410,13 @@ S2D_THIN_CASES = [
     ("signs", 5, 64, 24, 33, 29),     # 24 real channels: the padding channels of the last block come out as zeros
     ("plain", 4, 32, 16, 2, 2),       # a single quad, two channel blocks
     ("signs", 3, 64, 32, 64, 64),
+    # 128 channels in two passes of 64 (layer 4 of base_model: one workgroup per CU, 147 KB of weight slices each)
+    ("signs", 2, 128, 128, 193, 258),
+    ("signs", 1, 128, 128, 20, 22),
+    ("mask", 2, 128, 128, 37, 41),
+    ("plain", 3, 128, 96, 50, 66),    # 96 real channels: the second pass stores two of its four block pairs
+    ("signs", 40, 128, 128, 30, 30),  # every wavefront walks several tiles, image changes at the seams
+    ("mask", 5, 128, 72, 3, 2),
 ]
 
 
@@ -440,10 +447,11 @@ def test_direct_stride2_dgrad_against_the_tiled_kernel_and_cpu(kind, B, K, M, OH
         w = wf.to(torch.bfloat16).double().cpu()
         want = F.conv_transpose2d(dy.double().cpu(), w, stride=2, padding=1, output_padding=(OH - ((IH - 1) * 2 + 1), OW - ((IW - 1) * 2 + 1)))
         if kind == "signs":
-            s = sg.cpu().view(B, 2, OH, OW, 2).long()   # byte (h, pixel, q), bit i + 4e = (channel 16 q + 8 e + 4 h + i > 0)
-            pos = torch.zeros(B, 32, OH, OW, dtype=torch.bool)
+            sq = 2 if M <= 32 else 8
+            s = sg.cpu().view(B, 2, OH, OW, sq).long()   # byte (h, pixel, q), bit i + 4e = (channel 16 q + 8 e + 4 h + i > 0)
+            pos = torch.zeros(B, 16 * sq, OH, OW, dtype=torch.bool)
             for h in range(2):
-                for q in range(2):
+                for q in range(sq):
                     for e in range(2):
                         for i in range(4):
                             pos[:, 16 * q + 8 * e + 4 * h + i] = ((s[:, h, :, :, q] >> (i + 4 * e)) & 1).bool()

@@ -23,11 +23,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct ConvDirectS2dParams {
   const u32x4* in;    // dy: bf16 NCHW8c [B][Kb][IH][IW] units
-  const u32x4* wp;    // packed weights, mode 2: [9 slices in parity-class order][Kb][32] units
-  u32x4* out;         // dx: bf16 NCHW8c [B][4][OH][OW] units
-  const unsigned char* signs;   // optional LeakyReLU sign map of the block output dx flows into ([B][2][OH][OW][2] bytes), or null
+  const u32x4* wp;    // packed weights, mode 2: [9 slices in parity-class order][Kb][Mpad] units
+  u32x4* out;         // dx: bf16 NCHW8c [B][Mb][OH][OW] units
+  const unsigned char* signs;   // optional LeakyReLU sign map of the block output dx flows into ([B][2][OH][OW][Mpad / 16] bytes), or null
   const float* chan_scale;      // optional [B][M]
-  int B, Kb, M, Mb, IH, IW, OH, OW;   // Mb: channel blocks of dx (2 or 4)
+  int B, Kb, M, Mb, Mpad, IH, IW, OH, OW;   // Mb: channel blocks of dx (even)
+  int npass;                    // channel passes: Mpad / (32 NMB); the workgroups of a pass hold ITS weight slices
   int tiles_per_img, ntiles;
   unsigned m_iw, m_tpi;         // ceil(2^32 / d) magic numbers of IW and tiles_per_img
 };
@@ -36,20 +37,34 @@ namespace {
 __device__ __forceinline__ int dd_udivm1(int n, int d, unsigned m) { return d == 1 ? n : (int)__umulhi((unsigned)n, m); }
 }  // namespace
 
-// NK: 16-channel steps of the contraction (K / 16: 2 or 4)
-template <int NK, bool SIGNS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_bf16_s2d_direct_kernel(const ConvDirectS2dParams p) {
-  extern __shared__ __attribute__((aligned(16))) u32x4 lds_w[];   // [9][2 NK][32] units
+// NK: 16-channel steps of the contraction (K / 16); NMB: 32-channel blocks of dx per wavefront tile (1: 4 wavefronts per workgroup, four
+// workgroups per CU; 2: 8 wavefronts, ONE workgroup per CU whose 147 KB of LDS hold the nine slices of 64 of the 128 channels -- the other
+// 64 belong to the partner workgroup of the same XCD, 8 workgroup ids further on, which walks the same tiles at the same time: the second
+// read of a gradient tile comes out of the XCD's L2)
+template <int NK, int NMB, bool SIGNS>
+__global__ __launch_bounds__(256 * NMB) __attribute__((amdgpu_waves_per_eu(NMB == 1 ? 4 : 2, NMB == 1 ? 4 : 2))) void conv_bf16_s2d_direct_kernel(
+    const ConvDirectS2dParams p) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 lds_w[];   // [9][2 NK][32 NMB] units, then [wavefronts][32 NMB] fp32 channel scales
   constexpr int OOB = (int)0x80000000u;
-  constexpr int KB = 2 * NK;
+  constexpr int KB = 2 * NK, MP = 32 * NMB, NT = 256 * NMB, NWV = 4 * NMB;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < 9 * KB * 32; i += 256) lds_w[i] = p.wp[i];
+  // workgroup -> (pass, walker): passes of one walker sit 8 ids apart (same XCD)
+  const int bid = blockIdx.x;
+  const int pass = p.npass == 1 ? 0 : (bid >> 3) % p.npass;
+  const int walker = p.npass == 1 ? bid : (bid & 7) + 8 * (bid / (8 * p.npass));
+  const int nwalk = gridDim.x / p.npass;
+  for (int i = tid; i < 9 * KB * MP; i += NT) {
+    const int m = i % MP, r = i / MP;   // r = slice * KB + kb
+    lds_w[i] = p.wp[(size_t)r * p.Mpad + pass * MP + m];
+  }
+  float* my_scale = reinterpret_cast<float*>(lds_w + 9 * KB * MP) + wave * MP;
   __syncthreads();
   const int IH = p.IH, IW = p.IW, OH = p.OH, OW = p.OW;
   const int kcb = IH * IW * 16, plane = OH * OW, plane16 = plane * 16, nq = IH * IW;
-  const int nwaves = gridDim.x * 4;
-  for (int tile = blockIdx.x * 4 + wave; tile < p.ntiles; tile += nwaves) {
+  const int sq = p.Mpad >> 4;   // sign bytes per (pixel, half-wave)
+  const int ch0 = pass * MP;    // first channel of this pass
+  for (int tile = walker * NWV + wave; tile < p.ntiles; tile += nwalk * NWV) {
     const int b = dd_udivm1(tile, p.tiles_per_img, p.m_tpi);
     const int t = tile - b * p.tiles_per_img;
     const int q = t * 32 + l31;
@@ -65,24 +80,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int vsh[4] = {v00, cx ? v00 + 16 : OOB, cy ? v00 + IW * 16 : OOB, (cx && cy) ? v00 + IW * 16 + 16 : OOB};
     const int pix = 2 * a * OW + 2 * c;   // output pixel (2a, 2c) of the quad
     // the epilogue's small inputs first (they are older than the operand loads: landed when the MFMAs are through)
-    unsigned sg[2][2] = {{0u, 0u}, {0u, 0u}};
+    float my_s = 0.f;   // lanes < MP: the scale of channel ch0 + lane (1 without a scale, 0 for the padding channels)
+    if (lane < MP) my_s = ch0 + lane < p.M ? (p.chan_scale != nullptr ? p.chan_scale[(size_t)b * p.M + ch0 + lane] : 1.f) : 0.f;
+    unsigned sg[2][2] = {{0u, 0u}, {0u, 0u}};   // byte j = the lane's sign bits of channel group 2 pass NMB + j
     if constexpr (SIGNS) {
-      const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)(p.signs + (size_t)b * plane * 4), (short)0, plane * 4, 0x00020000);
+      const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)(p.signs + (size_t)b * plane * 2 * sq), (short)0, plane * 2 * sq, 0x00020000);
 #pragma unroll
       for (int py = 0; py < 2; ++py)
 #pragma unroll
         for (int px = 0; px < 2; ++px) {
           const bool ok = qv && (px == 0 || vx) && (py == 0 || vy);
-          sg[py][px] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs_s, ok ? (half * plane + pix + py * OW + px) * 2 : OOB, 0, 0);
+          const int vs = ok ? (half * plane + pix + py * OW + px) * sq + pass * 2 * NMB : OOB;
+          if constexpr (NMB == 2) sg[py][px] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs_s, vs, 0, 0);
+          else sg[py][px] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs_s, vs, 0, 0);
         }
     }
-    f32x16 acc[2][2];
+    f32x16 acc[NMB][2][2];
 #pragma unroll
-    for (int py = 0; py < 2; ++py)
+    for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
-      for (int px = 0; px < 2; ++px)
+      for (int py = 0; py < 2; ++py)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[py][px][r] = 0.f;
+        for (int px = 0; px < 2; ++px)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mb][py][px][r] = 0.f;
     u32x4 Bq[2][4];
     auto load_step = [&](int kc, u32x4 (&dst)[4]) __attribute__((always_inline)) {
 #pragma unroll
@@ -93,10 +114,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int kc = 0; kc < NK; ++kc) {
       if (kc + 1 < NK) load_step(kc + 1, Bq[(kc + 1) & 1]);
       const u32x4(&Bc)[4] = Bq[kc & 1];
-      const u32x4* wk = lds_w + (2 * kc + half) * 32 + l31;   // slice s at + s * KB * 32
+      const u32x4* wk = lds_w + (2 * kc + half) * MP + l31;   // slice s at + s * KB * MP, channel block mb at + 32 mb
       // slice -> (row parity, column parity, dy shift): 0 (0,0,0) | 1 (0,1,0) 2 (0,1,1) | 3 (1,0,0) 4 (1,0,2) | 5 (1,1,0) 6 (1,1,1) 7 (1,1,2) 8 (1,1,3)
-#define DD_MF(PY, PX, S, SH) acc[PY][PX] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wk[(S) * KB * 32]), __builtin_bit_cast(bf16x8, Bc[SH]), acc[PY][PX], 0, 0, 0);
-      // (three taps at a time between scheduling barriers: left alone, hipcc hoists all 36 weight quads of a tile and spills 150 registers)
+#define DD_MF(PY, PX, S, SH)                                                                                                                     \
+  _Pragma("unroll") for (int mb = 0; mb < NMB; ++mb) acc[mb][PY][PX] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                  \
+      __builtin_bit_cast(bf16x8, wk[(S) * KB * MP + 32 * mb]), __builtin_bit_cast(bf16x8, Bc[SH]), acc[mb][PY][PX], 0, 0, 0);
+      // (three taps at a time between scheduling barriers: left alone, hipcc hoists all the weight quads of a tile and spills 150 registers)
       __builtin_amdgcn_sched_barrier(0);
       DD_MF(0, 0, 0, 0) DD_MF(0, 1, 1, 0) DD_MF(1, 0, 3, 0)
       __builtin_amdgcn_sched_barrier(0);
@@ -107,39 +130,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #undef DD_MF
     }
     __builtin_amdgcn_sched_barrier(0);
-    float sa[2][8];   // channel scale of this lane's channels: [gp][4 of block 2 gp | 4 of block 2 gp + 1]
+    // the tile's channel scales through this wavefront's own LDS row (no barrier: a wavefront's LDS operations complete in order)
+    if (lane < MP) my_scale[lane] = my_s;
+    // ---- epilogue: (mb, gp, py) -> two 16-byte stores per lane
 #pragma unroll
-    for (int gp = 0; gp < 2; ++gp)
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int ch = 16 * gp + 8 * e + 4 * half;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) sa[gp][4 * e + i] = (p.chan_scale != nullptr && ch + i < p.M) ? p.chan_scale[(size_t)b * p.M + ch + i] : (ch + i < p.M ? 1.f : 0.f);
-      }
-    // ---- epilogue: (py, px, gp) -> one 16-byte store per lane: lanes 0-31 channel block 2 gp, lanes 32-63 block 2 gp + 1
+    for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
     for (int gp = 0; gp < 2; ++gp) {
+      const int cb = pass * 4 * NMB + 4 * mb + 2 * gp;   // channel block of the group's lower half (uniform)
+      const int cl = 32 * mb + 16 * gp + 4 * half;       // this lane's channels: cl .. cl + 3 and cl + 8 .. cl + 11 of the pass
+      const float4 sA = *reinterpret_cast<const float4*>(my_scale + cl), sB = *reinterpret_cast<const float4*>(my_scale + cl + 8);
+      const float sa[8] = {sA.x, sA.y, sA.z, sA.w, sB.x, sB.y, sB.z, sB.w};
       float sl[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) sl[i] = LEAKY_SLOPE * sa[gp][i];
+      for (int i = 0; i < 8; ++i) sl[i] = LEAKY_SLOPE * sa[i];
 #pragma unroll
       for (int py = 0; py < 2; ++py) {
-        u32x4 un[2];   // [px]: this lane's unit of channel block 2 gp + half
+        u32x4 un[2];   // [px]: this lane's unit of channel block cb + half
 #pragma unroll
         for (int px = 0; px < 2; ++px) {
           float v[8];
           if constexpr (SIGNS) {
-            const unsigned m = sg[py][px] >> (8 * gp);
+            const unsigned m = sg[py][px] >> (8 * (2 * mb + gp));
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
               const int tt = (int)(m << (31 - i)) >> 31;   // bit i spread over the word selects scale or 0.01 * scale
               unsigned f;
-              asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(f) : "v"(tt), "v"(sa[gp][i]), "v"(sl[i]));
-              v[i] = acc[py][px][8 * gp + i] * __builtin_bit_cast(float, f);
+              asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(f) : "v"(tt), "v"(sa[i]), "v"(sl[i]));
+              v[i] = acc[mb][py][px][8 * gp + i] * __builtin_bit_cast(float, f);
             }
           } else {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = fmaf(acc[py][px][8 * gp + i], sa[gp][i], 0.f * sa[gp][i]);
+            for (int i = 0; i < 8; ++i) v[i] = fmaf(acc[mb][py][px][8 * gp + i], sa[i], 0.f * sa[i]);
           }
           bf16x8 o;
 #pragma unroll
@@ -150,8 +172,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           un[px] = u32x4{r0[0], r1[0], r0[1], r1[1]};
         }
         // a second exchange makes every store a CONTIGUOUS kilobyte: lanes 0-31 the even pixel, lanes 32-63 the odd pixel of ONE channel
-        // block (un[0]'s upper half-wave = (px 0, block 2 gp + 1) trades places with un[1]'s lower half-wave = (px 1, block 2 gp))
-        u32x4 se[2];   // [e]: lanes 0-31 pixel (2c), lanes 32-63 pixel (2c + 1) of channel block 2 gp + e
+        // block (un[0]'s upper half-wave = (px 0, block cb + 1) trades places with un[1]'s lower half-wave = (px 1, block cb))
+        u32x4 se[2];   // [e]: lanes 0-31 pixel (2c), lanes 32-63 pixel (2c + 1) of channel block cb + e
         {
           const auto x0 = __builtin_amdgcn_permlane32_swap(un[0].x, un[1].x, false, false);
           const auto x1 = __builtin_amdgcn_permlane32_swap(un[0].y, un[1].y, false, false);
@@ -164,17 +186,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const bool okp = qv && (half == 0 || vx) && (py == 0 || vy);
 #pragma unroll
         for (int e = 0; e < 2; ++e)
-          __builtin_amdgcn_raw_buffer_store_b128(se[e], rs_o, (okp && 2 * gp + e < p.Mb) ? (pix + py * OW + half) * 16 + (2 * gp + e) * plane16 : OOB, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(se[e], rs_o, (okp && cb + e < p.Mb) ? (pix + py * OW + half) * 16 + (cb + e) * plane16 : OOB, 0, 0);
       }
     }
   }
 }
 
 bool conv_bf16_s2d_direct_eligible(int K, int M, int OH, int OW, int B) {
-  if (M > 32 || M < 1 || (K != 32 && K != 64)) return false;
+  if (M < 1 || !((M <= 32 && (K == 32 || K == 64)) || (M > 64 && M <= 128 && K == 128))) return false;
   if (OH < 2 || OW < 2 || B <= 0) return false;
-  const long long IH = (OH + 1) / 2, IW = (OW + 1) / 2;
-  if ((long long)(K / 8) * IH * IW * 16 >= (1ll << 31) || 4ll * OH * OW * 16 >= (1ll << 31) || (long long)B * ((IH * IW + 31) / 32) >= (1ll << 31)) return false;
+  const long long IH = (OH + 1) / 2, IW = (OW + 1) / 2, Mb = ((M + 15) / 16) * 2;
+  if ((long long)(K / 8) * IH * IW * 16 >= (1ll << 31) || Mb * OH * OW * 16 >= (1ll << 31) || (long long)B * ((IH * IW + 31) / 32) >= (1ll << 31)) return false;
   return true;
 }
 
@@ -182,11 +204,14 @@ int launch_conv_bf16_s2d_direct(const void* in, const void* packed, void* out, c
                                 int OH, int OW, hipStream_t stream) {
   static std::mutex mu;
   static int n_cu_of[64] = {0};
+  static bool attr_set[64] = {false};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
     yogo_set_error("conv_bf16_s2d_direct: hipGetDevice failed");
     return YOGO_ERR_HIP;
   }
+  const int nmb = M <= 32 ? 1 : 2;
+  const int lds = 9 * (K / 8) * 32 * nmb * 16 + 4 * nmb * 32 * nmb * 4;   // 18 / 36 KB (four workgroups per CU); 147 KB + 2 KB (one)
   int n_cu;
   {
     std::lock_guard<std::mutex> lk(mu);
@@ -195,26 +220,37 @@ int launch_conv_bf16_s2d_direct(const void* in, const void* packed, void* out, c
       n_cu_of[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
     n_cu = n_cu_of[dev];
+    if (nmb == 2 && !attr_set[dev]) {   // more than 64 KB of dynamic LDS has to be asked for
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_s2d_direct_kernel<8, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_s2d_direct_kernel<8, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) {
+        yogo_set_error("conv_bf16_s2d_direct: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return YOGO_ERR_HIP;
+      }
+      attr_set[dev] = true;
+    }
   }
   ConvDirectS2dParams p{};
   p.in = reinterpret_cast<const u32x4*>(in); p.wp = reinterpret_cast<const u32x4*>(packed); p.out = reinterpret_cast<u32x4*>(out);
   p.signs = reinterpret_cast<const unsigned char*>(signs); p.chan_scale = chan_scale;
-  p.B = B; p.Kb = K / 8; p.M = M; p.Mb = ((M + 15) / 16) * 2; p.IH = IH; p.IW = IW; p.OH = OH; p.OW = OW;
+  p.B = B; p.Kb = K / 8; p.M = M; p.Mb = ((M + 15) / 16) * 2; p.Mpad = nmb == 1 ? 32 : 128; p.IH = IH; p.IW = IW; p.OH = OH; p.OW = OW;
+  p.npass = p.Mpad / (32 * nmb);
   p.tiles_per_img = cdiv(IH * IW, 32);
   p.ntiles = B * p.tiles_per_img;
   auto magic = [](int d) -> unsigned { return d <= 1 ? 0xFFFFFFFFu : (unsigned)(((1ull << 32) + (unsigned)d - 1ull) / (unsigned)d); };
   p.m_iw = magic(IW); p.m_tpi = magic(p.tiles_per_img);
   if (p.ntiles <= 0) return YOGO_OK;
-  const int lds = 9 * p.Kb * 32 * 16;           // 18 KB (K = 32) / 36 KB (K = 64): four workgroups per CU
-  const int grid = min(cdiv(p.ntiles, 4), 4 * n_cu);
+  // NMB = 1: up to four workgroups per CU; NMB = 2: walkers x passes, a multiple of 16 workgroups so that the partners (8 ids apart) exist
+  const int grid = nmb == 1 ? min(cdiv(p.ntiles, 4), 4 * n_cu) : 16 * max(1, min(cdiv(p.ntiles, 8 * 8), n_cu / 16));
   const bool sg = signs != nullptr;
-#define DD_LAUNCH(NK, S) hipLaunchKernelGGL((conv_bf16_s2d_direct_kernel<NK, S>), dim3(grid), dim3(256), lds, stream, p)
-  if (K == 64) { if (sg) DD_LAUNCH(4, true); else DD_LAUNCH(4, false); }
-  else { if (sg) DD_LAUNCH(2, true); else DD_LAUNCH(2, false); }
+#define DD_LAUNCH(NK, NMB, S) hipLaunchKernelGGL((conv_bf16_s2d_direct_kernel<NK, NMB, S>), dim3(grid), dim3(256 * NMB), lds, stream, p)
+  if (K == 128) { if (sg) DD_LAUNCH(8, 2, true); else DD_LAUNCH(8, 2, false); }
+  else if (K == 64) { if (sg) DD_LAUNCH(4, 1, true); else DD_LAUNCH(4, 1, false); }
+  else { if (sg) DD_LAUNCH(2, 1, true); else DD_LAUNCH(2, 1, false); }
 #undef DD_LAUNCH
   if (yogo_launch_log_enabled())
-    yogo_launch_log("conv_bf16_s2d_direct_kernel<%d, %s> | K=%d M=%d dy=%dx%d dx=%dx%d tiles=%d grid=%d lds=%d signs=%d scale=%d", K / 16, sg ? "true" : "false", K, M,
-                    IH, IW, OH, OW, p.ntiles, grid, lds, sg, chan_scale != nullptr);
+    yogo_launch_log("conv_bf16_s2d_direct_kernel<%d, %d, %s> | K=%d M=%d dy=%dx%d dx=%dx%d tiles=%d grid=%d lds=%d signs=%d scale=%d", K / 16, nmb, sg ? "true" : "false",
+                    K, M, IH, IW, OH, OW, p.ntiles, grid, lds, sg, chan_scale != nullptr);
   YOGO_CHECK_LAUNCH("conv_bf16_s2d_direct");
   return YOGO_OK;
 }
