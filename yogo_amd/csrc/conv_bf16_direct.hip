@@ -17,6 +17,9 @@
 #include "common.h"
 #include <mutex>
 
+#ifndef DD_ABL
+#define DD_ABL 0   // (ablation variant builds: 1 = no stores, 2 = no MFMAs, 4 = no operand loads, 8 = no weight reads)
+#endif
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -64,21 +67,42 @@ __global__ __launch_bounds__(256 * NMB) __attribute__((amdgpu_waves_per_eu(NMB =
   const int kcb = IH * IW * 16, plane = OH * OW, plane16 = plane * 16, nq = IH * IW;
   const int sq = p.Mpad >> 4;   // sign bytes per (pixel, half-wave)
   const int ch0 = pass * MP;    // first channel of this pass
-  for (int tile = walker * NWV + wave; tile < p.ntiles; tile += nwalk * NWV) {
-    const int b = dd_udivm1(tile, p.tiles_per_img, p.m_tpi);
-    const int t = tile - b * p.tiles_per_img;
+  // a tile's geometry for this lane: its quad (a, c) of image b, the offsets of the four dy operands, which members of the quad exist
+  struct Geo {
+    int b, pix;          // image; output pixel (2a, 2c) of the quad
+    int vsh[4];          // dy operand offsets: the quad's pixel and its right / lower / diagonal neighbours, channel block `half` of a 16-channel step
+    bool qv, vx, vy;     // the quad exists; its odd column / row exists
+  };
+  auto geo_of = [&](int tile) __attribute__((always_inline)) {
+    Geo g;
+    g.b = dd_udivm1(tile, p.tiles_per_img, p.m_tpi);
+    const int t = tile - g.b * p.tiles_per_img;
     const int q = t * 32 + l31;
-    const bool qv = q < nq;
-    const int qc = qv ? q : nq - 1;
+    g.qv = q < nq;
+    const int qc = g.qv ? q : nq - 1;
     const int a = dd_udivm1(qc, IW, p.m_iw), c = qc - a * IW;
-    const bool cx = c + 1 < IW, cy = a + 1 < IH;          // the right / lower dy neighbour exists
-    const bool vx = 2 * c + 1 < OW, vy = 2 * a + 1 < OH;  // the quad's odd column / row exists
-    const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (size_t)b * KB * IH * IW), (short)0, KB * kcb, 0x00020000);
-    const auto rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (size_t)b * p.Mb * plane), (short)0, p.Mb * plane16, 0x00020000);
-    // dy operand offsets of this lane: its quad's pixel and the three neighbours, channel block `half` of a 16-channel step
+    const bool cx = c + 1 < IW, cy = a + 1 < IH;   // the right / lower dy neighbour exists
+    g.vx = 2 * c + 1 < OW; g.vy = 2 * a + 1 < OH;
     const int v00 = (a * IW + c) * 16 + half * kcb;
-    const int vsh[4] = {v00, cx ? v00 + 16 : OOB, cy ? v00 + IW * 16 : OOB, (cx && cy) ? v00 + IW * 16 + 16 : OOB};
-    const int pix = 2 * a * OW + 2 * c;   // output pixel (2a, 2c) of the quad
+    g.vsh[0] = v00; g.vsh[1] = cx ? v00 + 16 : OOB; g.vsh[2] = cy ? v00 + IW * 16 : OOB; g.vsh[3] = (cx && cy) ? v00 + IW * 16 + 16 : OOB;
+    g.pix = 2 * a * OW + 2 * c;
+    return g;
+  };
+  u32x4 Bq[2][4];
+  auto load_step = [&](const Geo& g, int kc, u32x4 (&dst)[4]) __attribute__((always_inline)) {
+    const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (size_t)g.b * KB * IH * IW), (short)0, KB * kcb, 0x00020000);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) dst[s] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (DD_ABL & 4) ? OOB : g.vsh[s], (2 * kc) * kcb, 0));
+  };
+  static_assert(NK % 2 == 0, "the first operand set of the NEXT tile is requested while the last step still reads the second");
+  const int tstep = nwalk * NWV;
+  int tile = walker * NWV + wave;
+  Geo G = geo_of(min(tile, p.ntiles - 1));
+  if (tile < p.ntiles) load_step(G, 0, Bq[0]);
+  for (; tile < p.ntiles; tile += tstep) {
+    const int b = G.b, pix = G.pix;
+    const bool qv = G.qv, vx = G.vx, vy = G.vy;
+    const auto rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (size_t)b * p.Mb * plane), (short)0, p.Mb * plane16, 0x00020000);
     // the epilogue's small inputs first (they are older than the operand loads: landed when the MFMAs are through)
     float my_s = 0.f;   // lanes < MP: the scale of channel ch0 + lane (1 without a scale, 0 for the padding channels)
     if (lane < MP) my_s = ch0 + lane < p.M ? (p.chan_scale != nullptr ? p.chan_scale[(size_t)b * p.M + ch0 + lane] : 1.f) : 0.f;
@@ -104,21 +128,16 @@ __global__ __launch_bounds__(256 * NMB) __attribute__((amdgpu_waves_per_eu(NMB =
         for (int px = 0; px < 2; ++px)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[mb][py][px][r] = 0.f;
-    u32x4 Bq[2][4];
-    auto load_step = [&](int kc, u32x4 (&dst)[4]) __attribute__((always_inline)) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) dst[s] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, vsh[s], (2 * kc) * kcb, 0));
-    };
-    load_step(0, Bq[0]);
 #pragma unroll
     for (int kc = 0; kc < NK; ++kc) {
-      if (kc + 1 < NK) load_step(kc + 1, Bq[(kc + 1) & 1]);
+      if (kc + 1 < NK) load_step(G, kc + 1, Bq[(kc + 1) & 1]);
       const u32x4(&Bc)[4] = Bq[kc & 1];
       const u32x4* wk = lds_w + (2 * kc + half) * MP + l31;   // slice s at + s * KB * MP, channel block mb at + 32 mb
       // slice -> (row parity, column parity, dy shift): 0 (0,0,0) | 1 (0,1,0) 2 (0,1,1) | 3 (1,0,0) 4 (1,0,2) | 5 (1,1,0) 6 (1,1,1) 7 (1,1,2) 8 (1,1,3)
 #define DD_MF(PY, PX, S, SH)                                                                                                                     \
-  _Pragma("unroll") for (int mb = 0; mb < NMB; ++mb) acc[mb][PY][PX] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                  \
-      __builtin_bit_cast(bf16x8, wk[(S) * KB * MP + 32 * mb]), __builtin_bit_cast(bf16x8, Bc[SH]), acc[mb][PY][PX], 0, 0, 0);
+  _Pragma("unroll") for (int mb = 0; mb < NMB; ++mb) if (!(DD_ABL & 2)) acc[mb][PY][PX] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(               \
+      __builtin_bit_cast(bf16x8, (DD_ABL & 8) ? Bc[(SH) ^ 1] : wk[(S) * KB * MP + 32 * mb]), __builtin_bit_cast(bf16x8, Bc[SH]), acc[mb][PY][PX], 0, 0, 0); \
+  else acc[mb][PY][PX][0] += __builtin_bit_cast(float, Bc[SH].x);
       // (three taps at a time between scheduling barriers: left alone, hipcc hoists all the weight quads of a tile and spills 150 registers)
       __builtin_amdgcn_sched_barrier(0);
       DD_MF(0, 0, 0, 0) DD_MF(0, 1, 1, 0) DD_MF(1, 0, 3, 0)
@@ -128,6 +147,13 @@ __global__ __launch_bounds__(256 * NMB) __attribute__((amdgpu_waves_per_eu(NMB =
       DD_MF(1, 0, 4, 2) DD_MF(1, 1, 7, 2) DD_MF(1, 1, 8, 3)
       __builtin_amdgcn_sched_barrier(0);
 #undef DD_MF
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // the NEXT tile's first operands go out in front of this tile's stores (the CU's vector-memory path is in order; measured: no
+    // difference either way, gpurun_out/r5_d128_ab2.log -- the other wavefronts of the SIMD cover the wait)
+    if (tile + tstep < p.ntiles) {
+      G = geo_of(tile + tstep);
+      load_step(G, 0, Bq[0]);
     }
     __builtin_amdgcn_sched_barrier(0);
     // the tile's channel scales through this wavefront's own LDS row (no barrier: a wavefront's LDS operations complete in order)
@@ -186,7 +212,7 @@ __global__ __launch_bounds__(256 * NMB) __attribute__((amdgpu_waves_per_eu(NMB =
         const bool okp = qv && (half == 0 || vx) && (py == 0 || vy);
 #pragma unroll
         for (int e = 0; e < 2; ++e)
-          __builtin_amdgcn_raw_buffer_store_b128(se[e], rs_o, (okp && cb + e < p.Mb) ? (pix + py * OW + half) * 16 + (cb + e) * plane16 : OOB, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(se[e], rs_o, (okp && cb + e < p.Mb && !(DD_ABL & 1)) ? (pix + py * OW + half) * 16 + (cb + e) * plane16 : OOB, 0, 0);
       }
     }
   }
