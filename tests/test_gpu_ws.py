@@ -165,115 +165,6 @@ def test_scaled_modes_against_cpu_fp32(mode, B, Cin, H, W):
     assert bool(((got - want).abs() <= tol).all()), float(((got - want).abs() - tol).max())
 
 
-# ---- the stride-2 data gradient: conv_bf16_ws2_kernel against conv_bf16_kernel<4, 1, 8, S2D> ------------------------------------
-def _run_s2d(persistent, kind, B, K, OH, OW, seed):
-    """dx [B][128][OH][OW] = conv_transpose(dy [B][K][ceil(OH/2)][ceil(OW/2)]) x (LeakyReLU'(sign map) x) channel mask: autograd of
-    yogo/model_defns.py:54-56 (conv 128 -> K, stride 2) into the LeakyReLU + Dropout2d block in front of it"""
-    import contextlib
-
-    from _util import hooks_library
-    from yogo_amd import _hip as Hh
-
-    # (the product's plan for this layer is the direct kernel, conv_bf16_direct.hip; the tiled kernel and conv_bf16_ws2_kernel -- built,
-    #  parity-green, not faster: DESIGN.md -- both run only when the hooks library switches the plan)
-    with hooks_library():
-        st = Hh.stream_ptr()
-        g = torch.Generator(device="cuda").manual_seed(seed)
-        IH, IW = (OH + 1) // 2, (OW + 1) // 2
-        # (forward geometry: a 3x3 / stride-2 / pad-1 conv of an OH x OW image gives ceil(OH / 2) x ceil(OW / 2))
-        wf = torch.randn(K, 128, 3, 3, device="cuda", generator=g) * 0.05
-        dy8 = torch.randn(B, _blocks(K), IH, IW, 8, device="cuda", generator=g).to(torch.bfloat16)
-        dx8 = torch.full((B, 16, OH, OW, 8), 7.0, device="cuda").to(torch.bfloat16)   # poisoned: every unit must be written
-        msk = (torch.rand(B, 128, device="cuda", generator=g) > 0.2).float() / 0.8
-        sg = torch.randint(0, 256, (Hh.query_size("yogo_bf16_signs_bytes", B, 128, OH, OW),), dtype=torch.uint8, device="cuda", generator=g)
-        packed = torch.empty(Hh.query_size("yogo_conv_bf16_packed_bytes", 128, K, 3, 2), dtype=torch.uint8, device="cuda")
-        Hh.call("yogo_conv_bf16_pack", wf, None, packed, 128, K, 3, 2, st)
-        Hh.call("yogo_hook_conv_bf16_direct", 0)
-        Hh.call("yogo_hook_conv_bf16_ws2", 1 if persistent else 0)
-        Hh.launch_log(True)
-        try:
-            if kind == "signs":
-                Hh.call("yogo_conv2d_dgrad_bf16_signs", dy8, packed, dx8, sg, msk, B, 128, K, OH, OW, 3, 2, st)
-            elif kind == "signs_nomask":
-                Hh.call("yogo_conv2d_dgrad_bf16_signs", dy8, packed, dx8, sg, None, B, 128, K, OH, OW, 3, 2, st)
-            else:
-                Hh.call("yogo_conv2d_dgrad_bf16", dy8, packed, dx8, None, 0, msk if kind == "mask" else None, B, 128, K, OH, OW, 3, 2, st)
-            torch.cuda.synchronize()
-            log = Hh.read_launch_log()
-        finally:
-            Hh.launch_log(False)
-        return dx8, log, (wf, dy8, msk, sg)
-
-
-S2D_CASES = [
-    # (kind, B, K, OH, OW)
-    ("signs", 2, 128, 193, 258),      # layer 4 of base_model at 772x1032
-    ("signs", 1, 128, 20, 22),        # one tile per band
-    ("mask", 2, 128, 37, 41),         # odd sizes: the last quad row / column has no odd member
-    ("plain", 3, 96, 50, 66),         # 6 chunks: three pass-A periods (the weight buffers alternate across tiles)
-    ("signs_nomask", 2, 64, 30, 34),  # 4 chunks: two pass-A periods
-    ("signs", 40, 128, 97, 129),      # every workgroup walks several tiles, image changes at the seams
-    ("mask", 1, 96, 9, 300),          # short and wide: several bands
-    ("signs", 2, 128, 300, 5),        # tall and narrow
-    ("plain", 5, 128, 2, 2),          # a single quad
-    ("signs", 3, 128, 64, 64),        # even sizes
-]
-
-
-@pytest.mark.parametrize("kind,B,K,OH,OW", S2D_CASES)
-def test_persistent_stride2_dgrad_is_bit_identical_to_the_tiled_kernel(kind, B, K, OH, OW):
-    d_old, log_old, _ = _run_s2d(False, kind, B, K, OH, OW, seed=23)
-    d_new, log_new, _ = _run_s2d(True, kind, B, K, OH, OW, seed=23)
-    assert any(ln.startswith("conv_bf16_kernel<4, 1, 8, true") for ln in log_old), log_old
-    assert any(ln.startswith("conv_bf16_ws2_kernel<") for ln in log_new), log_new
-    plan = next(ln for ln in log_old if ln.startswith("conv_bf16_kernel<4, 1, 8, true"))
-    if " CKb=2 " in plan:   # the tiled kernel stepped through K in 16-channel chunks too: the same MFMA sequence per accumulator
-        assert torch.equal(d_old.view(torch.int16), d_new.view(torch.int16)), (
-            f"{(d_old.float() - d_new.float()).abs().max().item()} max abs difference, "
-            f"{(d_old.view(torch.int16) != d_new.view(torch.int16)).float().mean().item()} of the values differ")
-    else:
-        a, b = d_old.float(), d_new.float()
-        ulp = 2.0 ** -7 * torch.maximum(a.abs(), b.abs()) + 1e-6 * a.abs().max()
-        assert bool(((a - b).abs() <= ulp).all()), f"{((a - b).abs() - ulp).max().item()} beyond one bf16 step"
-        assert (a != b).float().mean().item() < 5e-3
-
-
-@pytest.mark.parametrize("kind,B,K,OH,OW", [("signs", 2, 128, 45, 53), ("mask", 1, 64, 33, 70), ("plain", 2, 128, 18, 16)])
-def test_persistent_stride2_dgrad_against_cpu_fp32(kind, B, K, OH, OW):
-    """an independent reference for the new kernel: torch's CPU conv_transpose2d (float64) on the same bf16-rounded operands, the
-    LeakyReLU derivative from the sign map as include/yogo_hip.h lays it out, one bf16 rounding of the result"""
-    import torch.nn.functional as F
-
-    from yogo_amd import _hip as Hh
-
-    d_new, log, (wf, dy8, msk, sg) = _run_s2d(True, kind, B, K, OH, OW, seed=31)
-    assert any(ln.startswith("conv_bf16_ws2_kernel<") for ln in log), log
-    st = Hh.stream_ptr()
-    IH, IW = (OH + 1) // 2, (OW + 1) // 2
-    dy = torch.empty(B, K, IH, IW, device="cuda")
-    Hh.call("yogo_bf16_8c_to_nchw_f32", dy8, dy, B, K, IH * IW, st)
-    got = torch.empty(B, 128, OH, OW, device="cuda")
-    Hh.call("yogo_bf16_8c_to_nchw_f32", d_new, got, B, 128, OH * OW, st)
-    w = wf.to(torch.bfloat16).double().cpu()
-    want = F.conv_transpose2d(dy.double().cpu(), w, stride=2, padding=1, output_padding=(OH - ((IH - 1) * 2 + 1), OW - ((IW - 1) * 2 + 1)))
-    assert want.shape == (B, 128, OH, OW)
-    if kind == "signs":
-        # byte (h, pixel, q), bit i + 4e = (channel 4h + i of channel block 2q + e > 0): channel = 16 q + 8 e + 4 h + i
-        s = sg.cpu().view(B, 2, OH, OW, 8).long()
-        pos = torch.zeros(B, 128, OH, OW, dtype=torch.bool)
-        for h in range(2):
-            for q in range(8):
-                for e in range(2):
-                    for i in range(4):
-                        pos[:, 16 * q + 8 * e + 4 * h + i] = ((s[:, h, :, :, q] >> (i + 4 * e)) & 1).bool()
-        want = want * torch.where(pos, 1.0, 0.01)
-    if kind in ("signs", "mask"):
-        want = want * msk.double().cpu()[:, :, None, None]
-    got = got.cpu().double()
-    tol = 2.0 ** -8 * want.abs() + 2e-5 * float(want.abs().max())
-    assert bool(((got - want).abs() <= tol).all()), float(((got - want).abs() - tol).max())
-
-
 # ---- the stride-2 forward: conv_bf16_ws3_kernel against conv_bf16_kernel<4, 1, 8> -------------------------------------------------
 def _run_s2f(persistent, kind, B, Cin, H, W, seed):
     """y [B][128][ceil(H/2)][ceil(W/2)] = [mask x] [LeakyReLU] (conv3x3 stride 2 (x [B][Cin][H][W]) + bias): yogo/model_defns.py:54-56"""

@@ -15,7 +15,6 @@
 // kernel is built around few, wide memory operations rather than around MFMA issue.
 #include "common.h"
 #include "conv_bf16_ws.h"
-#include "conv_bf16_ws2.h"
 #include "conv_bf16_ws3.h"
 #include <type_traits>
 #include <utility>
@@ -1341,23 +1340,18 @@ static bool g_bf_rowdma = true;
 // (diagnostic build: yogo_diag_conv_bf16_rowdma(0) keeps the per-lane slot staging of the lean 4-wavefront tiles)
 static bool g_bf_lean4 = true; // (diagnostic build: yogo_diag_conv_bf16_lean4(0) selects the generic step loop of the 4-wavefront tiles)
 static bool g_bf_ring = true; // (diagnostic build: yogo_diag_conv_bf16_ring(0) selects the two-buffer loop of the stride-2 data gradient)
-// the persistent wavefront-specialised kernels (conv_bf16_ws.hip, conv_bf16_ws2.hip) take the launches they are eligible for.  The
+// the persistent wavefront-specialised kernels (conv_bf16_ws.hip, conv_bf16_ws3.hip) take the launches they are eligible for.  The
 // product has NO run-time plan switch (no mutable global state in the library): the switch below exists in the test-hooks build
 // (build.sh: libyogo_hip_hooks.so, -DYOGO_TEST_HOOKS; loaded by tests/ and tools/ only) and in the diagnostic build.
 #if defined(YOGO_TEST_HOOKS) || defined(YOGO_DIAG)
 static bool g_bf_ws = true;
 // 0 = every launch goes to the tiled conv_bf16_kernel (A/B runs and the bit-identity tests of the two kernel families)
 extern "C" int yogo_hook_conv_bf16_persistent(int on) { g_bf_ws = on != 0; return YOGO_OK; }
-// The stride-2 data-gradient member (conv_bf16_ws2.hip) is built, parity-green and NOT faster than the tiled kernel: off in
-// the product, switched on by the tests / A-B tools through the hooks library
-static bool g_bf_ws2 = false;
-extern "C" int yogo_hook_conv_bf16_ws2(int on) { g_bf_ws2 = on != 0; return YOGO_OK; }
-// the direct (weights-resident, no staging) kernels of the thin layers (conv_bf16_direct.hip)
+// the direct (weights-resident, no staging) stride-2 data gradients (conv_bf16_direct.hip)
 static bool g_bf_direct = true;
 extern "C" int yogo_hook_conv_bf16_direct(int on) { g_bf_direct = on != 0; return YOGO_OK; }
 #else
 static constexpr bool g_bf_ws = true;
-static constexpr bool g_bf_ws2 = false;
 static constexpr bool g_bf_direct = true;
 #endif
 bool conv_bf16_s2d_direct_eligible(int K, int M, int OH, int OW, int B);
@@ -1468,26 +1462,11 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
 #endif
     if (conv_bf16_ws3_plan(&q)) return launch_conv_bf16_ws3(q, stream);
   }
-  // stride-2 3x3 data gradient into <= 32 channels (scale / LeakyReLU-sign-map epilogue): weights resident in LDS, operands straight from memory
+  // stride-2 3x3 data gradient into <= 32 or 65 - 128 channels (scale / LeakyReLU-sign-map epilogue): weights resident in LDS, operands straight from memory
   if (in != nullptr && g_bf_direct && s2d && ks == 3 && out_f32 == nullptr && out_pre == nullptr && act_ref == nullptr && bias == nullptr &&
       stats_part == nullptr && act == ACT_NONE && (!signs_read || (signs != nullptr && ref_act == ACT_LEAKY)) && (signs_read || signs == nullptr) &&
       conv_bf16_s2d_direct_eligible(K, M, OH, OW, B))
     return launch_conv_bf16_s2d_direct(in, packed, out, signs_read ? signs : nullptr, chan_scale, B, K, M, IH, IW, OH, OW, stream);
-  // stride-2 3x3 data gradient into 128 channels (scale / LeakyReLU-sign-map epilogue): the persistent wavefront-specialised kernel
-  // that stages the gradient tile once for both row parities (conv_bf16_ws2.hip)
-  if (in != nullptr && g_bf_ws && g_bf_ws2 && s2d && ks == 3 && out_f32 == nullptr && out_pre == nullptr && act_ref == nullptr && bias == nullptr &&
-      stats_part == nullptr && act == ACT_NONE && (!signs_read || (signs != nullptr && ref_act == ACT_LEAKY)) && (signs_read || signs == nullptr) &&
-      conv_bf16_ws2_eligible(K, M, OH, OW, B)) {
-    ConvWs2Params q{};
-    q.in = in; q.wp = packed; q.out = out; q.signs = signs_read ? reinterpret_cast<const unsigned char*>(signs) : nullptr; q.chan_scale = chan_scale;
-    q.B = B; q.Kb = bf_kb_of(K); q.IH = IH; q.IW = IW; q.OH = OH; q.OW = OW;
-#ifdef YOGO_DIAG
-    q.dbg = g_diag_dbg;
-    q.stamps = (g_diag_stamps != nullptr && g_diag_stamps_bytes >= 512 * 128) ? g_diag_stamps : nullptr;
-    if (q.stamps) (void)hipMemsetAsync(g_diag_stamps, 0, 512 * 128, stream);
-#endif
-    if (conv_bf16_ws2_plan(&q)) return launch_conv_bf16_ws2(q, stream);
-  }
   const int MW = bf_pick_mw(M);
   const bool small_n = s2d || a == 2;  // two accumulator sets / four-fold input tile: half the pixel groups per wavefront
   // 64 GEMM rows at stride 1 with a long contraction: 8 wavefronts x 4 pixel groups (64 rows x 1024 px), the same staged
