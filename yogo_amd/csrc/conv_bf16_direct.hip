@@ -52,11 +52,17 @@ __global__ __launch_bounds__(256 * NMB) __attribute__((amdgpu_waves_per_eu(NMB =
   constexpr int KB = 2 * NK, MP = 32 * NMB, NT = 256 * NMB, NWV = 4 * NMB;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // workgroup -> (pass, walker): passes of one walker sit 8 ids apart (same XCD)
+  // workgroup -> (XCD, pass, slot): consecutive workgroup ids go round the 8 XCDs; the passes of one slot sit 8 ids apart (same XCD).  An
+  // XCD owns a CONTIGUOUS eighth of the tiles and its wavefronts walk it together: a gradient row is read by the tiles of two quad rows
+  // (as the own row of one, as the lower neighbour of the other, IW / 32 tiles apart) -- dealt round-robin over the chip they met in
+  // different L2s and every row came from HBM twice (FETCH 2.45x the gradient, profiles/r05_hbm_traffic.txt before this change)
   const int bid = blockIdx.x;
-  const int pass = p.npass == 1 ? 0 : (bid >> 3) % p.npass;
-  const int walker = p.npass == 1 ? bid : (bid & 7) + 8 * (bid / (8 * p.npass));
-  const int nwalk = gridDim.x / p.npass;
+  const int xcd = bid & 7;
+  const int pass = (bid >> 3) % p.npass;
+  const int slot = bid / (8 * p.npass);
+  const int nslot = gridDim.x / (8 * p.npass);
+  const int t8 = (p.ntiles + 7) >> 3;                 // tiles of an XCD
+  const int t_end = min(p.ntiles, (xcd + 1) * t8);
   for (int i = tid; i < 9 * KB * MP; i += NT) {
     const int m = i % MP, r = i / MP;   // r = slice * KB + kb
     lds_w[i] = p.wp[(size_t)r * p.Mpad + pass * MP + m];
@@ -95,11 +101,11 @@ __global__ __launch_bounds__(256 * NMB) __attribute__((amdgpu_waves_per_eu(NMB =
     for (int s = 0; s < 4; ++s) dst[s] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (DD_ABL & 4) ? OOB : g.vsh[s], (2 * kc) * kcb, 0));
   };
   static_assert(NK % 2 == 0, "the first operand set of the NEXT tile is requested while the last step still reads the second");
-  const int tstep = nwalk * NWV;
-  int tile = walker * NWV + wave;
+  const int tstep = nslot * NWV;
+  int tile = xcd * t8 + slot * NWV + wave;
   Geo G = geo_of(min(tile, p.ntiles - 1));
-  if (tile < p.ntiles) load_step(G, 0, Bq[0]);
-  for (; tile < p.ntiles; tile += tstep) {
+  if (tile < t_end) load_step(G, 0, Bq[0]);
+  for (; tile < t_end; tile += tstep) {
     const int b = G.b, pix = G.pix;
     const bool qv = G.qv, vx = G.vx, vy = G.vy;
     const auto rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (size_t)b * p.Mb * plane), (short)0, p.Mb * plane16, 0x00020000);
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(256 * NMB) __attribute__((amdgpu_waves_per_eu(NMB =
     __builtin_amdgcn_sched_barrier(0);
     // the NEXT tile's first operands go out in front of this tile's stores (the CU's vector-memory path is in order; measured: no
     // difference either way, gpurun_out/r5_d128_ab2.log -- the other wavefronts of the SIMD cover the wait)
-    if (tile + tstep < p.ntiles) {
+    if (tile + tstep < t_end) {
       G = geo_of(tile + tstep);
       load_step(G, 0, Bq[0]);
     }
@@ -266,8 +272,9 @@ int launch_conv_bf16_s2d_direct(const void* in, const void* packed, void* out, c
   auto magic = [](int d) -> unsigned { return d <= 1 ? 0xFFFFFFFFu : (unsigned)(((1ull << 32) + (unsigned)d - 1ull) / (unsigned)d); };
   p.m_iw = magic(IW); p.m_tpi = magic(p.tiles_per_img);
   if (p.ntiles <= 0) return YOGO_OK;
-  // NMB = 1: up to four workgroups per CU; NMB = 2: walkers x passes, a multiple of 16 workgroups so that the partners (8 ids apart) exist
-  const int grid = nmb == 1 ? min(cdiv(p.ntiles, 4), 4 * n_cu) : 16 * max(1, min(cdiv(p.ntiles, 8 * 8), n_cu / 16));
+  // whole rounds of the 8 XCDs (x the passes): NMB = 1 up to four workgroups per CU, NMB = 2 one
+  const int t8 = cdiv(p.ntiles, 8);
+  const int grid = nmb == 1 ? 8 * max(1, min(cdiv(t8, 4), 4 * n_cu / 8)) : 16 * max(1, min(cdiv(t8, 8), n_cu / 16));
   const bool sg = signs != nullptr;
 #define DD_LAUNCH(NK, NMB, S) hipLaunchKernelGGL((conv_bf16_s2d_direct_kernel<NK, NMB, S>), dim3(grid), dim3(256 * NMB), lds, stream, p)
   if (K == 128) { if (sg) DD_LAUNCH(8, 2, true); else DD_LAUNCH(8, 2, false); }
