@@ -290,6 +290,7 @@ __global__ __launch_bounds__(256) void conv_first_mfma2_kernel(const ConvFirstMf
     }
     CFM2_FETCH()
     unsigned sgn2 = 0;   // this lane's sign bytes of the pair: pixel 2m in bits 0..7, pixel 2m + 1 in bits 16..23
+    cfm_u32x4 sty[2];    // [e]: y of pixel 2m + e: lanes 0-31 channel block 0, lanes 32-63 block 1 (after the half-wave exchange)
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       // bytes 1, 2, 3 of a word = kernel columns 0, 1, 2: pixel 2m reads (4m - 1, 4m, 4m + 1), pixel 2m + 1 (4m + 1, 4m + 2, 4m + 3)
@@ -358,9 +359,30 @@ __global__ __launch_bounds__(256) void conv_first_mfma2_kernel(const ConvFirstMf
       const cfm_u32x4 w4 = __builtin_bit_cast(cfm_u32x4, yo);
       const auto r0s = __builtin_amdgcn_permlane32_swap(w4.x, w4.z, false, false);
       const auto r1s = __builtin_amdgcn_permlane32_swap(w4.y, w4.w, false, false);
-      const cfm_u32x4 st = {r0s[0], r1s[0], r0s[1], r1s[1]};
+      sty[e] = cfm_u32x4{r0s[0], r1s[0], r0s[1], r1s[1]};
+    }
+#ifndef CFM_DENSE
+#define CFM_DENSE 1   // (A/B variant builds: 0 = one half-filled store per pixel parity)
+#endif
+    if (p.y != nullptr && !CFM_DENSE) {
       const auto rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (size_t)b * 2 * npix), (short)0, 2 * npix * 16, 0x00020000);
-      __builtin_amdgcn_raw_buffer_store_b128(st, rs_y, vo, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) __builtin_amdgcn_raw_buffer_store_b128(sty[e], rs_y, valid ? (half * npix + pix + e) * 16 : (int)OOB, 0, 0);
+    } else
+    if (p.y != nullptr) {   // (uniform)
+      // A lane's two pixels are neighbours, so the store of pixel parity e alone fills HALF of every 64-byte segment it touches (16 bytes
+      // every 32).  A second half-wave exchange (parity 0's block-1 half trades places with parity 1's block-0 half) turns the two
+      // half-filled stores into two CONTIGUOUS kilobytes: lanes 0-31 pixel 2m, lanes 32-63 pixel 2m + 1 of one channel block
+      // (measured first on the stride-2 data gradients, conv_bf16_direct.hip: -12 %).
+      const auto x0 = __builtin_amdgcn_permlane32_swap(sty[0].x, sty[1].x, false, false);
+      const auto x1 = __builtin_amdgcn_permlane32_swap(sty[0].y, sty[1].y, false, false);
+      const auto x2 = __builtin_amdgcn_permlane32_swap(sty[0].z, sty[1].z, false, false);
+      const auto x3 = __builtin_amdgcn_permlane32_swap(sty[0].w, sty[1].w, false, false);
+      const cfm_u32x4 se0 = {x0[0], x1[0], x2[0], x3[0]}, se1 = {x0[1], x1[1], x2[1], x3[1]};
+      const auto rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (size_t)b * 2 * npix), (short)0, 2 * npix * 16, 0x00020000);
+      const int vd = valid ? (pix + half) * 16 : (int)OOB;   // (npix is even: a pair is valid or not as a whole)
+      __builtin_amdgcn_raw_buffer_store_b128(se0, rs_y, vd, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(se1, rs_y, valid ? vd + npix * 16 : (int)OOB, 0, 0);   // (vector offset: conv_bf16_epi_groups.inc on scalar store offsets)
     }
     if (p.signs != nullptr) {
       // a pixel's two bytes are (half 0, half 1): the partner lane's pair comes over the crossbar, the lower half-wave stores the pair's
