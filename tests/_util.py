@@ -218,8 +218,9 @@ def teacher_forced_bf16_step_check(O, tr, model, x, lab, spec, sd0, what):
 # ---- the test-hooks library ------------------------------------------------------------------------------------------------------
 # libyogo_hip_hooks.so (yogo_amd/csrc/build.sh) = the product's objects with the three files that own a plan choice recompiled under
 # -DYOGO_TEST_HOOKS: the same kernels plus yogo_hook_conv_bf16_persistent / yogo_hook_conv_first_mfma_pairs /
-# yogo_hook_conv_first_bn_wgrad_pairs / yogo_hook_conv_bf16_ws2 (the stride-2 data-gradient member of the persistent family: off in the product).  The product library has no such switch (no mutable global state); A/B and bit-identity tests
-# bind the hooks library in place of the product's for their duration.
+# yogo_hook_conv_first_bn_wgrad_pairs / yogo_hook_conv_bf16_direct (0 = the tiled kernel in place of the direct stride-2 data gradients).
+# The product library has no such switch (no mutable global state); A/B and bit-identity tests bind the hooks library in place of the
+# product's for their duration.
 import contextlib
 
 
