@@ -354,3 +354,116 @@ def test_direct_stride2_dgrad_against_the_tiled_kernel_and_cpu(kind, B, K, M, OH
         assert bool(((got - want).abs() <= tol).all()), float(((got - want).abs() - tol).max())
         padc = d_new.float().permute(0, 1, 4, 2, 3).reshape(B, -1, OH, OW)[:, M:]
         assert padc.numel() == 0 or float(padc.abs().max()) == 0.0
+
+
+# ---- the independent-wavefront kernel of the thin forward-type layers: conv_bf16_staged_kernel against conv_bf16_kernel ----
+def _run_thin(staged, kind, B, Cin, Cout, H, W, s, seed):
+    """y [B][Cout <= 64][OH][OW] = [mask x] [LeakyReLU] (conv3x3 stride s (x [B][Cin = 16 / 32][H][W]) + bias) [+ the sign map of y]:
+    yogo/model_defns.py:41-46 (the kernel takes stride 2 only)"""
+    import contextlib
+
+    from _util import hooks_library
+    from yogo_amd import _hip as Hh
+
+    with (contextlib.nullcontext() if staged else hooks_library()):
+        st = Hh.stream_ptr()
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        OH, OW = (H - 1) // s + 1, (W - 1) // s + 1
+        x8 = torch.randn(B, _blocks(Cin), H, W, 8, device="cuda", generator=g).to(torch.bfloat16)
+        y8 = torch.full((B, _blocks(Cout), OH, OW, 8), 7.0, device="cuda").to(torch.bfloat16)   # poisoned: every unit must be written
+        bias = torch.randn(Cout, device="cuda", generator=g)
+        msk = (torch.rand(B, Cout, device="cuda", generator=g) > 0.2).float() / 0.8
+        sg = torch.full((Hh.query_size("yogo_bf16_signs_bytes", B, Cout, OH, OW),), 0xA5, dtype=torch.uint8, device="cuda")
+        if kind == "dgrad":   # the layer is Cout -> Cin (its weight [Cin][Cout][3][3]); x8 plays dy, y8 plays dx
+            w = torch.randn(Cin, Cout, 3, 3, device="cuda", generator=g) * 0.05
+            packed = torch.empty(Hh.query_size("yogo_conv_bf16_packed_bytes", Cout, Cin, 3, 1), dtype=torch.uint8, device="cuda")
+            Hh.call("yogo_conv_bf16_pack", w, None, packed, Cout, Cin, 3, 1, st)
+        else:
+            w = torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) * 0.05
+            packed = torch.empty(Hh.query_size("yogo_conv_bf16_packed_bytes", Cin, Cout, 3, 0), dtype=torch.uint8, device="cuda")
+            Hh.call("yogo_conv_bf16_pack", w, None, packed, Cin, Cout, 3, 0, st)
+        if not staged:
+            Hh.call("yogo_hook_conv_bf16_staged", 0)
+        Hh.launch_log(True)
+        try:
+            if kind == "signs":
+                Hh.call("yogo_conv2d_fwd_bf16_signs", x8, packed, bias, y8, sg, msk, B, Cin, Cout, H, W, 3, s, 1, st)
+            elif kind == "dgrad":
+                Hh.call("yogo_conv2d_dgrad_bf16", x8, packed, y8, None, 0, None, B, Cout, Cin, H, W, 3, 1, st)
+            else:
+                Hh.call("yogo_conv2d_fwd_bf16", x8, packed, None if kind == "nobias" else bias, y8, None, msk if kind == "mask" else None, None, B, Cin, Cout, H, W, 3, s,
+                        1 if kind in ("leaky", "mask") else 0, st)
+            torch.cuda.synchronize()
+            log = Hh.read_launch_log()
+        finally:
+            Hh.launch_log(False)
+        return y8, sg, log, (w, x8, bias, msk)
+
+
+THIN_CASES = [
+    # (kind, B, Cin, Cout, H, W, stride)
+    ("signs", 2, 32, 64, 386, 516, 2),    # layer 2 of base_model at 772x1032
+    ("signs", 1, 32, 64, 20, 22, 2),
+    ("mask", 2, 32, 64, 37, 41, 2),       # odd sizes
+    ("plain", 3, 32, 32, 50, 66, 2),
+    ("leaky", 5, 16, 24, 33, 29, 2),      # 24 real channels: the padding channels of the last block come out as zeros
+    ("nobias", 4, 32, 48, 2, 2, 2),
+    ("signs", 3, 32, 64, 64, 64, 2),      # even sizes: the last column's right tap is the padding
+    ("signs", 40, 16, 64, 30, 30, 2),     # every wavefront walks several tiles, image changes at the seams
+    ("mask", 1, 16, 8, 5, 300, 2),        # one channel block pair, short and wide
+    ("leaky", 2, 32, 64, 1, 70, 2),       # a single row
+    ("signs", 2, 32, 40, 70, 1, 2),       # a single column
+    ("plain", 2, 16, 32, 193, 258, 2),
+]
+
+
+@pytest.mark.parametrize("kind,B,Cin,Cout,H,W,s", THIN_CASES)
+def test_staged_thin_convolution_against_the_tiled_kernel_and_cpu(kind, B, Cin, Cout, H, W, s):
+    import torch.nn.functional as F
+
+    from yogo_amd import _hip as Hh
+
+    y_old, sg_old, log_old, _ = _run_thin(False, kind, B, Cin, Cout, H, W, s, seed=61)
+    y_new, sg_new, log_new, (w, x8, bias, msk) = _run_thin(True, kind, B, Cin, Cout, H, W, s, seed=61)
+    assert any(ln.startswith("conv_bf16_kernel<") for ln in log_old), log_old
+    assert any(ln.startswith("conv_bf16_staged_kernel<") for ln in log_new), log_new
+    plan = next(ln for ln in log_old if ln.startswith("conv_bf16_kernel<"))
+    a, b = y_old.float(), y_new.float()
+    if " CKb=2 " in plan:   # the tiled kernel stepped through K in 16-channel chunks too: the same MFMA sequence per accumulator
+        assert torch.equal(y_old.view(torch.int16), y_new.view(torch.int16)), f"{(a - b).abs().max().item()} max abs difference, {(a != b).float().mean().item()} differ"
+        if kind == "signs":
+            assert torch.equal(sg_old, sg_new)
+    else:
+        ulp = 2.0 ** -7 * torch.maximum(a.abs(), b.abs()) + 1e-6 * a.abs().max()
+        assert bool(((a - b).abs() <= ulp).all()), f"{((a - b).abs() - ulp).max().item()} beyond one bf16 step"
+        assert (a != b).float().mean().item() < 5e-3
+    OH, OW = (H - 1) // s + 1, (W - 1) // s + 1
+    if kind == "signs":   # the sign map is the sign of what was stored: byte (h, pixel, q), bit i + 4e = (channel 16 q + 8 e + 4 h + i > 0)
+        sq = 2 if Cout <= 32 else 4
+        sb = sg_new.view(B, 2, OH, OW, sq).long()
+        yv = y_new.float().permute(0, 1, 4, 2, 3).reshape(B, -1, OH, OW)   # [B][channels padded to 16][OH][OW]
+        for ch in range(0, Cout, 5):
+            q, e, h, i = ch // 16, (ch % 16) // 8, (ch % 8) // 4, ch % 4
+            bit = ((sb[:, h, :, :, q] >> (i + 4 * e)) & 1).bool()
+            assert torch.equal(bit, yv[:, ch] > 0), ch
+    padc = y_new.float().permute(0, 1, 4, 2, 3).reshape(B, -1, OH, OW)[:, Cout:]
+    assert padc.numel() == 0 or float(padc.abs().max()) == 0.0
+    # ... and an independent reference: torch's CPU conv2d (float64) on the same bf16-rounded operands, one bf16 rounding of the result
+    if B * OH * OW <= 40000:
+        st = Hh.stream_ptr()
+        x = torch.empty(B, Cin, H, W, device="cuda")
+        Hh.call("yogo_bf16_8c_to_nchw_f32", x8, x, B, Cin, H * W, st)
+        got = torch.empty(B, Cout, OH, OW, device="cuda")
+        Hh.call("yogo_bf16_8c_to_nchw_f32", y_new, got, B, Cout, OH * OW, st)
+        wd = w.to(torch.bfloat16).double().cpu()
+        if kind == "dgrad":
+            want = F.conv_transpose2d(x.double().cpu(), wd, stride=1, padding=1)
+        else:
+            want = F.conv2d(x.double().cpu(), wd, None if kind == "nobias" else bias.double().cpu(), stride=s, padding=1)
+        if kind in ("leaky", "mask", "signs"):
+            want = F.leaky_relu(want, 0.01)
+        if kind in ("mask", "signs"):
+            want = want * msk.double().cpu()[:, :, None, None]
+        got = got.cpu().double()
+        tol = 2.0 ** -8 * want.abs() + 2e-5 * float(want.abs().max())
+        assert bool(((got - want).abs() <= tol).all()), float(((got - want).abs() - tol).max())

@@ -1350,13 +1350,20 @@ extern "C" int yogo_hook_conv_bf16_persistent(int on) { g_bf_ws = on != 0; retur
 // the direct (weights-resident, no staging) stride-2 data gradients (conv_bf16_direct.hip)
 static bool g_bf_direct = true;
 extern "C" int yogo_hook_conv_bf16_direct(int on) { g_bf_direct = on != 0; return YOGO_OK; }
+// the independent-wavefront kernel of the thin forward-type layers (conv_bf16_staged.hip)
+static bool g_bf_staged = true;
+extern "C" int yogo_hook_conv_bf16_staged(int on) { g_bf_staged = on != 0; return YOGO_OK; }
 #else
+static constexpr bool g_bf_staged = true;
 static constexpr bool g_bf_ws = true;
 static constexpr bool g_bf_direct = true;
 #endif
 bool conv_bf16_s2d_direct_eligible(int K, int M, int OH, int OW, int B);
 int launch_conv_bf16_s2d_direct(const void* in, const void* packed, void* out, const void* signs, const float* chan_scale, int B, int K, int M, int IH, int IW,
                                 int OH, int OW, hipStream_t stream);
+bool conv_bf16_staged_eligible(int K, int M, int stride, int IH, int IW, int OH, int OW, int B);
+int launch_conv_bf16_staged(const void* in, const void* packed, const float* bias, void* out, void* signs, const float* chan_scale, int B, int K, int M, int IH,
+                            int IW, int OH, int OW, int stride, int act, hipStream_t stream);
 static bool g_bf_pp = true;   // (diagnostic build: yogo_diag_conv_bf16_pp(0) selects the interleaved main loop for A/B runs)
 #ifdef YOGO_DIAG
 extern "C" int yogo_diag_conv_bf16_pp(int on) { g_bf_pp = on != 0; return YOGO_OK; }
@@ -1462,6 +1469,10 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
 #endif
     if (conv_bf16_ws3_plan(&q)) return launch_conv_bf16_ws3(q, stream);
   }
+  // 3x3 convolutions out of 16 / 32 channels into <= 64 with the lean epilogue: independent wavefronts, weights resident, private LDS staging
+  if (in != nullptr && g_bf_staged && !s2d && ks == 3 && out_f32 == nullptr && out_pre == nullptr && act_ref == nullptr && !signs_read && stats_part == nullptr &&
+      (act == ACT_NONE || act == ACT_LEAKY) && !(signs != nullptr && act != ACT_LEAKY) && conv_bf16_staged_eligible(K, M, a, IH, IW, OH, OW, B))
+    return launch_conv_bf16_staged(in, packed, bias, out, signs, chan_scale, B, K, M, IH, IW, OH, OW, a, act, stream);
   // stride-2 3x3 data gradient into <= 32 or 65 - 128 channels (scale / LeakyReLU-sign-map epilogue): weights resident in LDS, operands straight from memory
   if (in != nullptr && g_bf_direct && s2d && ks == 3 && out_f32 == nullptr && out_pre == nullptr && act_ref == nullptr && bias == nullptr &&
       stats_part == nullptr && act == ACT_NONE && (!signs_read || (signs != nullptr && ref_act == ACT_LEAKY)) && (signs_read || signs == nullptr) &&
