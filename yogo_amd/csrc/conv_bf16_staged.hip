@@ -244,6 +244,9 @@ int cs_launch(ConvStagedParams p, int n_cu, bool sg, hipStream_t stream, int* gr
   if (sg) hipLaunchKernelGGL((conv_bf16_staged_kernel<S, NK, NMB, true, NWV, R>), dim3(grid), dim3(64 * NWV), lds, stream, p);
   else hipLaunchKernelGGL((conv_bf16_staged_kernel<S, NK, NMB, false, NWV, R>), dim3(grid), dim3(64 * NWV), lds, stream, p);
   *grid_out = grid; *lds_out = lds;
+  if (yogo_launch_log_enabled())
+    yogo_launch_log("conv_bf16_staged_kernel<%d, %d, %d, %s, %d, %d> | K=%d M=%d in=%dx%d out=%dx%d tiles=%d grid=%d lds=%d act=%d bias=%d scale=%d", S, NK, NMB,
+                    sg ? "true" : "false", NWV, R, 16 * NK, p.M, p.IH, p.IW, p.OH, p.OW, p.ntiles, grid, lds, p.act, p.bias != nullptr, p.chan_scale != nullptr);
   return YOGO_OK;
 }
 }  // namespace
@@ -280,9 +283,6 @@ int launch_conv_bf16_staged(const void* in, const void* packed, const float* bia
   if (nk == 1) rc = nmb == 1 ? cs_launch<2, 1, 1, 4, 1>(p, n_cu, sg, stream, &grid, &lds) : cs_launch<2, 1, 2, 4, 1>(p, n_cu, sg, stream, &grid, &lds);
   else rc = nmb == 1 ? cs_launch<2, 2, 1, 4, 1>(p, n_cu, sg, stream, &grid, &lds) : cs_launch<2, 2, 2, 8, 1>(p, n_cu, sg, stream, &grid, &lds);
   if (rc != YOGO_OK) return rc;
-  if (yogo_launch_log_enabled())
-    yogo_launch_log("conv_bf16_staged_kernel<%d, %d, %d, %s> | K=%d M=%d in=%dx%d out=%dx%d tiles=%d grid=%d lds=%d act=%d bias=%d scale=%d", stride, nk, nmb,
-                    sg ? "true" : "false", K, M, IH, IW, OH, OW, B * OH * cdiv(OW, 32), grid, lds, act, bias != nullptr, chan_scale != nullptr);
   YOGO_CHECK_LAUNCH("conv_bf16_staged");
   return YOGO_OK;
 }
