@@ -15,6 +15,12 @@
 // tiles (py, px), per 16-channel step four pixel operands (the quad's dy pixel and its right / lower / diagonal neighbours) serve the nine
 // taps.  Epilogue as the tiled kernel: x channel scale [x LeakyReLU'(sign bit)], bf16, half-wave exchange, 16-byte stores.
 #include "common.h"
+// cache policy of the output stores: 2 = nt (non-temporal).  The 1.6 GB a launch writes are read again by a later kernel, long after they
+// left the 4 MB L2: stored as ordinary lines they push the gradient rows the tiles of the next quad row (and the partner pass) are about
+// to read out of it.  Same-box A/B (gpurun_out/r5_nt_ab1.log, r5_nt_ab2.log): L4 -8.5 ... -10 %, L2 -5 % (A/B variant builds: 0 = cached)
+#ifndef YOGO_ST_AUX
+#define YOGO_ST_AUX 2
+#endif
 #include <mutex>
 
 #ifndef DD_ABL
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(256 * NMB) __attribute__((amdgpu_waves_per_eu(NMB =
         const bool okp = qv && (half == 0 || vx) && (py == 0 || vy);
 #pragma unroll
         for (int e = 0; e < 2; ++e)
-          __builtin_amdgcn_raw_buffer_store_b128(se[e], rs_o, (okp && cb + e < p.Mb && !(DD_ABL & 1)) ? (pix + py * OW + half) * 16 + (cb + e) * plane16 : OOB, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(se[e], rs_o, (okp && cb + e < p.Mb && !(DD_ABL & 1)) ? (pix + py * OW + half) * 16 + (cb + e) * plane16 : OOB, 0, YOGO_ST_AUX);
       }
     }
   }

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(64 * NWV) void conv_bf16_staged_kernel(const ConvSt
         const auto r0 = __builtin_amdgcn_permlane32_swap(w.x, w.z, false, false);
         const auto r1 = __builtin_amdgcn_permlane32_swap(w.y, w.w, false, false);
         const u32x4 st = {r0[0], r1[0], r0[1], r1[1]};
-        __builtin_amdgcn_raw_buffer_store_b128(st, rs_o, (ov && cb + half < p.Mb) ? o * 16 + (cb + half) * plane16 : OOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(st, rs_o, (ov && cb + half < p.Mb) ? o * 16 + (cb + half) * plane16 : OOB, 0, 0);   // (non-temporal stores: no difference here, gpurun_out/r5_nt_ab3.log)
       }
     if constexpr (SIGN_OUT) {
       constexpr int sq = 2 * NMB;   // sign bytes per (pixel, half-wave)
@@ -221,7 +221,7 @@ bool conv_bf16_staged_eligible(int K, int M, int stride, int IH, int IW, int OH,
 namespace {
 unsigned cs_magic(int d) { return d <= 1 ? 0xFFFFFFFFu : (unsigned)(((1ull << 32) + (unsigned)d - 1ull) / (unsigned)d); }
 template <int S, int NK, int NMB, int NWV, int R>
-int cs_launch(ConvStagedParams p, int n_cu, bool sg, hipStream_t stream, int* grid_out, int* lds_out) {
+int cs_launch(ConvStagedParams p, int dev, int n_cu, bool sg, hipStream_t stream, int* grid_out, int* lds_out) {
   constexpr int KB = 2 * NK, MP = 32 * NMB, ROWU = S == 2 ? 66 : 34, NDMA = (KB * ((R - 1) * S + 3) * ROWU + 63) / 64;
   p.tiles_per_row = cdiv(p.OW, 32);
   p.tiles_per_img = cdiv(p.OH, R) * p.tiles_per_row;
@@ -233,12 +233,18 @@ int cs_launch(ConvStagedParams p, int n_cu, bool sg, hipStream_t stream, int* gr
   const int per_cu = max(1, min(16 / NWV, (160 * 1024) / lds));   // workgroups a CU holds
   const int t8 = cdiv(p.ntiles, 8);
   const int grid = 8 * max(1, min(cdiv(t8, NWV), per_cu * n_cu / 8));
-  if (lds > 64 * 1024) {   // (more than 64 KB of dynamic LDS has to be asked for; idempotent, cheap)
-    hipError_t e = sg ? hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_staged_kernel<S, NK, NMB, true, NWV, R>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)
-                      : hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_staged_kernel<S, NK, NMB, false, NWV, R>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) {
-      yogo_set_error("conv_bf16_staged: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return YOGO_ERR_HIP;
+  if (lds > 64 * 1024) {   // more than 64 KB of dynamic LDS has to be asked for: once per device and instantiation
+    static std::mutex mu;
+    static bool done[64][2] = {};
+    std::lock_guard<std::mutex> lk(mu);
+    if (!done[dev][sg ? 1 : 0]) {
+      hipError_t e = sg ? hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_staged_kernel<S, NK, NMB, true, NWV, R>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)
+                        : hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_staged_kernel<S, NK, NMB, false, NWV, R>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) {
+        yogo_set_error("conv_bf16_staged: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return YOGO_ERR_HIP;
+      }
+      done[dev][sg ? 1 : 0] = true;
     }
   }
   if (sg) hipLaunchKernelGGL((conv_bf16_staged_kernel<S, NK, NMB, true, NWV, R>), dim3(grid), dim3(64 * NWV), lds, stream, p);
@@ -280,8 +286,8 @@ int launch_conv_bf16_staged(const void* in, const void* packed, const float* bia
   // wavefronts per workgroup: 4 where four workgroups' weights + tile images fit a CU, 8 for the 36 KB of layer 2's weights (one workgroup per CU)
   // (stride 1 -- layer 1 forward and data gradient -- was measured with tiles of 1 - 8 rows and 4 / 6 wavefronts per workgroup: 0.625 / 0.545 ms
   //  against the tiled kernel's 0.614 / 0.55, gpurun_out/r5_cs_ab3.log; those launches stay with conv_bf16_kernel and are not instantiated here)
-  if (nk == 1) rc = nmb == 1 ? cs_launch<2, 1, 1, 4, 1>(p, n_cu, sg, stream, &grid, &lds) : cs_launch<2, 1, 2, 4, 1>(p, n_cu, sg, stream, &grid, &lds);
-  else rc = nmb == 1 ? cs_launch<2, 2, 1, 4, 1>(p, n_cu, sg, stream, &grid, &lds) : cs_launch<2, 2, 2, 8, 1>(p, n_cu, sg, stream, &grid, &lds);
+  if (nk == 1) rc = nmb == 1 ? cs_launch<2, 1, 1, 4, 1>(p, dev, n_cu, sg, stream, &grid, &lds) : cs_launch<2, 1, 2, 4, 1>(p, dev, n_cu, sg, stream, &grid, &lds);
+  else rc = nmb == 1 ? cs_launch<2, 2, 1, 4, 1>(p, dev, n_cu, sg, stream, &grid, &lds) : cs_launch<2, 2, 2, 8, 1>(p, dev, n_cu, sg, stream, &grid, &lds);
   if (rc != YOGO_OK) return rc;
   YOGO_CHECK_LAUNCH("conv_bf16_staged");
   return YOGO_OK;

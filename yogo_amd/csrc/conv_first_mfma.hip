@@ -361,6 +361,9 @@ __global__ __launch_bounds__(256) void conv_first_mfma2_kernel(const ConvFirstMf
       const auto r1s = __builtin_amdgcn_permlane32_swap(w4.y, w4.w, false, false);
       sty[e] = cfm_u32x4{r0s[0], r1s[0], r0s[1], r1s[1]};
     }
+#ifndef CFM_ST_AUX
+#define CFM_ST_AUX 2   // non-temporal y stores: 0.243 -> 0.211 ms in the same-box A/B (gpurun_out/r5_nt_ab5.log; A/B variant builds: 0 = cached)
+#endif
 #ifndef CFM_DENSE
 #define CFM_DENSE 1   // (A/B variant builds: 0 = one half-filled store per pixel parity)
 #endif
@@ -381,8 +384,8 @@ __global__ __launch_bounds__(256) void conv_first_mfma2_kernel(const ConvFirstMf
       const cfm_u32x4 se0 = {x0[0], x1[0], x2[0], x3[0]}, se1 = {x0[1], x1[1], x2[1], x3[1]};
       const auto rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (size_t)b * 2 * npix), (short)0, 2 * npix * 16, 0x00020000);
       const int vd = valid ? (pix + half) * 16 : (int)OOB;   // (npix is even: a pair is valid or not as a whole)
-      __builtin_amdgcn_raw_buffer_store_b128(se0, rs_y, vd, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b128(se1, rs_y, valid ? vd + npix * 16 : (int)OOB, 0, 0);   // (vector offset: conv_bf16_epi_groups.inc on scalar store offsets)
+      __builtin_amdgcn_raw_buffer_store_b128(se0, rs_y, vd, 0, CFM_ST_AUX);
+      __builtin_amdgcn_raw_buffer_store_b128(se1, rs_y, valid ? vd + npix * 16 : (int)OOB, 0, CFM_ST_AUX);   // (vector offset: conv_bf16_epi_groups.inc on scalar store offsets)
     }
     if (p.signs != nullptr) {
       // a pixel's two bytes are (half 0, half 1): the partner lane's pair comes over the crossbar, the lower half-wave stores the pair's
