@@ -981,7 +981,10 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_bf16_kernel(const ConvBf16Pa
     const auto rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (size_t)b * p.Mb * plane * 2), (short)0, p.Mb * plane16, 0x00020000);
     // cache policy of the bf16 output stores: non-temporal for the sign-writing forward of the 4-wavefront tiles (layer 1 forward: 1.8 GB out per
     // 0.8 GB in, -5.3 % in the same-box A/B gpurun_out/r5_nt_ab3.log); everywhere else it made no difference or lost (head data gradient +43 %)
-    constexpr int BF_ST_AUX = (REF == 3 && NWV == 4 && !S2D) ? 2 : 0;
+#ifndef BF_NT_L1
+#define BF_NT_L1 1   // (A/B variant builds: 0 = cached stores everywhere)
+#endif
+    constexpr int BF_ST_AUX = (BF_NT_L1 && REF == 3 && NWV == 4 && !S2D) ? 2 : 0;
 #ifndef BF_S2D_HALF_DENSE
 #define BF_S2D_HALF_DENSE 0   // (A/B variant builds: 1 = the stride-2 data gradient's units go out as they are, one half-filled store per column parity)
 #endif
