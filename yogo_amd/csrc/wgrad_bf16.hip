@@ -25,6 +25,9 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define WGB_LDS_MAX (160 * 1024)
+#ifndef WGB_BLK4
+#define WGB_BLK4 1   // (A/B variant builds: 0 = 16 consecutive pixels of a row per k-step on the 128 x 64 tiling too)
+#endif
 #define WGB_GSLOTS 4  // LDS-DMA slots per lane and unit: gradient tile
 #define WGB_XSLOTS 6  // ... input tile
 
@@ -106,8 +109,13 @@ __device__ __forceinline__ void wb_static_for(F&& f, std::integer_sequence<int, 
 // NBW * NPW ci-blocks).  MPW = 2, NPW = 1 reads 4 + 6 transposed operand halves per 6 MFMAs where MPW = 1, NPW = 2 reads 2 + 12.
 // PACK2 (16 input channels): the 32 output columns of an MFMA hold TWO taps -- lanes of columns 16-31 read the input one pixel
 // further instead of re-reading channels that do not exist -- so a kernel row costs 2 MFMAs and 4 B reads instead of 3 and 6.
-template <int MBW, int NBW, int NPW, int KS, int T, int S, int R, int MPW = 1, bool ROT = false, bool PACK2 = false>
+// BLK4 (the 128 x 64 tiling, stride 1): a k-step is a BLOCK of 4 rows x 4 columns of the unit (R = 4 rows, staged width 36 = 9 steps) instead of
+// 16 consecutive pixels of a row.  A row of 129 (= 8 x 16 + 1) or 258 output columns cannot be cut into 16-column steps without 10 - 12 %
+// zero padding whatever the chunking; cut into 4-column blocks the chunks are 32 or 33 columns wide (8 steps, a ninth for the wide ones) and
+// the padding is 2.3 % in the columns + 1.6 - 3 % in the rows: 7.4 - 7.9 % fewer MFMAs on layers 3 / 5 / 6.
+template <int MBW, int NBW, int NPW, int KS, int T, int S, int R, int MPW = 1, bool ROT = false, bool PACK2 = false, bool BLK4 = false>
 __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_bf16_kernel(const WgradBf16Params p) {
+  static_assert(!BLK4 || (KS == 1 && !PACK2 && !ROT && S == 1 && T == 9 && R == 4 && NPW == 1), "BLK4: the lean 3x3 stride-1 loop only");
   // LEAN: the instruction-lean step loop below (one pixel split per wavefront grid, 64-byte pixels in the staged x image; the
   // launcher only instantiates KS = 1 tilings with xcb = 4)
   constexpr bool LEAN = KS == 1 && !PACK2 && !ROT;
@@ -234,8 +242,9 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
   const int gbase = mb * MPW * (R * p.wce * 64) + lane_ch_off;
   // 16-channel image: the lanes of channels 16-31 re-read channels 0-15 (those output columns lie beyond N and are dropped)
   const int xbase = p.ngs * NT * 16 + nb * NPW * xblk + (lane_ch_off & (xpb - 1)) + (PACK2 ? (gi & 1) * xpb : 0);
-  [[maybe_unused]] const int lean_a0 = gbase + lane_px * 64;                                     // (xpb = 64 on this path)
-  [[maybe_unused]] const int lean_b0 = xbase + ((T == 1 ? 0 : tg) * p.xw + lane_px * S) * 64;
+  // (BLK4: k = 8 (gi >> 1) + 4 j + q -> block row 2 (gi >> 1) + j (j = the first / second transposed read), block column q)
+  [[maybe_unused]] const int lean_a0 = BLK4 ? gbase + ((gi >> 1) * 2 * p.wce + q4) * 64 : gbase + lane_px * 64;                                     // (xpb = 64 on this path)
+  [[maybe_unused]] const int lean_b0 = BLK4 ? xbase + (((gi >> 1) * 2 + tg) * p.xw + q4) * 64 : xbase + ((T == 1 ? 0 : tg) * p.xw + lane_px * S) * 64;
 
 #define WB_LOAD(AV, BV, I)                                                                                      \
   {                                                                                                             \
@@ -296,6 +305,64 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
     WB_STAMP(ti_)
     const unsigned char* buf = smem_b + ib * p.bufu * 16;
     ib = ib + 1 == p.depth ? 0 : ib + 1;
+    if constexpr (BLK4) {
+      WB_ISSUE_PREP(nb_)
+      // this unit's chunk: 33 columns take a ninth step
+      const int cwi_ = u % p.nchunk_w;
+      const bool wide = p.base_w + (cwi_ < p.rem_w ? 1 : 0) > 32;   // uniform
+      const int rowa = p.wce * 64, rowx = p.xw * 64;
+      const unsigned char* pa0 = buf + lean_a0;
+      const unsigned char* pa0j = pa0 + rowa;
+      const unsigned char* pa1 = pa0 + R * p.wce * 64;
+      const unsigned char* pa1j = pa1 + rowa;
+      const unsigned char* pb0 = buf + lean_b0;
+      const unsigned char* pb0j = pb0 + rowx;
+      typedef bf16x4 __attribute__((address_space(3))) * lds_v4b;
+      auto tr2 = [&](const unsigned char* b0, const unsigned char* b1, int off) __attribute__((always_inline)) {
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4b)(b0 + off));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4b)(b1 + off));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      };
+      bf16x8 av[2][MPW], bvv[2][NPW][TM];
+      auto fetch = [&](auto e_tag) __attribute__((always_inline)) {
+        constexpr int e = decltype(e_tag)::value, set = e & 1;
+        av[set][0] = tr2(pa0, pa0j, e * 256);
+#pragma unroll
+        for (int t = 0; t < TM; ++t) bvv[set][0][t] = tr2(pb0, pb0j, e * 256 + t * 64);
+        if constexpr (MPW == 2) av[set][1] = tr2(pa1, pa1j, e * 256);
+      };
+      if (!WB_DIAG(2)) {
+        fetch(std::integral_constant<int, 0>{});
+        auto step = [&](auto e_tag) __attribute__((always_inline)) {
+          constexpr int e = decltype(e_tag)::value, set = e & 1;
+          if constexpr (e + 1 < 8) fetch(std::integral_constant<int, e + 1>{});
+          else if constexpr (e + 1 == 8) { if (wide) fetch(std::integral_constant<int, 8>{}); }
+          if (!WB_DIAG(1)) { WB_MFMA(av[set], bvv[set]); }
+          if (issue_) {   // the next unit's DMA: one slot behind the MFMAs of each of the first steps
+            if constexpr (e < WGB_GSLOTS) { WB_ISSUE_G(e) }
+            else if constexpr (e - WGB_GSLOTS < WGB_XSLOTS) { WB_ISSUE_X(e - WGB_GSLOTS) }
+            if constexpr (e == 7) {
+#pragma unroll
+              for (int sl = 8 - WGB_GSLOTS; sl < WGB_XSLOTS; ++sl) { WB_ISSUE_X(sl) }
+            }
+          }
+          if (do_bias) {   // the NBW * TG wavefronts that hold the same gradient operand take turns summing it
+            if (--bias_turn < 0) {
+              bias_turn = NBW * TG - 1;
+#pragma unroll
+              for (int m = 0; m < MPW; ++m)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bsum[m] += (float)av[set][m][j];
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        wb_static_for(step, std::make_integer_sequence<int, 8>{});
+        if (wide) step(std::integral_constant<int, 8>{});
+      } else if (issue_) {
+        WB_ISSUE(nb_)
+      }
+    } else
     if constexpr (LEAN) {
       // the next unit's DMA: its slots ride behind the MFMAs of the first step of every row (KSL slots per row)
       constexpr int KSL = (WGB_GSLOTS + WGB_XSLOTS + R - 1) / R;
@@ -422,7 +489,9 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
     WB_STAMP(tc_)
   }
   };
-  if constexpr (LEAN) {
+  if constexpr (BLK4) {
+    unit_loop(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+  } else if constexpr (LEAN) {
     switch (ksteps_row) {
       case 1: unit_loop(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}); break;
       case 2: unit_loop(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}); break;
@@ -498,6 +567,7 @@ namespace {
 thread_local char g_wb_plan_txt[256] = "";  // planner parameters of the launch in flight (launch log)
 
 struct WbPlan {
+  bool blk4;
   int MBW, NBW, NPW, MPW, KS, R, Mpad, Npad, nchunk_w, base_w, rem_w, wce, nrowg, xw, units, nsplit, units_per_split, ngs, nxs, bufu,
       depth, lds_bytes, xcb;
   dim3 grid;
@@ -521,10 +591,13 @@ bool wb_plan(int B, int N, int M, int IH, int IW, int ks, int stride, WbPlan* pl
   const int KS = 4 / (MBW * NBW);
   // rows per unit: few channels -> little MFMA work per row, so take more rows per barrier
   const bool tall = MBW == 1 && NBW == 1 && ks == 3 && stride == 1 && OH >= 64;
-  const int R = (NPW == 2 || MPW == 2) ? (stride == 1 ? 3 : 2) : (stride == 1 ? (tall ? 8 : 4) : 2);
-  pl->MBW = MBW; pl->NBW = NBW; pl->NPW = NPW; pl->MPW = MPW; pl->KS = KS; pl->R = R;
+  int R = (NPW == 2 || MPW == 2) ? (stride == 1 ? 3 : 2) : (stride == 1 ? (tall ? 8 : 4) : 2);
+  const bool blk4 = MPW == 2 && stride == 1 && ks == 3 && WGB_BLK4;   // 4 x 4-pixel k-steps (wgrad_bf16_kernel, BLK4)
+  pl->blk4 = blk4;
+  pl->MBW = MBW; pl->NBW = NBW; pl->NPW = NPW; pl->MPW = MPW; pl->KS = KS; pl->R = blk4 ? 4 : R;
   pl->Mpad = round_up(M, 32 * MBW * MPW);
   pl->Npad = round_up(N, 32 * NBW * NPW);
+  if (blk4) R = 4;
   const int TG = ks == 3 ? 3 : 1;
   const int NT = 64 * MBW * NBW * KS * TG;
   const int XR = ks == 3 ? (R - 1) * stride + 3 : R;
@@ -534,6 +607,15 @@ bool wb_plan(int B, int N, int M, int IH, int IW, int ks, int stride, WbPlan* pl
   // count with the least zero padding
   bool found = false;
   int best_waste = 1 << 30;
+  if (blk4) {   // chunks of at most 36 columns (9 four-column steps), staged 36 wide
+    const int w = 36, xw = w + 2;
+    const int ngs = cdiv(MBW * MPW * 4 * R * w, NT), nxs = cdiv(NBW * NPW * xcb * XR * xw, NT);
+    const int bufu = (ngs + nxs) * NT;
+    if (ngs <= WGB_GSLOTS && nxs <= WGB_XSLOTS && 2 * bufu * 16 <= WGB_LDS_MAX) {
+      pl->nchunk_w = cdiv(OW, w); pl->wce = w; pl->xw = xw; pl->ngs = ngs; pl->nxs = nxs; pl->bufu = bufu;
+      found = true;
+    }
+  }
   for (int wmax = 64; wmax >= 16 && !found; wmax -= 16) {
     for (int nc = cdiv(OW, wmax); nc <= cdiv(OW, wmax) + 4 && nc <= OW; ++nc) {
       const int w = round_up(cdiv(OW, nc), 16);
@@ -573,18 +655,22 @@ int wb_bias_rows(const WbPlan& pl, int T) {
   return pl.nsplit * pl.KS * (lean ? pl.NBW * (T == 1 ? 1 : 3) : 1);
 }
 
-template <int MBW, int NBW, int NPW, int KS, int T, int S, int R, int MPW = 1, bool ROT = false, bool PACK2 = false>
+template <int MBW, int NBW, int NPW, int KS, int T, int S, int R, int MPW = 1, bool ROT = false, bool PACK2 = false, bool BLK4 = false>
 void wb_launch_one(const WgradBf16Params& p, const WbPlan& pl, hipStream_t stream) {
   static bool s = false;
   if (!s) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<MBW, NBW, NPW, KS, T, S, R, MPW, ROT, PACK2>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<MBW, NBW, NPW, KS, T, S, R, MPW, ROT, PACK2, BLK4>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, WGB_LDS_MAX);
     s = true;
   }
-  hipLaunchKernelGGL((wgrad_bf16_kernel<MBW, NBW, NPW, KS, T, S, R, MPW, ROT, PACK2>), pl.grid, dim3(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)),
+  hipLaunchKernelGGL((wgrad_bf16_kernel<MBW, NBW, NPW, KS, T, S, R, MPW, ROT, PACK2, BLK4>), pl.grid, dim3(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)),
                      pl.lds_bytes, stream, p);
-  yogo_launch_log("wgrad_bf16_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %s, %s> | %s", MBW, NBW, NPW, KS, T, S, R, MPW, ROT ? "true" : "false",
-                  PACK2 ? "true" : "false", g_wb_plan_txt);
+  if (BLK4)
+    yogo_launch_log("wgrad_bf16_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %s, %s, true> | %s", MBW, NBW, NPW, KS, T, S, R, MPW, ROT ? "true" : "false",
+                    PACK2 ? "true" : "false", g_wb_plan_txt);
+  else
+    yogo_launch_log("wgrad_bf16_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %s, %s> | %s", MBW, NBW, NPW, KS, T, S, R, MPW, ROT ? "true" : "false",
+                    PACK2 ? "true" : "false", g_wb_plan_txt);
 }
 
 template <int MBW, int NBW, int KS>
@@ -651,7 +737,8 @@ static int conv2d_wgrad_bf16_impl(const void* x, const void* g, float* dw, float
              Cin, Cout, IH, IW, stride, T, B, pl.R, pl.wce, pl.nchunk_w, pl.xw, pl.ngs, pl.nxs, pl.depth, pl.lds_bytes, pl.units, pl.units_per_split,
              pl.grid.x, pl.grid.y, pl.grid.z);
   if (pl.MPW == 2) {
-    if (stride == 1) wb_launch_one<2, 2, 1, 1, 9, 1, 3, 2>(p, pl, stream);
+    if (stride == 1 && pl.blk4) wb_launch_one<2, 2, 1, 1, 9, 1, 4, 2, false, false, true>(p, pl, stream);
+    else if (stride == 1) wb_launch_one<2, 2, 1, 1, 9, 1, 3, 2>(p, pl, stream);
     else wb_launch_one<2, 2, 1, 1, 9, 2, 2, 2>(p, pl, stream);
   } else {
     const int cfg = pl.MBW * 100 + pl.NBW * 10 + pl.KS;
