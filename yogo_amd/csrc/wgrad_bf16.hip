@@ -665,12 +665,8 @@ void wb_launch_one(const WgradBf16Params& p, const WbPlan& pl, hipStream_t strea
   }
   hipLaunchKernelGGL((wgrad_bf16_kernel<MBW, NBW, NPW, KS, T, S, R, MPW, ROT, PACK2, BLK4>), pl.grid, dim3(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)),
                      pl.lds_bytes, stream, p);
-  if (BLK4)
-    yogo_launch_log("wgrad_bf16_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %s, %s, true> | %s", MBW, NBW, NPW, KS, T, S, R, MPW, ROT ? "true" : "false",
-                    PACK2 ? "true" : "false", g_wb_plan_txt);
-  else
-    yogo_launch_log("wgrad_bf16_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %s, %s> | %s", MBW, NBW, NPW, KS, T, S, R, MPW, ROT ? "true" : "false",
-                    PACK2 ? "true" : "false", g_wb_plan_txt);
+  yogo_launch_log("wgrad_bf16_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %s, %s, %s> | %s", MBW, NBW, NPW, KS, T, S, R, MPW, ROT ? "true" : "false",
+                  PACK2 ? "true" : "false", BLK4 ? "true" : "false", g_wb_plan_txt);
 }
 
 template <int MBW, int NBW, int KS>
