@@ -359,7 +359,7 @@ def test_direct_stride2_dgrad_against_the_tiled_kernel_and_cpu(kind, B, K, M, OH
 # ---- the independent-wavefront kernel of the thin forward-type layers: conv_bf16_staged_kernel against conv_bf16_kernel ----
 def _run_thin(staged, kind, B, Cin, Cout, H, W, s, seed):
     """y [B][Cout <= 64][OH][OW] = [mask x] [LeakyReLU] (conv3x3 stride s (x [B][Cin = 16 / 32][H][W]) + bias) [+ the sign map of y]:
-    yogo/model_defns.py:41-46 (the kernel takes stride 2 only)"""
+    yogo/model_defns.py:36-46; kind "dgrad": dx = conv3x3(dy, flipped transposed weights), the stride-1 data gradient of model_defns.py:36-40"""
     import contextlib
 
     from _util import hooks_library
@@ -402,17 +402,25 @@ def _run_thin(staged, kind, B, Cin, Cout, H, W, s, seed):
 
 THIN_CASES = [
     # (kind, B, Cin, Cout, H, W, stride)
-    ("signs", 2, 32, 64, 386, 516, 2),    # layer 2 of base_model at 772x1032
+    ("signs", 2, 16, 32, 386, 516, 1),    # layer 1 of base_model at 772x1032
+    ("signs", 2, 32, 64, 386, 516, 2),    # layer 2
+    ("signs", 1, 16, 32, 20, 22, 1),
     ("signs", 1, 32, 64, 20, 22, 2),
     ("mask", 2, 32, 64, 37, 41, 2),       # odd sizes
     ("plain", 3, 32, 32, 50, 66, 2),
     ("leaky", 5, 16, 24, 33, 29, 2),      # 24 real channels: the padding channels of the last block come out as zeros
+    ("leaky", 5, 16, 24, 33, 29, 1),      # (8-row tiles: the last tile row has one row)
     ("nobias", 4, 32, 48, 2, 2, 2),
     ("signs", 3, 32, 64, 64, 64, 2),      # even sizes: the last column's right tap is the padding
     ("signs", 40, 16, 64, 30, 30, 2),     # every wavefront walks several tiles, image changes at the seams
+    ("signs", 40, 16, 32, 30, 30, 1),
     ("mask", 1, 16, 8, 5, 300, 2),        # one channel block pair, short and wide
     ("leaky", 2, 32, 64, 1, 70, 2),       # a single row
+    ("leaky", 2, 16, 32, 1, 70, 1),
+    ("nobias", 4, 16, 20, 2, 2, 1),
+    ("plain", 3, 16, 32, 50, 66, 1),
     ("signs", 2, 32, 40, 70, 1, 2),       # a single column
+    ("signs", 2, 16, 32, 70, 1, 1),
     ("plain", 2, 16, 32, 193, 258, 2),
 ]
 

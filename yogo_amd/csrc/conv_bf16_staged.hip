@@ -1,6 +1,5 @@
-// Thin stride-2 3x3 convolutions (16 / 32 input channels, <= 64 output channels: layer 2 of base_model forward, yogo/model_defns.py:41-46;
-// the kernel is written for stride 1 as well -- R-row tiles -- but there it only matches the tiled kernel, see the launcher) as INDEPENDENT
-// wavefronts: the packed weights are resident in LDS (4.6 - 36 KB, staged once per workgroup), every wavefront owns tiles of 32 consecutive
+// Thin 3x3 convolutions (stride 2 out of 16 / 32 channels into <= 64, stride 1 out of 16 into <= 32: layers 2 and 1 of base_model forward,
+// yogo/model_defns.py:36-46) as INDEPENDENT wavefronts: the packed weights are resident in LDS (4.6 - 36 KB, staged once per workgroup), every wavefront owns tiles of 32 consecutive
 // output pixels of one output row, stages ITS three input rows into ITS OWN piece of LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 4 - 13
 // kilobyte pieces per tile), waits for them with its own vmcnt, multiplies and stores -- no barrier after the weight staging.
 //
@@ -60,8 +59,9 @@ __device__ __forceinline__ i32x4 cs_rsrc(const void* ptr, unsigned bytes) {
 }  // namespace
 
 // S: stride; NK: 16-channel steps of the contraction (1 or 2); NMB: 32-channel blocks of the output (1 or 2); NWV: wavefronts per workgroup;
-// R: output rows of a tile (R x 32 pixels: (R - 1) S + 3 staged input rows -- taller tiles re-read fewer halo rows and reuse a weight operand R times)
-template <int S, int NK, int NMB, bool SIGN_OUT, int NWV, int R>
+// R: output rows of a tile (R x 32 pixels: (R - 1) S + 3 staged input rows -- taller tiles re-read fewer halo rows and reuse a weight operand R times);
+// NTS: non-temporal output stores (where a launch writes more than it reads: layer 1 forward)
+template <int S, int NK, int NMB, bool SIGN_OUT, int NWV, int R, bool NTS>
 __global__ __launch_bounds__(64 * NWV) void conv_bf16_staged_kernel(const ConvStagedParams p) {
   extern __shared__ __attribute__((aligned(16))) u32x4 lds_u[];   // (the dynamic block starts at LDS address 0: LDS-DMA takes addresses, not pointers)
   constexpr int OOB = (int)0x80000000u;
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(64 * NWV) void conv_bf16_staged_kernel(const ConvSt
         const auto r0 = __builtin_amdgcn_permlane32_swap(w.x, w.z, false, false);
         const auto r1 = __builtin_amdgcn_permlane32_swap(w.y, w.w, false, false);
         const u32x4 st = {r0[0], r1[0], r0[1], r1[1]};
-        __builtin_amdgcn_raw_buffer_store_b128(st, rs_o, (ov && cb + half < p.Mb) ? o * 16 + (cb + half) * plane16 : OOB, 0, 0);   // (non-temporal stores: no difference here, gpurun_out/r5_nt_ab3.log)
+        __builtin_amdgcn_raw_buffer_store_b128(st, rs_o, (ov && cb + half < p.Mb) ? o * 16 + (cb + half) * plane16 : OOB, 0, NTS ? 2 : 0);
       }
     if constexpr (SIGN_OUT) {
       constexpr int sq = 2 * NMB;   // sign bytes per (pixel, half-wave)
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(64 * NWV) void conv_bf16_staged_kernel(const ConvSt
 }
 
 bool conv_bf16_staged_eligible(int K, int M, int stride, int IH, int IW, int OH, int OW, int B) {
-  if ((K != 16 && K != 32) || M < 1 || M > 64 || stride != 2) return false;   // (stride 1: see launch_conv_bf16_staged)
+  if ((K != 16 && K != 32) || M < 1 || M > 64 || (stride != 2 && !(stride == 1 && K == 16 && M <= 32))) return false;   // (stride 1: see launch_conv_bf16_staged)
   if (IH < 1 || IW < 1 || OH < 1 || OW < 1 || B <= 0 || IH >= 32000 || IW >= 32768) return false;
   const long long Mb = ((M + 15) / 16) * 2;
   if ((long long)(K / 8) * IH * IW * 16 >= (1ll << 31) || Mb * OH * OW * 16 >= (1ll << 31) || (long long)B * OH * ((OW + 31) / 32) >= (1ll << 31)) return false;
@@ -220,7 +220,7 @@ bool conv_bf16_staged_eligible(int K, int M, int stride, int IH, int IW, int OH,
 
 namespace {
 unsigned cs_magic(int d) { return d <= 1 ? 0xFFFFFFFFu : (unsigned)(((1ull << 32) + (unsigned)d - 1ull) / (unsigned)d); }
-template <int S, int NK, int NMB, int NWV, int R>
+template <int S, int NK, int NMB, int NWV, int R, bool NT = false>
 int cs_launch(ConvStagedParams p, int dev, int n_cu, bool sg, hipStream_t stream, int* grid_out, int* lds_out) {
   constexpr int KB = 2 * NK, MP = 32 * NMB, ROWU = S == 2 ? 66 : 34, NDMA = (KB * ((R - 1) * S + 3) * ROWU + 63) / 64;
   p.tiles_per_row = cdiv(p.OW, 32);
@@ -238,8 +238,8 @@ int cs_launch(ConvStagedParams p, int dev, int n_cu, bool sg, hipStream_t stream
     static bool done[64][2] = {};
     std::lock_guard<std::mutex> lk(mu);
     if (!done[dev][sg ? 1 : 0]) {
-      hipError_t e = sg ? hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_staged_kernel<S, NK, NMB, true, NWV, R>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)
-                        : hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_staged_kernel<S, NK, NMB, false, NWV, R>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipError_t e = sg ? hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_staged_kernel<S, NK, NMB, true, NWV, R, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)
+                        : hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_staged_kernel<S, NK, NMB, false, NWV, R, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       if (e != hipSuccess) {
         yogo_set_error("conv_bf16_staged: hipFuncSetAttribute: %s", hipGetErrorString(e));
         return YOGO_ERR_HIP;
@@ -247,12 +247,12 @@ int cs_launch(ConvStagedParams p, int dev, int n_cu, bool sg, hipStream_t stream
       done[dev][sg ? 1 : 0] = true;
     }
   }
-  if (sg) hipLaunchKernelGGL((conv_bf16_staged_kernel<S, NK, NMB, true, NWV, R>), dim3(grid), dim3(64 * NWV), lds, stream, p);
-  else hipLaunchKernelGGL((conv_bf16_staged_kernel<S, NK, NMB, false, NWV, R>), dim3(grid), dim3(64 * NWV), lds, stream, p);
+  if (sg) hipLaunchKernelGGL((conv_bf16_staged_kernel<S, NK, NMB, true, NWV, R, NT>), dim3(grid), dim3(64 * NWV), lds, stream, p);
+  else hipLaunchKernelGGL((conv_bf16_staged_kernel<S, NK, NMB, false, NWV, R, NT>), dim3(grid), dim3(64 * NWV), lds, stream, p);
   *grid_out = grid; *lds_out = lds;
   if (yogo_launch_log_enabled())
-    yogo_launch_log("conv_bf16_staged_kernel<%d, %d, %d, %s, %d, %d> | K=%d M=%d in=%dx%d out=%dx%d tiles=%d grid=%d lds=%d act=%d bias=%d scale=%d", S, NK, NMB,
-                    sg ? "true" : "false", NWV, R, 16 * NK, p.M, p.IH, p.IW, p.OH, p.OW, p.ntiles, grid, lds, p.act, p.bias != nullptr, p.chan_scale != nullptr);
+    yogo_launch_log("conv_bf16_staged_kernel<%d, %d, %d, %s, %d, %d, %s> | K=%d M=%d in=%dx%d out=%dx%d tiles=%d grid=%d lds=%d act=%d bias=%d scale=%d", S, NK, NMB,
+                    sg ? "true" : "false", NWV, R, NT ? "true" : "false", 16 * NK, p.M, p.IH, p.IW, p.OH, p.OW, p.ntiles, grid, lds, p.act, p.bias != nullptr, p.chan_scale != nullptr);
   return YOGO_OK;
 }
 }  // namespace
@@ -284,8 +284,11 @@ int launch_conv_bf16_staged(const void* in, const void* packed, const float* bia
   const bool sg = signs != nullptr;
   int grid = 0, lds = 0, rc;
   // wavefronts per workgroup: 4 where four workgroups' weights + tile images fit a CU, 8 for the 36 KB of layer 2's weights (one workgroup per CU)
-  // (stride 1 -- layer 1 forward and data gradient -- was measured with tiles of 1 - 8 rows and 4 / 6 wavefronts per workgroup: 0.625 / 0.545 ms
-  //  against the tiled kernel's 0.614 / 0.55, gpurun_out/r5_cs_ab3.log; those launches stay with conv_bf16_kernel and are not instantiated here)
+  // stride 1 out of 16 into <= 32 channels (layer 1 forward): tiles of 8 rows and non-temporal stores (it writes twice what it reads): 7 - 9 % ahead of
+  // the tiled kernel with the same stores (gpurun_out/r5_s1_ab1.log, r5_cs_ab4.log); with cached stores the two were equal, and layer 1's data
+  // gradient (32 -> 16 channels: reads twice what it writes) came out equal either way (-2 ... +1 %): it stays with the tiled kernel, not instantiated
+  if (stride == 1) rc = cs_launch<1, 1, 1, 4, 8, true>(p, dev, n_cu, sg, stream, &grid, &lds);
+  else
   if (nk == 1) rc = nmb == 1 ? cs_launch<2, 1, 1, 4, 1>(p, dev, n_cu, sg, stream, &grid, &lds) : cs_launch<2, 1, 2, 4, 1>(p, dev, n_cu, sg, stream, &grid, &lds);
   else rc = nmb == 1 ? cs_launch<2, 2, 1, 4, 1>(p, dev, n_cu, sg, stream, &grid, &lds) : cs_launch<2, 2, 2, 8, 1>(p, dev, n_cu, sg, stream, &grid, &lds);
   if (rc != YOGO_OK) return rc;
