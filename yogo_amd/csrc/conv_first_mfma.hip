@@ -15,6 +15,9 @@
 // z (saved for backward) and y = act(BN(z)) (the next layer's input) -- 0.1 + 0.1 GB read and 1.6 GB written per 128 images
 // where conv + separate BatchNorm apply read 0.9 GB and wrote 1.6 GB.
 #include "common.h"
+#ifndef CFM_ST_AUX
+#define CFM_ST_AUX 2   // non-temporal y / z stores of the pair kernel: 0.243 -> 0.211 ms in the same-box A/B (gpurun_out/r5_nt_ab5.log; A/B variant builds: 0 = cached)
+#endif
 
 typedef float cfm_f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 cfm_bf16x8 __attribute__((ext_vector_type(8)));
@@ -291,6 +294,7 @@ __global__ __launch_bounds__(256) void conv_first_mfma2_kernel(const ConvFirstMf
     CFM2_FETCH()
     unsigned sgn2 = 0;   // this lane's sign bytes of the pair: pixel 2m in bits 0..7, pixel 2m + 1 in bits 16..23
     cfm_u32x4 sty[2];    // [e]: y of pixel 2m + e: lanes 0-31 channel block 0, lanes 32-63 block 1 (after the half-wave exchange)
+    cfm_u32x4 stz[2];    // ... and z (the inference forward stores z = act(conv + bias) only)
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       // bytes 1, 2, 3 of a word = kernel columns 0, 1, 2: pixel 2m reads (4m - 1, 4m, 4m + 1), pixel 2m + 1 (4m + 1, 4m + 2, 4m + 3)
@@ -323,14 +327,11 @@ __global__ __launch_bounds__(256) void conv_first_mfma2_kernel(const ConvFirstMf
       cfm_bf16x8 o;
 #pragma unroll
       for (int i = 0; i < 8; ++i) o[i] = (__bf16)v[i];
-      const int vo = valid ? (half * npix + pix + e) * 16 : (int)OOB;
       if (p.z != nullptr) {
         const cfm_u32x4 w4 = __builtin_bit_cast(cfm_u32x4, o);
         const auto r0s = __builtin_amdgcn_permlane32_swap(w4.x, w4.z, false, false);
         const auto r1s = __builtin_amdgcn_permlane32_swap(w4.y, w4.w, false, false);
-        const cfm_u32x4 st = {r0s[0], r1s[0], r0s[1], r1s[1]};
-        const auto rs_z = __builtin_amdgcn_make_buffer_rsrc((void*)(p.z + (size_t)b * 2 * npix), (short)0, 2 * npix * 16, 0x00020000);
-        __builtin_amdgcn_raw_buffer_store_b128(st, rs_z, vo, 0, 0);
+        stz[e] = cfm_u32x4{r0s[0], r1s[0], r0s[1], r1s[1]};
       }
       if (p.y == nullptr) continue;   // (uniform)
       float r[8];   // BatchNorm + activation of the ROUNDED z, as yogo_bn_apply_act_bf16 computes it from the stored tensor
@@ -361,9 +362,17 @@ __global__ __launch_bounds__(256) void conv_first_mfma2_kernel(const ConvFirstMf
       const auto r1s = __builtin_amdgcn_permlane32_swap(w4.y, w4.w, false, false);
       sty[e] = cfm_u32x4{r0s[0], r1s[0], r0s[1], r1s[1]};
     }
-#ifndef CFM_ST_AUX
-#define CFM_ST_AUX 2   // non-temporal y stores: 0.243 -> 0.211 ms in the same-box A/B (gpurun_out/r5_nt_ab5.log; A/B variant builds: 0 = cached)
-#endif
+    if (p.z != nullptr) {   // (uniform) the pair's z units as two contiguous kilobytes, non-temporal: the same exchange as for y below
+      const auto x0 = __builtin_amdgcn_permlane32_swap(stz[0].x, stz[1].x, false, false);
+      const auto x1 = __builtin_amdgcn_permlane32_swap(stz[0].y, stz[1].y, false, false);
+      const auto x2 = __builtin_amdgcn_permlane32_swap(stz[0].z, stz[1].z, false, false);
+      const auto x3 = __builtin_amdgcn_permlane32_swap(stz[0].w, stz[1].w, false, false);
+      const cfm_u32x4 se0 = {x0[0], x1[0], x2[0], x3[0]}, se1 = {x0[1], x1[1], x2[1], x3[1]};
+      const auto rs_z = __builtin_amdgcn_make_buffer_rsrc((void*)(p.z + (size_t)b * 2 * npix), (short)0, 2 * npix * 16, 0x00020000);
+      const int vdz = valid ? (pix + half) * 16 : (int)OOB;
+      __builtin_amdgcn_raw_buffer_store_b128(se0, rs_z, vdz, 0, CFM_ST_AUX);
+      __builtin_amdgcn_raw_buffer_store_b128(se1, rs_z, valid ? vdz + npix * 16 : (int)OOB, 0, CFM_ST_AUX);
+    }
 #ifndef CFM_DENSE
 #define CFM_DENSE 1   // (A/B variant builds: 0 = one half-filled store per pixel parity)
 #endif
