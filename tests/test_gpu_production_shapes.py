@@ -290,14 +290,14 @@ def test_production_batch_step_and_kernel_set():
     assert profs, "no committed rocprofv3 summary"
     want = set()
     for ln in open(profs[-1]):
-        mm = re.search(r"((?:conv_bf16_kernel|conv_bf16_ws\d?_kernel|conv_bf16_s2d_direct_kernel|conv_bf16_staged_kernel|wgrad_bf16_kernel)<[^>]*>)", ln)
+        mm = re.search(r"((?:conv_bf16_kernel|conv_bf16_ws\d?_kernel|conv_bf16_s2d_direct_kernel|conv_bf16_staged_kernel|conv_bf16_1x1_f32_kernel|wgrad_bf16_kernel)<[^>]*>)", ln)
         if mm:
             want.add(re.sub(r"\s+", "", mm.group(1)))
     assert want, profs[-1]
     missing = want - launched
     assert not missing, f"instantiations of {os.path.basename(profs[-1])} that this step did not launch: {sorted(missing)}"
     if SEEN:
-        conv = {k for k in launched if k.startswith(("conv_bf16_kernel", "conv_bf16_ws_kernel", "conv_bf16_ws3_kernel", "conv_bf16_s2d_direct_kernel", "conv_bf16_staged_kernel", "wgrad_bf16_kernel"))}
+        conv = {k for k in launched if k.startswith(("conv_bf16_kernel", "conv_bf16_ws_kernel", "conv_bf16_ws3_kernel", "conv_bf16_s2d_direct_kernel", "conv_bf16_staged_kernel", "conv_bf16_1x1_f32_kernel", "wgrad_bf16_kernel"))}
         assert conv <= SEEN, f"launched at B=128 but not covered by the per-layer parity tests: {sorted(conv - SEEN)}"
     loss_ref, grads_ref, ns = _oracle_step(sd0, x2, lab2, "cpu")
     _compare_step(tr, m, loss_ref, grads_ref, ns, "B=128 (64 x 2 images) vs bf16-emulating CPU oracle on the 2 images")

@@ -475,3 +475,115 @@ def test_staged_thin_convolution_against_the_tiled_kernel_and_cpu(kind, B, Cin, 
         got = got.cpu().double()
         tol = 2.0 ** -8 * want.abs() + 2e-5 * float(want.abs().max())
         assert bool(((got - want).abs() <= tol).all()), float(((got - want).abs() - tol).max())
+
+
+# ---- the 1x1 head's forward with its weights in registers: conv_bf16_1x1_f32_kernel against conv_bf16_kernel ----
+def _run_head(new, kind, B, Cin, Cout, H, W, seed):
+    """forward: pred fp32 [B][Cout <= 32][H][W] = conv1x1(x bf16 [B][Cin][H][W]) + bias (yogo/model_defns.py:66);
+    data gradient: dx bf16 [B][Cin][H][W] = conv1x1^T(dpred bf16 [B][Cout <= 16]) x LeakyReLU'(sign map of x) [x channel mask]"""
+    import contextlib
+
+    from _util import hooks_library
+    from yogo_amd import _hip as Hh
+
+    with (contextlib.nullcontext() if new else hooks_library()):
+        st = Hh.stream_ptr()
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        w = torch.randn(Cout, Cin, 1, 1, device="cuda", generator=g) * 0.1
+        bias = torch.randn(Cout, device="cuda", generator=g)
+        if not new:
+            Hh.call("yogo_hook_conv_bf16_head", 0)
+        Hh.launch_log(True)
+        try:
+            if kind == "fwd":
+                x8 = torch.randn(B, _blocks(Cin), H, W, 8, device="cuda", generator=g).to(torch.bfloat16)
+                out = torch.full((B, Cout, H, W), 7.0, device="cuda")
+                packed = torch.empty(Hh.query_size("yogo_conv_bf16_packed_bytes", Cin, Cout, 1, 0), dtype=torch.uint8, device="cuda")
+                Hh.call("yogo_conv_bf16_pack", w, None, packed, Cin, Cout, 1, 0, st)
+                Hh.call("yogo_conv2d_fwd_bf16", x8, packed, bias, None, out, None, None, B, Cin, Cout, H, W, 1, 1, 0, st)
+                aux = (w, x8, bias, None, None)
+            else:
+                dy8 = torch.randn(B, _blocks(Cout), H, W, 8, device="cuda", generator=g).to(torch.bfloat16)
+                if Cout % 16:   # the padding channels of a gradient tensor are zeros (what decode_loss_bwd_bf16_kernel writes)
+                    dyf = dy8.float().permute(0, 1, 4, 2, 3).reshape(B, -1, H, W)
+                    dyf[:, Cout:] = 0
+                    dy8 = dyf.reshape(B, _blocks(Cout), 8, H, W).permute(0, 1, 3, 4, 2).contiguous().to(torch.bfloat16)
+                out = torch.full((B, _blocks(Cin), H, W, 8), 7.0, device="cuda").to(torch.bfloat16)
+                msk = (torch.rand(B, Cin, device="cuda", generator=g) > 0.2).float() / 0.8
+                sg = torch.randint(0, 256, (Hh.query_size("yogo_bf16_signs_bytes", B, Cin, H, W),), dtype=torch.uint8, device="cuda", generator=g)
+                packed = torch.empty(Hh.query_size("yogo_conv_bf16_packed_bytes", Cin, Cout, 1, 1), dtype=torch.uint8, device="cuda")
+                Hh.call("yogo_conv_bf16_pack", w, None, packed, Cin, Cout, 1, 1, st)
+                if kind == "dgrad_signs":
+                    Hh.call("yogo_conv2d_dgrad_bf16_signs", dy8, packed, out, sg, None, B, Cin, Cout, H, W, 1, 1, st)
+                elif kind == "dgrad_signs_mask":
+                    Hh.call("yogo_conv2d_dgrad_bf16_signs", dy8, packed, out, sg, msk, B, Cin, Cout, H, W, 1, 1, st)
+                else:
+                    Hh.call("yogo_conv2d_dgrad_bf16", dy8, packed, out, None, 0, msk if kind == "dgrad_mask" else None, B, Cin, Cout, H, W, 1, 1, st)
+                aux = (w, dy8, None, msk, sg)
+            torch.cuda.synchronize()
+            log = Hh.read_launch_log()
+        finally:
+            Hh.launch_log(False)
+        return out, log, aux
+
+
+HEAD_CASES = [
+    # (kind, B, Cin, Cout, H, W)
+    ("fwd", 2, 128, 12, 97, 129),            # the head of base_model at 772x1032 (7 classes)
+    ("fwd", 3, 128, 12, 5, 7),
+    ("fwd", 2, 64, 9, 31, 33),               # 4 classes, 4 steps
+    ("fwd", 1, 32, 25, 20, 22),              # more than 16 output channels
+    ("fwd", 40, 128, 12, 12, 13),            # every wavefront walks several tiles, image changes at the seams
+    ("fwd", 2, 16, 32, 9, 11),               # one step, all 32 output channels
+]
+
+
+@pytest.mark.parametrize("kind,B,Cin,Cout,H,W", HEAD_CASES)
+def test_head_kernels_are_bit_identical_to_the_tiled_kernel_and_match_cpu(kind, B, Cin, Cout, H, W):
+    from yogo_amd import _hip as Hh
+
+    o_old, log_old, _ = _run_head(False, kind, B, Cin, Cout, H, W, seed=71)
+    o_new, log_new, (w, x8, bias, msk, sg) = _run_head(True, kind, B, Cin, Cout, H, W, seed=71)
+    assert any(ln.startswith("conv_bf16_kernel<") for ln in log_old), log_old
+    name = "conv_bf16_1x1_f32_kernel<" if kind == "fwd" else "conv_bf16_1x1_dgrad_kernel<"
+    assert any(ln.startswith(name) for ln in log_new), log_new
+    plan = next(ln for ln in log_old if ln.startswith("conv_bf16_kernel<"))
+    if kind == "fwd":
+        if " CKb=2 " in plan or Cin == 16:
+            assert torch.equal(o_old, o_new), float((o_old - o_new).abs().max())
+        else:
+            assert float((o_old - o_new).abs().max()) <= 2e-5 * float(o_old.abs().max())
+    else:
+        assert torch.equal(o_old.view(torch.int16), o_new.view(torch.int16)), float((o_old.float() - o_new.float()).abs().max())
+    # ... and an independent CPU reference (float64 on the same bf16-rounded operands)
+    st = Hh.stream_ptr()
+    wd = w.to(torch.bfloat16).double().cpu()[:, :, 0, 0]
+    if kind == "fwd":
+        x = torch.empty(B, Cin, H, W, device="cuda")
+        Hh.call("yogo_bf16_8c_to_nchw_f32", x8, x, B, Cin, H * W, st)
+        want = torch.einsum("oc,bchw->bohw", wd, x.double().cpu()) + bias.double().cpu()[None, :, None, None]
+        got = o_new.double().cpu()
+        assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    else:
+        dy = torch.empty(B, Cout, H, W, device="cuda")
+        Hh.call("yogo_bf16_8c_to_nchw_f32", x8, dy, B, Cout, H * W, st)
+        want = torch.einsum("oc,bohw->bchw", wd, dy.double().cpu())
+        if "signs" in kind:
+            sq = 2 if Cin <= 32 else (4 if Cin <= 64 else 8)
+            s = sg.cpu().view(B, 2, H, W, sq).long()   # byte (h, pixel, q), bit i + 4e = (channel 16 q + 8 e + 4 h + i > 0)
+            pos = torch.zeros(B, 16 * sq, H, W, dtype=torch.bool)
+            for h in range(2):
+                for q in range(sq):
+                    for e in range(2):
+                        for i in range(4):
+                            pos[:, 16 * q + 8 * e + 4 * h + i] = ((s[:, h, :, :, q] >> (i + 4 * e)) & 1).bool()
+            want = want * torch.where(pos[:, :Cin], 1.0, 0.01)
+        if "mask" in kind:
+            want = want * msk.double().cpu()[:, :, None, None]
+        got = torch.empty(B, Cin, H, W, device="cuda")
+        Hh.call("yogo_bf16_8c_to_nchw_f32", o_new, got, B, Cin, H * W, st)
+        got = got.cpu().double()
+        tol = 2.0 ** -8 * want.abs() + 2e-5 * float(want.abs().max())
+        assert bool(((got - want).abs() <= tol).all()), float(((got - want).abs() - tol).max())
+        padc = o_new.float().permute(0, 1, 4, 2, 3).reshape(B, -1, H, W)[:, Cin:]
+        assert padc.numel() == 0 or float(padc.abs().max()) == 0.0

@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from yogo_amd import _hip as H
 H.LIB_PATH = os.path.join(ROOT, "yogo_amd", "lib", "libyogo_hip_hooks.so")   # the product's objects + the yogo_hook_* switches
 import ctypes
-for _n in ("yogo_hook_conv_bf16_persistent", "yogo_hook_conv_bf16_direct", "yogo_hook_conv_bf16_staged"):
+for _n in ("yogo_hook_conv_bf16_persistent", "yogo_hook_conv_bf16_direct", "yogo_hook_conv_bf16_staged", "yogo_hook_conv_bf16_head"):
     _f = getattr(H.lib(), _n)
     _f.restype, _f.argtypes = ctypes.c_int, [ctypes.c_int]
 import bench_conv_bf16 as BC
@@ -30,6 +30,7 @@ if __name__ == "__main__":
     for r in range(rounds + 1):
         for mode in (0, 1):
             H.call("yogo_hook_conv_bf16_persistent", mode)
+            H.call("yogo_hook_conv_bf16_head", mode)     # (the 1x1 head kernels)
             H.call("yogo_hook_conv_bf16_staged", mode)   # (the independent-wavefront kernel of the thin layers)
             H.call("yogo_hook_conv_bf16_direct", mode)   # (the direct stride-2 data gradients)
             for w in which:

@@ -26,7 +26,7 @@ def bench(name, B, Cin, Cout, IH, IW, k, s, kind, reps=10):
     w = torch.randn(Cout, Cin, k, k, device="cuda") * 0.05
     x8 = torch.randn(B, blocks(Cin), IH, IW, 8, device="cuda").to(torch.bfloat16)
     y8 = torch.randn(B, blocks(Cout), OH, OW, 8, device="cuda").to(torch.bfloat16)
-    mode = 0 if kind in "fasp" else (2 if (s == 2 and k == 3) else 1)
+    mode = 0 if kind in "fasph" else (2 if (s == 2 and k == 3) else 1)
     packed = torch.empty(H.query_size("yogo_conv_bf16_packed_bytes", Cin, Cout, k, mode), dtype=torch.uint8, device="cuda")
     H.call("yogo_conv_bf16_pack", w, None, packed, Cin, Cout, k, mode, st)
     if kind == "s":
@@ -40,6 +40,11 @@ def bench(name, B, Cin, Cout, IH, IW, k, s, kind, reps=10):
         msk = (torch.rand(B, Cin, device="cuda") > 0.1).float() if kind == "m" else None
         f = lambda: H.call("yogo_conv2d_dgrad_bf16_signs", y8, packed, x8, sg, msk, B, Cin, Cout, IH, IW, k, s, st)
         nbytes = B * (17 * blocks(Cin) * IH * IW + 16 * blocks(Cout) * OH * OW)
+    elif kind == "h":   # the head's forward: conv + bias into an fp32 NCHW tensor
+        bias = torch.randn(Cout, device="cuda")
+        o32 = torch.empty(B, Cout, OH, OW, device="cuda")
+        f = lambda: H.call("yogo_conv2d_fwd_bf16", x8, packed, bias, None, o32, None, None, B, Cin, Cout, IH, IW, k, s, 0, st)
+        nbytes = B * (16 * blocks(Cin) * IH * IW + 4 * Cout * OH * OW)
     elif kind == "p":   # plain forward: conv + bias, no activation, no BatchNorm sums (the training step's layers in front of a BatchNorm)
         bias = torch.randn(Cout, device="cuda")
         f = lambda: H.call("yogo_conv2d_fwd_bf16", x8, packed, bias, y8, None, None, None, B, Cin, Cout, IH, IW, k, s, 0, st)

@@ -1359,7 +1359,11 @@ extern "C" int yogo_hook_conv_bf16_direct(int on) { g_bf_direct = on != 0; retur
 // the independent-wavefront kernel of the thin forward-type layers (conv_bf16_staged.hip)
 static bool g_bf_staged = true;
 extern "C" int yogo_hook_conv_bf16_staged(int on) { g_bf_staged = on != 0; return YOGO_OK; }
+// the 1x1 head's forward with the weights in registers (conv_bf16_head.hip)
+static bool g_bf_head = true;
+extern "C" int yogo_hook_conv_bf16_head(int on) { g_bf_head = on != 0; return YOGO_OK; }
 #else
+static constexpr bool g_bf_head = true;
 static constexpr bool g_bf_staged = true;
 static constexpr bool g_bf_ws = true;
 static constexpr bool g_bf_direct = true;
@@ -1370,6 +1374,8 @@ int launch_conv_bf16_s2d_direct(const void* in, const void* packed, void* out, c
 bool conv_bf16_staged_eligible(int K, int M, int stride, int IH, int IW, int OH, int OW, int B);
 int launch_conv_bf16_staged(const void* in, const void* packed, const float* bias, void* out, void* signs, const float* chan_scale, int B, int K, int M, int IH,
                             int IW, int OH, int OW, int stride, int act, hipStream_t stream);
+bool conv_bf16_head_fwd_eligible(int K, int M, int plane, int B);
+int launch_conv_bf16_head_fwd(const void* in, const void* packed, const float* bias, float* out_f32, int B, int K, int M, int plane, hipStream_t stream);
 static bool g_bf_pp = true;   // (diagnostic build: yogo_diag_conv_bf16_pp(0) selects the interleaved main loop for A/B runs)
 #ifdef YOGO_DIAG
 extern "C" int yogo_diag_conv_bf16_pp(int on) { g_bf_pp = on != 0; return YOGO_OK; }
@@ -1475,6 +1481,10 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
 #endif
     if (conv_bf16_ws3_plan(&q)) return launch_conv_bf16_ws3(q, stream);
   }
+  // the 1x1 head's fp32-output forward (bias only) with the weights in registers
+  if (in != nullptr && g_bf_head && ks == 1 && a == 1 && !s2d && out_pre == nullptr && act_ref == nullptr && stats_part == nullptr && act == ACT_NONE &&
+      out_f32 != nullptr && out == nullptr && signs == nullptr && chan_scale == nullptr && conv_bf16_head_fwd_eligible(K, M, OH * OW, B))
+    return launch_conv_bf16_head_fwd(in, packed, bias, out_f32, B, K, M, OH * OW, stream);
   // 3x3 convolutions out of 16 / 32 channels into <= 64 with the lean epilogue: independent wavefronts, weights resident, private LDS staging
   if (in != nullptr && g_bf_staged && !s2d && ks == 3 && out_f32 == nullptr && out_pre == nullptr && act_ref == nullptr && !signs_read && stats_part == nullptr &&
       (act == ACT_NONE || act == ACT_LEAKY) && !(signs != nullptr && act != ACT_LEAKY) && conv_bf16_staged_eligible(K, M, a, IH, IW, OH, OW, B))
