@@ -30,7 +30,7 @@ if __name__ == "__main__":
     if kind == "conv":
         import bench_conv_bf16 as BC
         which = which or ["l5a", "l5d", "l3s", "l3m", "l4f"]
-        run = lambda w: BC.bench(w[:-1], B, *BC.LAYERS[w[:-1]], w[-1], reps=10)
+        run = lambda w: BC.bench(w[:-1], B, *BC.LAYERS[w[:-1]], w[-1], reps=int(os.environ.get("AB_REPS", "10")))
     else:
         import ab_wgrad_bf16 as BW
         which = which or list(BW.LAYERS)

@@ -41,10 +41,22 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // statements, .vgpr_spill_count 0, no scratch (cdna_hip_programming.md 5.7 item 4).
 // accumulator tile (mb, n) = a[16 * (2 mb + n) : +15]
 #define WS_ACC_CLOBBER "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95","a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127"
-#define WS_MFMA(TILE, AOP, BOP) \
-  "v_mfma_f32_32x32x16_bf16 a[16*" #TILE ":16*" #TILE "+15], %[" #AOP "], %[" #BOP "], a[16*" #TILE ":16*" #TILE "+15]\n\t"
-#define WS_MFMA0(TILE, AOP, BOP) \
-  "v_mfma_f32_32x32x16_bf16 a[16*" #TILE ":16*" #TILE "+15], %[" #AOP "], %[" #BOP "], 0\n\t"
+// compile-time ablations (build.sh variant TAG conv_bf16_ws -DWS_ABL=bits; timings only, the results are wrong): see WS_ABLATE below;
+// 256 = every 32x32x16 MFMA becomes two 16x16x32 MFMAs on eight of its sixteen accumulator registers (same operand registers, same
+// FLOPs, same LDS reads: the in-situ test of the clock the other MFMA shape holds, MI355X_MICROARCH.md "DVFS give-back" item 7)
+#ifndef WS_ABL
+#define WS_ABL 0
+#endif
+// one MFMA on accumulator tile T (text of 16 * tile), operands A / B (text), T accumulates (WS_MF) or starts from zero (WS_MFZ)
+#if (WS_ABL & 256)
+#define WS_MF(T, A, B) "v_mfma_f32_16x16x32_bf16 a[" T ":" T "+3], " A ", " B ", a[" T ":" T "+3]\n\tv_mfma_f32_16x16x32_bf16 a[" T "+4:" T "+7], " A ", " B ", a[" T "+4:" T "+7]"
+#define WS_MFZ(T, A, B) "v_mfma_f32_16x16x32_bf16 a[" T ":" T "+3], " A ", " B ", 0\n\tv_mfma_f32_16x16x32_bf16 a[" T "+4:" T "+7], " A ", " B ", 0"
+#else
+#define WS_MF(T, A, B) "v_mfma_f32_32x32x16_bf16 a[" T ":" T "+15], " A ", " B ", a[" T ":" T "+15]"
+#define WS_MFZ(T, A, B) "v_mfma_f32_32x32x16_bf16 a[" T ":" T "+15], " A ", " B ", 0"
+#endif
+#define WS_MFMA(TILE, AOP, BOP) WS_MF("16*" #TILE, "%[" #AOP "]", "%[" #BOP "]") "\n\t"
+#define WS_MFMA0(TILE, AOP, BOP) WS_MFZ("16*" #TILE, "%[" #AOP "]", "%[" #BOP "]") "\n\t"
 // operand reads of tap T1 (kernel column KX1): weights at pa + T1 * 4 KB + mb * 512 B, input at the row base + KX1 * 16 B
 // (T1 / KX1 name "n" operands of the statement, or are literal numbers)
 #define WS_RDA(DST, MB, T1) "ds_read_b128 %[" #DST "], %[pa] offset:4096*" T1 "+512*" #MB "\n\t"
@@ -188,8 +200,8 @@ template <int TILE, bool ZERO, int MBA, int T1, int KX1>
 __device__ __forceinline__ void ws_g1(const u32x4& a, const u32x4& b, u32x4& an, u32x4& bn, unsigned pa, unsigned pb) {
 #define WS_G1_OPS : [an] "=&v"(an), [bn] "=&v"(bn) : [a] "v"(a), [b] "v"(b), [pa] "v"(pa), [pb] "v"(pb), [tl] "n"(TILE), [mba] "n"(MBA), [t1] "n"(T1), [kx1] "n"(KX1) : "memory", WS_ACC_CLOBBER
 #define WS_G1_RD "ds_read_b128 %[an], %[pa] offset:4096*%[t1]+512*%[mba]\n\tds_read_b128 %[bn], %[pb] offset:16*%[kx1]"
-  if constexpr (ZERO) asm volatile("v_mfma_f32_32x32x16_bf16 a[16*%[tl]:16*%[tl]+15], %[a], %[b], 0\n\t" WS_G1_RD WS_G1_OPS);
-  else asm volatile("v_mfma_f32_32x32x16_bf16 a[16*%[tl]:16*%[tl]+15], %[a], %[b], a[16*%[tl]:16*%[tl]+15]\n\t" WS_G1_RD WS_G1_OPS);
+  if constexpr (ZERO) asm volatile(WS_MFZ("16*%[tl]", "%[a]", "%[b]") "\n\t" WS_G1_RD WS_G1_OPS);
+  else asm volatile(WS_MF("16*%[tl]", "%[a]", "%[b]") "\n\t" WS_G1_RD WS_G1_OPS);
 #undef WS_G1_OPS
 #undef WS_G1_RD
 }
@@ -197,17 +209,17 @@ __device__ __forceinline__ void ws_g1(const u32x4& a, const u32x4& b, u32x4& an,
 template <int TILE, bool ZERO, bool BARRIER = false>
 __device__ __forceinline__ void ws_g0(const u32x4& a, const u32x4& b) {
 #define WS_G0_OPS : : [a] "v"(a), [b] "v"(b), [tl] "n"(TILE) : "memory", WS_ACC_CLOBBER
-  if constexpr (ZERO) asm volatile("v_mfma_f32_32x32x16_bf16 a[16*%[tl]:16*%[tl]+15], %[a], %[b], 0" WS_G0_OPS);
-  else if constexpr (BARRIER) asm volatile("v_mfma_f32_32x32x16_bf16 a[16*%[tl]:16*%[tl]+15], %[a], %[b], a[16*%[tl]:16*%[tl]+15]\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" WS_G0_OPS);
-  else asm volatile("v_mfma_f32_32x32x16_bf16 a[16*%[tl]:16*%[tl]+15], %[a], %[b], a[16*%[tl]:16*%[tl]+15]" WS_G0_OPS);
+  if constexpr (ZERO) asm volatile(WS_MFZ("16*%[tl]", "%[a]", "%[b]") "" WS_G0_OPS);
+  else if constexpr (BARRIER) asm volatile(WS_MF("16*%[tl]", "%[a]", "%[b]") "\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" WS_G0_OPS);
+  else asm volatile(WS_MF("16*%[tl]", "%[a]", "%[b]") "" WS_G0_OPS);
 #undef WS_G0_OPS
 }
 // MFMA, then the step's four operand reads are retired
 template <int TILE, bool ZERO>
 __device__ __forceinline__ void ws_gw(const u32x4& a, const u32x4& b, u32x4& an0, u32x4& an1, u32x4& bn0, u32x4& bn1) {
 #define WS_GW_OPS : [an0] "+v"(an0), [an1] "+v"(an1), [bn0] "+v"(bn0), [bn1] "+v"(bn1) : [a] "v"(a), [b] "v"(b), [tl] "n"(TILE) : "memory", WS_ACC_CLOBBER
-  if constexpr (ZERO) asm volatile("v_mfma_f32_32x32x16_bf16 a[16*%[tl]:16*%[tl]+15], %[a], %[b], 0\n\ts_waitcnt lgkmcnt(0)" WS_GW_OPS);
-  else asm volatile("v_mfma_f32_32x32x16_bf16 a[16*%[tl]:16*%[tl]+15], %[a], %[b], a[16*%[tl]:16*%[tl]+15]\n\ts_waitcnt lgkmcnt(0)" WS_GW_OPS);
+  if constexpr (ZERO) asm volatile(WS_MFZ("16*%[tl]", "%[a]", "%[b]") "\n\ts_waitcnt lgkmcnt(0)" WS_GW_OPS);
+  else asm volatile(WS_MF("16*%[tl]", "%[a]", "%[b]") "\n\ts_waitcnt lgkmcnt(0)" WS_GW_OPS);
 #undef WS_GW_OPS
 }
 // last step of a tile's FIRST chunk, behind the barrier: MFMA + three of the six operand quads of the next (tap-major) chunk's
@@ -216,14 +228,14 @@ template <int TILE, int MB0, bool WAIT>
 __device__ __forceinline__ void ws_g3(const u32x4& a, const u32x4& b, u32x4& an0, u32x4& an1, u32x4& bn, unsigned pa, unsigned pb, u32x4& x0, u32x4& x1,
                                       u32x4& x2) {
   if constexpr (WAIT)
-    asm volatile("v_mfma_f32_32x32x16_bf16 a[16*%[tl]:16*%[tl]+15], %[a], %[b], a[16*%[tl]:16*%[tl]+15]\n\t"
+    asm volatile(WS_MF("16*%[tl]", "%[a]", "%[b]") "\n\t"
                  "ds_read_b128 %[an0], %[pa] offset:512*%[mb0]\n\tds_read_b128 %[an1], %[pa] offset:512*%[mb0]+512\n\tds_read_b128 %[bn], %[pb]\n\t"
                  "s_waitcnt lgkmcnt(0)"
                  : [an0] "=&v"(an0), [an1] "=&v"(an1), [bn] "=&v"(bn), [x0] "+v"(x0), [x1] "+v"(x1), [x2] "+v"(x2)
                  : [a] "v"(a), [b] "v"(b), [pa] "v"(pa), [pb] "v"(pb), [tl] "n"(TILE), [mb0] "n"(MB0)
                  : "memory", WS_ACC_CLOBBER);
   else
-    asm volatile("v_mfma_f32_32x32x16_bf16 a[16*%[tl]:16*%[tl]+15], %[a], %[b], a[16*%[tl]:16*%[tl]+15]\n\t"
+    asm volatile(WS_MF("16*%[tl]", "%[a]", "%[b]") "\n\t"
                  "ds_read_b128 %[an0], %[pa] offset:512*%[mb0]\n\tds_read_b128 %[an1], %[pa] offset:512*%[mb0]+512\n\tds_read_b128 %[bn], %[pb]"
                  : [an0] "=&v"(an0), [an1] "=&v"(an1), [bn] "=&v"(bn)
                  : [a] "v"(a), [b] "v"(b), [pa] "v"(pa), [pb] "v"(pb), [tl] "n"(TILE), [mb0] "n"(MB0)
@@ -261,9 +273,6 @@ __device__ __forceinline__ void ws_prefetch(u32x4& an0, u32x4& an1, u32x4& an2, 
 // not decode the next tile (its input then comes out of L2: the clock rises), 16 = no epilogue in the gaps of the
 // group-major chunks, 32 = the slot decode twice, 64 = plain moves instead of accumulator reads, 128 = chunk 1 does not stage the parked units
 // (0.3 k of layer 5's 22 k cycles per tile)
-#ifndef WS_ABL
-#define WS_ABL 0
-#endif
 #define WS_ABLATE(BIT) ((WS_ABL & (BIT)) != 0)
 #ifdef YOGO_DIAG
 #define WS_DBG(BIT) (p.dbg & (BIT))
