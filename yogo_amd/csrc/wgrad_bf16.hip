@@ -16,6 +16,7 @@
 // offsets (which the buffer unit writes as zeros).  One barrier per unit, up to two units in flight ahead of the MFMAs.  Split-K slabs + the fixed-order reduction of
 // wgrad_f32.hip (clamp, OIHW, bias) finish the gradient.
 #include "common.h"
+#include <mutex>
 #include <type_traits>
 #include <utility>
 
@@ -27,6 +28,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define WGB_LDS_MAX (160 * 1024)
 #ifndef WGB_BLK4
 #define WGB_BLK4 1   // (A/B variant builds: 0 = 16 consecutive pixels of a row per k-step on the 128 x 64 tiling too)
+#endif
+#ifndef WGB_BLK4_W
+#define WGB_BLK4_W 36  // BLK4: widest column chunk: 36 = 9 four-column steps, ring of two (the default); 20 = 5 steps, piece-tight buffers in a ring of FOUR -- built, parity-green and 8-13 % slower on layer 5 (gpurun_out/r6_wg_ab1.log): the kernel is not waiting for memory
 #endif
 #define WGB_GSLOTS 4  // LDS-DMA slots per lane and unit: gradient tile
 #define WGB_XSLOTS 6  // ... input tile
@@ -42,6 +46,8 @@ struct WgradBf16Params {
   int xw;                             // staged input columns per unit
   int units, units_per_split;
   int ngs, nxs, bufu;                 // g / x slots in use, 16-byte units per LDS buffer
+  int xoff;                           // first unit of the x image inside an LDS buffer (ngs * threads, or the g image rounded up to a whole piece)
+  int nsb;                            // BLK4: four-column steps of an ordinary chunk (8 or 4; a wide chunk takes one more)
   int xcb;                            // channel blocks per pixel of the staged x image: 4, or 2 for 16-channel inputs
   int depth;                          // LDS buffers in the ring (2 or 3): units in flight ahead of the MFMAs = depth - 1
 #ifdef YOGO_DIAG
@@ -59,7 +65,14 @@ extern "C" int yogo_diag_wgrad_bf16_stamps(void* buf, size_t bytes) { g_wb_stamp
 #define WB_T() (p.stamps ? __builtin_amdgcn_s_memtime() : 0ull)
 #define WB_STAMP(ACC) if (p.stamps) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ACC += t_ - tk_; tk_ = t_; __builtin_amdgcn_sched_barrier(0); }
 #else
-#define WB_DIAG(BIT) 0
+// compile-time ablations of the product build (build.sh variant TAG wgrad_bf16 -DWGB_ABL=bits + tools/ab_variants.py; timings only, the
+// results are wrong): 1 = no MFMAs, 2 = no operand reads, 4 = no LDS-DMA, 8 = every DMA piece out of range (zero fill, no memory traffic),
+// 16 = the second ci-half workgroup zero-fills its gradient tile (what sharing it would save), 32 = the halo rows of the input tile are
+// zero-filled (what a row ring would save), 64 = BLK4: the next unit's DMA in one block behind the barrier instead of one slot per step
+#ifndef WGB_ABL
+#define WGB_ABL 0
+#endif
+#define WB_DIAG(BIT) ((WGB_ABL & (BIT)) != 0)
 #define WB_T() 0ull
 #define WB_STAMP(ACC)
 #endif
@@ -86,7 +99,7 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* ptr, int bytes) {
 __device__ __forceinline__ void wait_dma(int n) {
   switch (n) {
 #define WD_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-    WD_CASE(1) WD_CASE(2) WD_CASE(3) WD_CASE(4) WD_CASE(5) WD_CASE(6) WD_CASE(7) WD_CASE(8) WD_CASE(9) WD_CASE(10)
+    WD_CASE(1) WD_CASE(2) WD_CASE(3) WD_CASE(4) WD_CASE(5) WD_CASE(6) WD_CASE(7) WD_CASE(8) WD_CASE(9) WD_CASE(10) WD_CASE(11) WD_CASE(12) WD_CASE(13) WD_CASE(14) WD_CASE(15) WD_CASE(16)
 #undef WD_CASE
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
@@ -162,8 +175,15 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
   // lc = byte offset inside the image for unit origin (0, 0), rc = r << 16 | c (all ones: never valid)
   int glc[WGB_GSLOTS], xlc[WGB_XSLOTS];
   unsigned grc[WGB_GSLOTS], xrc[WGB_XSLOTS];
+  const int gtot = MBW * MPW * 4 * R * p.wce, xtot = NBW * NPW * p.xcb * XR * p.xw;
+  // a piece (this wavefront's 64 units of a slot) that lies wholly behind the image is not issued: the images can then be packed
+  // piece-tight (xoff), and the counted waits below go by what THIS wavefront issues per unit
+  int my_pieces = 0;
+#pragma unroll
+  for (int i = 0; i < WGB_GSLOTS; ++i) my_pieces += (i < p.ngs && i * NT + wave * 64 < gtot) ? 1 : 0;
+#pragma unroll
+  for (int i = 0; i < WGB_XSLOTS; ++i) my_pieces += (i < p.nxs && i * NT + wave * 64 < xtot) ? 1 : 0;
   {
-    const int gtot = MBW * MPW * 4 * R * p.wce, xtot = NBW * NPW * p.xcb * XR * p.xw;
 #pragma unroll
     for (int i = 0; i < WGB_GSLOTS; ++i) {
       const int e = tid + i * NT;
@@ -210,22 +230,24 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
     /* input columns this chunk's VALID gradient columns touch: the rest of the staged width is zero-filled, not fetched */ \
     const int xneed_ = (wc_ - 1) * S + (T == 1 ? 1 : 3);
 #define WB_ISSUE_G(i)                                                                                                 \
-      if ((i) < p.ngs && !WB_DIAG(4)) {                                                                               \
+      if ((i) < p.ngs && (i) * NT + wave * 64 < gtot && !WB_DIAG(4)) {                                                \
         const int c_ = (int)(grc[i] & 0xFFFFu), r_ = (int)(grc[i] >> 16);                                             \
-        const bool ok_ = (c_ < wc_) && (r_ < rmax_) && !WB_DIAG(8);                                                   \
+        const bool ok_ = (c_ < wc_) && (r_ < rmax_) && !WB_DIAG(8) && !(WB_DIAG(16) && blockIdx.y == 1);              \
         dma16(rs_g, lb_ + (i) * NT * 16, ok_ ? glc[i] + gorg_ : (int)OOB);                                            \
       }
 #define WB_ISSUE_X(i)                                                                                                 \
-      if ((i) < p.nxs && !WB_DIAG(4)) {                                                                               \
+      if ((i) < p.nxs && (i) * NT + wave * 64 < xtot && !WB_DIAG(4)) {                                                \
         const int c_ = (int)(xrc[i] & 0xFFFFu), r_ = (int)(xrc[i] >> 16);                                             \
-        const bool ok_ = ((unsigned)(iy0_ + r_) < (unsigned)p.IH) && ((unsigned)(ix0_ + c_) < (unsigned)p.IW) && (c_ < xneed_) && !WB_DIAG(8); \
-        dma16(rs_x, lb_ + (p.ngs + (i)) * NT * 16, ok_ ? xlc[i] + xorg_ : (int)OOB);                                  \
+        const bool ok_ = ((unsigned)(iy0_ + r_) < (unsigned)p.IH) && ((unsigned)(ix0_ + c_) < (unsigned)p.IW) && (c_ < xneed_) && !WB_DIAG(8) && !(WB_DIAG(32) && r_ >= R); \
+        dma16(rs_x, lb_ + (p.xoff + (i) * NT) * 16, ok_ ? xlc[i] + xorg_ : (int)OOB);                                 \
       }
+#define WB_ISSUE_SLOTS                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < WGB_GSLOTS; ++i) { WB_ISSUE_G(i) }                                          \
+    _Pragma("unroll") for (int i = 0; i < WGB_XSLOTS; ++i) { WB_ISSUE_X(i) }
 #define WB_ISSUE(BUF)                                                                                                 \
   {                                                                                                                   \
     WB_ISSUE_PREP(BUF)                                                                                                \
-    _Pragma("unroll") for (int i = 0; i < WGB_GSLOTS; ++i) { WB_ISSUE_G(i) }                                          \
-    _Pragma("unroll") for (int i = 0; i < WGB_XSLOTS; ++i) { WB_ISSUE_X(i) }                                          \
+    WB_ISSUE_SLOTS                                                                                                    \
   }
 
   // ---- per-lane operand addressing for the transposed reads ----------------------------------------------------------
@@ -241,7 +263,7 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
   const int xblk = XR * p.xw * xpb;                       // bytes of one channel-block group of the x image
   const int gbase = mb * MPW * (R * p.wce * 64) + lane_ch_off;
   // 16-channel image: the lanes of channels 16-31 re-read channels 0-15 (those output columns lie beyond N and are dropped)
-  const int xbase = p.ngs * NT * 16 + nb * NPW * xblk + (lane_ch_off & (xpb - 1)) + (PACK2 ? (gi & 1) * xpb : 0);
+  const int xbase = p.xoff * 16 + nb * NPW * xblk + (lane_ch_off & (xpb - 1)) + (PACK2 ? (gi & 1) * xpb : 0);
   // (BLK4: k = 8 (gi >> 1) + 4 j + q -> block row 2 (gi >> 1) + j (j = the first / second transposed read), block column q)
   [[maybe_unused]] const int lean_a0 = BLK4 ? gbase + ((gi >> 1) * 2 * p.wce + q4) * 64 : gbase + lane_px * 64;                                     // (xpb = 64 on this path)
   [[maybe_unused]] const int lean_b0 = BLK4 ? xbase + (((gi >> 1) * 2 + tg) * p.xw + q4) * 64 : xbase + ((T == 1 ? 0 : tg) * p.xw + lane_px * S) * 64;
@@ -275,9 +297,8 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
   // ring of p.depth LDS buffers: unit u + depth - 1 streams in while unit u is multiplied.  Ordering (LDS-DMA is invisible to
   // the barrier): every wave waits for ITS loads of unit u with a counted vmcnt, then the barrier makes all of them visible and
   // proves that nobody still reads the buffer the next issue overwrites.
-  const int nslots = p.ngs + p.nxs;
-  if (u_begin < u_end) WB_ISSUE(0)
-  if (p.depth == 3 && u_begin + 1 < u_end) WB_ISSUE(1)
+  for (int d = 0; d + 1 < p.depth; ++d)
+    if (u_begin + d < u_end) WB_ISSUE(d)
   int ib = 0;
   [[maybe_unused]] unsigned long long tw_ = 0, ti_ = 0, tc_ = 0, t0_ = WB_T(), tk_ = t0_;
   // (LEAN: one copy of the unit loop per number of 16-pixel steps in a row, so that the steps of a unit unroll completely)
@@ -291,7 +312,7 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
   [[maybe_unused]] constexpr int KR = decltype(kr_tag)::value;
   [[maybe_unused]] constexpr bool LEAN2 = decltype(mode_tag)::value == 2;
   for (int u = u_begin; u < u_end; ++u) {
-    wait_dma((p.depth == 3 && u + 1 < u_end) ? nslots : 0);
+    wait_dma(max(0, min(p.depth - 2, u_end - 1 - u)) * my_pieces);   // (the units behind u that are already in flight)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     WB_STAMP(tw_)
@@ -309,7 +330,9 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
       WB_ISSUE_PREP(nb_)
       // this unit's chunk: 33 columns take a ninth step
       const int cwi_ = u % p.nchunk_w;
-      const bool wide = p.base_w + (cwi_ < p.rem_w ? 1 : 0) > 32;   // uniform
+      constexpr int NSB = KR;                                            // steps of an ordinary chunk (8: chunks of <= 36 columns, 4: <= 20)
+      constexpr int GS = NSB == 8 ? WGB_GSLOTS : 2;                      // steps that carry a gradient slot of the next unit (the planner keeps ngs <= GS)
+      const bool wide = p.base_w + (cwi_ < p.rem_w ? 1 : 0) > 4 * NSB;   // uniform
       const int rowa = p.wce * 64, rowx = p.xw * 64;
       const unsigned char* pa0 = buf + lean_a0;
       const unsigned char* pa0j = pa0 + rowa;
@@ -335,15 +358,18 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
         fetch(std::integral_constant<int, 0>{});
         auto step = [&](auto e_tag) __attribute__((always_inline)) {
           constexpr int e = decltype(e_tag)::value, set = e & 1;
-          if constexpr (e + 1 < 8) fetch(std::integral_constant<int, e + 1>{});
-          else if constexpr (e + 1 == 8) { if (wide) fetch(std::integral_constant<int, 8>{}); }
+          if constexpr (e + 1 < NSB) fetch(std::integral_constant<int, e + 1>{});
+          else if constexpr (e + 1 == NSB) { if (wide) fetch(std::integral_constant<int, NSB>{}); }
           if (!WB_DIAG(1)) { WB_MFMA(av[set], bvv[set]); }
+          if (issue_ && WB_DIAG(64)) {
+            if constexpr (e == 0) { WB_ISSUE_SLOTS }
+          } else
           if (issue_) {   // the next unit's DMA: one slot behind the MFMAs of each of the first steps
-            if constexpr (e < WGB_GSLOTS) { WB_ISSUE_G(e) }
-            else if constexpr (e - WGB_GSLOTS < WGB_XSLOTS) { WB_ISSUE_X(e - WGB_GSLOTS) }
-            if constexpr (e == 7) {
+            if constexpr (e < GS) { WB_ISSUE_G(e) }
+            else if constexpr (e < NSB && e - GS < WGB_XSLOTS) { WB_ISSUE_X(e - GS) }
+            if constexpr (e == NSB - 1) {
 #pragma unroll
-              for (int sl = 8 - WGB_GSLOTS; sl < WGB_XSLOTS; ++sl) { WB_ISSUE_X(sl) }
+              for (int sl = NSB - GS; sl < WGB_XSLOTS; ++sl) { WB_ISSUE_X(sl) }
             }
           }
           if (do_bias) {   // the NBW * TG wavefronts that hold the same gradient operand take turns summing it
@@ -357,10 +383,10 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
           }
           __builtin_amdgcn_sched_barrier(0);
         };
-        wb_static_for(step, std::make_integer_sequence<int, 8>{});
-        if (wide) step(std::integral_constant<int, 8>{});
+        wb_static_for(step, std::make_integer_sequence<int, NSB>{});
+        if (wide) step(std::integral_constant<int, NSB>{});
       } else if (issue_) {
-        WB_ISSUE(nb_)
+        WB_ISSUE_SLOTS   // (diagnostic: no operand reads -- the DMA still goes out; PREP above has advanced the iterators)
       }
     } else
     if constexpr (LEAN) {
@@ -453,7 +479,7 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
         };
         wb_static_for(step, std::make_integer_sequence<int, NS2>{});
       } else if (issue_) {
-        WB_ISSUE(nb_)   // (diagnostic: no operand reads -- the DMA still has to go out; the iterators were advanced by PREP above)
+        WB_ISSUE_SLOTS   // (diagnostic: no operand reads -- the DMA still has to go out; the iterators were advanced by PREP above)
       }
     } else
     if (cnt > 0) {
@@ -490,7 +516,8 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
   }
   };
   if constexpr (BLK4) {
-    unit_loop(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+    if (p.nsb == 4) unit_loop(std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{});
+    else unit_loop(std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{});
   } else if constexpr (LEAN) {
     switch (ksteps_row) {
       case 1: unit_loop(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}); break;
@@ -519,6 +546,7 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
   }
 #endif
 #undef WB_ISSUE
+#undef WB_ISSUE_SLOTS
 #undef WB_ISSUE_PREP
 #undef WB_ISSUE_G
 #undef WB_ISSUE_X
@@ -569,7 +597,7 @@ thread_local char g_wb_plan_txt[256] = "";  // planner parameters of the launch 
 struct WbPlan {
   bool blk4;
   int MBW, NBW, NPW, MPW, KS, R, Mpad, Npad, nchunk_w, base_w, rem_w, wce, nrowg, xw, units, nsplit, units_per_split, ngs, nxs, bufu,
-      depth, lds_bytes, xcb;
+      depth, lds_bytes, xcb, xoff, nsb;
   dim3 grid;
 };
 
@@ -592,9 +620,9 @@ bool wb_plan(int B, int N, int M, int IH, int IW, int ks, int stride, WbPlan* pl
   // rows per unit: few channels -> little MFMA work per row, so take more rows per barrier
   const bool tall = MBW == 1 && NBW == 1 && ks == 3 && stride == 1 && OH >= 64;
   int R = (NPW == 2 || MPW == 2) ? (stride == 1 ? 3 : 2) : (stride == 1 ? (tall ? 8 : 4) : 2);
-  const bool blk4 = MPW == 2 && stride == 1 && ks == 3 && WGB_BLK4;   // 4 x 4-pixel k-steps (wgrad_bf16_kernel, BLK4)
-  pl->blk4 = blk4;
-  pl->MBW = MBW; pl->NBW = NBW; pl->NPW = NPW; pl->MPW = MPW; pl->KS = KS; pl->R = blk4 ? 4 : R;
+  bool blk4 = MPW == 2 && stride == 1 && ks == 3 && WGB_BLK4;   // 4 x 4-pixel k-steps (wgrad_bf16_kernel, BLK4)
+  const int R_row = R;                                          // rows per unit of the row-step loop (when the BLK4 staging does not fit)
+  pl->MBW = MBW; pl->NBW = NBW; pl->NPW = NPW; pl->MPW = MPW; pl->KS = KS;
   pl->Mpad = round_up(M, 32 * MBW * MPW);
   pl->Npad = round_up(N, 32 * NBW * NPW);
   if (blk4) R = 4;
@@ -607,27 +635,48 @@ bool wb_plan(int B, int N, int M, int IH, int IW, int ks, int stride, WbPlan* pl
   // count with the least zero padding
   bool found = false;
   int best_waste = 1 << 30;
-  if (blk4) {   // chunks of at most 36 columns (9 four-column steps), staged 36 wide
-    const int w = 36, xw = w + 2;
-    const int ngs = cdiv(MBW * MPW * 4 * R * w, NT), nxs = cdiv(NBW * NPW * xcb * XR * xw, NT);
-    const int bufu = (ngs + nxs) * NT;
-    if (ngs <= WGB_GSLOTS && nxs <= WGB_XSLOTS && 2 * bufu * 16 <= WGB_LDS_MAX) {
-      pl->nchunk_w = cdiv(OW, w); pl->wce = w; pl->xw = xw; pl->ngs = ngs; pl->nxs = nxs; pl->bufu = bufu;
+  pl->depth = 0;
+  if (blk4) {
+    // chunks of at most w columns = nsb four-column steps + a last one for a wide chunk; the two images are packed piece-tight (the
+    // kernel does not issue a piece that lies wholly behind its image), the ring is as deep as the LDS allows (at most four).  Among
+    // the chunk counts the one with the fewest steps per row: 129 columns = 17 + 7 x 16 (33 steps), 258 = 11 x 20 + 2 x 19 (65).
+    const int wlist[2] = {WGB_BLK4_W, 36};
+    for (int wi = 0; wi < 2 && !found; ++wi) {
+      const int w = wlist[wi], xw = w + 2, nsb = w / 4 - 1;
+      if (nsb != 8 && nsb != 4) continue;
+      const int gtot = MBW * MPW * 4 * R * w, xtot = NBW * NPW * xcb * XR * xw;
+      const int ngs = cdiv(gtot, NT), nxs = cdiv(xtot, NT);
+      const int xoff = round_up(gtot, 64), bufu = xoff + round_up(xtot, 64);
+      if (ngs > (nsb == 8 ? WGB_GSLOTS : 2) || nxs > WGB_XSLOTS || 2 * bufu * 16 > WGB_LDS_MAX) continue;
+      int best_steps = 1 << 30, best_nc = 0;
+      for (int nc = cdiv(OW, w); nc <= cdiv(OW, w) + 3 && nc <= OW; ++nc) {
+        const int base = OW / nc, rem = OW - base * nc;
+        if (base + (rem ? 1 : 0) > w) continue;
+        const int steps = rem * (base + 1 > 4 * nsb ? nsb + 1 : nsb) + (nc - rem) * (base > 4 * nsb ? nsb + 1 : nsb);
+        if (steps < best_steps) { best_steps = steps; best_nc = nc; }
+      }
+      if (best_nc == 0) continue;
+      pl->nchunk_w = best_nc; pl->wce = w; pl->xw = xw; pl->ngs = ngs; pl->nxs = nxs; pl->bufu = bufu; pl->xoff = xoff; pl->nsb = nsb;
+      pl->depth = min(4, WGB_LDS_MAX / (bufu * 16));
       found = true;
     }
+    if (!found) { blk4 = false; R = R_row; }   // (unreachable with today's constants: the row-step loop then takes the launch)
   }
+  pl->blk4 = blk4;
+  pl->R = R;
+  const int XR_row = ks == 3 ? (R - 1) * stride + 3 : R;
   for (int wmax = 64; wmax >= 16 && !found; wmax -= 16) {
     for (int nc = cdiv(OW, wmax); nc <= cdiv(OW, wmax) + 4 && nc <= OW; ++nc) {
       const int w = round_up(cdiv(OW, nc), 16);
       if (w > wmax) continue;
       const int xw = (w - 1) * stride + (ks == 3 ? 3 : 1);
-      const int ngs = cdiv(MBW * MPW * 4 * R * w, NT), nxs = cdiv(NBW * NPW * xcb * XR * xw, NT);
+      const int ngs = cdiv(MBW * MPW * 4 * R * w, NT), nxs = cdiv(NBW * NPW * xcb * XR_row * xw, NT);
       const int bufu = (ngs + nxs) * NT;
       if (ngs > WGB_GSLOTS || nxs > WGB_XSLOTS || 2 * bufu * 16 > WGB_LDS_MAX) continue;
       const int waste = nc * w - OW;
       if (waste < best_waste) {
         best_waste = waste;
-        pl->nchunk_w = nc; pl->wce = w; pl->xw = xw; pl->ngs = ngs; pl->nxs = nxs; pl->bufu = bufu;
+        pl->nchunk_w = nc; pl->wce = w; pl->xw = xw; pl->ngs = ngs; pl->nxs = nxs; pl->bufu = bufu; pl->xoff = ngs * NT; pl->nsb = 0;
         found = true;
       }
     }
@@ -635,7 +684,7 @@ bool wb_plan(int B, int N, int M, int IH, int IW, int ks, int stride, WbPlan* pl
   if (!found) return false;
   pl->base_w = OW / pl->nchunk_w;
   pl->rem_w = OW - pl->base_w * pl->nchunk_w;
-  pl->depth = 3 * pl->bufu * 16 <= WGB_LDS_MAX ? 3 : 2;
+  if (pl->depth == 0) pl->depth = 3 * pl->bufu * 16 <= WGB_LDS_MAX ? 3 : 2;
   pl->lds_bytes = pl->depth * pl->bufu * 16;
   pl->nrowg = cdiv(OH, R);
   pl->units = B * pl->nrowg * pl->nchunk_w;
@@ -656,24 +705,40 @@ int wb_bias_rows(const WbPlan& pl, int T) {
 }
 
 template <int MBW, int NBW, int NPW, int KS, int T, int S, int R, int MPW = 1, bool ROT = false, bool PACK2 = false, bool BLK4 = false>
-void wb_launch_one(const WgradBf16Params& p, const WbPlan& pl, hipStream_t stream) {
-  static bool s = false;
-  if (!s) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<MBW, NBW, NPW, KS, T, S, R, MPW, ROT, PACK2, BLK4>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, WGB_LDS_MAX);
-    s = true;
+int wb_launch_one(const WgradBf16Params& p, const WbPlan& pl, hipStream_t stream) {
+  // per device, once per instantiation: the dynamic-LDS limit (a second device in the process, or a first call from two host threads,
+  // must not see another device's state)
+  static std::mutex mu;
+  static bool done[64] = {false};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+    yogo_set_error("wgrad_bf16: hipGetDevice failed");
+    return YOGO_ERR_HIP;
+  }
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (!done[dev]) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<MBW, NBW, NPW, KS, T, S, R, MPW, ROT, PACK2, BLK4>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, WGB_LDS_MAX);
+      if (e != hipSuccess) {
+        yogo_set_error("wgrad_bf16: hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) failed: %s", WGB_LDS_MAX, hipGetErrorString(e));
+        return YOGO_ERR_HIP;
+      }
+      done[dev] = true;
+    }
   }
   hipLaunchKernelGGL((wgrad_bf16_kernel<MBW, NBW, NPW, KS, T, S, R, MPW, ROT, PACK2, BLK4>), pl.grid, dim3(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)),
                      pl.lds_bytes, stream, p);
   yogo_launch_log("wgrad_bf16_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %s, %s, %s> | %s", MBW, NBW, NPW, KS, T, S, R, MPW, ROT ? "true" : "false",
                   PACK2 ? "true" : "false", BLK4 ? "true" : "false", g_wb_plan_txt);
+  return YOGO_OK;
 }
 
 template <int MBW, int NBW, int KS>
-void wb_launch(const WgradBf16Params& p, const WbPlan& pl, int T, int stride, hipStream_t stream) {
-  if (T == 1) wb_launch_one<MBW, NBW, 1, KS, 1, 1, 4>(p, pl, stream);
-  else if (stride == 1) wb_launch_one<MBW, NBW, 1, KS, 9, 1, 4>(p, pl, stream);
-  else wb_launch_one<MBW, NBW, 1, KS, 9, 2, 2>(p, pl, stream);
+int wb_launch(const WgradBf16Params& p, const WbPlan& pl, int T, int stride, hipStream_t stream) {
+  if (T == 1) return wb_launch_one<MBW, NBW, 1, KS, 1, 1, 4>(p, pl, stream);
+  if (stride == 1) return wb_launch_one<MBW, NBW, 1, KS, 9, 1, 4>(p, pl, stream);
+  return wb_launch_one<MBW, NBW, 1, KS, 9, 2, 2>(p, pl, stream);
 }
 
 }  // namespace
@@ -727,34 +792,36 @@ static int conv2d_wgrad_bf16_impl(const void* x, const void* g, float* dw, float
     if (p.stamps) (void)hipMemsetAsync(p.stamps, 0, nwg * 32, stream);
   }
 #endif
-  p.units = pl.units; p.units_per_split = pl.units_per_split; p.ngs = pl.ngs; p.nxs = pl.nxs; p.bufu = pl.bufu; p.depth = pl.depth; p.xcb = pl.xcb;
+  p.units = pl.units; p.units_per_split = pl.units_per_split; p.ngs = pl.ngs; p.nxs = pl.nxs; p.bufu = pl.bufu; p.depth = pl.depth; p.xcb = pl.xcb; p.xoff = pl.xoff; p.nsb = pl.nsb;
   if (yogo_launch_log_enabled())
-    snprintf(g_wb_plan_txt, sizeof(g_wb_plan_txt), "N=%d M=%d in=%dx%d s=%d T=%d B=%d R=%d wce=%d nchunk_w=%d xw=%d slots=%d+%d depth=%d lds=%d units=%d units_per_split=%d grid=%ux%ux%u",
-             Cin, Cout, IH, IW, stride, T, B, pl.R, pl.wce, pl.nchunk_w, pl.xw, pl.ngs, pl.nxs, pl.depth, pl.lds_bytes, pl.units, pl.units_per_split,
+    snprintf(g_wb_plan_txt, sizeof(g_wb_plan_txt), "N=%d M=%d in=%dx%d s=%d T=%d B=%d R=%d wce=%d nchunk_w=%d xw=%d nsb=%d slots=%d+%d depth=%d lds=%d units=%d units_per_split=%d grid=%ux%ux%u",
+             Cin, Cout, IH, IW, stride, T, B, pl.R, pl.wce, pl.nchunk_w, pl.xw, pl.nsb, pl.ngs, pl.nxs, pl.depth, pl.lds_bytes, pl.units, pl.units_per_split,
              pl.grid.x, pl.grid.y, pl.grid.z);
+  int lrc = YOGO_OK;
   if (pl.MPW == 2) {
-    if (stride == 1 && pl.blk4) wb_launch_one<2, 2, 1, 1, 9, 1, 4, 2, false, false, true>(p, pl, stream);
-    else if (stride == 1) wb_launch_one<2, 2, 1, 1, 9, 1, 3, 2>(p, pl, stream);
-    else wb_launch_one<2, 2, 1, 1, 9, 2, 2, 2>(p, pl, stream);
+    if (stride == 1 && pl.blk4) lrc = wb_launch_one<2, 2, 1, 1, 9, 1, 4, 2, false, false, true>(p, pl, stream);
+    else if (stride == 1) lrc = wb_launch_one<2, 2, 1, 1, 9, 1, 3, 2>(p, pl, stream);
+    else lrc = wb_launch_one<2, 2, 1, 1, 9, 2, 2, 2>(p, pl, stream);
   } else {
     const int cfg = pl.MBW * 100 + pl.NBW * 10 + pl.KS;
     if (pl.R == 8 && pl.xcb == 2) {
-      wb_launch_one<1, 1, 1, 4, 9, 1, 8, 1, false, true>(p, pl, stream);
+      lrc = wb_launch_one<1, 1, 1, 4, 9, 1, 8, 1, false, true>(p, pl, stream);
     } else if (pl.R == 8) {
-      wb_launch_one<1, 1, 1, 4, 9, 1, 8>(p, pl, stream);
+      lrc = wb_launch_one<1, 1, 1, 4, 9, 1, 8>(p, pl, stream);
     } else
     switch (cfg) {
-      case 411: wb_launch<4, 1, 1>(p, pl, T, stride, stream); break;
-      case 221: wb_launch<2, 2, 1>(p, pl, T, stride, stream); break;
-      case 212: wb_launch<2, 1, 2>(p, pl, T, stride, stream); break;
-      case 141: wb_launch<1, 4, 1>(p, pl, T, stride, stream); break;
-      case 122: wb_launch<1, 2, 2>(p, pl, T, stride, stream); break;
-      case 114: wb_launch<1, 1, 4>(p, pl, T, stride, stream); break;
+      case 411: lrc = wb_launch<4, 1, 1>(p, pl, T, stride, stream); break;
+      case 221: lrc = wb_launch<2, 2, 1>(p, pl, T, stride, stream); break;
+      case 212: lrc = wb_launch<2, 1, 2>(p, pl, T, stride, stream); break;
+      case 141: lrc = wb_launch<1, 4, 1>(p, pl, T, stride, stream); break;
+      case 122: lrc = wb_launch<1, 2, 2>(p, pl, T, stride, stream); break;
+      case 114: lrc = wb_launch<1, 1, 4>(p, pl, T, stride, stream); break;
       default:
         yogo_set_error("wgrad_bf16: unsupported wave layout %d", cfg);
         return YOGO_ERR_ARG;
     }
   }
+  if (lrc != YOGO_OK) return lrc;
   YOGO_CHECK_LAUNCH("conv2d_wgrad_bf16");
   const int nbias = wb_bias_rows(pl, T);
   return yogo_internal_wgrad_reduce_q(queue, p.slab, pl.nsplit * pl.KS, T, Cout, Cin, pl.Mpad, pl.Npad, clip, dw, p.bias_part, nbias, db, stream);
