@@ -236,7 +236,7 @@ def hooks_library():
         raise RuntimeError(f"{path} missing: run `bash yogo_amd/csrc/build.sh` (it builds the product and the hooks library)")
     _hip.lib()
     L = _hip.bind(path, _hip.prototypes())
-    hooks = ("yogo_hook_conv_bf16_persistent", "yogo_hook_conv_first_mfma_pairs", "yogo_hook_conv_first_bn_wgrad_pairs", "yogo_hook_conv_bf16_direct", "yogo_hook_conv_bf16_staged", "yogo_hook_conv_bf16_head")
+    hooks = ("yogo_hook_conv_bf16_persistent", "yogo_hook_conv_first_mfma_pairs", "yogo_hook_conv_first_bn_wgrad_pairs", "yogo_hook_conv_bf16_direct", "yogo_hook_conv_bf16_staged", "yogo_hook_conv_bf16_head", "yogo_hook_conv_bf16_ws16")
     for name in hooks:
         fn = getattr(L, name)
         fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_int]

@@ -14,18 +14,19 @@ def _blocks(c):
     return ((c + 15) // 16) * 2
 
 
-def _run(persistent, kind, B, Cin, H, W, seed):
-    """persistent: the PRODUCT library (libyogo_hip.so, which has no plan switch); tiled: the test-hooks library -- the same objects
-    plus yogo_hook_conv_bf16_persistent (tests/_util.py:hooks_library)"""
+def _run(persistent, kind, B, Cin, H, W, seed, ws16=True):
+    """persistent: the PRODUCT library (libyogo_hip.so, which has no plan switch); tiled, or persistent without the 16x16x32 member
+    (ws16 = False: conv_bf16_ws_kernel<0> takes the plain-epilogue launches as it did until round 5): the test-hooks library -- the same
+    objects plus the yogo_hook_* switches (tests/_util.py:hooks_library)"""
     import contextlib
 
     from _util import hooks_library
 
-    with (contextlib.nullcontext() if persistent else hooks_library()):
-        return _run_in(persistent, kind, B, Cin, H, W, seed)
+    with (contextlib.nullcontext() if (persistent and ws16) else hooks_library()):
+        return _run_in(persistent, kind, B, Cin, H, W, seed, ws16)
 
 
-def _run_in(persistent, kind, B, Cin, H, W, seed):
+def _run_in(persistent, kind, B, Cin, H, W, seed, ws16=True):
     from yogo_amd import _hip as Hh
 
     Cout = 128
@@ -38,6 +39,8 @@ def _run_in(persistent, kind, B, Cin, H, W, seed):
     msk = (torch.rand(B, Cout, device="cuda", generator=g) > 0.2).float() / 0.8
     if not persistent:
         Hh.call("yogo_hook_conv_bf16_persistent", 0)
+    elif not ws16:
+        Hh.call("yogo_hook_conv_bf16_ws16", 0)
     try:
         Hh.launch_log(True)
         sg = None
@@ -89,7 +92,7 @@ CASES = [
 @pytest.mark.parametrize("kind,B,Cin,H,W", CASES)
 def test_persistent_kernel_is_bit_identical_to_the_tiled_kernel(kind, B, Cin, H, W):
     y_old, s_old, log_old = _run(False, kind, B, Cin, H, W, seed=11)
-    y_new, s_new, log_new = _run(True, kind, B, Cin, H, W, seed=11)
+    y_new, s_new, log_new = _run(True, kind, B, Cin, H, W, seed=11, ws16=False)
     assert any(ln.startswith("conv_bf16_kernel<4, 2, 8") for ln in log_old), log_old
     assert any(ln.startswith("conv_bf16_ws_kernel<") for ln in log_new), log_new
     plan = next(ln for ln in log_old if ln.startswith("conv_bf16_kernel<4, 2, 8"))
@@ -109,6 +112,66 @@ def test_persistent_kernel_is_bit_identical_to_the_tiled_kernel(kind, B, Cin, H,
         assert (a != b).float().mean().item() < 5e-3
         if s_old is not None:
             assert (s_old != s_new).float().mean().item() < 5e-3
+
+
+# ---- the 16x16x32 member of the family (conv_bf16_ws16_kernel: convolution [+ bias], K a multiple of 64) ------------------------------
+WS16_CASES = [
+    ("fwd_plain", 2, 128, 97, 129),     # layer 5's forward at 772x1032
+    ("dgrad", 2, 128, 97, 129),         # the data gradients of layers 5 / 6
+    ("fwd_plain", 3, 64, 13, 17),       # two chunk pairs = six periods, fewer tiles than CUs, a partial tile per image
+    ("dgrad", 1, 64, 40, 300),          # several column bands
+    ("fwd_plain", 1, 128, 5, 700),      # short and wide
+    ("dgrad", 5, 128, 3, 3),            # 9 pixels: one pixel block partly in use
+    ("fwd_plain", 40, 128, 97, 129),    # 1 000 tiles: every workgroup walks several tiles, the image changes at the seams
+    ("dgrad", 2, 256, 20, 22),          # eight chunk pairs per tile
+    ("fwd_plain", 1, 128, 300, 3),      # one band of width 3
+    ("fwd_plain", 1, 64, 3, 1000),      # three rows: every tile holds the whole height
+    ("dgrad", 7, 128, 50, 131),
+    ("fwd_plain", 1, 192, 33, 35),      # six chunk pairs... (K = 192: Kb = 24)
+]
+
+
+@pytest.mark.parametrize("kind,B,Cin,H,W", WS16_CASES)
+def test_ws16_against_the_32x32x16_kernel_and_cpu(kind, B, Cin, H, W):
+    """conv_bf16_ws16_kernel sums the two 16-channel chunks of a pair inside one v_mfma_f32_16x16x32_bf16: another fp32 summation order
+    than conv_bf16_ws_kernel<0> (bit-identical to the tiled kernel, above) -- the bf16 outputs may differ by one rounding step on a few
+    values.  Plus an independent reference: torch's CPU float64 convolution of the same bf16-rounded operands
+    (yogo/model_defns.py:54-65: conv + bias in front of BatchNorm; the data gradient = conv_transpose2d)."""
+    import torch.nn.functional as F
+
+    from yogo_amd import _hip as Hh
+
+    y_old, _, log_old = _run(True, kind, B, Cin, H, W, seed=29, ws16=False)
+    y_new, _, log_new = _run(True, kind, B, Cin, H, W, seed=29)
+    assert any(ln.startswith("conv_bf16_ws_kernel<0>") for ln in log_old), log_old
+    assert any(ln.startswith("conv_bf16_ws16_kernel<") for ln in log_new), log_new
+    a, b = y_old.float(), y_new.float()
+    ulp = 2.0 ** -7 * torch.maximum(a.abs(), b.abs()) + 1e-6 * a.abs().max()
+    bad = (a - b).abs() > ulp
+    assert not bool(bad.any()), f"{int(bad.sum())} values beyond one bf16 step, first at {bad.nonzero()[0].tolist()}, max excess {((a - b).abs() - ulp).max().item()}"
+    assert (a != b).float().mean().item() < 5e-3
+    # two launches give the same bits
+    y_again, _, _ = _run(True, kind, B, Cin, H, W, seed=29)
+    assert torch.equal(y_new.view(torch.int16), y_again.view(torch.int16))
+    if B * H * W <= 40000:
+        st = Hh.stream_ptr()
+        g = torch.Generator(device="cuda").manual_seed(29)   # (the operands of _run_in, drawn again in the same order)
+        w = torch.randn(128, Cin, 3, 3, device="cuda", generator=g) * 0.05
+        x8 = torch.randn(B, _blocks(Cin), H, W, 8, device="cuda", generator=g).to(torch.bfloat16)
+        bias = torch.randn(128, device="cuda", generator=g)
+        _ = torch.rand(B, 128, device="cuda", generator=g)
+        x = torch.empty(B, Cin, H, W, device="cuda")
+        Hh.call("yogo_bf16_8c_to_nchw_f32", x8, x, B, Cin, H * W, st)
+        if kind == "fwd_plain":
+            want = F.conv2d(x.double().cpu(), w.to(torch.bfloat16).double().cpu(), bias.double().cpu(), padding=1)
+        else:
+            wf = torch.randn(Cin, 128, 3, 3, device="cuda", generator=g) * 0.05
+            want = F.conv_transpose2d(x.double().cpu(), wf.to(torch.bfloat16).double().cpu(), padding=1)
+        got = torch.empty(B, 128, H, W, device="cuda")
+        Hh.call("yogo_bf16_8c_to_nchw_f32", y_new, got, B, 128, H * W, st)
+        got = got.cpu().double()
+        tol = 2.0 ** -8 * want.abs() + 2e-5 * float(want.abs().max())
+        assert bool(((got - want).abs() <= tol).all()), float(((got - want).abs() - tol).max())
 
 
 def test_persistent_kernel_repeats_itself():

@@ -15,6 +15,7 @@
 // kernel is built around few, wide memory operations rather than around MFMA issue.
 #include "common.h"
 #include "conv_bf16_ws.h"
+#include "conv_bf16_ws16.h"
 #include "conv_bf16_ws3.h"
 #include <type_traits>
 #include <utility>
@@ -1353,6 +1354,9 @@ static bool g_bf_ring = true; // (diagnostic build: yogo_diag_conv_bf16_ring(0) 
 static bool g_bf_ws = true;
 // 0 = every launch goes to the tiled conv_bf16_kernel (A/B runs and the bit-identity tests of the two kernel families)
 extern "C" int yogo_hook_conv_bf16_persistent(int on) { g_bf_ws = on != 0; return YOGO_OK; }
+// 0 = the plain-epilogue launches stay on conv_bf16_ws_kernel<0> (32x32x16 MFMAs) instead of conv_bf16_ws16_kernel (16x16x32)
+static bool g_bf_ws16 = true;
+extern "C" int yogo_hook_conv_bf16_ws16(int on) { g_bf_ws16 = on != 0; return YOGO_OK; }
 // the direct (weights-resident, no staging) stride-2 data gradients (conv_bf16_direct.hip)
 static bool g_bf_direct = true;
 extern "C" int yogo_hook_conv_bf16_direct(int on) { g_bf_direct = on != 0; return YOGO_OK; }
@@ -1366,6 +1370,7 @@ extern "C" int yogo_hook_conv_bf16_head(int on) { g_bf_head = on != 0; return YO
 static constexpr bool g_bf_head = true;
 static constexpr bool g_bf_staged = true;
 static constexpr bool g_bf_ws = true;
+static constexpr bool g_bf_ws16 = true;
 static constexpr bool g_bf_direct = true;
 #endif
 bool conv_bf16_s2d_direct_eligible(int K, int M, int OH, int OW, int B);
@@ -1466,7 +1471,11 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
     q.stamps = (g_diag_stamps != nullptr && g_diag_stamps_bytes >= 512 * 128) ? g_diag_stamps : nullptr;
     if (q.stamps) (void)hipMemsetAsync(g_diag_stamps, 0, 512 * 128, stream);
 #endif
-    if (conv_bf16_ws_plan(&q)) return launch_conv_bf16_ws(q, stream);
+    if (conv_bf16_ws_plan(&q)) {
+      // the plain epilogue (convolution [+ bias]): the 16x16x32 member of the family
+      if (g_bf_ws16 && act == ACT_NONE && signs == nullptr && chan_scale == nullptr && conv_bf16_ws16_eligible(K, M, IH, IW, B)) return launch_conv_bf16_ws16(q, stream);
+      return launch_conv_bf16_ws(q, stream);
+    }
   }
   // stride-2 3x3 forward with 128 output channels and the lean epilogue: its persistent wavefront-specialised member (conv_bf16_ws3.hip)
   if (in != nullptr && g_bf_ws && !s2d && a == 2 && ks == 3 && out_f32 == nullptr && out_pre == nullptr && act_ref == nullptr && !signs_read &&
