@@ -25,8 +25,12 @@ kinds: M  tap-major (passes = taps, 8 slots each; the B set in use flips from pe
 epilogue of an accumulator tile: 4 v_accvgpr_read (+ 4 v_add_f32 of the bias), 2 v_cvt_pk_bf16_f32, one ds_write_b64 (temporaries v104..v127)
 """
 import re
+import sys
 
 NA, DA = 8, 6
+# timing-only ablations (wrong results): python tools/gen_ws16.py noepi|nobarx|... > yogo_amd/csrc/obj_var/TAG.inc, then
+# bash yogo_amd/csrc/build.sh variant TAG conv_bf16_ws16 -DW16_ASM_INC='"obj_var/TAG.inc"'
+ABL = set(sys.argv[1:])
 WSLOT, ISLOT = 24576, 32768
 T_RD = [[104, 105, 106, 107], [108, 109, 110, 111]]          # accumulator read-outs (two rotating sets)
 T_OUT = [[112, 113], [114, 115], [116, 117], [118, 119]]     # converted pairs (four rotating)
@@ -175,8 +179,9 @@ def gen(kind, bias, par=0, wslot=0):
                 st.mfma(4 * (4 * (s - 16) + pb), f"a{s % NA}", f"c{pb}", False)
         st.emit("s_nop 15")
         st.emit("s_nop 15")
-        st.emit("s_barrier")
-        for op in epilogue_ops([4, 5, 6, 7], bias):
+        if "nobarx" not in ABL:
+            st.emit("s_barrier")
+        for op in ([] if "noepi" in ABL else epilogue_ops([4, 5, 6, 7], bias)):
             emit_op(st, op)
         st.drain()
         st.emit("s_barrier")
@@ -202,7 +207,9 @@ def gen(kind, bias, par=0, wslot=0):
                         a_read(i)
             assert not rds
     epi, epi_from, epi_to = [], None, None
-    if kind == "F":
+    if "noepi" in ABL:
+        pass
+    elif kind == "F":
         epi, epi_from, epi_to = epilogue_ops([4, 5, 6, 7], bias), 3, 14
     elif kind == "L":
         epi, epi_from, epi_to = epilogue_ops([0, 1, 2, 3], bias), 10, 19
@@ -227,7 +234,7 @@ def gen(kind, bias, par=0, wslot=0):
                     rds += [("b", 0), ("b", 1)]
                 elif pos_in_pass == 1:
                     rds += [("b", 2), ("b", 3)]
-        if kind in ("F", "F0") and s == 3:
+        if kind in ("F", "F0") and s == 3 and "nobarx" not in ABL:
             st.emit("s_barrier")   # (X: the loaders have taken the staged half of the previous tile into registers)
         if kind == "L" and s == 18:   # the next tile's mailbox (written by the loaders in period 1): rides the DS queue of the period
             st.read_fixed([V_PBL, V_PBL + 1, V_PBL + 2, V_PBL + 3], "%[mba]", 0, "mbl")
@@ -268,7 +275,7 @@ def verify(kind, lines):
         m = re.match(r"v_mfma_f32_16x16x32_bf16 a\[(\d+):", l)
         if m:
             t = int(m.group(1))
-            if l.endswith(", 0") and kind == "F":
+            if l.endswith(", 0") and kind == "F" and "noepi" not in ABL:
                 for r in range(t, t + 4):
                     assert t < 64 or r in reads, f"{kind}: a{r} started again before its read-out"
             for r in range(t, t + 4):
@@ -280,9 +287,9 @@ def verify(kind, lines):
             assert r not in reads
             reads[r] = n_mfma
             assert n_mfma - last_mfma.get(r, -100) >= 8, f"{kind}: a{r} read {n_mfma - last_mfma[r]} MFMAs after its last MFMA"
-    if kind == "F":
+    if kind == "F" and "noepi" not in ABL:
         assert sorted(reads) == list(range(64, 128)), kind
-    if kind == "L":
+    if kind == "L" and "noepi" not in ABL:
         assert sorted(reads) == list(range(0, 64)), kind
 
 

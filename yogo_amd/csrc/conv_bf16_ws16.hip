@@ -24,7 +24,15 @@
 // Summation order: the two chunks of a pair are summed inside one MFMA, so results differ from conv_bf16_ws_kernel / the tiled kernel
 // in the last fp32 bits: contract = one bf16 ulp on a small fraction of the outputs + the CPU fp64 reference (tests/test_gpu_ws.py).
 #include "conv_bf16_ws16.h"
-#include "conv_bf16_ws16_asm.inc"
+#ifndef W16_ASM_INC
+#define W16_ASM_INC "conv_bf16_ws16_asm.inc"
+#endif
+#include W16_ASM_INC
+// timing-only ablations of the loaders (build.sh variant TAG conv_bf16_ws16 -DW16_ABL=bits; wrong results): 1 = the weight slices are
+// requested for a tile's first two periods only, 2 = no output stores, 4 = no barrier X, 8 = no input requests behind the first tile's
+#ifndef W16_ABL
+#define W16_ABL 0
+#endif
 #include <mutex>
 #include <type_traits>
 #include <utility>
@@ -51,27 +59,30 @@ __device__ __forceinline__ i32x4 w16_rsrc(const void* ptr, unsigned bytes) {
   const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
   return i32x4{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
 }
-// four LDS-DMA pieces (64 lanes x 16 bytes each) of one descriptor with one scalar offset: LDS destinations lds + k * 4 KB
-__device__ __forceinline__ void w16_dma4(i32x4 rs, unsigned lds, int v0, int v1, int v2, int v3, unsigned soff) {
+// four LDS-DMA pieces (64 lanes x 16 bytes each) of one descriptor with one scalar offset: LDS destinations lds + k * 2 KB
+__device__ __forceinline__ void w16_dma4s(i32x4 rs, unsigned lds, int v0, int v1, int v2, int v3, unsigned soff) {
   asm volatile(
       "s_mov_b32 m0, %5\n\ts_nop 4\n\tbuffer_load_dwordx4 %0, %4, %6 offen lds\n\t"
-      "s_add_u32 m0, m0, 4096\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %4, %6 offen lds\n\t"
-      "s_add_u32 m0, m0, 4096\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %4, %6 offen lds\n\t"
-      "s_add_u32 m0, m0, 4096\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %4, %6 offen lds"
+      "s_add_u32 m0, m0, 2048\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %4, %6 offen lds\n\t"
+      "s_add_u32 m0, m0, 2048\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %4, %6 offen lds\n\t"
+      "s_add_u32 m0, m0, 2048\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %4, %6 offen lds"
       ::"v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(rs), "s"(lds), "s"(soff) : "memory", "scc");
 }
-// six pieces of one descriptor with one per-lane offset: LDS destinations lds + k * 4 KB, scalar offsets soff, + sj, + sk, + sj, + sk, + sj
-// (the weight slices [3 kx][2 chunks] of a period for this wavefront's channel block and column half)
-__device__ __forceinline__ void w16_dma6(i32x4 rs, unsigned lds, int voff, unsigned soff, unsigned sj, unsigned sk) {
+// twelve pieces of one descriptor with one per-lane offset: the weight slices [3 kx][2 chunks][2 column halves] of one channel block of
+// a period.  LDS: lds + (2 kx + j) * 4 KB + half * 1 KB; source: soff + kx * tap pitch + j * 4 KB + half * 1 KB (sk = tap pitch - 5 KB)
+__device__ __forceinline__ void w16_dma12(i32x4 rs, unsigned lds, int voff, unsigned soff, unsigned sk) {
   unsigned so;
-#define W16_PJ "s_add_u32 m0, m0, 4096\n\ts_add_u32 %0, %0, %5\n\tbuffer_load_dwordx4 %1, %2, %0 offen lds\n\t"
-#define W16_PK "s_add_u32 m0, m0, 4096\n\ts_add_u32 %0, %0, %6\n\tbuffer_load_dwordx4 %1, %2, %0 offen lds\n\t"
-  asm volatile("s_mov_b32 m0, %3\n\ts_mov_b32 %0, %4\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %0 offen lds\n\t" W16_PJ W16_PK W16_PJ W16_PK W16_PJ
+#define W16_PA "s_add_u32 m0, m0, 1024\n\ts_add_u32 %0, %0, 1024\n\tbuffer_load_dwordx4 %1, %2, %0 offen lds\n\t"   /* the other column half */
+#define W16_PB "s_add_u32 m0, m0, 3072\n\ts_add_u32 %0, %0, 3072\n\tbuffer_load_dwordx4 %1, %2, %0 offen lds\n\t"   /* the pair's second chunk */
+#define W16_PC "s_add_u32 m0, m0, 3072\n\ts_add_u32 %0, %0, %5\n\tbuffer_load_dwordx4 %1, %2, %0 offen lds\n\t"     /* the next tap */
+  asm volatile("s_mov_b32 m0, %3\n\ts_mov_b32 %0, %4\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %0 offen lds\n\t" W16_PA W16_PB W16_PA W16_PC W16_PA W16_PB W16_PA W16_PC W16_PA
+                   W16_PB W16_PA
                : "=&s"(so)
-               : "v"(voff), "s"(rs), "s"(lds), "s"(soff), "s"(sj), "s"(sk)
+               : "v"(voff), "s"(rs), "s"(lds), "s"(soff), "s"(sk)
                : "memory", "scc");
-#undef W16_PJ
-#undef W16_PK
+#undef W16_PA
+#undef W16_PB
+#undef W16_PC
 }
 __device__ __forceinline__ void w16_store16(u32x4 data, int voff, i32x4 rs, unsigned soff) {
   asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen" ::"v"(data), "v"(voff), "s"(rs), "s"(soff) : "memory");
@@ -142,23 +153,66 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (tid < 128) ldsf[W16_EB / 4 + tid] = (BIAS && p.bias != nullptr) ? p.bias[tid] : 0.f;
   __syncthreads();
 
-  if (team == 1) {
+  if (team == 1 && tw < 2) {
     // =====================================================================================================================
-    // LOADERS.  Per period: [period 0: the staged half of the previous tile -> registers, barrier X] the NEXT period's weight
-    // slices (6 pieces per wavefront), chunk r of the NEXT pair's input tiles in the pair's periods r = 0, 1 (4 pieces), four output
-    // stores in each of the periods 0..3, [period 0: next-tile lookup + decode; period 1: the mailbox], counted vmcnt, barrier.
+    // WEIGHT LOADERS (wavefronts 4, 5).  A wavefront's vector-memory operations retire IN ORDER: in the family's first form every
+    // loader issued weight slices (L2 hits), input tiles (HBM) and output stores, and a period's weight slices could not retire --
+    // nor its barrier open -- before the older input pieces and stores had (ablations, gpurun_out/r6_w16_abl1.log: without the
+    // input requests -10 %, without the stores -8 %, without the weight requests -5 %).  Here the weight stream has wavefronts of its
+    // own: per period the 12 pieces of channel block `tw` of the NEXT period's slices [3 kx][2 chunks][2 column halves], vmcnt(0), barrier.
     // =====================================================================================================================
     const int lane = w16_lane();
-    const int ttid = tw * 64 + lane;
-    const int rowb = p.IW * 16, kcb = p.IH * p.IW * 16;
-    const unsigned ibytes = (unsigned)p.Kb * kcb, obytes = 16u * plane16, wbytes = 9u * p.Kb * 2048u;
-    const unsigned so_i = 2u * kcb;                  // bytes between the 16-channel chunks of an image
+    const unsigned wbytes = 9u * p.Kb * 2048u;
     const unsigned wstep = (unsigned)p.Kb * 2048u;   // bytes between the taps of the packed weights
     const i32x4 rs_w = w16_rsrc(p.wp, wbytes);
     const int lane16 = lane * 16;
-    const int kbw = tw >> 1, colh = tw & 1;          // this wavefront's weight pieces: channel block of the chunk, column half
-    // DMA source offsets of the 4 input slots: element ttid + i * 256 of the flattened [2][rows_in][lw] tile -> (channel block, row, column)
-    auto decode_slots = [&](const TileS& t, int (&voff)[WS_NI]) {
+    auto req_w = [&](int P, int r, int par) {
+      const unsigned soff = (unsigned)(((3 * r) * p.Kb + 4 * P + tw) * 2048);
+      w16_dma12(rs_w, (unsigned)(W16_W0 + par * W16_WSLOT + tw * 2048), lane16, soff, wstep - 5120u);
+    };
+    req_w(0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // (#1)
+    bool has_next = true;
+    unsigned kw = k_ord;
+    while (has_next) {
+      int P = 0, r = 0;
+      for (int c = 0; c < nper; ++c) {
+        if (c == 0) {   // (uniform: every loader looks the next tile up for itself)
+          unsigned kn = kw + 1;
+          TileS Tn{};
+          has_next = find_tile(kn, Tn);
+          kw = kn;
+        }
+        const int rn = r == 2 ? 0 : r + 1, Pn = r == 2 ? P + 1 : P;
+        if ((W16_ABL & 1) && c >= 1) {
+        } else if (c + 1 < nper) req_w(Pn, rn, (c + 1) & 1);
+        else if (has_next) req_w(0, 0, 0);
+        if (c == 0 && !(W16_ABL & 4)) __builtin_amdgcn_s_barrier();   // (X)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (++r == 3) { r = 0; ++P; }
+      }
+    }
+    if (!(W16_ABL & 4)) __builtin_amdgcn_s_barrier();   // (X of the tail)
+    __builtin_amdgcn_s_barrier();
+    return;
+  }
+  if (team == 1) {
+    // =====================================================================================================================
+    // INPUT / OUTPUT LOADERS (wavefronts 6, 7; iw = 0, 1).  Per period: [period 0: the staged half of the previous tile -> registers,
+    // barrier X] chunk r of the NEXT pair's input tiles in the pair's periods r = 0, 1 (8 pieces per wavefront), eight output stores in
+    // each of the periods 0..3, [period 0: next-tile lookup + decode; period 1: the mailbox], the pair's last period waits for the
+    // next pair's tiles, barrier.
+    // =====================================================================================================================
+    const int iw = tw - 2;
+    const int lane = w16_lane();
+    const int t128 = iw * 64 + lane;
+    const int rowb = p.IW * 16, kcb = p.IH * p.IW * 16;
+    const unsigned ibytes = (unsigned)p.Kb * kcb, obytes = 16u * plane16;
+    const unsigned so_i = 2u * kcb;                  // bytes between the 16-channel chunks of an image
+    // DMA source offsets of the 8 input slots: element t128 + i * 128 of the flattened [2][rows_in][lw] tile -> (channel block, row, column)
+    auto decode_slots = [&](const TileS& t, int (&voff)[8]) {
       const unsigned m_bw = t.lastband ? p.m_bwl : p.m_bw;
       const int bw = t.bw;
       const int i_lo = w16_udivm(t.p0, m_bw), i_hi = w16_udivm(t.p1 - 1, m_bw);
@@ -168,16 +222,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int per_kb = rows_in * lw;
       const unsigned inv_lw = t.lastband ? p.m_lwl : p.m_lw;
       const unsigned inv_perkb = 0xFFFFFFFFu / (unsigned)per_kb + 1u;
-      const int skc = w16_udivm(WS_NT, inv_perkb);
-      const int srm = WS_NT - skc * per_kb;
+      const int skc = w16_udivm(128, inv_perkb);
+      const int srm = 128 - skc * per_kb;
       const int sr = w16_udivm(srm, inv_lw);
       const int sx = srm - sr * lw;
-      int kc_ = w16_udivm(ttid, inv_perkb);
-      const int rm0 = ttid - kc_ * per_kb;
+      int kc_ = w16_udivm(t128, inv_perkb);
+      const int rm0 = t128 - kc_ * per_kb;
       int r_ = w16_udivm(rm0, inv_lw);
       int x_ = rm0 - r_ * lw;
 #pragma unroll
-      for (int i = 0; i < WS_NI; ++i) {
+      for (int i = 0; i < 8; ++i) {
         const int iy_ = iy0 + r_, ix_ = ix0 + x_;
         const bool ok = (kc_ < 2) && (iy_ >= 0) && (iy_ < p.IH) && (ix_ >= 0) && (ix_ < p.IW);
         voff[i] = ok ? kc_ * kcb + iy_ * rowb + ix_ * 16 : (int)OOB;
@@ -186,97 +240,98 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (r_ >= rows_in) { r_ -= rows_in; ++kc_; }
       }
     };
-    static_assert(WS_NI == 4, "w16_dma4 issues the four input slots");
-    // weight slices of period cn (pair cn / 3, kernel row cn % 3) -> weight slot cn & 1
-    auto req_w = [&](int P, int r, int par) {
-      const unsigned soff = (unsigned)(((3 * r) * p.Kb + 4 * P + kbw) * 2048 + colh * 1024);
-      w16_dma6(rs_w, (unsigned)(W16_W0 + par * W16_WSLOT + kbw * 2048 + colh * 1024), lane16, soff, 4096u, wstep - 4096u);
+    // input tile of chunk cn of the image behind (rs, voff) -> pair slot ps, chunk half j (8 pieces of this wavefront, 2 KB apart)
+    auto req_i = [&](i32x4 rs, const int (&voff)[8], int cn, int ps, int j) {
+      const unsigned l0 = (unsigned)(W16_I0 + ps * W16_ISLOT + j * WS_IB + iw * 1024);
+      w16_dma4s(rs, l0, voff[0], voff[1], voff[2], voff[3], (unsigned)cn * so_i);
+      w16_dma4s(rs, l0 + 8192u, voff[4], voff[5], voff[6], voff[7], (unsigned)cn * so_i);
     };
-    // input tile of chunk cn of the image behind (rs, voff) -> pair slot ps, chunk half j
-    auto req_i = [&](i32x4 rs, const int (&voff)[WS_NI], int cn, int ps, int j) {
-      w16_dma4(rs, (unsigned)(W16_I0 + ps * W16_ISLOT + j * WS_IB + tw * 64 * 16), voff[0], voff[1], voff[2], voff[3], (unsigned)cn * so_i);
-    };
-    // Output hand-over: the staged half (8 channel blocks x this wavefront's 64 pixels) -> registers, four stores per period
-    const unsigned stg_rd = (unsigned)(W16_STG + tw * 8192 + lane * 16);
-    u32x4 fifo[8];
-    int f_vo = (int)OOB;
+    // Output hand-over: the staged half of compute wavefronts 2 iw and 2 iw + 1 (8 channel blocks x 64 pixels each) -> registers,
+    // eight stores per period
+    // (the FIFO = a[0:63] of THIS wavefront, named literally: DS loads and buffer stores take accumulator registers as data, so the 64
+    //  registers cost the loaders neither arch VGPRs nor moves; the compute wavefronts' a[0:127] are other wavefronts' registers)
+    int vo[2], vo_prev[2] = {(int)OOB, (int)OOB};   // output offsets of this lane's pixel of the two compute wavefronts: the tile being computed / handed over
     i32x4 f_rs = w16_rsrc(p.out, 0u);
     int f_cb0 = 0;
-    auto fifo_fill = [&](int cb0, int vop, i32x4 rs_o) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) fifo[u] = *reinterpret_cast<const u32x4*>(lds + stg_rd + u * 1024);
-      f_vo = vop; f_rs = rs_o; f_cb0 = cb0;
+    const unsigned stg_rd = (unsigned)(W16_STG + (2 * iw) * 8192 + lane * 16);
+#define W16_FILL(U) "ds_read_b128 a[4*" #U ":4*" #U "+3], %0 offset:(" #U "/8)*8192+(" #U "%%8)*1024\n\t"
+#define W16_FIFO_CLOBBER "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63"
+    auto fifo_fill = [&](int cb0, i32x4 rs_o) {
+      asm volatile(W16_FILL(0) W16_FILL(1) W16_FILL(2) W16_FILL(3) W16_FILL(4) W16_FILL(5) W16_FILL(6) W16_FILL(7) W16_FILL(8) W16_FILL(9) W16_FILL(10)
+                       W16_FILL(11) W16_FILL(12) W16_FILL(13) W16_FILL(14) W16_FILL(15) "s_waitcnt lgkmcnt(0)"
+                   :
+                   : "v"(stg_rd)
+                   : "memory", W16_FIFO_CLOBBER);
+      f_rs = rs_o; f_cb0 = cb0;
     };
-    auto fifo_store4 = [&](auto h_tag) {   // units 4 h .. 4 h + 3 of the FIFO
+#undef W16_FILL
+    auto fifo_store8 = [&](auto h_tag) {   // the eight units of compute wavefront 2 iw + h (of the tile vo_prev describes)
       constexpr int Hh = decltype(h_tag)::value;
       const i32x4 rs = {__builtin_amdgcn_readfirstlane(f_rs.x), __builtin_amdgcn_readfirstlane(f_rs.y), __builtin_amdgcn_readfirstlane(f_rs.z),
                         __builtin_amdgcn_readfirstlane(f_rs.w)};
       const int cb0 = __builtin_amdgcn_readfirstlane(f_cb0);
-#pragma unroll
-      for (int u = 4 * Hh; u < 4 * Hh + 4; ++u) w16_store16(fifo[u], f_vo, rs, (unsigned)(cb0 + u) * (unsigned)plane16);
+      const int vof = (W16_ABL & 2) ? (int)OOB : vo_prev[Hh];
+      const unsigned so0 = (unsigned)cb0 * (unsigned)plane16, sp = (unsigned)plane16;
+      unsigned so;
+      // (unit u of this half = a[32 Hh + 4 u : + 3]; scalar offset so0 + u * plane16)
+#define W16_ST(U) "buffer_store_dwordx4 a[32*%6+4*" #U ":32*%6+4*" #U "+3], %1, %2, %0 offen\n\ts_add_u32 %0, %0, %4\n\t"
+      asm volatile("s_mov_b32 %0, %3\n\ts_nop 4\n\t" W16_ST(0) W16_ST(1) W16_ST(2) W16_ST(3) W16_ST(4) W16_ST(5) W16_ST(6) W16_ST(7) "s_nop 0"
+                   : "=&s"(so)
+                   : "v"(vof), "s"(rs), "s"(so0), "s"(sp), "n"(0), "n"(Hh)
+                   : "memory", "scc");
+#undef W16_ST
     };
     using IC0 = std::integral_constant<int, 0>;
     using IC1 = std::integral_constant<int, 1>;
 
-    int voff[WS_NI];
+    int voff[8];
     decode_slots(T, voff);
-    unsigned pbase_ = 0, lw16_ = 0, perkb16_ = 0;
-    int vo = (int)OOB, vo_prev = (int)OOB;
-    pix_geom(T, ttid, pbase_, vo);
+    unsigned pbase_[2] = {0u, 0u}, lw16_ = 0, perkb16_ = 0;
+    pix_geom(T, (2 * iw) * 64 + lane, pbase_[0], vo[0]);
+    pix_geom(T, (2 * iw + 1) * 64 + lane, pbase_[1], vo[1]);
     i32x4 rs_in = w16_rsrc(reinterpret_cast<const unsigned char*>(p.in) + (size_t)T.b * ibytes, ibytes);
     i32x4 rs_out = w16_rsrc(reinterpret_cast<unsigned char*>(p.out) + (size_t)T.b * obytes, obytes);
     i32x4 rs_out_prev = w16_rsrc(p.out, 0u);
     req_i(rs_in, voff, 0, 0, 0);
     req_i(rs_in, voff, 1, 0, 1);
-    req_w(0, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // (#1) pair 0 and the weight slices of period 0 of the first tile have landed
+    __builtin_amdgcn_s_barrier();   // (#1) pair 0 of the first tile has landed
     bool has_next = true;
     TileS Tn{};
-    int voff_n[WS_NI] = {(int)OOB, (int)OOB, (int)OOB, (int)OOB}, vo_n = (int)OOB;
+    int vo_n[2] = {(int)OOB, (int)OOB};
     i32x4 rs_in_n = rs_in, rs_out_n = rs_out;
     while (has_next) {
       int P = 0, r = 0;   // pair and kernel row of period c
       for (int c = 0; c < nper; ++c) {
         if (c == 0) {   // the half of the previous tile's output the compute wavefronts staged in its last period
-          fifo_fill(0, vo_prev, rs_out_prev);
+          fifo_fill(0, rs_out_prev);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();   // (X) the staging area is free for the other half
+          if (!(W16_ABL & 4)) __builtin_amdgcn_s_barrier();   // (X) the staging area is free for the other half
         }
-        // oldest first: the weight slices of the NEXT period (needed at this period's barrier) ...
-        {
-          const int rn = r == 2 ? 0 : r + 1, Pn = r == 2 ? P + 1 : P;
-          if (c + 1 < nper) req_w(Pn, rn, (c + 1) & 1);
-          else if (has_next) req_w(0, 0, 0);
-        }
-        // ... then chunk r of the next pair's input tiles (needed at the barrier of this pair's last period: they may stay in flight)
-        bool req = false;   // (uniform)
-        if (r < 2) {
+        // chunk r of the next pair's input tiles (needed at the barrier of this pair's last period: they stay in flight until then)
+        if (r < 2 && !(W16_ABL & 8)) {
           if (P + 1 < npairs) {
             req_i(rs_in, voff, 2 * (P + 1) + r, (P + 1) & 1, r);
-            req = true;
           } else if (has_next) {   // the request stream crosses into the next tile (pair 0 -> pair slot 0)
-            if (r == 0) {
-#pragma unroll
-              for (int i = 0; i < WS_NI; ++i) voff[i] = voff_n[i];
+            if (r == 0) {   // (the next tile's slots are decoded here, where the stream needs them: a second set of eight offsets held since period 0 costs registers)
+              decode_slots(Tn, voff);
               rs_in = rs_in_n;
             }
             req_i(rs_in, voff, r, 0, r);
-            req = true;
           }
         }
-        if (c == 0) fifo_store4(IC0{});
-        else if (c == 1) fifo_store4(IC1{});
-        else if (c == 2) { fifo_fill(8, vo_prev, rs_out_prev); fifo_store4(IC0{}); }   // (the other half: staged during period 0)
-        else if (c == 3) fifo_store4(IC1{});
-        const bool dr = c < 4;   // (uniform) four stores were issued
+        if (c == 0) fifo_store8(IC0{});
+        else if (c == 1) fifo_store8(IC1{});
+        else if (c == 2) { fifo_fill(8, rs_out_prev); fifo_store8(IC0{}); }   // (the other half: staged during period 0)
+        else if (c == 3) fifo_store8(IC1{});
+        const bool dr = c < 4;   // (uniform) eight stores were issued
         if (c == 0) {   // the NEXT tile: looked up and decoded behind this period's requests and stores
           unsigned kn = k_ord + 1;
           has_next = find_tile(kn, Tn);
           k_ord = kn;
           if (has_next) {
-            decode_slots(Tn, voff_n);
-            pix_geom(Tn, ttid, pbase_, vo_n);
+            pix_geom(Tn, (2 * iw) * 64 + lane, pbase_[0], vo_n[0]);
+            pix_geom(Tn, (2 * iw + 1) * 64 + lane, pbase_[1], vo_n[1]);
             tile_pitch(Tn, lw16_, perkb16_);
             rs_in_n = w16_rsrc(reinterpret_cast<const unsigned char*>(p.in) + (size_t)Tn.b * ibytes, ibytes);
             rs_out_n = w16_rsrc(reinterpret_cast<unsigned char*>(p.out) + (size_t)Tn.b * obytes, obytes);
@@ -285,34 +340,37 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // the NEXT tile's operand addresses for the compute wavefronts: written in period 1 (they read the previous message at their
         // tile seam, in front of this tile's period 0) and read at the next seam
         if (c == 1) {
-          *reinterpret_cast<unsigned*>(lds + W16_MB + tw * 256 + ((lane & 15) * 4 + (lane >> 4)) * 4) = pbase_;
-          if (tw == 0 && lane == 0) *reinterpret_cast<u32x4*>(lds + W16_MBS) = u32x4{has_next ? 1u : 0u, lw16_, perkb16_, 0u};
+#pragma unroll
+          for (int h = 0; h < 2; ++h) *reinterpret_cast<unsigned*>(lds + W16_MB + (2 * iw + h) * 256 + ((lane & 15) * 4 + (lane >> 4)) * 4) = pbase_[h];
+          if (iw == 0 && lane == 0) *reinterpret_cast<u32x4*>(lds + W16_MBS) = u32x4{has_next ? 1u : 0u, lw16_, perkb16_, 0u};
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        // vector-memory operations retire in order: everything but this period's input request (4) and stores (4) has to be done
-        if (dr && req) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (dr || req) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // a pair's last period: the next pair's tiles (requested in its periods 0, 1) have to be there; this period's stores may fly on
+        if (r == 2) {
+          if (dr) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         if (++r == 3) { r = 0; ++P; }
       }
-      vo_prev = vo;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) vo_prev[h] = vo[h];
       rs_out_prev = rs_out;
       if (has_next) {
-        vo = vo_n;
+        vo[0] = vo_n[0]; vo[1] = vo_n[1];
         rs_out = rs_out_n;
       }
     }
     // the last tile: the staged half, barrier X, (compute: the other half), barrier, the other half
-    fifo_fill(0, vo_prev, rs_out_prev);
+    fifo_fill(0, rs_out_prev);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (!(W16_ABL & 4)) __builtin_amdgcn_s_barrier();
+    fifo_store8(IC0{});
+    fifo_store8(IC1{});
     __builtin_amdgcn_s_barrier();
-    fifo_store4(IC0{});
-    fifo_store4(IC1{});
-    __builtin_amdgcn_s_barrier();
-    fifo_fill(8, vo_prev, rs_out_prev);
-    fifo_store4(IC0{});
-    fifo_store4(IC1{});
+    fifo_fill(8, rs_out_prev);
+    fifo_store8(IC0{});
+    fifo_store8(IC1{});
     return;
   }
 
