@@ -68,21 +68,15 @@ __device__ __forceinline__ void w16_dma4s(i32x4 rs, unsigned lds, int v0, int v1
       "s_add_u32 m0, m0, 2048\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %4, %6 offen lds"
       ::"v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(rs), "s"(lds), "s"(soff) : "memory", "scc");
 }
-// twelve pieces of one descriptor with one per-lane offset: the weight slices [3 kx][2 chunks][2 column halves] of one channel block of
-// a period.  LDS: lds + (2 kx + j) * 4 KB + half * 1 KB; source: soff + kx * tap pitch + j * 4 KB + half * 1 KB (sk = tap pitch - 5 KB)
-__device__ __forceinline__ void w16_dma12(i32x4 rs, unsigned lds, int voff, unsigned soff, unsigned sk) {
+// eight pieces of one descriptor with one per-lane offset: 8 KB, contiguous at the source (from soff) and in LDS (from lds)
+__device__ __forceinline__ void w16_dma8(i32x4 rs, unsigned lds, int voff, unsigned soff) {
   unsigned so;
-#define W16_PA "s_add_u32 m0, m0, 1024\n\ts_add_u32 %0, %0, 1024\n\tbuffer_load_dwordx4 %1, %2, %0 offen lds\n\t"   /* the other column half */
-#define W16_PB "s_add_u32 m0, m0, 3072\n\ts_add_u32 %0, %0, 3072\n\tbuffer_load_dwordx4 %1, %2, %0 offen lds\n\t"   /* the pair's second chunk */
-#define W16_PC "s_add_u32 m0, m0, 3072\n\ts_add_u32 %0, %0, %5\n\tbuffer_load_dwordx4 %1, %2, %0 offen lds\n\t"     /* the next tap */
-  asm volatile("s_mov_b32 m0, %3\n\ts_mov_b32 %0, %4\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %0 offen lds\n\t" W16_PA W16_PB W16_PA W16_PC W16_PA W16_PB W16_PA W16_PC W16_PA
-                   W16_PB W16_PA
+#define W16_PN "s_add_u32 m0, m0, 1024\n\ts_add_u32 %0, %0, 1024\n\tbuffer_load_dwordx4 %1, %2, %0 offen lds\n\t"
+  asm volatile("s_mov_b32 m0, %3\n\ts_mov_b32 %0, %4\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %0 offen lds\n\t" W16_PN W16_PN W16_PN W16_PN W16_PN W16_PN W16_PN
                : "=&s"(so)
-               : "v"(voff), "s"(rs), "s"(lds), "s"(soff), "s"(sk)
+               : "v"(voff), "s"(rs), "s"(lds), "s"(soff)
                : "memory", "scc");
-#undef W16_PA
-#undef W16_PB
-#undef W16_PC
+#undef W16_PN
 }
 __device__ __forceinline__ void w16_store16(u32x4 data, int voff, i32x4 rs, unsigned soff) {
   asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen" ::"v"(data), "v"(voff), "s"(rs), "s"(soff) : "memory");
@@ -153,63 +147,126 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (tid < 128) ldsf[W16_EB / 4 + tid] = (BIAS && p.bias != nullptr) ? p.bias[tid] : 0.f;
   __syncthreads();
 
-  if (team == 1 && tw < 2) {
+  if (team == 1) {
     // =====================================================================================================================
-    // WEIGHT LOADERS (wavefronts 4, 5).  A wavefront's vector-memory operations retire IN ORDER: in the family's first form every
-    // loader issued weight slices (L2 hits), input tiles (HBM) and output stores, and a period's weight slices could not retire --
-    // nor its barrier open -- before the older input pieces and stores had (ablations, gpurun_out/r6_w16_abl1.log: without the
-    // input requests -10 %, without the stores -8 %, without the weight requests -5 %).  Here the weight stream has wavefronts of its
-    // own: per period the 12 pieces of channel block `tw` of the NEXT period's slices [3 kx][2 chunks][2 column halves], vmcnt(0), barrier.
+    // LOADERS.  A wavefront's vector-memory operations retire IN ORDER, and a period's barrier opens when the next period's weight
+    // slices have retired.  With every loader issuing weight slices (L2 hits), input tiles (HBM reads) and output stores (HBM write
+    // acknowledgements) the slices wait behind the older input pieces and stores (ablations, gpurun_out/r6_w16_abl1.log: without the
+    // stores -8 %, without the input requests -10 %, without the weight requests -5 %); two weight-only wavefronts of 12 pieces
+    // per period were issue-bound instead (+2 ... +5 %, profiles/r06_ws16_split_loaders_ab.log).  So:
+    //   wavefront 4 (tw 0): the weight slices of kernel column 0 (8 pieces per period) + the next tile's lookup / decode / mailbox
+    //   wavefronts 5, 6   : the weight slices of kernel columns 1, 2 + half of the input tiles each (8 pieces per chunk)
+    //   wavefront 7       : ALL output stores (the staged half -> a[0:127] of this wavefront -> 32 stores per half): never waited for
     // =====================================================================================================================
     const int lane = w16_lane();
     const unsigned wbytes = 9u * p.Kb * 2048u;
+    const unsigned obytes = 16u * plane16;
+    bool has_next = true;
+    TileS Tn{};
+    if (tw == 3) {
+      // ---- the store wavefront
+      int vo[4], vo_prev[4] = {(int)OOB, (int)OOB, (int)OOB, (int)OOB}, vo_n[4] = {(int)OOB, (int)OOB, (int)OOB, (int)OOB};
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        unsigned pb_unused;
+        pix_geom(T, h * 64 + lane, pb_unused, vo[h]);
+      }
+      i32x4 rs_out = w16_rsrc(reinterpret_cast<unsigned char*>(p.out) + (size_t)T.b * obytes, obytes);
+      i32x4 rs_out_prev = w16_rsrc(p.out, 0u), rs_out_n = rs_out;
+      const unsigned stg_rd = (unsigned)(W16_STG + lane * 16);
+#define W16_FILL(U) "ds_read_b128 a[4*" #U ":4*" #U "+3], %0 offset:" #U "*1024\n\t"
+#define W16_ALL_ACC "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95","a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127"
+      // the staged half (compute wavefront h, channel block u: unit 8 h + u at 8 h + u KB) -> a[4 (8 h + u) : + 3] of THIS wavefront (DS loads and
+      // buffer stores take accumulator registers as data: the 128 registers cost neither arch VGPRs nor moves)
+      auto fifo_fill = [&]() {
+        asm volatile(W16_FILL(0) W16_FILL(1) W16_FILL(2) W16_FILL(3) W16_FILL(4) W16_FILL(5) W16_FILL(6) W16_FILL(7) W16_FILL(8) W16_FILL(9) W16_FILL(10)
+                         W16_FILL(11) W16_FILL(12) W16_FILL(13) W16_FILL(14) W16_FILL(15) W16_FILL(16) W16_FILL(17) W16_FILL(18) W16_FILL(19) W16_FILL(20)
+                             W16_FILL(21) W16_FILL(22) W16_FILL(23) W16_FILL(24) W16_FILL(25) W16_FILL(26) W16_FILL(27) W16_FILL(28) W16_FILL(29) W16_FILL(30)
+                                 W16_FILL(31) "s_waitcnt lgkmcnt(0)"
+                     :
+                     : "v"(stg_rd)
+                     : "memory", W16_ALL_ACC);
+      };
+#define W16_ST(U) "buffer_store_dwordx4 a[32*%6+4*" #U ":32*%6+4*" #U "+3], %1, %2, %0 offen\n\ts_add_u32 %0, %0, %4\n\t"
+      // the eight units of compute wavefront h (channel blocks cb0 .. cb0 + 7 of the tile vo_prev / rs describe)
+      auto store8 = [&](auto h_tag, int cb0, i32x4 rs_o) {
+        constexpr int Hh = decltype(h_tag)::value;
+        const i32x4 rs = {__builtin_amdgcn_readfirstlane(rs_o.x), __builtin_amdgcn_readfirstlane(rs_o.y), __builtin_amdgcn_readfirstlane(rs_o.z),
+                          __builtin_amdgcn_readfirstlane(rs_o.w)};
+        const int vof = (W16_ABL & 2) ? (int)OOB : vo_prev[Hh];
+        const unsigned so0 = (unsigned)__builtin_amdgcn_readfirstlane(cb0) * (unsigned)plane16, sp = (unsigned)plane16;
+        unsigned so;
+        asm volatile("s_mov_b32 %0, %3\n\ts_nop 4\n\t" W16_ST(0) W16_ST(1) W16_ST(2) W16_ST(3) W16_ST(4) W16_ST(5) W16_ST(6) W16_ST(7) "s_nop 0"
+                     : "=&s"(so)
+                     : "v"(vof), "s"(rs), "s"(so0), "s"(sp), "n"(0), "n"(Hh)
+                     : "memory", "scc");
+      };
+      using H0 = std::integral_constant<int, 0>;
+      using H1 = std::integral_constant<int, 1>;
+      using H2 = std::integral_constant<int, 2>;
+      using H3 = std::integral_constant<int, 3>;
+      __builtin_amdgcn_s_barrier();   // (#1)
+      while (has_next) {
+        for (int c = 0; c < nper; ++c) {
+          if (c == 0) {   // the half of the previous tile's output the compute wavefronts staged in its last period
+            fifo_fill();
+            if (!(W16_ABL & 4)) __builtin_amdgcn_s_barrier();   // (X) the staging area is free for the other half
+            store8(H0{}, 0, rs_out_prev); store8(H1{}, 0, rs_out_prev);
+            unsigned kn = k_ord + 1;
+            has_next = find_tile(kn, Tn);
+            k_ord = kn;
+            if (has_next) {
+#pragma unroll
+              for (int h = 0; h < 4; ++h) {
+                unsigned pb_unused;
+                pix_geom(Tn, h * 64 + lane, pb_unused, vo_n[h]);
+              }
+              rs_out_n = w16_rsrc(reinterpret_cast<unsigned char*>(p.out) + (size_t)Tn.b * obytes, obytes);
+            }
+          } else if (c == 1) {
+            store8(H2{}, 0, rs_out_prev); store8(H3{}, 0, rs_out_prev);
+          } else if (c == 2) {   // the other half: staged during period 0
+            fifo_fill();
+            store8(H0{}, 8, rs_out_prev); store8(H1{}, 8, rs_out_prev);
+          } else if (c == 3) {
+            store8(H2{}, 8, rs_out_prev); store8(H3{}, 8, rs_out_prev);
+          }
+          __builtin_amdgcn_s_barrier();
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) vo_prev[h] = vo[h];
+        rs_out_prev = rs_out;
+        if (has_next) {
+#pragma unroll
+          for (int h = 0; h < 4; ++h) vo[h] = vo_n[h];
+          rs_out = rs_out_n;
+        }
+      }
+      // the last tile: the staged half, barrier X, (compute: the other half), barrier, the other half
+      fifo_fill();
+      if (!(W16_ABL & 4)) __builtin_amdgcn_s_barrier();
+      store8(H0{}, 0, rs_out_prev); store8(H1{}, 0, rs_out_prev); store8(H2{}, 0, rs_out_prev); store8(H3{}, 0, rs_out_prev);
+      __builtin_amdgcn_s_barrier();
+      fifo_fill();
+      store8(H0{}, 8, rs_out_prev); store8(H1{}, 8, rs_out_prev); store8(H2{}, 8, rs_out_prev); store8(H3{}, 8, rs_out_prev);
+#undef W16_FILL
+#undef W16_ST
+#undef W16_ALL_ACC
+      return;
+    }
+    // ---- the weight (+ input / + mailbox) wavefronts: tw = kernel column of their weight pieces
     const unsigned wstep = (unsigned)p.Kb * 2048u;   // bytes between the taps of the packed weights
     const i32x4 rs_w = w16_rsrc(p.wp, wbytes);
     const int lane16 = lane * 16;
+    // the 8 KB of kernel column tw of period (pair P, kernel row r): [2 chunks][2 channel blocks][128 channels] = 4 consecutive channel
+    // blocks of tap 3 r + tw in the packed weights, contiguous in the slot too
     auto req_w = [&](int P, int r, int par) {
-      const unsigned soff = (unsigned)(((3 * r) * p.Kb + 4 * P + tw) * 2048);
-      w16_dma12(rs_w, (unsigned)(W16_W0 + par * W16_WSLOT + tw * 2048), lane16, soff, wstep - 5120u);
+      w16_dma8(rs_w, (unsigned)(W16_W0 + par * W16_WSLOT + tw * 8192), lane16, (unsigned)(((3 * r + tw) * p.Kb + 4 * P) * 2048));
     };
-    req_w(0, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // (#1)
-    bool has_next = true;
-    unsigned kw = k_ord;
-    while (has_next) {
-      int P = 0, r = 0;
-      for (int c = 0; c < nper; ++c) {
-        if (c == 0) {   // (uniform: every loader looks the next tile up for itself)
-          unsigned kn = kw + 1;
-          TileS Tn{};
-          has_next = find_tile(kn, Tn);
-          kw = kn;
-        }
-        const int rn = r == 2 ? 0 : r + 1, Pn = r == 2 ? P + 1 : P;
-        if ((W16_ABL & 1) && c >= 1) {
-        } else if (c + 1 < nper) req_w(Pn, rn, (c + 1) & 1);
-        else if (has_next) req_w(0, 0, 0);
-        if (c == 0 && !(W16_ABL & 4)) __builtin_amdgcn_s_barrier();   // (X)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (++r == 3) { r = 0; ++P; }
-      }
-    }
-    if (!(W16_ABL & 4)) __builtin_amdgcn_s_barrier();   // (X of the tail)
-    __builtin_amdgcn_s_barrier();
-    return;
-  }
-  if (team == 1) {
-    // =====================================================================================================================
-    // INPUT / OUTPUT LOADERS (wavefronts 6, 7; iw = 0, 1).  Per period: [period 0: the staged half of the previous tile -> registers,
-    // barrier X] chunk r of the NEXT pair's input tiles in the pair's periods r = 0, 1 (8 pieces per wavefront), eight output stores in
-    // each of the periods 0..3, [period 0: next-tile lookup + decode; period 1: the mailbox], the pair's last period waits for the
-    // next pair's tiles, barrier.
-    // =====================================================================================================================
-    const int iw = tw - 2;
-    const int lane = w16_lane();
+    const int iw = tw - 1;   // (tw 1, 2: input half)
     const int t128 = iw * 64 + lane;
     const int rowb = p.IW * 16, kcb = p.IH * p.IW * 16;
-    const unsigned ibytes = (unsigned)p.Kb * kcb, obytes = 16u * plane16;
+    const unsigned ibytes = (unsigned)p.Kb * kcb;
     const unsigned so_i = 2u * kcb;                  // bytes between the 16-channel chunks of an image
     // DMA source offsets of the 8 input slots: element t128 + i * 128 of the flattened [2][rows_in][lw] tile -> (channel block, row, column)
     auto decode_slots = [&](const TileS& t, int (&voff)[8]) {
@@ -246,131 +303,76 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       w16_dma4s(rs, l0, voff[0], voff[1], voff[2], voff[3], (unsigned)cn * so_i);
       w16_dma4s(rs, l0 + 8192u, voff[4], voff[5], voff[6], voff[7], (unsigned)cn * so_i);
     };
-    // Output hand-over: the staged half of compute wavefronts 2 iw and 2 iw + 1 (8 channel blocks x 64 pixels each) -> registers,
-    // eight stores per period
-    // (the FIFO = a[0:63] of THIS wavefront, named literally: DS loads and buffer stores take accumulator registers as data, so the 64
-    //  registers cost the loaders neither arch VGPRs nor moves; the compute wavefronts' a[0:127] are other wavefronts' registers)
-    int vo[2], vo_prev[2] = {(int)OOB, (int)OOB};   // output offsets of this lane's pixel of the two compute wavefronts: the tile being computed / handed over
-    i32x4 f_rs = w16_rsrc(p.out, 0u);
-    int f_cb0 = 0;
-    const unsigned stg_rd = (unsigned)(W16_STG + (2 * iw) * 8192 + lane * 16);
-#define W16_FILL(U) "ds_read_b128 a[4*" #U ":4*" #U "+3], %0 offset:(" #U "/8)*8192+(" #U "%%8)*1024\n\t"
-#define W16_FIFO_CLOBBER "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63"
-    auto fifo_fill = [&](int cb0, i32x4 rs_o) {
-      asm volatile(W16_FILL(0) W16_FILL(1) W16_FILL(2) W16_FILL(3) W16_FILL(4) W16_FILL(5) W16_FILL(6) W16_FILL(7) W16_FILL(8) W16_FILL(9) W16_FILL(10)
-                       W16_FILL(11) W16_FILL(12) W16_FILL(13) W16_FILL(14) W16_FILL(15) "s_waitcnt lgkmcnt(0)"
-                   :
-                   : "v"(stg_rd)
-                   : "memory", W16_FIFO_CLOBBER);
-      f_rs = rs_o; f_cb0 = cb0;
-    };
-#undef W16_FILL
-    auto fifo_store8 = [&](auto h_tag) {   // the eight units of compute wavefront 2 iw + h (of the tile vo_prev describes)
-      constexpr int Hh = decltype(h_tag)::value;
-      const i32x4 rs = {__builtin_amdgcn_readfirstlane(f_rs.x), __builtin_amdgcn_readfirstlane(f_rs.y), __builtin_amdgcn_readfirstlane(f_rs.z),
-                        __builtin_amdgcn_readfirstlane(f_rs.w)};
-      const int cb0 = __builtin_amdgcn_readfirstlane(f_cb0);
-      const int vof = (W16_ABL & 2) ? (int)OOB : vo_prev[Hh];
-      const unsigned so0 = (unsigned)cb0 * (unsigned)plane16, sp = (unsigned)plane16;
-      unsigned so;
-      // (unit u of this half = a[32 Hh + 4 u : + 3]; scalar offset so0 + u * plane16)
-#define W16_ST(U) "buffer_store_dwordx4 a[32*%6+4*" #U ":32*%6+4*" #U "+3], %1, %2, %0 offen\n\ts_add_u32 %0, %0, %4\n\t"
-      asm volatile("s_mov_b32 %0, %3\n\ts_nop 4\n\t" W16_ST(0) W16_ST(1) W16_ST(2) W16_ST(3) W16_ST(4) W16_ST(5) W16_ST(6) W16_ST(7) "s_nop 0"
-                   : "=&s"(so)
-                   : "v"(vof), "s"(rs), "s"(so0), "s"(sp), "n"(0), "n"(Hh)
-                   : "memory", "scc");
-#undef W16_ST
-    };
-    using IC0 = std::integral_constant<int, 0>;
-    using IC1 = std::integral_constant<int, 1>;
-
-    int voff[8];
-    decode_slots(T, voff);
-    unsigned pbase_[2] = {0u, 0u}, lw16_ = 0, perkb16_ = 0;
-    pix_geom(T, (2 * iw) * 64 + lane, pbase_[0], vo[0]);
-    pix_geom(T, (2 * iw + 1) * 64 + lane, pbase_[1], vo[1]);
+    int voff[8] = {(int)OOB, (int)OOB, (int)OOB, (int)OOB, (int)OOB, (int)OOB, (int)OOB, (int)OOB};
     i32x4 rs_in = w16_rsrc(reinterpret_cast<const unsigned char*>(p.in) + (size_t)T.b * ibytes, ibytes);
-    i32x4 rs_out = w16_rsrc(reinterpret_cast<unsigned char*>(p.out) + (size_t)T.b * obytes, obytes);
-    i32x4 rs_out_prev = w16_rsrc(p.out, 0u);
-    req_i(rs_in, voff, 0, 0, 0);
-    req_i(rs_in, voff, 1, 0, 1);
+    i32x4 rs_in_n = rs_in;
+    unsigned pbase_[4] = {0u, 0u, 0u, 0u}, lw16_ = 0, perkb16_ = 0;   // (tw 0: the next tile's mailbox)
+    if (tw != 0) {
+      decode_slots(T, voff);
+      req_i(rs_in, voff, 0, 0, 0);
+      req_i(rs_in, voff, 1, 0, 1);
+    }
+    req_w(0, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // (#1) pair 0 of the first tile has landed
-    bool has_next = true;
-    TileS Tn{};
-    int vo_n[2] = {(int)OOB, (int)OOB};
-    i32x4 rs_in_n = rs_in, rs_out_n = rs_out;
+    __builtin_amdgcn_s_barrier();   // (#1) pair 0 and the weight slices of period 0 of the first tile have landed
     while (has_next) {
       int P = 0, r = 0;   // pair and kernel row of period c
       for (int c = 0; c < nper; ++c) {
-        if (c == 0) {   // the half of the previous tile's output the compute wavefronts staged in its last period
-          fifo_fill(0, rs_out_prev);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          if (!(W16_ABL & 4)) __builtin_amdgcn_s_barrier();   // (X) the staging area is free for the other half
+        if (c == 0) {   // (uniform: every loader looks the next tile up for itself)
+          unsigned kn = k_ord + 1;
+          has_next = find_tile(kn, Tn);
+          k_ord = kn;
+          if (has_next) rs_in_n = w16_rsrc(reinterpret_cast<const unsigned char*>(p.in) + (size_t)Tn.b * ibytes, ibytes);
         }
-        // chunk r of the next pair's input tiles (needed at the barrier of this pair's last period: they stay in flight until then)
-        if (r < 2 && !(W16_ABL & 8)) {
+        // oldest first: the weight slices of the NEXT period (needed at this period's barrier) ...
+        {
+          const int rn = r == 2 ? 0 : r + 1, Pn = r == 2 ? P + 1 : P;
+          if ((W16_ABL & 1) && c >= 1) {
+          } else if (c + 1 < nper) req_w(Pn, rn, (c + 1) & 1);
+          else if (has_next) req_w(0, 0, 0);
+        }
+        // ... then (tw 1, 2) chunk r of the next pair's input tiles: needed at the barrier of this pair's last period
+        bool req = false;   // (uniform)
+        if (tw != 0 && r < 2 && !(W16_ABL & 8)) {
           if (P + 1 < npairs) {
             req_i(rs_in, voff, 2 * (P + 1) + r, (P + 1) & 1, r);
+            req = true;
           } else if (has_next) {   // the request stream crosses into the next tile (pair 0 -> pair slot 0)
-            if (r == 0) {   // (the next tile's slots are decoded here, where the stream needs them: a second set of eight offsets held since period 0 costs registers)
+            if (r == 0) {
               decode_slots(Tn, voff);
               rs_in = rs_in_n;
             }
             req_i(rs_in, voff, r, 0, r);
+            req = true;
           }
         }
-        if (c == 0) fifo_store8(IC0{});
-        else if (c == 1) fifo_store8(IC1{});
-        else if (c == 2) { fifo_fill(8, rs_out_prev); fifo_store8(IC0{}); }   // (the other half: staged during period 0)
-        else if (c == 3) fifo_store8(IC1{});
-        const bool dr = c < 4;   // (uniform) eight stores were issued
-        if (c == 0) {   // the NEXT tile: looked up and decoded behind this period's requests and stores
-          unsigned kn = k_ord + 1;
-          has_next = find_tile(kn, Tn);
-          k_ord = kn;
-          if (has_next) {
-            pix_geom(Tn, (2 * iw) * 64 + lane, pbase_[0], vo_n[0]);
-            pix_geom(Tn, (2 * iw + 1) * 64 + lane, pbase_[1], vo_n[1]);
-            tile_pitch(Tn, lw16_, perkb16_);
-            rs_in_n = w16_rsrc(reinterpret_cast<const unsigned char*>(p.in) + (size_t)Tn.b * ibytes, ibytes);
-            rs_out_n = w16_rsrc(reinterpret_cast<unsigned char*>(p.out) + (size_t)Tn.b * obytes, obytes);
-          }
-        }
-        // the NEXT tile's operand addresses for the compute wavefronts: written in period 1 (they read the previous message at their
-        // tile seam, in front of this tile's period 0) and read at the next seam
-        if (c == 1) {
+        if (c == 0 && !(W16_ABL & 4)) __builtin_amdgcn_s_barrier();   // (X)
+        if (tw == 0) {
+          if (c == 0 && has_next) {   // the next tile's operand addresses for the compute wavefronts (pixel h * 64 + lane)
 #pragma unroll
-          for (int h = 0; h < 2; ++h) *reinterpret_cast<unsigned*>(lds + W16_MB + (2 * iw + h) * 256 + ((lane & 15) * 4 + (lane >> 4)) * 4) = pbase_[h];
-          if (iw == 0 && lane == 0) *reinterpret_cast<u32x4*>(lds + W16_MBS) = u32x4{has_next ? 1u : 0u, lw16_, perkb16_, 0u};
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int h = 0; h < 4; ++h) {
+              int vo_unused;
+              pix_geom(Tn, h * 64 + lane, pbase_[h], vo_unused);
+            }
+            tile_pitch(Tn, lw16_, perkb16_);
+          }
+          // written in period 1 (the compute wavefronts read the previous message at their tile seam, in front of this tile's period 0)
+          if (c == 1) {
+#pragma unroll
+            for (int h = 0; h < 4; ++h) *reinterpret_cast<unsigned*>(lds + W16_MB + h * 256 + ((lane & 15) * 4 + (lane >> 4)) * 4) = pbase_[h];
+            if (lane == 0) *reinterpret_cast<u32x4*>(lds + W16_MBS) = u32x4{has_next ? 1u : 0u, lw16_, perkb16_, 0u};
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          }
         }
-        // a pair's last period: the next pair's tiles (requested in its periods 0, 1) have to be there; this period's stores may fly on
-        if (r == 2) {
-          if (dr) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        // in order: everything but this period's input request (8 pieces) has to be done
+        if (req) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (++r == 3) { r = 0; ++P; }
       }
-#pragma unroll
-      for (int h = 0; h < 2; ++h) vo_prev[h] = vo[h];
-      rs_out_prev = rs_out;
-      if (has_next) {
-        vo[0] = vo_n[0]; vo[1] = vo_n[1];
-        rs_out = rs_out_n;
-      }
     }
-    // the last tile: the staged half, barrier X, (compute: the other half), barrier, the other half
-    fifo_fill(0, rs_out_prev);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (!(W16_ABL & 4)) __builtin_amdgcn_s_barrier();
-    fifo_store8(IC0{});
-    fifo_store8(IC1{});
+    if (!(W16_ABL & 4)) __builtin_amdgcn_s_barrier();   // (X of the tail)
     __builtin_amdgcn_s_barrier();
-    fifo_fill(8, rs_out_prev);
-    fifo_store8(IC0{});
-    fifo_store8(IC1{});
     return;
   }
 
