@@ -59,24 +59,27 @@ __device__ __forceinline__ i32x4 w16_rsrc(const void* ptr, unsigned bytes) {
   const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
   return i32x4{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
 }
-// four LDS-DMA pieces (64 lanes x 16 bytes each) of one descriptor with one scalar offset: LDS destinations lds + k * 2 KB
-__device__ __forceinline__ void w16_dma4s(i32x4 rs, unsigned lds, int v0, int v1, int v2, int v3, unsigned soff) {
+// four LDS-DMA pieces (64 lanes x 16 bytes each) of one descriptor with one scalar offset: LDS destinations lds + k * 4 KB
+__device__ __forceinline__ void w16_dma4(i32x4 rs, unsigned lds, int v0, int v1, int v2, int v3, unsigned soff) {
   asm volatile(
       "s_mov_b32 m0, %5\n\ts_nop 4\n\tbuffer_load_dwordx4 %0, %4, %6 offen lds\n\t"
-      "s_add_u32 m0, m0, 2048\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %4, %6 offen lds\n\t"
-      "s_add_u32 m0, m0, 2048\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %4, %6 offen lds\n\t"
-      "s_add_u32 m0, m0, 2048\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %4, %6 offen lds"
+      "s_add_u32 m0, m0, 4096\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %4, %6 offen lds\n\t"
+      "s_add_u32 m0, m0, 4096\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %4, %6 offen lds\n\t"
+      "s_add_u32 m0, m0, 4096\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %4, %6 offen lds"
       ::"v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(rs), "s"(lds), "s"(soff) : "memory", "scc");
 }
-// eight pieces of one descriptor with one per-lane offset: 8 KB, contiguous at the source (from soff) and in LDS (from lds)
-__device__ __forceinline__ void w16_dma8(i32x4 rs, unsigned lds, int voff, unsigned soff) {
+// six pieces of one descriptor with one per-lane offset: LDS destinations lds + k * 4 KB, scalar offsets soff, + sj, + sk, + sj, + sk, + sj
+// (the weight slices [3 kx][2 chunks] of a period for this wavefront's channel block and column half)
+__device__ __forceinline__ void w16_dma6(i32x4 rs, unsigned lds, int voff, unsigned soff, unsigned sj, unsigned sk) {
   unsigned so;
-#define W16_PN "s_add_u32 m0, m0, 1024\n\ts_add_u32 %0, %0, 1024\n\tbuffer_load_dwordx4 %1, %2, %0 offen lds\n\t"
-  asm volatile("s_mov_b32 m0, %3\n\ts_mov_b32 %0, %4\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %0 offen lds\n\t" W16_PN W16_PN W16_PN W16_PN W16_PN W16_PN W16_PN
+#define W16_PJ "s_add_u32 m0, m0, 4096\n\ts_add_u32 %0, %0, %5\n\tbuffer_load_dwordx4 %1, %2, %0 offen lds\n\t"
+#define W16_PK "s_add_u32 m0, m0, 4096\n\ts_add_u32 %0, %0, %6\n\tbuffer_load_dwordx4 %1, %2, %0 offen lds\n\t"
+  asm volatile("s_mov_b32 m0, %3\n\ts_mov_b32 %0, %4\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %0 offen lds\n\t" W16_PJ W16_PK W16_PJ W16_PK W16_PJ
                : "=&s"(so)
-               : "v"(voff), "s"(rs), "s"(lds), "s"(soff)
+               : "v"(voff), "s"(rs), "s"(lds), "s"(soff), "s"(sj), "s"(sk)
                : "memory", "scc");
-#undef W16_PN
+#undef W16_PJ
+#undef W16_PK
 }
 __device__ __forceinline__ void w16_store16(u32x4 data, int voff, i32x4 rs, unsigned soff) {
   asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen" ::"v"(data), "v"(voff), "s"(rs), "s"(soff) : "memory");
@@ -149,127 +152,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   if (team == 1) {
     // =====================================================================================================================
-    // LOADERS.  A wavefront's vector-memory operations retire IN ORDER, and a period's barrier opens when the next period's weight
-    // slices have retired.  With every loader issuing weight slices (L2 hits), input tiles (HBM reads) and output stores (HBM write
-    // acknowledgements) the slices wait behind the older input pieces and stores (ablations, gpurun_out/r6_w16_abl1.log: without the
-    // stores -8 %, without the input requests -10 %, without the weight requests -5 %); two weight-only wavefronts of 12 pieces
-    // per period were issue-bound instead (+2 ... +5 %, profiles/r06_ws16_split_loaders_ab.log).  So:
-    //   wavefront 4 (tw 0): the weight slices of kernel column 0 (8 pieces per period) + the next tile's lookup / decode / mailbox
-    //   wavefronts 5, 6   : the weight slices of kernel columns 1, 2 + half of the input tiles each (8 pieces per chunk)
-    //   wavefront 7       : ALL output stores (the staged half -> a[0:127] of this wavefront -> 32 stores per half): never waited for
+    // LOADERS.  (Ablations of this arrangement, gpurun_out/r6_w16_abl1.log: without the epilogue -2.4 ... -4 %, without the weight requests
+    // -5 %, without the output stores -8 %, without the input requests -10 %: what keeps the matrix pipes at ~0.75 busy is the CU's
+    // vector-memory work -- ~40 kilobyte-pieces per 1 536-cycle period through four wavefronts --, not one stream blocking another:
+    // two weight-only + two input / output wavefronts measured +2 ... +5 % (profiles/r06_ws16_split_loaders_ab.log), three weight (+ input)
+    // wavefronts + one store-only wavefront +0.5 ... +1 % (profiles/r06_ws16_3plus1_loaders_ab.log); both are in the history of this file.)
+    // Per period: [period 0: the staged half of the previous tile -> registers, barrier X] the NEXT period's weight
+    // slices (6 pieces per wavefront), chunk r of the NEXT pair's input tiles in the pair's periods r = 0, 1 (4 pieces), four output
+    // stores in each of the periods 0..3, [period 0: next-tile lookup + decode; period 1: the mailbox], counted vmcnt, barrier.
     // =====================================================================================================================
     const int lane = w16_lane();
-    const unsigned wbytes = 9u * p.Kb * 2048u;
-    const unsigned obytes = 16u * plane16;
-    bool has_next = true;
-    TileS Tn{};
-    if (tw == 3) {
-      // ---- the store wavefront
-      int vo[4], vo_prev[4] = {(int)OOB, (int)OOB, (int)OOB, (int)OOB}, vo_n[4] = {(int)OOB, (int)OOB, (int)OOB, (int)OOB};
-#pragma unroll
-      for (int h = 0; h < 4; ++h) {
-        unsigned pb_unused;
-        pix_geom(T, h * 64 + lane, pb_unused, vo[h]);
-      }
-      i32x4 rs_out = w16_rsrc(reinterpret_cast<unsigned char*>(p.out) + (size_t)T.b * obytes, obytes);
-      i32x4 rs_out_prev = w16_rsrc(p.out, 0u), rs_out_n = rs_out;
-      const unsigned stg_rd = (unsigned)(W16_STG + lane * 16);
-#define W16_FILL(U) "ds_read_b128 a[4*" #U ":4*" #U "+3], %0 offset:" #U "*1024\n\t"
-#define W16_ALL_ACC "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95","a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127"
-      // the staged half (compute wavefront h, channel block u: unit 8 h + u at 8 h + u KB) -> a[4 (8 h + u) : + 3] of THIS wavefront (DS loads and
-      // buffer stores take accumulator registers as data: the 128 registers cost neither arch VGPRs nor moves)
-      auto fifo_fill = [&]() {
-        asm volatile(W16_FILL(0) W16_FILL(1) W16_FILL(2) W16_FILL(3) W16_FILL(4) W16_FILL(5) W16_FILL(6) W16_FILL(7) W16_FILL(8) W16_FILL(9) W16_FILL(10)
-                         W16_FILL(11) W16_FILL(12) W16_FILL(13) W16_FILL(14) W16_FILL(15) W16_FILL(16) W16_FILL(17) W16_FILL(18) W16_FILL(19) W16_FILL(20)
-                             W16_FILL(21) W16_FILL(22) W16_FILL(23) W16_FILL(24) W16_FILL(25) W16_FILL(26) W16_FILL(27) W16_FILL(28) W16_FILL(29) W16_FILL(30)
-                                 W16_FILL(31) "s_waitcnt lgkmcnt(0)"
-                     :
-                     : "v"(stg_rd)
-                     : "memory", W16_ALL_ACC);
-      };
-#define W16_ST(U) "buffer_store_dwordx4 a[32*%6+4*" #U ":32*%6+4*" #U "+3], %1, %2, %0 offen\n\ts_add_u32 %0, %0, %4\n\t"
-      // the eight units of compute wavefront h (channel blocks cb0 .. cb0 + 7 of the tile vo_prev / rs describe)
-      auto store8 = [&](auto h_tag, int cb0, i32x4 rs_o) {
-        constexpr int Hh = decltype(h_tag)::value;
-        const i32x4 rs = {__builtin_amdgcn_readfirstlane(rs_o.x), __builtin_amdgcn_readfirstlane(rs_o.y), __builtin_amdgcn_readfirstlane(rs_o.z),
-                          __builtin_amdgcn_readfirstlane(rs_o.w)};
-        const int vof = (W16_ABL & 2) ? (int)OOB : vo_prev[Hh];
-        const unsigned so0 = (unsigned)__builtin_amdgcn_readfirstlane(cb0) * (unsigned)plane16, sp = (unsigned)plane16;
-        unsigned so;
-        asm volatile("s_mov_b32 %0, %3\n\ts_nop 4\n\t" W16_ST(0) W16_ST(1) W16_ST(2) W16_ST(3) W16_ST(4) W16_ST(5) W16_ST(6) W16_ST(7) "s_nop 0"
-                     : "=&s"(so)
-                     : "v"(vof), "s"(rs), "s"(so0), "s"(sp), "n"(0), "n"(Hh)
-                     : "memory", "scc");
-      };
-      using H0 = std::integral_constant<int, 0>;
-      using H1 = std::integral_constant<int, 1>;
-      using H2 = std::integral_constant<int, 2>;
-      using H3 = std::integral_constant<int, 3>;
-      __builtin_amdgcn_s_barrier();   // (#1)
-      while (has_next) {
-        for (int c = 0; c < nper; ++c) {
-          if (c == 0) {   // the half of the previous tile's output the compute wavefronts staged in its last period
-            fifo_fill();
-            if (!(W16_ABL & 4)) __builtin_amdgcn_s_barrier();   // (X) the staging area is free for the other half
-            store8(H0{}, 0, rs_out_prev); store8(H1{}, 0, rs_out_prev);
-            unsigned kn = k_ord + 1;
-            has_next = find_tile(kn, Tn);
-            k_ord = kn;
-            if (has_next) {
-#pragma unroll
-              for (int h = 0; h < 4; ++h) {
-                unsigned pb_unused;
-                pix_geom(Tn, h * 64 + lane, pb_unused, vo_n[h]);
-              }
-              rs_out_n = w16_rsrc(reinterpret_cast<unsigned char*>(p.out) + (size_t)Tn.b * obytes, obytes);
-            }
-          } else if (c == 1) {
-            store8(H2{}, 0, rs_out_prev); store8(H3{}, 0, rs_out_prev);
-          } else if (c == 2) {   // the other half: staged during period 0
-            fifo_fill();
-            store8(H0{}, 8, rs_out_prev); store8(H1{}, 8, rs_out_prev);
-          } else if (c == 3) {
-            store8(H2{}, 8, rs_out_prev); store8(H3{}, 8, rs_out_prev);
-          }
-          __builtin_amdgcn_s_barrier();
-        }
-#pragma unroll
-        for (int h = 0; h < 4; ++h) vo_prev[h] = vo[h];
-        rs_out_prev = rs_out;
-        if (has_next) {
-#pragma unroll
-          for (int h = 0; h < 4; ++h) vo[h] = vo_n[h];
-          rs_out = rs_out_n;
-        }
-      }
-      // the last tile: the staged half, barrier X, (compute: the other half), barrier, the other half
-      fifo_fill();
-      if (!(W16_ABL & 4)) __builtin_amdgcn_s_barrier();
-      store8(H0{}, 0, rs_out_prev); store8(H1{}, 0, rs_out_prev); store8(H2{}, 0, rs_out_prev); store8(H3{}, 0, rs_out_prev);
-      __builtin_amdgcn_s_barrier();
-      fifo_fill();
-      store8(H0{}, 8, rs_out_prev); store8(H1{}, 8, rs_out_prev); store8(H2{}, 8, rs_out_prev); store8(H3{}, 8, rs_out_prev);
-#undef W16_FILL
-#undef W16_ST
-#undef W16_ALL_ACC
-      return;
-    }
-    // ---- the weight (+ input / + mailbox) wavefronts: tw = kernel column of their weight pieces
+    const int ttid = tw * 64 + lane;
+    const int rowb = p.IW * 16, kcb = p.IH * p.IW * 16;
+    const unsigned ibytes = (unsigned)p.Kb * kcb, obytes = 16u * plane16, wbytes = 9u * p.Kb * 2048u;
+    const unsigned so_i = 2u * kcb;                  // bytes between the 16-channel chunks of an image
     const unsigned wstep = (unsigned)p.Kb * 2048u;   // bytes between the taps of the packed weights
     const i32x4 rs_w = w16_rsrc(p.wp, wbytes);
     const int lane16 = lane * 16;
-    // the 8 KB of kernel column tw of period (pair P, kernel row r): [2 chunks][2 channel blocks][128 channels] = 4 consecutive channel
-    // blocks of tap 3 r + tw in the packed weights, contiguous in the slot too
-    auto req_w = [&](int P, int r, int par) {
-      w16_dma8(rs_w, (unsigned)(W16_W0 + par * W16_WSLOT + tw * 8192), lane16, (unsigned)(((3 * r + tw) * p.Kb + 4 * P) * 2048));
-    };
-    const int iw = tw - 1;   // (tw 1, 2: input half)
-    const int t128 = iw * 64 + lane;
-    const int rowb = p.IW * 16, kcb = p.IH * p.IW * 16;
-    const unsigned ibytes = (unsigned)p.Kb * kcb;
-    const unsigned so_i = 2u * kcb;                  // bytes between the 16-channel chunks of an image
-    // DMA source offsets of the 8 input slots: element t128 + i * 128 of the flattened [2][rows_in][lw] tile -> (channel block, row, column)
-    auto decode_slots = [&](const TileS& t, int (&voff)[8]) {
+    const int kbw = tw >> 1, colh = tw & 1;          // this wavefront's weight pieces: channel block of the chunk, column half
+    // DMA source offsets of the 4 input slots: element ttid + i * 256 of the flattened [2][rows_in][lw] tile -> (channel block, row, column)
+    auto decode_slots = [&](const TileS& t, int (&voff)[WS_NI]) {
       const unsigned m_bw = t.lastband ? p.m_bwl : p.m_bw;
       const int bw = t.bw;
       const int i_lo = w16_udivm(t.p0, m_bw), i_hi = w16_udivm(t.p1 - 1, m_bw);
@@ -279,16 +181,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int per_kb = rows_in * lw;
       const unsigned inv_lw = t.lastband ? p.m_lwl : p.m_lw;
       const unsigned inv_perkb = 0xFFFFFFFFu / (unsigned)per_kb + 1u;
-      const int skc = w16_udivm(128, inv_perkb);
-      const int srm = 128 - skc * per_kb;
+      const int skc = w16_udivm(WS_NT, inv_perkb);
+      const int srm = WS_NT - skc * per_kb;
       const int sr = w16_udivm(srm, inv_lw);
       const int sx = srm - sr * lw;
-      int kc_ = w16_udivm(t128, inv_perkb);
-      const int rm0 = t128 - kc_ * per_kb;
+      int kc_ = w16_udivm(ttid, inv_perkb);
+      const int rm0 = ttid - kc_ * per_kb;
       int r_ = w16_udivm(rm0, inv_lw);
       int x_ = rm0 - r_ * lw;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < WS_NI; ++i) {
         const int iy_ = iy0 + r_, ix_ = ix0 + x_;
         const bool ok = (kc_ < 2) && (iy_ >= 0) && (iy_ < p.IH) && (ix_ >= 0) && (ix_ < p.IW);
         voff[i] = ok ? kc_ * kcb + iy_ * rowb + ix_ * 16 : (int)OOB;
@@ -297,82 +199,135 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (r_ >= rows_in) { r_ -= rows_in; ++kc_; }
       }
     };
-    // input tile of chunk cn of the image behind (rs, voff) -> pair slot ps, chunk half j (8 pieces of this wavefront, 2 KB apart)
-    auto req_i = [&](i32x4 rs, const int (&voff)[8], int cn, int ps, int j) {
-      const unsigned l0 = (unsigned)(W16_I0 + ps * W16_ISLOT + j * WS_IB + iw * 1024);
-      w16_dma4s(rs, l0, voff[0], voff[1], voff[2], voff[3], (unsigned)cn * so_i);
-      w16_dma4s(rs, l0 + 8192u, voff[4], voff[5], voff[6], voff[7], (unsigned)cn * so_i);
+    static_assert(WS_NI == 4, "w16_dma4 issues the four input slots");
+    // weight slices of period cn (pair cn / 3, kernel row cn % 3) -> weight slot cn & 1
+    auto req_w = [&](int P, int r, int par) {
+      const unsigned soff = (unsigned)(((3 * r) * p.Kb + 4 * P + kbw) * 2048 + colh * 1024);
+      w16_dma6(rs_w, (unsigned)(W16_W0 + par * W16_WSLOT + kbw * 2048 + colh * 1024), lane16, soff, 4096u, wstep - 4096u);
     };
-    int voff[8] = {(int)OOB, (int)OOB, (int)OOB, (int)OOB, (int)OOB, (int)OOB, (int)OOB, (int)OOB};
+    // input tile of chunk cn of the image behind (rs, voff) -> pair slot ps, chunk half j
+    auto req_i = [&](i32x4 rs, const int (&voff)[WS_NI], int cn, int ps, int j) {
+      w16_dma4(rs, (unsigned)(W16_I0 + ps * W16_ISLOT + j * WS_IB + tw * 64 * 16), voff[0], voff[1], voff[2], voff[3], (unsigned)cn * so_i);
+    };
+    // Output hand-over: the staged half (8 channel blocks x this wavefront's 64 pixels) -> registers, four stores per period
+    const unsigned stg_rd = (unsigned)(W16_STG + tw * 8192 + lane * 16);
+    u32x4 fifo[8];
+    int f_vo = (int)OOB;
+    i32x4 f_rs = w16_rsrc(p.out, 0u);
+    int f_cb0 = 0;
+    auto fifo_fill = [&](int cb0, int vop, i32x4 rs_o) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) fifo[u] = *reinterpret_cast<const u32x4*>(lds + stg_rd + u * 1024);
+      f_vo = vop; f_rs = rs_o; f_cb0 = cb0;
+    };
+    auto fifo_store4 = [&](auto h_tag) {   // units 4 h .. 4 h + 3 of the FIFO
+      constexpr int Hh = decltype(h_tag)::value;
+      const i32x4 rs = {__builtin_amdgcn_readfirstlane(f_rs.x), __builtin_amdgcn_readfirstlane(f_rs.y), __builtin_amdgcn_readfirstlane(f_rs.z),
+                        __builtin_amdgcn_readfirstlane(f_rs.w)};
+      const int cb0 = __builtin_amdgcn_readfirstlane(f_cb0);
+#pragma unroll
+      for (int u = 4 * Hh; u < 4 * Hh + 4; ++u) w16_store16(fifo[u], (W16_ABL & 2) ? (int)OOB : f_vo, rs, (unsigned)(cb0 + u) * (unsigned)plane16);
+    };
+    using IC0 = std::integral_constant<int, 0>;
+    using IC1 = std::integral_constant<int, 1>;
+
+    int voff[WS_NI];
+    decode_slots(T, voff);
+    unsigned pbase_ = 0, lw16_ = 0, perkb16_ = 0;
+    int vo = (int)OOB, vo_prev = (int)OOB;
+    pix_geom(T, ttid, pbase_, vo);
     i32x4 rs_in = w16_rsrc(reinterpret_cast<const unsigned char*>(p.in) + (size_t)T.b * ibytes, ibytes);
-    i32x4 rs_in_n = rs_in;
-    unsigned pbase_[4] = {0u, 0u, 0u, 0u}, lw16_ = 0, perkb16_ = 0;   // (tw 0: the next tile's mailbox)
-    if (tw != 0) {
-      decode_slots(T, voff);
-      req_i(rs_in, voff, 0, 0, 0);
-      req_i(rs_in, voff, 1, 0, 1);
-    }
+    i32x4 rs_out = w16_rsrc(reinterpret_cast<unsigned char*>(p.out) + (size_t)T.b * obytes, obytes);
+    i32x4 rs_out_prev = w16_rsrc(p.out, 0u);
+    req_i(rs_in, voff, 0, 0, 0);
+    req_i(rs_in, voff, 1, 0, 1);
     req_w(0, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // (#1) pair 0 and the weight slices of period 0 of the first tile have landed
+    bool has_next = true;
+    TileS Tn{};
+    int voff_n[WS_NI] = {(int)OOB, (int)OOB, (int)OOB, (int)OOB}, vo_n = (int)OOB;
+    i32x4 rs_in_n = rs_in, rs_out_n = rs_out;
     while (has_next) {
       int P = 0, r = 0;   // pair and kernel row of period c
       for (int c = 0; c < nper; ++c) {
-        if (c == 0) {   // (uniform: every loader looks the next tile up for itself)
-          unsigned kn = k_ord + 1;
-          has_next = find_tile(kn, Tn);
-          k_ord = kn;
-          if (has_next) rs_in_n = w16_rsrc(reinterpret_cast<const unsigned char*>(p.in) + (size_t)Tn.b * ibytes, ibytes);
-        }
-        // oldest first: the weight slices of the NEXT period (needed at this period's barrier) ...
+        // oldest first: the weight slices of the NEXT period (needed at this period's barrier; a period is 1 536 MFMA cycles, the six
+        // pieces take ~600 to issue and an L2 round trip to land) ...
         {
           const int rn = r == 2 ? 0 : r + 1, Pn = r == 2 ? P + 1 : P;
           if ((W16_ABL & 1) && c >= 1) {
           } else if (c + 1 < nper) req_w(Pn, rn, (c + 1) & 1);
           else if (has_next) req_w(0, 0, 0);
         }
-        // ... then (tw 1, 2) chunk r of the next pair's input tiles: needed at the barrier of this pair's last period
+        if (c == 0) {   // the half of the previous tile's output the compute wavefronts staged in its last period
+          fifo_fill(0, vo_prev, rs_out_prev);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (!(W16_ABL & 4)) __builtin_amdgcn_s_barrier();   // (X) the staging area is free for the other half
+        }
+        // ... then chunk r of the next pair's input tiles (needed at the barrier of this pair's last period: they may stay in flight)
         bool req = false;   // (uniform)
-        if (tw != 0 && r < 2 && !(W16_ABL & 8)) {
+        if (r < 2 && !(W16_ABL & 8)) {
           if (P + 1 < npairs) {
             req_i(rs_in, voff, 2 * (P + 1) + r, (P + 1) & 1, r);
             req = true;
           } else if (has_next) {   // the request stream crosses into the next tile (pair 0 -> pair slot 0)
             if (r == 0) {
-              decode_slots(Tn, voff);
+#pragma unroll
+              for (int i = 0; i < WS_NI; ++i) voff[i] = voff_n[i];
               rs_in = rs_in_n;
             }
             req_i(rs_in, voff, r, 0, r);
             req = true;
           }
         }
-        if (c == 0 && !(W16_ABL & 4)) __builtin_amdgcn_s_barrier();   // (X)
-        if (tw == 0) {
-          if (c == 0 && has_next) {   // the next tile's operand addresses for the compute wavefronts (pixel h * 64 + lane)
-#pragma unroll
-            for (int h = 0; h < 4; ++h) {
-              int vo_unused;
-              pix_geom(Tn, h * 64 + lane, pbase_[h], vo_unused);
-            }
+        if (c == 0) fifo_store4(IC0{});
+        else if (c == 1) fifo_store4(IC1{});
+        else if (c == 2) { fifo_fill(8, vo_prev, rs_out_prev); fifo_store4(IC0{}); }   // (the other half: staged during period 0)
+        else if (c == 3) fifo_store4(IC1{});
+        const bool dr = c < 4;   // (uniform) four stores were issued
+        if (c == 0) {   // the NEXT tile: looked up and decoded behind this period's requests and stores
+          unsigned kn = k_ord + 1;
+          has_next = find_tile(kn, Tn);
+          k_ord = kn;
+          if (has_next) {
+            decode_slots(Tn, voff_n);
+            pix_geom(Tn, ttid, pbase_, vo_n);
             tile_pitch(Tn, lw16_, perkb16_);
-          }
-          // written in period 1 (the compute wavefronts read the previous message at their tile seam, in front of this tile's period 0)
-          if (c == 1) {
-#pragma unroll
-            for (int h = 0; h < 4; ++h) *reinterpret_cast<unsigned*>(lds + W16_MB + h * 256 + ((lane & 15) * 4 + (lane >> 4)) * 4) = pbase_[h];
-            if (lane == 0) *reinterpret_cast<u32x4*>(lds + W16_MBS) = u32x4{has_next ? 1u : 0u, lw16_, perkb16_, 0u};
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            rs_in_n = w16_rsrc(reinterpret_cast<const unsigned char*>(p.in) + (size_t)Tn.b * ibytes, ibytes);
+            rs_out_n = w16_rsrc(reinterpret_cast<unsigned char*>(p.out) + (size_t)Tn.b * obytes, obytes);
           }
         }
-        // in order: everything but this period's input request (8 pieces) has to be done
-        if (req) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        // the NEXT tile's operand addresses for the compute wavefronts: written in period 1 (they read the previous message at their
+        // tile seam, in front of this tile's period 0) and read at the next seam
+        if (c == 1) {
+          *reinterpret_cast<unsigned*>(lds + W16_MB + tw * 256 + ((lane & 15) * 4 + (lane >> 4)) * 4) = pbase_;
+          if (tw == 0 && lane == 0) *reinterpret_cast<u32x4*>(lds + W16_MBS) = u32x4{has_next ? 1u : 0u, lw16_, perkb16_, 0u};
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        // vector-memory operations retire in order: everything but this period's input request (4) and stores (4) has to be done
+        if (dr && req) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (dr || req) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (++r == 3) { r = 0; ++P; }
       }
+      vo_prev = vo;
+      rs_out_prev = rs_out;
+      if (has_next) {
+        vo = vo_n;
+        rs_out = rs_out_n;
+      }
     }
-    if (!(W16_ABL & 4)) __builtin_amdgcn_s_barrier();   // (X of the tail)
+    // the last tile: the staged half, barrier X, (compute: the other half), barrier, the other half
+    fifo_fill(0, vo_prev, rs_out_prev);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (!(W16_ABL & 4)) __builtin_amdgcn_s_barrier();
+    fifo_store4(IC0{});
+    fifo_store4(IC1{});
     __builtin_amdgcn_s_barrier();
+    fifo_fill(8, vo_prev, rs_out_prev);
+    fifo_store4(IC0{});
+    fifo_store4(IC1{});
     return;
   }
 
