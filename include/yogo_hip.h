@@ -134,6 +134,13 @@ int yogo_decode_format_preds_batched(const float* raw, const float* cxs, const f
                                      float anchor_h, float width_multiplier, float height_multiplier, int inference,
                                      double obj_thresh, double iou_thresh, int box_format, double min_class_confidence_threshold,
                                      yogo_stream_t stream);
+/* Eval-mode `model(x)` (yogo/model.py:275-313: self.model(x), then the decode) with the 1x1 head and the box decode in ONE launch
+ * (SURVEY.md 8(b) `head1x1_decode_fwd`): x = the last 3x3 block's output, bf16 NCHW8c [B][Cin][Sy][Sx] (Cin a multiple of 16, <= 128),
+ * packed = yogo_conv_bf16_pack(w [P][Cin][1][1], mode 0), bias [P] or null; out fp32 [B][P][Sy][Sx] = what yogo_conv2d_fwd_bf16 with an
+ * fp32 output followed by yogo_decode_fwd writes, bit for bit -- the raw head output never goes through memory.  6 <= P <= 16.      */
+int yogo_head1x1_decode_fwd_bf16(const void* x, const void* packed, const float* bias, float* out, const float* cxs, const float* cys,
+                                 int B, int Cin, int P, int Sy, int Sx, float anchor_w, float anchor_h, float width_multiplier,
+                                 float height_multiplier, int inference, yogo_stream_t stream);
 
 /* ---- bf16 path: the bf16-autocast forward of `yogo infer` (yogo/infer.py:313-317) and half-precision training
  * (yogo/train.py:315-318, --half) -------------------------------------------------------------------------------------------

@@ -196,3 +196,35 @@ def test_configs4_batch_256_inference_plan_and_results():
     want_out = O.yogo_forward(x2, sd, O.arch("base_model", 7), 0.0425, 0.0555, inference=True)
     err = (dec[0:2].cpu() - want_out).abs().max().item()
     assert err <= 3e-2 * float(want_out.abs().max()), err
+
+
+@pytest.mark.parametrize("num_classes,hw", [(7, (193, 258)), (1, (130, 70)), (11, (96, 128)), (7, (772, 1032))])
+def test_eval_model_call_runs_head_and_decode_as_one_launch_bit_identical(num_classes, hw):
+    """`model(x)` in eval mode on the bf16 path (yogo/model.py:275-313 under yogo/infer.py:313-317's autocast): the 1x1 head and the box
+    decode in ONE launch (yogo_head1x1_decode_fwd_bf16, SURVEY.md 8(b) head1x1_decode_fwd) -- the bits of the two launches it replaces
+    (conv_bf16_1x1_f32_kernel + decode_fwd_kernel, reached through forward_raw(x).decoded()), softmax and raw class channels both."""
+    from yogo_amd import _hip as Hh
+    from yogo_amd.model import YOGO
+
+    torch.manual_seed(3)
+    m = YOGO(hw, 0.0425, 0.0555, num_classes).cuda().eval()
+    for k, v in m.state_dict().items():   # trained-like running statistics keep the activations finite
+        if k.endswith("running_var"):
+            v.fill_(900.0)
+    x = torch.randint(0, 256, (2, 1, *hw), dtype=torch.uint8, generator=torch.Generator().manual_seed(4)).cuda()
+    for inference in (True, False):
+        m.inference = inference
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            Hh.launch_log(True)
+            try:
+                fused = m(x)
+                torch.cuda.synchronize()
+                log = Hh.read_launch_log()
+            finally:
+                Hh.launch_log(False)
+            two = m.forward_raw(x).decoded()
+        assert any(ln.startswith("conv_bf16_1x1_f32_kernel<8, true>") for ln in log), log
+        assert not any(ln.startswith("decode_fwd_kernel") for ln in log), log
+        assert fused.shape == two.shape == (2, 5 + num_classes, m.Sy, m.Sx)
+        assert torch.isfinite(fused).all()
+        assert torch.equal(fused.view(torch.int32), two.view(torch.int32)), float((fused - two).abs().max())

@@ -37,7 +37,7 @@ WS_SPILL_OK="${WS_SPILL_OK:-0}"   # (experiments: WS_SPILL_OK=1 turns a spill in
 if [[ "${1:-}" == "variant" ]]; then
   TAG="$2"; FILE="$3"; shift 3
   VOBJ="$HERE/obj_var"; mkdir -p "$VOBJ" "$OUT"
-  extra=(); case "$FILE" in nms|decode_loss) extra=(-ffp-contract=off) ;; conv_bf16_ws|conv_bf16_ws3|conv_bf16_ws16) extra=(-save-temps=obj -fno-slp-vectorize) ;; conv_bf16) extra=(-fno-slp-vectorize) ;; esac
+  extra=(); case "$FILE" in nms|decode_loss|conv_bf16_head) extra=(-ffp-contract=off) ;; conv_bf16_ws|conv_bf16_ws3|conv_bf16_ws16) extra=(-save-temps=obj -fno-slp-vectorize) ;; conv_bf16) extra=(-fno-slp-vectorize) ;; esac
   "$HIPCC" -O3 --offload-arch=gfx950 -fPIC -std=c++17 -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -I"$HERE" -I"$HERE/../../include" "$@" "${extra[@]}" -c "$HERE/$FILE.hip" -o "$VOBJ/${TAG}_$FILE.o"
   audit_ws "$VOBJ/${TAG}_$FILE-hip-amdgcn-amd-amdhsa-gfx950.s" 0   # (ablation variants are timings, not results: a warning)
   objs=(); for f in "$HERE"/*.hip; do b="$(basename "$f" .hip)"; [[ "$b" == "$FILE" ]] || objs+=("$HERE/obj/$b.o"); done
@@ -54,7 +54,7 @@ for f in "$HERE"/*.hip; do
   base="$(basename "$f" .hip)"
   extra=()
   case "$base" in
-    nms|decode_loss) extra=(-ffp-contract=off) ;;
+    nms|decode_loss|conv_bf16_head) extra=(-ffp-contract=off) ;;
     conv_bf16_ws|conv_bf16_ws3|conv_bf16_ws16) extra=(-save-temps=obj -fno-slp-vectorize) ;;   # the assembly is audited below (asm-owned accumulator registers); no SLP packing: v_pk_*_f32 beside MFMAs costs more than it saves
     conv_bf16) extra=(-fno-slp-vectorize) ;;   # the same for the tiled kernels: the merged-epilogue forward instantiations -5 ... -9.5 % in the same-box A/B (gpurun_out/r4_abnoslp.log); the training step's launches take the lean epilogue with its explicit packed math and do not change
   esac

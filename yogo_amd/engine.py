@@ -886,7 +886,10 @@ class InferEngineBF16:
         self._key = key
 
     @torch.no_grad()
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, decode=None) -> torch.Tensor:
+        """raw head output [B, 5 + C, Sy, Sx] -- or, given the decode's operands ``(cxs, cys, anchor_w, anchor_h, width_mult,
+        height_mult, inference)`` and a 1x1 head the fused kernel takes, the DECODED tensor of yogo/model.py:277-313 (one launch for
+        head + decode, bit-identical to the two)"""
         _hip.require_cuda(x, "the input batch")
         if x.ndim != 4:
             raise RuntimeError(f"yogo_amd: expected a [B,C,H,W] batch, got {tuple(x.shape)}")
@@ -917,13 +920,24 @@ class InferEngineBF16:
                     raise RuntimeError("yogo_amd: a one-layer network is not supported by the bf16 inference path")
             elif last:
                 out = torch.empty(B, L.cout, OH, OW, dtype=torch.float32, device=dev)
-                _hip.call("yogo_conv2d_fwd_bf16", cur, wq, bias, None, out, None, None, B, L.cin, L.cout, H, W, L.k, L.s, L.act, st)
+                if decode is not None and head_decode_fusable(L):
+                    cxs, cys, aw, ah, wm, hm, inference = decode
+                    _hip.call("yogo_head1x1_decode_fwd_bf16", cur, wq, bias, out, cxs, cys, B, L.cin, L.cout, OH, OW, aw, ah, wm, hm, 1 if inference else 0, st)
+                    self.decoded = True
+                else:
+                    _hip.call("yogo_conv2d_fwd_bf16", cur, wq, bias, None, out, None, None, B, L.cin, L.cout, H, W, L.k, L.s, L.act, st)
+                    self.decoded = False
             else:
                 mb = _hip.lib().yogo_bf16_channel_blocks(L.cout)
                 out = torch.empty(B, mb, OH, OW, 8, dtype=torch.bfloat16, device=dev)
                 _hip.call("yogo_conv2d_fwd_bf16", cur, wq, bias, out, None, None, None, B, L.cin, L.cout, H, W, L.k, L.s, L.act, st)
             cur, H, W = out, OH, OW
         return cur
+
+
+def head_decode_fusable(L) -> bool:
+    """the last layer is a plain 1x1 head the fused head + decode kernel takes (yogo_head1x1_decode_fwd_bf16)"""
+    return L.k == 1 and L.s == 1 and L.bn is None and L.act == 0 and 6 <= L.cout <= 16 and L.cin % 16 == 0 and L.cin <= 128
 
 
 def bf16_inference_requested() -> bool:
@@ -934,8 +948,10 @@ def bf16_inference_requested() -> bool:
         return False
 
 
-def backbone_infer_bf16(backbone: nn.Sequential, x: torch.Tensor) -> Optional[torch.Tensor]:
-    """raw head output via the bf16 path, or None when the model state does not allow it (train-mode BatchNorm, ...)"""
+def backbone_infer_bf16(backbone: nn.Sequential, x: torch.Tensor, decode=None):
+    """raw head output via the bf16 path, or None when the model state does not allow it (train-mode BatchNorm, ...).  With ``decode``
+    (the decode's operands, see InferEngineBF16.forward) the result is ``(tensor, decoded)``: decoded = True when head + decode ran as one
+    launch and ``tensor`` already is the decoded prediction"""
     eng = get_engine(backbone)
     inf = getattr(eng, "_infer_bf16", None)
     if inf is None:
@@ -944,4 +960,7 @@ def backbone_infer_bf16(backbone: nn.Sequential, x: torch.Tensor) -> Optional[to
     if not inf.supported():
         return None
     with torch.cuda.device(x.device):
-        return inf.forward(x)
+        if decode is None:
+            return inf.forward(x)
+        out = inf.forward(x, decode=decode)
+        return out, bool(inf.decoded)

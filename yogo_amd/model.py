@@ -247,8 +247,22 @@ class YOGO(nn.Module):
         return RawPredictions(raw, self._Cxs, self._Cys, *self._decode_scalars(), bool(self.inference))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        raw = self._backbone(x)
         aw, ah, wm, hm = self._decode_scalars()
+        if not self.model.training and not torch.is_grad_enabled():
+            # eval-mode `model(x)` on the bf16 path (yogo/infer.py:313-317's autocast): the 1x1 head and the decode below in ONE launch
+            # (yogo_head1x1_decode_fwd_bf16, bit-identical to the two) where the head is one the fused kernel takes
+            from yogo_amd.engine import backbone_infer_bf16, bf16_inference_requested
+
+            if bf16_inference_requested() or getattr(self.model, "bf16_inference", False):
+                if x.ndim == 3:
+                    x.unsqueeze_(0)
+                _hip.require_cuda(x, "the input batch")
+                xin = x if (x.is_floating_point() or x.dtype == torch.uint8) else x.float()
+                res = backbone_infer_bf16(self.model, xin, decode=(self._Cxs, self._Cys, aw, ah, wm, hm, bool(self.inference)))
+                if res is not None:
+                    out, decoded = res
+                    return out if decoded else _decode(out, self._Cxs, self._Cys, aw, ah, wm, hm, bool(self.inference))
+        raw = self._backbone(x)
         if torch.is_grad_enabled() and raw.requires_grad:
             return _DecodeFn.apply(raw, self._Cxs, self._Cys, aw, ah, wm, hm, bool(self.inference))
         return _decode(raw, self._Cxs, self._Cys, aw, ah, wm, hm, bool(self.inference))
