@@ -22,7 +22,12 @@
 // separate decode pass would have stored): the decoded [B, 5+C, Sy, Sx] tensor of `yogo infer` (yogo/model.py:277-313 ->
 // yogo/infer.py:45,73) is never written or read back, and the kept rows / cells / counts are identical.
 #include "common.h"
+#include <cmath>
+#include <cstring>
 
+#ifndef NMS_UNROLL
+#define NMS_UNROLL 4   // (A/B builds) unroll factor of the suppression loop over a chunk's kept boxes
+#endif
 #define NMS_THREADS 1024
 #define NMS_WAVES 16
 #define NMS_SLOTS 16
@@ -40,6 +45,7 @@ struct NmsParams {
   int B, P, cells, cap;
   float obj_thresh;       // float32(obj_thresh)
   double iou_thresh;
+  int iou_half;           // iou_thresh == 0.5: the division-free form of the test (nms_over)
   float min_cls;          // float32(min_class_confidence_threshold)
   int do_nms, use_cls_filter, xyxy;
   // DEC only: the decode's operands (yogo_decode_fwd)
@@ -106,6 +112,23 @@ struct PredView {
     }
   }
 };
+
+// THE SUPPRESSION TEST.  torchvision's CPU kernel (restated in oracle/yogo_oracle.py:324-361) suppresses a box when
+// (double) fl32(inter / union) > iou_thresh: an fp32 division (~10 instructions), a float -> double conversion and an fp64 compare per
+// pair of boxes -- half of the suppression loop of the dense case (every cell fires: ~47 M pairs per image).  For the threshold every caller
+// uses, 0.5 (yogo/utils/prediction_formatting.py:27 iou_thresh default, yogo/infer.py), the same predicate in four fp32 instructions:
+// the floats just above 0.5 are 0.5 + k 2^-24, so with round-to-nearest-even (monotone; a quotient exactly half way rounds DOWN to 0.5,
+// whose mantissa is even)
+//     fl32(inter / union) > 0.5  <=>  inter / union > 0.5 + 2^-25  <=>  inter - 0.5 union > 2^-25 union        (union > 0)
+// where 0.5 union and 2^-25 union are exact (union >= 2^-100) and d = fl32(inter - 0.5 union) is exact whenever inter lies within
+// [0.25, 1] union (Sterbenz) and keeps its sign and more than 2^-25 union of magnitude outside that range.  Every other input (union
+// <= 0, tiny, infinite or NaN: degenerate boxes) and every other threshold takes the division: same truth value for every input
+// (tests/test_gpu_parity.py, test_gpu_infer_fused.py: torch.equal to the oracle, degenerate boxes and thresholds 0.01 / 0.999 included).
+// Measured on the way (dense batch of 256, one box, gpurun_out/r6_nms_ab*.log; 16.2 ms at the start): the general-threshold form of the
+// idea in double precision (inter >= M * union with M the rounding boundary: exact too) 20.6 ms -- two conversions and an fp64 multiply
+// cost more than the fp32 division here; the kept boxes in the outer loop (one LDS read per kept box, not per pair) 17.0 ms; a per-lane
+// select between the two forms 18.8 ms (hipcc computes both); the uniform loop below with bare v_max / v_min 14.1 ms; the division
+// path out of line (inlined into the 16 slots it spilled 250 registers) and the cell array out of the loop's live range: 12.0 ms.
 
 __device__ __forceinline__ unsigned monotone_key(float s) {
   if (s != s) return 0xFFFFFFFFu;  // NaN sorts first (torch: NaN is the largest)
@@ -196,7 +219,6 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_batched_kernel(const NmsParam
   __threadfence_block();
   __syncthreads();
 
-  int mycell[NMS_SLOTS];
   float bx1[NMS_SLOTS], by1[NMS_SLOTS], bx2[NMS_SLOTS], by2[NMS_SLOTS], bar[NMS_SLOTS];
   unsigned alive = 0;  // bit k: slot k holds a live candidate
 
@@ -234,12 +256,10 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_batched_kernel(const NmsParam
 #pragma unroll
     for (int k = 0; k < NMS_SLOTS; ++k) {
       const int j = tid + k * NMS_THREADS;
-      mycell[k] = -1;
       bx1[k] = by1[k] = bx2[k] = by2[k] = bar[k] = 0.f;
       if (j < n) {
         const unsigned ci = 0xFFFFFFFFu - (unsigned)(keys[j] & 0xFFFFFFFFull);
         const int cell = ws_cells[ci];
-        mycell[k] = cell;
         float cx, cy, w, h;
         pv.box(cell, cx, cy, w, h);
         bx1[k] = cx - 0.5f * w;
@@ -282,8 +302,8 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_batched_kernel(const NmsParam
             const float xx2 = fminf(ix2, bb.z), yy2 = fminf(iy2, bb.w);
             const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
             const float inter = w * h;
-            const float ovr = inter / (iar + ar - inter);
-            if ((double)ovr > p.iou_thresh) live = false;
+            // (the reference's own form here: this serial part is latency-bound, the division-free test pays in the throughput-bound part below)
+            if ((double)(inter / (iar + ar - inter)) > p.iou_thresh) live = false;
           }
           const unsigned long long above = (i == 63) ? 0ull : (~0ull << (i + 1));
           todo = __ballot(live) & above;
@@ -299,25 +319,68 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_batched_kernel(const NmsParam
       __syncthreads();
       const int kn = kept_n;
       const int jmin = (c + 1) * 64;
+      unsigned odd_slots = 0u;   // slots of this lane whose candidate met a union outside the division-free test's range in this chunk
       if (kn > 0) {
+        // Every later live candidate against the chunk's kept boxes.  The loop over the kept boxes is UNIFORM (no per-lane break: with
+        // one, hipcc wraps every iteration in exec-mask bookkeeping -- 45 instructions per pair for 18 of arithmetic) and the four
+        // max / min of the intersection are bare v_max_f32 / v_min_f32 (fmaxf / fminf canonicalise both operands first -- four extra
+        // instructions per pair for values that come out of arithmetic and are never signalling NaNs; for every other input the
+        // instruction IS fmaxf / fminf).  A suppressed candidate stays suppressed: the surplus tests change nothing.
+        // (measured: skipping the rest when inter == 0 -- exact, the threshold is positive -- makes the dense case 14 % SLOWER: some lane
+        //  of the 64 nearly always overlaps, so the wave pays both sides of the branch)
 #pragma unroll
         for (int k = 0; k < NMS_SLOTS; ++k) {
+          if ((k + 1) * NMS_THREADS <= jmin || k * NMS_THREADS >= n) continue;   // uniform: nobody behind this chunk in slot k
           const int j = tid + k * NMS_THREADS;
-          if (((alive >> k) & 1u) && j >= jmin) {
+          const bool mine = ((alive >> k) & 1u) && j >= jmin;
+          if (__ballot(mine) == 0ull) continue;   // uniform
+          if (!p.iou_half) {   // (uniform) another threshold than 0.5: the division for every pair, below
+            if (mine) odd_slots |= 1u << k;
+            continue;
+          }
+          const float cx1 = bx1[k], cy1 = by1[k], cx2 = bx2[k], cy2 = by2[k], ca = bar[k];
+          // the hot loop carries the division-free test only; a lane that meets a union outside its range (degenerate boxes: never in
+          // a decoded prediction) is marked and goes through its candidate again with the division, below
+          bool dead = false, odd = false;
+          const float u_lo = 0x1p-100f, u_hi = 3.402823466e+38f;
+#pragma unroll NMS_UNROLL
+          for (int i = 0; i < kn; ++i) {
+            const float4 kb = kept_box[i];
+            const float ka = kept_area[i];
+            float xx1, yy1, xx2, yy2;
+            asm("v_max_f32 %0, %1, %2" : "=v"(xx1) : "v"(kb.x), "v"(cx1));
+            asm("v_max_f32 %0, %1, %2" : "=v"(yy1) : "v"(kb.y), "v"(cy1));
+            asm("v_min_f32 %0, %1, %2" : "=v"(xx2) : "v"(kb.z), "v"(cx2));
+            asm("v_min_f32 %0, %1, %2" : "=v"(yy2) : "v"(kb.w), "v"(cy2));
+            const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+            const float inter = w * h;
+            const float uni = ka + ca - inter;
+            const bool ok = uni >= u_lo && uni <= u_hi;
+            dead |= ok && (inter - 0.5f * uni > 0x1p-25f * uni);
+            odd |= !ok;
+          }
+          if (mine && dead) alive &= ~(1u << k);
+          if (mine && odd) odd_slots |= 1u << k;
+        }
+        // the marked candidates again, with the division (ONE copy of this loop, the candidate's box out of the sorted arrays: inlined
+        // into each of the 16 slots above it cost the kernel 250 spilled registers)
+        if (__ballot(odd_slots != 0u) != 0ull) {   // (uniform)
+#pragma nounroll
+          for (int k = 0; k < NMS_SLOTS; ++k) {
+            if (!((odd_slots >> k) & 1u)) continue;
+            const int j = tid + k * NMS_THREADS;
+            const float4 cb = ws_box[j];
+            const float ca = ws_area[j];
+            bool dead = false;
             for (int i = 0; i < kn; ++i) {
               const float4 kb = kept_box[i];
-              const float xx1 = fmaxf(kb.x, bx1[k]), yy1 = fmaxf(kb.y, by1[k]);
-              const float xx2 = fminf(kb.z, bx2[k]), yy2 = fminf(kb.w, by2[k]);
+              const float xx1 = fmaxf(kb.x, cb.x), yy1 = fmaxf(kb.y, cb.y);
+              const float xx2 = fminf(kb.z, cb.z), yy2 = fminf(kb.w, cb.w);
               const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
               const float inter = w * h;
-              // (measured: skipping the division when inter == 0 -- exact, the threshold is positive -- makes the dense case 14 %
-              //  SLOWER: some lane of the 64 nearly always overlaps, so the wave pays the division plus the branch)
-              const float ovr = inter / (kept_area[i] + bar[k] - inter);
-              if ((double)ovr > p.iou_thresh) {
-                alive &= ~(1u << k);
-                break;
-              }
+              dead |= (double)(inter / (kept_area[i] + ca - inter)) > p.iou_thresh;
             }
+            if (dead) alive &= ~(1u << k);
           }
         }
       }
@@ -328,11 +391,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_batched_kernel(const NmsParam
 #pragma unroll
     for (int k = 0; k < NMS_SLOTS; ++k) {
       const int j = tid + k * NMS_THREADS;
-      mycell[k] = -1;
-      if (j < n) {
-        mycell[k] = ws_cells[j];
-        alive |= 1u << k;
-      }
+      if (j < n) alive |= 1u << k;
     }
   }
 
@@ -344,7 +403,11 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_batched_kernel(const NmsParam
   for (int k = 0; k < NMS_SLOTS; ++k) {
     if (k * NMS_THREADS >= n) break;  // uniform
     bool keep = ((alive >> k) & 1u) != 0u;
-    const int cell = mycell[k];
+    // (the candidate's cell is looked up again here -- sorted position -> candidate -> cell -- instead of living in 16 registers per lane
+    //  through the suppression loop, whose 5 x 16 box registers leave the 128-register budget of a 1024-lane workgroup no slack)
+    const int jj = tid + k * NMS_THREADS;
+    int cell = -1;
+    if (jj < n) cell = (p.do_nms && n > 0) ? ws_cells[0xFFFFFFFFu - (unsigned)(keys[jj] & 0xFFFFFFFFull)] : ws_cells[jj];
     if (keep && p.use_cls_filter) keep = pv.max_cls(cell) > p.min_cls;
     int tot;
     const int r = block_rank(keep, sh_wave, &tot);
@@ -398,6 +461,7 @@ static int launch_format_preds(NmsParams p, void* workspace, double obj_thresh, 
   p.ws_cells = reinterpret_cast<int*>(ws + off);
   p.obj_thresh = (float)obj_thresh;
   p.iou_thresh = iou_thresh;
+  p.iou_half = iou_thresh == 0.5;
   p.min_cls = (float)min_class_confidence_threshold;
   p.do_nms = iou_thresh > 0.0;
   p.use_cls_filter = min_class_confidence_threshold > 0.0;
