@@ -185,7 +185,13 @@ int yogo_bf16_signs_bytes(int B, int C, int H, int W, size_t* bytes);
 int yogo_conv2d_fwd_bf16_signs(const void* in, const void* packed, const float* bias, void* out, void* signs,
                                const float* chan_scale, int B, int Cin, int Cout, int IH, int IW, int ksize, int stride, int act,
                                yogo_stream_t stream);
-/* yogo_conv2d_dgrad_bf16 for a LeakyReLU reference given as its sign map: dx = conv_transpose(dy) * (bit ? 1 : 0.01) * chan_scale */
+/* yogo_conv2d_dgrad_bf16 for a LeakyReLU reference given as its sign map: dx = conv_transpose(dy) * (bit ? 1 : 0.01) * chan_scale.
+ * Contract against yogo_conv2d_dgrad_bf16 with the bf16 reference tensor: the same bits wherever both run on the same kernel; the
+ * stride-2 3x3 shapes conv_bf16_s2d_direct_kernel takes (<= 32 or 65..128 input channels of the forward convolution) step the
+ * contraction 16 channels at a time where the tiled kernel takes 32 / 64: equal to ONE bf16 rounding step on < 0.5 % of the values
+ * (tests/test_gpu_bf16.py, tests/test_gpu_ws.py).  The same one-step contract holds between conv_bf16_ws16_kernel (the plain-epilogue
+ * stride-1 launches with 128 output channels and a multiple of 64 input channels: two 16-channel chunks summed inside one MFMA) and
+ * the 32x32x16 kernels. */
 int yogo_conv2d_dgrad_bf16_signs(const void* dy, const void* packed_dgrad, void* dx, const void* signs,
                                  const float* chan_scale, int B, int Cin, int Cout, int IH, int IW, int ksize, int stride,
                                  yogo_stream_t stream);

@@ -144,14 +144,25 @@ def test_conv_bf16_fwd_dgrad_wgrad(case):
     assert torch.equal(out_s.view(torch.int16), out_p.view(torch.int16)), case
     assert torch.equal(sign_bytes_used(sg.cpu(), Cout), sign_bytes_used(sign_map(out_p.cpu().float(), Cout), Cout)), case
     dx_ref = dx.clone()
-    h.call("yogo_conv2d_dgrad_bf16_signs", gy8, pd, dx, sign_map(to8c(refy).cpu().float(), Cin).cuda(), cmask.cuda(), B, Cin, Cout, IH, IW, k, s, st)
+    h.launch_log(True)
+    try:
+        h.call("yogo_conv2d_dgrad_bf16_signs", gy8, pd, dx, sign_map(to8c(refy).cpu().float(), Cin).cuda(), cmask.cuda(), B, Cin, Cout, IH, IW, k, s, st)
+        torch.cuda.synchronize()
+        log_signs = h.read_launch_log()
+    finally:
+        h.launch_log(False)
+    # bit-identity of the two routes is the contract wherever they run on the same kernel; the one-ulp branch below is taken ONLY when the
+    # launch log shows that the sign-map route really ran on the direct stride-2 kernel (include/yogo_hip.h: yogo_conv2d_dgrad_bf16_signs)
+    on_direct = any(ln.startswith("conv_bf16_s2d_direct_kernel") for ln in log_signs)
+    if not on_direct:
+        assert torch.equal(dx.view(torch.int16), dx_ref.view(torch.int16)), (case, log_signs)
     if not torch.equal(dx.view(torch.int16), dx_ref.view(torch.int16)):
         # the two routes may run on different kernels (stride-2 data gradients into <= 32 channels: the sign-map route takes the direct kernel
         # -- 16-channel steps --, the bf16-reference route the tiled one -- 32 / 64-channel chunks): another fp32 summation order, the bf16
         # results within one rounding step of each other on a few values
         a_, b_ = dx.float(), dx_ref.float()
         ulp = 2.0 ** -7 * torch.maximum(a_.abs(), b_.abs()) + 1e-6 * a_.abs().max()
-        assert s == 2 and Cin <= 32 and bool(((a_ - b_).abs() <= ulp).all()) and (a_ != b_).float().mean().item() < 5e-3, case
+        assert s == 2 and on_direct and bool(((a_ - b_).abs() <= ulp).all()) and (a_ != b_).float().mean().item() < 5e-3, case
     # wgrad from bf16 inputs is exact fp32 MFMA on the widened values
     ws = torch.empty(h.query_size("yogo_conv2d_wgrad_workspace_bytes", B, Cin, Cout, IH, IW, k, s) // 4, device="cuda")
     dw = torch.full((Cout, Cin, k, k), float("nan"), device="cuda")

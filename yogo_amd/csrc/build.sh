@@ -82,6 +82,10 @@ for p in "${pids[@]:-}"; do [[ -n "$p" ]] && wait "$p"; done
 # (the diagnostic build's stamps cost registers: its numbers are timings, not results -- a warning there, an error in the product)
 for wsf in $WS_FILES; do
   if ! audit_ws "$OBJ/$wsf-hip-amdgcn-amd-amdhsa-gfx950.s" "$([[ "${#DEFS[@]}" == 0 ]] && echo 1 || echo 0)"; then rm -f "$OBJ/$wsf.o"; exit 1; fi
+  # ... and no compiler instruction reads a register whose LDS read an asm statement left in flight (tools/audit_inflight.py)
+  if [[ "${#DEFS[@]}" == 0 && -f "$OBJ/$wsf-hip-amdgcn-amd-amdhsa-gfx950.s" ]]; then
+    if ! python3 "$HERE/../../tools/audit_inflight.py" "$OBJ/$wsf-hip-amdgcn-amd-amdhsa-gfx950.s"; then rm -f "$OBJ/$wsf.o"; exit 1; fi
+  fi
 done
 objs=(); for f in "$HERE"/*.hip; do objs+=("$OBJ/$(basename "$f" .hip).o"); done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -ldl -o "$OUT/$LIBNAME"

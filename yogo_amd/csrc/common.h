@@ -36,6 +36,15 @@ void yogo_launch_log(const char* fmt, ...);
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
+// The kernels divide by run-time constants with n / d = __umulhi(n, m), m = ceil(2^32 / d): exact for every 0 <= n <= nmax iff
+// nmax * (m * d - 2^32) < 2^32.  Planners / eligibility checks call this with the largest dividend a launch can produce and leave the
+// launch to the tiled kernel otherwise (a very large batch of small images is where it could fail).
+static inline bool magic_div_exact(long long nmax, int d) {
+  if (d <= 1 || nmax <= 0) return true;
+  const unsigned long long m = ((1ull << 32) + (unsigned)d - 1ull) / (unsigned)d;
+  const unsigned long long e = m * (unsigned long long)d - (1ull << 32);
+  return e == 0 || (unsigned long long)nmax < ((1ull << 32) + e - 1ull) / e;
+}
 
 #define ACT_NONE 0
 #define ACT_LEAKY 1

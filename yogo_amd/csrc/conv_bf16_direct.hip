@@ -235,6 +235,9 @@ bool conv_bf16_s2d_direct_eligible(int K, int M, int OH, int OW, int B) {
   if (OH < 2 || OW < 2 || B <= 0) return false;
   const long long IH = (OH + 1) / 2, IW = (OW + 1) / 2, Mb = ((M + 15) / 16) * 2;
   if ((long long)(K / 8) * IH * IW * 16 >= (1ll << 31) || Mb * OH * OW * 16 >= (1ll << 31) || (long long)B * ((IH * IW + 31) / 32) >= (1ll << 31)) return false;
+  // the kernel's divisions by multiplication: tile -> image (by tiles per image), pixel -> row (by IW)
+  const long long tpi = (IH * IW + 31) / 32;
+  if (!magic_div_exact(B * tpi - 1, (int)tpi) || !magic_div_exact(tpi * 32, (int)IW)) return false;
   return true;
 }
 

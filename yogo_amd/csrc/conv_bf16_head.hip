@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void conv_bf16_1x1_f32_kernel(const ConvHeadPa
 
 bool conv_bf16_head_fwd_eligible(int K, int M, int plane, int B) {
   return K >= 16 && K <= 128 && K % 16 == 0 && M >= 1 && M <= 32 && B > 0 && plane > 0 && (long long)(K / 8) * plane * 16 < (1ll << 31) &&
-         (long long)B * ((plane + 31) / 32) < (1ll << 31);
+         (long long)B * ((plane + 31) / 32) < (1ll << 31) && magic_div_exact((long long)B * ((plane + 31) / 32) - 1, (plane + 31) / 32);   // (tile -> image by multiplication)
 }
 struct ConvHeadDecode {   // the decode's operands (null cxs: no decode)
   const float* cxs;

@@ -924,6 +924,11 @@ bool conv_bf16_ws_plan(ConvWsParams* p) {
   p->m_bw = magic(p->TW); p->m_bwl = magic(bw_last);
   p->m_lw = magic(p->TW + 2); p->m_lwl = magic(bw_last + 2);
   p->nchunk = p->Kb / 2;
+  // the kernels' divisions by multiplication: tile -> image / band / tile of the band, pixel -> row of its band, staged element -> row
+  const int bw_l = OW - (p->ncb - 1) * p->TW;
+  if (!magic_div_exact((long long)p->ntiles - 1, p->gx) || !magic_div_exact(p->gx, p->tiles_per_band) || !magic_div_exact((long long)OH * p->TW, p->TW) ||
+      !magic_div_exact((long long)OH * bw_l, bw_l) || !magic_div_exact(2 * WS_NI * WS_NT, p->TW + 2) || !magic_div_exact(2 * WS_NI * WS_NT, bw_l + 2))
+    return false;
   return true;
 }
 

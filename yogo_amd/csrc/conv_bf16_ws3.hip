@@ -534,6 +534,10 @@ bool conv_bf16_ws3_plan(ConvWs3Params* p) {
   p->m_gx = magic(p->gx); p->m_tpb = magic(p->tiles_per_band);
   p->m_bw = magic(p->TW); p->m_bwl = magic(bw_last);
   p->nchunk = p->Kb / 2;
+  // the kernel's divisions by multiplication: tile -> image / band / tile of the band, pixel -> row of its band
+  if (!magic_div_exact((long long)p->ntiles - 1, p->gx) || !magic_div_exact(p->gx, p->tiles_per_band) || !magic_div_exact((long long)OH * p->TW, p->TW) ||
+      !magic_div_exact((long long)OH * bw_last, bw_last))
+    return false;
   return true;
 }
 
