@@ -144,6 +144,12 @@ def test_ws16_against_the_32x32x16_kernel_and_cpu(kind, B, Cin, H, W):
     y_old, _, log_old = _run(True, kind, B, Cin, H, W, seed=29, ws16=False)
     y_new, _, log_new = _run(True, kind, B, Cin, H, W, seed=29)
     assert any(ln.startswith("conv_bf16_ws_kernel<0>") for ln in log_old), log_old
+    if (H, W) == (300, 3):
+        # a band three pixels wide: a 256-pixel tile spans 86 rows, its staged input tile (880 units) does not fit the 768 units of the
+        # 16x16x32 member's input buffers -- the planner leaves the launch to conv_bf16_ws_kernel<0> (the fallback is part of the contract)
+        assert any(ln.startswith("conv_bf16_ws_kernel<0>") for ln in log_new), log_new
+        assert torch.equal(y_old.view(torch.int16), y_new.view(torch.int16))
+        return
     assert any(ln.startswith("conv_bf16_ws16_kernel<") for ln in log_new), log_new
     a, b = y_old.float(), y_new.float()
     ulp = 2.0 ** -7 * torch.maximum(a.abs(), b.abs()) + 1e-6 * a.abs().max()

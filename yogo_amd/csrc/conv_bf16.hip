@@ -1370,7 +1370,11 @@ extern "C" int yogo_hook_conv_bf16_head(int on) { g_bf_head = on != 0; return YO
 static constexpr bool g_bf_head = true;
 static constexpr bool g_bf_staged = true;
 static constexpr bool g_bf_ws = true;
+#ifdef BF_NO_WS16   // (A/B variant builds: bash build.sh variant nows16 conv_bf16 -DBF_NO_WS16)
+static constexpr bool g_bf_ws16 = false;
+#else
 static constexpr bool g_bf_ws16 = true;
+#endif
 static constexpr bool g_bf_direct = true;
 #endif
 bool conv_bf16_s2d_direct_eligible(int K, int M, int OH, int OW, int B);
@@ -1471,11 +1475,12 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
     q.stamps = (g_diag_stamps != nullptr && g_diag_stamps_bytes >= 512 * 128) ? g_diag_stamps : nullptr;
     if (q.stamps) (void)hipMemsetAsync(g_diag_stamps, 0, 512 * 128, stream);
 #endif
-    if (conv_bf16_ws_plan(&q)) {
-      // the plain epilogue (convolution [+ bias]): the 16x16x32 member of the family
-      if (g_bf_ws16 && act == ACT_NONE && signs == nullptr && chan_scale == nullptr && conv_bf16_ws16_eligible(K, M, IH, IW, B)) return launch_conv_bf16_ws16(q, stream);
-      return launch_conv_bf16_ws(q, stream);
+    // the plain epilogue (convolution [+ bias]): the 16x16x32 member of the family (its own tile plan: smaller input buffers)
+    if (g_bf_ws16 && act == ACT_NONE && signs == nullptr && chan_scale == nullptr && conv_bf16_ws16_eligible(K, M, IH, IW, B)) {
+      ConvWsParams q16 = q;
+      if (conv_bf16_ws_plan(&q16, W16_NI)) return launch_conv_bf16_ws16(q16, stream);
     }
+    if (conv_bf16_ws_plan(&q)) return launch_conv_bf16_ws(q, stream);
   }
   // stride-2 3x3 forward with 128 output channels and the lean epilogue: its persistent wavefront-specialised member (conv_bf16_ws3.hip)
   if (in != nullptr && g_bf_ws && !s2d && a == 2 && ks == 3 && out_f32 == nullptr && out_pre == nullptr && act_ref == nullptr && !signs_read &&

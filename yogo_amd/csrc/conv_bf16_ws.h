@@ -41,5 +41,6 @@ struct ConvWsParams {
 // true when the kernel takes the launch (stride 1, 3x3, M = 128, K a multiple of 32 and >= 64, lean epilogue)
 bool conv_bf16_ws_eligible(int K, int M, int IH, int IW, int B);
 // fills the tiling part of `p` (ncb, TW, ..., magic numbers); false when no tiling fits the kernel's fixed LDS layout
-bool conv_bf16_ws_plan(ConvWsParams* p);
+// (slots: 256-element DMA slots of a chunk's staged input tile the kernel has -- WS_NI for conv_bf16_ws_kernel)
+bool conv_bf16_ws_plan(ConvWsParams* p, int slots = WS_NI);
 int launch_conv_bf16_ws(const ConvWsParams& p, hipStream_t stream);

@@ -895,18 +895,21 @@ bool conv_bf16_ws_eligible(int K, int M, int IH, int IW, int B) {
 // column bands of TW output columns, tiles of 256 consecutive pixels of a band (row-major inside the band): the staged input
 // tile of a chunk ([2 channel blocks][rows + 2][TW + 2] units) has to fit the 4 x 256 input slots; among the fitting band
 // counts take the one with the fewest tiles per image (MFMA work), then the fewest staged units
-bool conv_bf16_ws_plan(ConvWsParams* p) {
+bool conv_bf16_ws_plan(ConvWsParams* p, int slots) {
   const int OH = p->IH, OW = p->IW;
   long long best = -1;
   int best_ncb = 0;
   for (int ncb = 1; ncb <= 48 && ncb <= OW; ++ncb) {
+#ifdef WS_FORCE_NCB   // (A/B variant builds: the band count of the plan, whatever the score)
+    if (ncb != WS_FORCE_NCB) continue;
+#endif
     const int TW = cdiv(OW, ncb);
     const int bw_min = OW - (cdiv(OW, TW) - 1) * TW;
     if (cdiv(OW, TW) != ncb || bw_min < 2) continue;
     // rows a 256-pixel tile can touch in a band of width bw: a tile starts anywhere in a row
     auto rows_of = [&](int bw) { return min(OH, 1 + cdiv(WS_PT - 1, bw)) + 2; };
     const int need = 2 * max(rows_of(TW) * (TW + 2), rows_of(bw_min) * (bw_min + 2));
-    if (need > WS_NI * WS_NT) continue;
+    if (need > slots * WS_NT) continue;
     const long long tiles = (long long)(ncb - 1) * cdiv(OH * TW, WS_PT) + cdiv(OH * bw_min, WS_PT);
     const long long staged = (long long)(ncb - 1) * cdiv(OH * TW, WS_PT) * rows_of(TW) * (TW + 2) + (long long)cdiv(OH * bw_min, WS_PT) * rows_of(bw_min) * (bw_min + 2);
     const long long score = tiles * 100000000ll + staged;
@@ -927,7 +930,7 @@ bool conv_bf16_ws_plan(ConvWsParams* p) {
   // the kernels' divisions by multiplication: tile -> image / band / tile of the band, pixel -> row of its band, staged element -> row
   const int bw_l = OW - (p->ncb - 1) * p->TW;
   if (!magic_div_exact((long long)p->ntiles - 1, p->gx) || !magic_div_exact(p->gx, p->tiles_per_band) || !magic_div_exact((long long)OH * p->TW, p->TW) ||
-      !magic_div_exact((long long)OH * bw_l, bw_l) || !magic_div_exact(2 * WS_NI * WS_NT, p->TW + 2) || !magic_div_exact(2 * WS_NI * WS_NT, bw_l + 2))
+      !magic_div_exact((long long)OH * bw_l, bw_l) || !magic_div_exact(2 * slots * WS_NT, p->TW + 2) || !magic_div_exact(2 * slots * WS_NT, bw_l + 2))
     return false;
   return true;
 }
