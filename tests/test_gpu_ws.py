@@ -14,19 +14,20 @@ def _blocks(c):
     return ((c + 15) // 16) * 2
 
 
-def _run(persistent, kind, B, Cin, H, W, seed, ws16=True):
-    """persistent: the PRODUCT library (libyogo_hip.so, which has no plan switch); tiled, or persistent without the 16x16x32 member
-    (ws16 = False: conv_bf16_ws_kernel<0> takes the plain-epilogue launches as it did until round 5): the test-hooks library -- the same
-    objects plus the yogo_hook_* switches (tests/_util.py:hooks_library)"""
+def _run(persistent, kind, B, Cin, H, W, seed, ws16=True, product=False):
+    """product: the PRODUCT library (libyogo_hip.so, which has no plan switch) with its own plan.  Otherwise the test-hooks library -- the
+    same objects plus the yogo_hook_* switches (tests/_util.py:hooks_library): tiled (persistent = False), persistent without the 16x16x32
+    member (ws16 = False: conv_bf16_ws_kernel<0> takes the plain-epilogue launches as it did until round 5), or persistent with the
+    16x16x32 member on EVERY eligible launch (ws16 = True: the biased forward too, which the product leaves on conv_bf16_ws_kernel<0>)"""
     import contextlib
 
     from _util import hooks_library
 
-    with (contextlib.nullcontext() if (persistent and ws16) else hooks_library()):
-        return _run_in(persistent, kind, B, Cin, H, W, seed, ws16)
+    with (contextlib.nullcontext() if product else hooks_library()):
+        return _run_in(persistent, kind, B, Cin, H, W, seed, ws16, product)
 
 
-def _run_in(persistent, kind, B, Cin, H, W, seed, ws16=True):
+def _run_in(persistent, kind, B, Cin, H, W, seed, ws16=True, product=False):
     from yogo_amd import _hip as Hh
 
     Cout = 128
@@ -37,10 +38,13 @@ def _run_in(persistent, kind, B, Cin, H, W, seed, ws16=True):
     y8 = torch.full((B, _blocks(Cout), H, W, 8), 7.0, device="cuda").to(torch.bfloat16)   # poisoned: every unit must be written
     bias = torch.randn(Cout, device="cuda", generator=g)
     msk = (torch.rand(B, Cout, device="cuda", generator=g) > 0.2).float() / 0.8
-    if not persistent:
+    if product:
+        pass
+    elif not persistent:
         Hh.call("yogo_hook_conv_bf16_persistent", 0)
-    elif not ws16:
-        Hh.call("yogo_hook_conv_bf16_ws16", 0)
+    else:
+        # (ws16 = True: every eligible launch, the biased forward too -- the product sends only the bias-free data gradients there)
+        Hh.call("yogo_hook_conv_bf16_ws16", 2 if ws16 else 0)
     try:
         Hh.launch_log(True)
         sg = None
@@ -144,12 +148,6 @@ def test_ws16_against_the_32x32x16_kernel_and_cpu(kind, B, Cin, H, W):
     y_old, _, log_old = _run(True, kind, B, Cin, H, W, seed=29, ws16=False)
     y_new, _, log_new = _run(True, kind, B, Cin, H, W, seed=29)
     assert any(ln.startswith("conv_bf16_ws_kernel<0>") for ln in log_old), log_old
-    if (H, W) == (300, 3):
-        # a band three pixels wide: a 256-pixel tile spans 86 rows, its staged input tile (880 units) does not fit the 768 units of the
-        # 16x16x32 member's input buffers -- the planner leaves the launch to conv_bf16_ws_kernel<0> (the fallback is part of the contract)
-        assert any(ln.startswith("conv_bf16_ws_kernel<0>") for ln in log_new), log_new
-        assert torch.equal(y_old.view(torch.int16), y_new.view(torch.int16))
-        return
     assert any(ln.startswith("conv_bf16_ws16_kernel<") for ln in log_new), log_new
     a, b = y_old.float(), y_new.float()
     ulp = 2.0 ** -7 * torch.maximum(a.abs(), b.abs()) + 1e-6 * a.abs().max()
@@ -178,6 +176,18 @@ def test_ws16_against_the_32x32x16_kernel_and_cpu(kind, B, Cin, H, W):
         got = got.cpu().double()
         tol = 2.0 ** -8 * want.abs() + 2e-5 * float(want.abs().max())
         assert bool(((got - want).abs() <= tol).all()), float(((got - want).abs() - tol).max())
+
+
+def test_product_plan_of_the_plain_epilogue_launches():
+    """the product library (no plan switch): the bias-free data gradients of the 128 -> 128 layers run on conv_bf16_ws16_kernel, the biased
+    forward (layer 5) on conv_bf16_ws_kernel<0> -- and give the bits the hooks library gives for the same plan"""
+    y_d, _, log_d = _run(True, "dgrad", 2, 128, 97, 129, seed=29, product=True)
+    y_f, _, log_f = _run(True, "fwd_plain", 2, 128, 97, 129, seed=29, product=True)
+    assert any(ln.startswith("conv_bf16_ws16_kernel<false>") for ln in log_d), log_d
+    assert any(ln.startswith("conv_bf16_ws_kernel<0>") for ln in log_f), log_f
+    y_d2, _, _ = _run(True, "dgrad", 2, 128, 97, 129, seed=29)                   # hooks library, 16x16x32 everywhere
+    y_f2, _, _ = _run(True, "fwd_plain", 2, 128, 97, 129, seed=29, ws16=False)   # hooks library, 32x32x16
+    assert torch.equal(y_d.view(torch.int16), y_d2.view(torch.int16)) and torch.equal(y_f.view(torch.int16), y_f2.view(torch.int16))
 
 
 def test_persistent_kernel_repeats_itself():

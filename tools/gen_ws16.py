@@ -11,8 +11,7 @@ from barrier to barrier: the last four row-block slots of the PREVIOUS period (o
 reads of the new period in their gaps, then slots 0..19 of the new period, s_waitcnt lgkmcnt(0), s_barrier -- every s_waitcnt lgkmcnt in
 between is counted by the generator from the issue order of the DS operations.
   slot   = one (tap, row block): 4 MFMAs (pixel blocks 0..3); accumulator tile (rb, pb) = a[4 * (4 rb + pb) : +3]
-  A ring = 8 quads v[40:71]: slot s uses quad s % 8, read 6 slots ahead (ds_read_b128 at %[pa] / %[pa2] + weight slot + kx * 8192 + rb * 256;
-           the weight slot of a period = its kernel row: three slots, the loaders request the slices two periods ahead)
+  A ring = 8 quads v[40:71]: slot s uses quad s % 8, read 6 slots ahead (ds_read_b128 at %[pa] + weight slot + kx * 8192 + rb * 256)
   B sets = X = v[72:87], Y = v[88:103]: pass q + 1's four quads are read in the first slots of pass q (address v[36 + pb] + kx * 16)
   v[32:35] = this lane's pixel-block addresses of the tile (pair slot 0, kernel row 0); v[36:39] = ... of the period; the next period's
   are set in the gaps behind the period's last B read (v_add_u32 with the scalar s_io = pair slot + kernel row * row pitch)
@@ -32,7 +31,7 @@ NA, DA = 8, 6
 # timing-only ablations (wrong results): python tools/gen_ws16.py noepi|nobarx|... > yogo_amd/csrc/obj_var/TAG.inc, then
 # bash yogo_amd/csrc/build.sh variant TAG conv_bf16_ws16 -DW16_ASM_INC='"obj_var/TAG.inc"'
 ABL = set(sys.argv[1:])
-WSLOT, ISLOT = 24576, 24576   # bytes of a weight slot (a period's slices) / of a pair slot (two chunks' input tiles of 768 units)
+WSLOT, ISLOT = 24576, 32768
 T_RD = [[104, 105, 106, 107], [108, 109, 110, 111]]          # accumulator read-outs (two rotating sets)
 T_OUT = [[112, 113], [114, 115], [116, 117], [118, 119]]     # converted pairs (four rotating)
 T_BIAS = [[120, 121, 122, 123], [124, 125, 126, 127]]        # bias quads (two rotating)
@@ -87,11 +86,9 @@ class Stream:
             self.done = idx + 1
 
     def a_read(self, dst, imm):
-        # weight slot = the period's kernel row; slot 2 lies beyond the 16-bit offset of slot 0's base: it has a base operand of its own
-        base = "%[pa2]" if self.wslot == 2 else "%[pa]"
-        imm += (self.wslot % 2) * WSLOT
+        imm += self.wslot * WSLOT
         assert imm < 65536
-        self.emit(f"ds_read_b128 {self.reg(dst)}, {base} offset:{imm}")
+        self.emit(f"ds_read_b128 {self.reg(dst)}, %[pa] offset:{imm}")
         self.producer[dst] = self.issued
         self.issued += 1
 
@@ -298,7 +295,7 @@ def verify(kind, lines):
 
 def set_io():
     """s_io = (pair & 1) * ISLOT + kernel row * row pitch for the period (s_P, s_R); then (s_P, s_R) step to the following period"""
-    return [f"s_and_b32 {S_T0}, {S_P}, 1", f"s_mul_i32 {S_T0}, {S_T0}, {ISLOT}", f"s_mul_i32 {S_T1}, {S_R}, {S_LW}", f"s_add_u32 {S_IO}, {S_T0}, {S_T1}",
+    return [f"s_and_b32 {S_T0}, {S_P}, 1", f"s_lshl_b32 {S_T0}, {S_T0}, 15", f"s_mul_i32 {S_T1}, {S_R}, {S_LW}", f"s_add_u32 {S_IO}, {S_T0}, {S_T1}",
             f"s_add_u32 {S_R}, {S_R}, 1", f"s_cmp_eq_u32 {S_R}, 3", f"s_cselect_b32 {S_R}, 0, {S_R}", f"s_addc_u32 {S_P}, {S_P}, 0"]
 
 
@@ -311,16 +308,13 @@ def role(bias):
     L += ["s_branch Lw16_mid%="]
     L += ["Lw16_tile%=:", f"s_mov_b32 {S_P}, 0", f"s_mov_b32 {S_R}, 1"] + set_io()
     L += gen("F", bias, 0, 0)
-    # periods 1 .. nper - 2, tap-major: weight slot = c % 3 (the kernel row), B set in use X for odd c, Y for even c -- a cycle of six
-    # (slot, set) combinations, (nper - 6) / 6 times, then the first four of it again (nper = 6, 12, 18, ...: an even number of chunk pairs)
-    cyc = [(1, 0), (2, 1), (0, 0), (1, 1), (2, 0), (0, 1)]
-    L += ["Lw16_mid%=:", f"s_mov_b32 {S_CNT}, %[n6]", f"s_cmp_eq_u32 {S_CNT}, 0", "s_cbranch_scc1 Lw16_tail%=", "Lw16_m%=:"]
-    for slot, par in cyc:
-        L += set_io() + gen("M", bias, par, slot)
-    L += [f"s_sub_u32 {S_CNT}, {S_CNT}, 1", f"s_cmp_lg_u32 {S_CNT}, 0", "s_cbranch_scc1 Lw16_m%=", "Lw16_tail%=:"]
-    for slot, par in cyc[:4]:
-        L += set_io() + gen("M", bias, par, slot)
-    L += gen("L", bias, 0, 2)
+    # periods 1 .. nper - 2 in pairs (odd period: weight slot 1, B set X in use; even: slot 0, set Y)
+    L += ["Lw16_mid%=:", f"s_mov_b32 {S_CNT}, %[npp]", "Lw16_m%=:"] + set_io()
+    L += gen("M", bias, 0, 1)
+    L += set_io()
+    L += gen("M", bias, 1, 0)
+    L += [f"s_sub_u32 {S_CNT}, {S_CNT}, 1", f"s_cmp_lg_u32 {S_CNT}, 0", "s_cbranch_scc1 Lw16_m%="]
+    L += gen("L", bias, 0, 1)
     L += [f"s_cmp_lg_u32 {S_HAS}, 0", "s_cbranch_scc1 Lw16_tile%="]
     L += gen("T", bias, 0, 0)
     return L

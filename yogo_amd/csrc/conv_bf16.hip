@@ -1354,9 +1354,10 @@ static bool g_bf_ring = true; // (diagnostic build: yogo_diag_conv_bf16_ring(0) 
 static bool g_bf_ws = true;
 // 0 = every launch goes to the tiled conv_bf16_kernel (A/B runs and the bit-identity tests of the two kernel families)
 extern "C" int yogo_hook_conv_bf16_persistent(int on) { g_bf_ws = on != 0; return YOGO_OK; }
-// 0 = the plain-epilogue launches stay on conv_bf16_ws_kernel<0> (32x32x16 MFMAs) instead of conv_bf16_ws16_kernel (16x16x32)
-static bool g_bf_ws16 = true;
-extern "C" int yogo_hook_conv_bf16_ws16(int on) { g_bf_ws16 = on != 0; return YOGO_OK; }
+// conv_bf16_ws16_kernel (16x16x32 MFMAs) for the plain-epilogue launches: 0 = never (conv_bf16_ws_kernel<0> takes them, as until round 5),
+// 1 = the product's rule (the launches WITHOUT a bias: the data gradients), 2 = every eligible launch (bias too: its tests and A/B runs)
+static int g_bf_ws16 = 1;
+extern "C" int yogo_hook_conv_bf16_ws16(int mode) { g_bf_ws16 = mode; return YOGO_OK; }
 // the direct (weights-resident, no staging) stride-2 data gradients (conv_bf16_direct.hip)
 static bool g_bf_direct = true;
 extern "C" int yogo_hook_conv_bf16_direct(int on) { g_bf_direct = on != 0; return YOGO_OK; }
@@ -1370,10 +1371,10 @@ extern "C" int yogo_hook_conv_bf16_head(int on) { g_bf_head = on != 0; return YO
 static constexpr bool g_bf_head = true;
 static constexpr bool g_bf_staged = true;
 static constexpr bool g_bf_ws = true;
-#ifdef BF_NO_WS16   // (A/B variant builds: bash build.sh variant nows16 conv_bf16 -DBF_NO_WS16)
-static constexpr bool g_bf_ws16 = false;
+#ifdef BF_WS16_MODE   // (A/B variant builds: bash build.sh variant nows16 conv_bf16 -DBF_WS16_MODE=0)
+static constexpr int g_bf_ws16 = BF_WS16_MODE;
 #else
-static constexpr bool g_bf_ws16 = true;
+static constexpr int g_bf_ws16 = 1;
 #endif
 static constexpr bool g_bf_direct = true;
 #endif
@@ -1475,12 +1476,15 @@ int launch_conv_bf16(const void* in, const void* packed, const float* bias, void
     q.stamps = (g_diag_stamps != nullptr && g_diag_stamps_bytes >= 512 * 128) ? g_diag_stamps : nullptr;
     if (q.stamps) (void)hipMemsetAsync(g_diag_stamps, 0, 512 * 128, stream);
 #endif
-    // the plain epilogue (convolution [+ bias]): the 16x16x32 member of the family (its own tile plan: smaller input buffers)
-    if (g_bf_ws16 && act == ACT_NONE && signs == nullptr && chan_scale == nullptr && conv_bf16_ws16_eligible(K, M, IH, IW, B)) {
-      ConvWsParams q16 = q;
-      if (conv_bf16_ws_plan(&q16, W16_NI)) return launch_conv_bf16_ws16(q16, stream);
+    if (conv_bf16_ws_plan(&q)) {
+      // the plain epilogue without a bias (the data gradients of the 128 -> 128 layers): the 16x16x32 member of the family.  With a bias
+      // (layer 5's forward) it measured +7 % inside the training step (profiles/r06_kernel_stats.txt history) and stays
+      // on conv_bf16_ws_kernel<0>
+      if ((g_bf_ws16 == 2 || (g_bf_ws16 == 1 && bias == nullptr)) && act == ACT_NONE && signs == nullptr && chan_scale == nullptr &&
+          conv_bf16_ws16_eligible(K, M, IH, IW, B))
+        return launch_conv_bf16_ws16(q, stream);
+      return launch_conv_bf16_ws(q, stream);
     }
-    if (conv_bf16_ws_plan(&q)) return launch_conv_bf16_ws(q, stream);
   }
   // stride-2 3x3 forward with 128 output channels and the lean epilogue: its persistent wavefront-specialised member (conv_bf16_ws3.hip)
   if (in != nullptr && g_bf_ws && !s2d && a == 2 && ks == 3 && out_f32 == nullptr && out_pre == nullptr && act_ref == nullptr && !signs_read &&

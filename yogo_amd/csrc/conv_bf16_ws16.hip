@@ -10,8 +10,8 @@
 // slices and the staged input tiles keep the 16-byte units of the family unchanged.  Both chunks of a pair have to be resident, which
 // two whole-chunk weight buffers (2 x 72 KB) would not fit: the weights stream by KERNEL ROW instead.  A period = (chunk pair, kernel
 // row) = 3 taps x 8 row blocks x 4 pixel blocks = 96 MFMAs of 16 cycles per compute wavefront (1 536 cycles), 24 KB of weight slices
-// (three slots = the kernel rows, requested TWO periods ahead), and the pair's two input tiles (24 KB, two slots by pair parity,
-// requested while the previous pair is multiplied).  Roles as in the family: wavefronts 0-3 compute (128 channels x 64 pixels = 32 accumulator tiles of
+// (two slots by period parity, one period ahead), and the pair's two input tiles (32 KB, two slots by pair parity, requested while the
+// previous pair is multiplied).  Roles as in the family: wavefronts 0-3 compute (128 channels x 64 pixels = 32 accumulator tiles of
 // 16x16 in a[0:127]), wavefronts 4-7 load (LDS-DMA, next-tile decode, output stores out of the LDS staging area).
 //
 // The compute wavefronts' instruction stream is GENERATED (tools/gen_ws16.py -> conv_bf16_ws16_asm.inc) and is ONE asm statement: tile
@@ -59,13 +59,14 @@ __device__ __forceinline__ i32x4 w16_rsrc(const void* ptr, unsigned bytes) {
   const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
   return i32x4{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
 }
-// three LDS-DMA pieces (64 lanes x 16 bytes each) of one descriptor with one scalar offset: LDS destinations lds + k * 4 KB
-__device__ __forceinline__ void w16_dma3(i32x4 rs, unsigned lds, int v0, int v1, int v2, unsigned soff) {
+// four LDS-DMA pieces (64 lanes x 16 bytes each) of one descriptor with one scalar offset: LDS destinations lds + k * 4 KB
+__device__ __forceinline__ void w16_dma4(i32x4 rs, unsigned lds, int v0, int v1, int v2, int v3, unsigned soff) {
   asm volatile(
-      "s_mov_b32 m0, %4\n\ts_nop 4\n\tbuffer_load_dwordx4 %0, %3, %5 offen lds\n\t"
-      "s_add_u32 m0, m0, 4096\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %5 offen lds\n\t"
-      "s_add_u32 m0, m0, 4096\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %5 offen lds"
-      ::"v"(v0), "v"(v1), "v"(v2), "s"(rs), "s"(lds), "s"(soff) : "memory", "scc");
+      "s_mov_b32 m0, %5\n\ts_nop 4\n\tbuffer_load_dwordx4 %0, %4, %6 offen lds\n\t"
+      "s_add_u32 m0, m0, 4096\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %4, %6 offen lds\n\t"
+      "s_add_u32 m0, m0, 4096\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %4, %6 offen lds\n\t"
+      "s_add_u32 m0, m0, 4096\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %4, %6 offen lds"
+      ::"v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(rs), "s"(lds), "s"(soff) : "memory", "scc");
 }
 // six pieces of one descriptor with one per-lane offset: LDS destinations lds + k * 4 KB, scalar offsets soff, + sj, + sk, + sj, + sk, + sj
 // (the weight slices [3 kx][2 chunks] of a period for this wavefront's channel block and column half)
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int lane16 = lane * 16;
     const int kbw = tw >> 1, colh = tw & 1;          // this wavefront's weight pieces: channel block of the chunk, column half
     // DMA source offsets of the 4 input slots: element ttid + i * 256 of the flattened [2][rows_in][lw] tile -> (channel block, row, column)
-    auto decode_slots = [&](const TileS& t, int (&voff)[W16_NI]) {
+    auto decode_slots = [&](const TileS& t, int (&voff)[WS_NI]) {
       const unsigned m_bw = t.lastband ? p.m_bwl : p.m_bw;
       const int bw = t.bw;
       const int i_lo = w16_udivm(t.p0, m_bw), i_hi = w16_udivm(t.p1 - 1, m_bw);
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       int r_ = w16_udivm(rm0, inv_lw);
       int x_ = rm0 - r_ * lw;
 #pragma unroll
-      for (int i = 0; i < W16_NI; ++i) {
+      for (int i = 0; i < WS_NI; ++i) {
         const int iy_ = iy0 + r_, ix_ = ix0 + x_;
         const bool ok = (kc_ < 2) && (iy_ >= 0) && (iy_ < p.IH) && (ix_ >= 0) && (ix_ < p.IW);
         voff[i] = ok ? kc_ * kcb + iy_ * rowb + ix_ * 16 : (int)OOB;
@@ -198,15 +199,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (r_ >= rows_in) { r_ -= rows_in; ++kc_; }
       }
     };
-    static_assert(W16_NI == 3, "w16_dma3 issues the three input slots");
-    // weight slices of period (pair P, kernel row r) -> weight slot r
-    auto req_w = [&](int P, int r) {
+    static_assert(WS_NI == 4, "w16_dma4 issues the four input slots");
+    // weight slices of period cn (pair cn / 3, kernel row cn % 3) -> weight slot cn & 1
+    auto req_w = [&](int P, int r, int par) {
       const unsigned soff = (unsigned)(((3 * r) * p.Kb + 4 * P + kbw) * 2048 + colh * 1024);
-      w16_dma6(rs_w, (unsigned)(W16_W0 + r * W16_WSLOT + kbw * 2048 + colh * 1024), lane16, soff, 4096u, wstep - 4096u);
+      w16_dma6(rs_w, (unsigned)(W16_W0 + par * W16_WSLOT + kbw * 2048 + colh * 1024), lane16, soff, 4096u, wstep - 4096u);
     };
     // input tile of chunk cn of the image behind (rs, voff) -> pair slot ps, chunk half j
-    auto req_i = [&](i32x4 rs, const int (&voff)[W16_NI], int cn, int ps, int j) {
-      w16_dma3(rs, (unsigned)(W16_I0 + ps * W16_ISLOT + j * W16_IB + tw * 64 * 16), voff[0], voff[1], voff[2], (unsigned)cn * so_i);
+    auto req_i = [&](i32x4 rs, const int (&voff)[WS_NI], int cn, int ps, int j) {
+      w16_dma4(rs, (unsigned)(W16_I0 + ps * W16_ISLOT + j * WS_IB + tw * 64 * 16), voff[0], voff[1], voff[2], voff[3], (unsigned)cn * so_i);
     };
     // Output hand-over: the staged half (8 channel blocks x this wavefront's 64 pixels) -> registers, four stores per period
     const unsigned stg_rd = (unsigned)(W16_STG + tw * 8192 + lane * 16);
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     using IC0 = std::integral_constant<int, 0>;
     using IC1 = std::integral_constant<int, 1>;
 
-    int voff[W16_NI];
+    int voff[WS_NI];
     decode_slots(T, voff);
     unsigned pbase_ = 0, lw16_ = 0, perkb16_ = 0;
     int vo = (int)OOB, vo_prev = (int)OOB;
@@ -240,25 +241,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     i32x4 rs_out_prev = w16_rsrc(p.out, 0u);
     req_i(rs_in, voff, 0, 0, 0);
     req_i(rs_in, voff, 1, 0, 1);
-    req_w(0, 0);
-    req_w(0, 1);
+    req_w(0, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // (#1) pair 0 and the weight slices of periods 0, 1 of the first tile have landed
+    __builtin_amdgcn_s_barrier();   // (#1) pair 0 and the weight slices of period 0 of the first tile have landed
     bool has_next = true;
     TileS Tn{};
-    int voff_n[W16_NI] = {(int)OOB, (int)OOB, (int)OOB}, vo_n = (int)OOB;
+    int voff_n[WS_NI] = {(int)OOB, (int)OOB, (int)OOB, (int)OOB}, vo_n = (int)OOB;
     i32x4 rs_in_n = rs_in, rs_out_n = rs_out;
     while (has_next) {
       int P = 0, r = 0;   // pair and kernel row of period c
       for (int c = 0; c < nper; ++c) {
-        // the weight slices of the period AFTER the next (slot = its kernel row = the slot the period behind this one just left): they
-        // have two periods to land -- a period is 1 536 MFMA cycles, the six pieces take ~600 to issue plus an L2 round trip
-        bool reqw = false;   // (uniform)
+        // oldest first: the weight slices of the NEXT period (needed at this period's barrier; a period is 1 536 MFMA cycles, the six
+        // pieces take ~600 to issue and an L2 round trip to land) ...
         {
-          const int r2 = r == 0 ? 2 : r - 1, P2 = r == 0 ? P : P + 1;   // (period c + 2)
+          const int rn = r == 2 ? 0 : r + 1, Pn = r == 2 ? P + 1 : P;
           if ((W16_ABL & 1) && c >= 1) {
-          } else if (c + 2 < nper) { req_w(P2, r2); reqw = true; }
-          else if (has_next) { req_w(0, c + 2 - nper); reqw = true; }
+          } else if (c + 1 < nper) req_w(Pn, rn, (c + 1) & 1);
+          else if (has_next) req_w(0, 0, 0);
         }
         if (c == 0) {   // the half of the previous tile's output the compute wavefronts staged in its last period
           fifo_fill(0, vo_prev, rs_out_prev);
@@ -274,7 +273,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           } else if (has_next) {   // the request stream crosses into the next tile (pair 0 -> pair slot 0)
             if (r == 0) {
 #pragma unroll
-              for (int i = 0; i < W16_NI; ++i) voff[i] = voff_n[i];
+              for (int i = 0; i < WS_NI; ++i) voff[i] = voff_n[i];
               rs_in = rs_in_n;
             }
             req_i(rs_in, voff, r, 0, r);
@@ -305,15 +304,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           if (tw == 0 && lane == 0) *reinterpret_cast<u32x4*>(lds + W16_MBS) = u32x4{has_next ? 1u : 0u, lw16_, perkb16_, 0u};
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        // vector-memory operations retire in order: everything issued BEFORE this period has to be done (the next period's weight slices,
-        // requested a period ago; at a pair's end the next pair's input tiles) -- this period's weight request (6), input request (3) and
-        // stores (4) may stay in flight
-        switch ((reqw ? 6 : 0) + (req ? 3 : 0) + (dr ? 4 : 0)) {
-#define W16_WAIT(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-          W16_WAIT(13) W16_WAIT(10) W16_WAIT(9) W16_WAIT(7) W16_WAIT(6) W16_WAIT(4) W16_WAIT(3)
-#undef W16_WAIT
-          default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        }
+        // vector-memory operations retire in order: everything but this period's input request (4) and stores (4) has to be done
+        if (dr && req) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (dr || req) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (++r == 3) { r = 0; ++P; }
       }
@@ -353,25 +347,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     unsigned pbase;
     int vo_unused;
     pix_geom(T, tw * 64 + pb * 16 + c16, pbase, vo_unused);
-    pbl[pb] = pbase + (unsigned)(g & 1) * perkb16 + (unsigned)(g >> 1) * (unsigned)W16_IB + (unsigned)W16_I0;
+    pbl[pb] = pbase + (unsigned)(g & 1) * perkb16 + (unsigned)(g >> 1) * (unsigned)WS_IB + (unsigned)W16_I0;
   }
   __builtin_amdgcn_s_barrier();   // (#1)
   // K-group part of a pixel-block address as the seam recomputes it: (bytes of a channel block & kmask) + kconst
-  const unsigned kmask = (g & 1) ? 0xFFFFFFFFu : 0u, kconst = (unsigned)(g >> 1) * (unsigned)W16_IB + (unsigned)W16_I0;
+  const unsigned kmask = (g & 1) ? 0xFFFFFFFFu : 0u, kconst = (unsigned)(g >> 1) * (unsigned)WS_IB + (unsigned)W16_I0;
   const unsigned mba = (unsigned)(W16_MB + tw * 256 + c16 * 16), mbs = (unsigned)W16_MBS;
-  const unsigned n6 = (unsigned)((nper - 6) / 6);   // six-period cycles of (weight slot, pixel-quad set) between a tile's first period and its last five
-  const unsigned pa2 = pa_lane + 2u * (unsigned)W16_WSLOT;
+  const unsigned npp = (unsigned)((nper - 2) >> 1);   // pairs of tap-major periods between a tile's first and last period
   if constexpr (BIAS)
     asm volatile(W16_TXT_ROLEB
                  :
                  : [pa] "v"(pa_lane), [stg] "v"(stg), [eb] "v"(eb), [q0] "v"(pbl[0]), [q1] "v"(pbl[1]), [q2] "v"(pbl[2]), [q3] "v"(pbl[3]), [mba] "v"(mba),
-                   [mbs] "v"(mbs), [kmask] "v"(kmask), [kconst] "v"(kconst), [lw16] "s"(lw16), [n6] "s"(n6), [pa2] "v"(pa2)
+                   [mbs] "v"(mbs), [kmask] "v"(kmask), [kconst] "v"(kconst), [lw16] "s"(lw16), [npp] "s"(npp)
                  : W16_CLOBBER);
   else
     asm volatile(W16_TXT_ROLE
                  :
                  : [pa] "v"(pa_lane), [stg] "v"(stg), [eb] "v"(eb), [q0] "v"(pbl[0]), [q1] "v"(pbl[1]), [q2] "v"(pbl[2]), [q3] "v"(pbl[3]), [mba] "v"(mba),
-                   [mbs] "v"(mbs), [kmask] "v"(kmask), [kconst] "v"(kconst), [lw16] "s"(lw16), [n6] "s"(n6), [pa2] "v"(pa2)
+                   [mbs] "v"(mbs), [kmask] "v"(kmask), [kconst] "v"(kconst), [lw16] "s"(lw16), [npp] "s"(npp)
                  : W16_CLOBBER);
 }
 
