@@ -45,7 +45,7 @@ struct NmsParams {
   int B, P, cells, cap;
   float obj_thresh;       // float32(obj_thresh)
   double iou_thresh;
-  int iou_half;           // iou_thresh == 0.5: the division-free form of the test (nms_over)
+  int iou_half;           // iou_thresh == 0.5: the division-free form of the suppression test (see THE SUPPRESSION TEST below)
   float min_cls;          // float32(min_class_confidence_threshold)
   int do_nms, use_cls_filter, xyxy;
   // DEC only: the decode's operands (yogo_decode_fwd)
@@ -121,8 +121,9 @@ struct PredView {
 // whose mantissa is even)
 //     fl32(inter / union) > 0.5  <=>  inter / union > 0.5 + 2^-25  <=>  inter - 0.5 union > 2^-25 union        (union > 0)
 // where 0.5 union and 2^-25 union are exact (union >= 2^-100) and d = fl32(inter - 0.5 union) is exact whenever inter lies within
-// [0.25, 1] union (Sterbenz) and keeps its sign and more than 2^-25 union of magnitude outside that range.  Every other input (union
-// <= 0, tiny, infinite or NaN: degenerate boxes) and every other threshold takes the division: same truth value for every input
+// [0.25, 1] union (Sterbenz) and keeps its sign and more than 2^-25 union of magnitude outside that range; an infinite union makes both
+// sides infinite or NaN (false, like the quotient); for a zero union the test reads inter > 0 (the quotient is +inf, or NaN for 0 / 0); a
+// negative or NaN union never suppresses.  Only 0 < union < 2^-100 and every other threshold take the division: same truth value for every input
 // (tests/test_gpu_parity.py, test_gpu_infer_fused.py: torch.equal to the oracle, degenerate boxes and thresholds 0.01 / 0.999 included).
 // Measured on the way (dense batch of 256, one box, gpurun_out/r6_nms_ab*.log; 16.2 ms at the start): the general-threshold form of the
 // idea in double precision (inter >= M * union with M the rounding boundary: exact too) 20.6 ms -- two conversions and an fp64 multiply
@@ -342,7 +343,12 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_batched_kernel(const NmsParam
           // the hot loop carries the division-free test only; a lane that meets a union outside its range (degenerate boxes: never in
           // a decoded prediction) is marked and goes through its candidate again with the division, below
           bool dead = false, odd = false;
-          const float u_lo = 0x1p-100f, u_hi = 3.402823466e+38f;
+          // where the division-free test is exact: union >= 2^-100 -- an infinite union too (both sides of its comparison become -inf /
+          // +inf or NaN: false, like the quotient 0 or NaN) -- and union == 0 (it reads inter > 0: the quotient +inf, or NaN for 0 / 0).  A
+          // negative or NaN union never suppresses (the quotient is <= -0 or NaN).  What is left for the division is 0 < union < 2^-100.
+          // (A random-init network's predictions hold zero-area and infinite boxes: with those on the division path nearly every chunk
+          //  sent whole wavefronts through both loops -- 18.8 instead of 8.3 ms per batch of 256.)
+          const float u_lo = 0x1p-100f;
 #pragma unroll NMS_UNROLL
           for (int i = 0; i < kn; ++i) {
             const float4 kb = kept_box[i];
@@ -355,9 +361,9 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_batched_kernel(const NmsParam
             const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
             const float inter = w * h;
             const float uni = ka + ca - inter;
-            const bool ok = uni >= u_lo && uni <= u_hi;
-            dead |= ok && (inter - 0.5f * uni > 0x1p-25f * uni);
-            odd |= !ok;
+            const bool big = uni >= u_lo;
+            dead |= (big || uni == 0.f) && (inter - 0.5f * uni > 0x1p-25f * uni);
+            odd |= uni > 0.f && !big;
           }
           if (mine && dead) alive &= ~(1u << k);
           if (mine && odd) odd_slots |= 1u << k;
