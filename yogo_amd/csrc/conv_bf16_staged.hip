@@ -217,11 +217,9 @@ bool conv_bf16_staged_eligible(int K, int M, int stride, int IH, int IW, int OH,
   if ((long long)(K / 8) * IH * IW * 16 >= (1ll << 31) || Mb * OH * OW * 16 >= (1ll << 31) || (long long)B * OH * ((OW + 31) / 32) >= (1ll << 31)) return false;
   // the kernel's divisions by multiplication: tile -> image (by tiles per image, at most OH * tiles per row), tile in image -> row group
   const long long tpr = (OW + 31) / 32;
-  for (int R = 1; R <= 8; ++R) {   // (every row-tile height the launcher instantiates)
-    const long long tpi = ((OH + R - 1) / R) * tpr;
-    if (!magic_div_exact((long long)B * tpi - 1, (int)tpi)) return false;
-  }
-  if (!magic_div_exact((long long)OH * tpr, (int)tpr)) return false;
+  const int R = stride == 1 ? 8 : 1;   // (the row-tile height launch_conv_bf16_staged instantiates for this stride)
+  const long long tpi = ((OH + R - 1) / R) * tpr;
+  if (!magic_div_exact((long long)B * tpi - 1, (int)tpi) || !magic_div_exact(tpi, (int)tpr)) return false;
   return true;
 }
 
