@@ -11,9 +11,9 @@ from barrier to barrier: the last four row-block slots of the PREVIOUS period (o
 reads of the new period in their gaps, then slots 0..19 of the new period, s_waitcnt lgkmcnt(0), s_barrier -- every s_waitcnt lgkmcnt in
 between is counted by the generator from the issue order of the DS operations.
   slot   = one (tap, row block): 4 MFMAs (pixel blocks 0..3); accumulator tile (rb, pb) = a[4 * (4 rb + pb) : +3]
-  A ring = 8 quads v[40:71]: slot s uses quad s % 8, read 6 slots ahead (ds_read_b128 at %[pa] + weight slot + kx * 8192 + rb * 256)
-  B sets = X = v[72:87], Y = v[88:103]: pass q + 1's four quads are read in the first slots of pass q (address v[36 + pb] + kx * 16)
-  v[32:35] = this lane's pixel-block addresses of the tile (pair slot 0, kernel row 0); v[36:39] = ... of the period; the next period's
+  A ring = 8 quads v[24:55]: slot s uses quad s % 8, read 6 slots ahead (ds_read_b128 at %[pa] + weight slot + kx * 8192 + rb * 256)
+  B sets = X = v[56:71], Y = v[72:87]: pass q + 1's four quads are read in the first slots of pass q (address v[20 + pb] + kx * 16)
+  v[16:19] = this lane's pixel-block addresses of the tile (pair slot 0, kernel row 0); v[20:23] = ... of the period; the next period's
   are set in the gaps behind the period's last B read (v_add_u32 with the scalar s_io = pair slot + kernel row * row pitch)
 kinds: M  tap-major (passes = taps, 8 slots each; the B set in use flips from period to period)
        F  group-major first period of a tile (row blocks 0-3 all taps, then 4-7; a tile's first MFMAs start from 0), barrier X in front of
@@ -22,7 +22,8 @@ kinds: M  tap-major (passes = taps, 8 slots each; the B set in use flips from pe
        L  group-major last period: the epilogue of THIS tile's row blocks 0-3 in the gaps of slots 10..19 -> staging area; the mailbox of the
           next tile (written by the loaders in period 1) is read at its start and turned into v[32:39] / the scalars at its end
        T  tail of the workgroup's last tile: prefix MFMAs, barrier X, the epilogue of row blocks 4-7 on its own, barrier
-epilogue of an accumulator tile: 4 v_accvgpr_read (+ 4 v_add_f32 of the bias), 2 v_cvt_pk_bf16_f32, one ds_write_b64 (temporaries v104..v127)
+epilogue of an accumulator tile: 4 v_accvgpr_read, 2 v_cvt_pk_bf16_f32, one ds_write_b64 (temporaries v88..v95); the bias is the C operand of a
+tile's first MFMA (a[128:159], written once at the statement's start)
 """
 import re
 import sys
@@ -32,10 +33,12 @@ NA, DA = 8, 6
 # bash yogo_amd/csrc/build.sh variant TAG conv_bf16_ws16 -DW16_ASM_INC='"obj_var/TAG.inc"'
 ABL = set(sys.argv[1:])
 WSLOT, ISLOT = 24576, 32768
-T_RD = [[104, 105, 106, 107], [108, 109, 110, 111]]          # accumulator read-outs (two rotating sets)
-T_OUT = [[112, 113], [114, 115], [116, 117], [118, 119]]     # converted pairs (four rotating)
-T_BIAS = [[120, 121, 122, 123], [124, 125, 126, 127]]        # bias quads (two rotating)
-V_PBL, V_P, V_A, V_X, V_Y = 32, 36, 40, 72, 88
+# register map (96 arch VGPRs: v0..v15 hold the statement's inputs, the rest is named here; 160 accumulator registers: a[0:127] the tiles,
+# a[128:159] the bias of this lane's channels -- row block rb: a[128 + 4 rb : + 3] --, the C operand of a tile's first MFMA)
+T_RD = [[88, 89, 90, 91]]                                    # accumulator read-outs
+T_OUT = [[92, 93], [94, 95]]                                 # converted pairs (two rotating)
+V_PBL, V_P, V_A, V_X, V_Y = 16, 20, 24, 56, 72
+A_BIAS = 128
 # scalars (fixed, clobbered): row pitch of the staged tile, next period's offset, kernel row / pair of the next period, loop count, temporaries
 S_LW, S_IO, S_R, S_P, S_CNT, S_T0, S_T1, S_HAS, S_PERKB = "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s87"
 
@@ -58,7 +61,8 @@ def quad(base, i):
 
 
 class Stream:
-    def __init__(self, par, wslot):
+    def __init__(self, par, wslot, bias=False):
+        self.bias = bias
         self.lines = []
         self.issued = 0          # DS operations issued so far
         self.done = 0            # ... known complete (by an emitted s_waitcnt)
@@ -111,24 +115,20 @@ class Stream:
         self.done = self.issued
 
     def mfma(self, tile, a, b, zero):
-        c = "0" if zero else f"a[{tile}:{tile + 3}]"
+        # a tile's first MFMA: C = 0, or this lane's bias of the tile's row block (tile = 4 * (4 rb + pb))
+        c = (f"a[{A_BIAS + 4 * (tile // 16)}:{A_BIAS + 4 * (tile // 16) + 3}]" if self.bias else "0") if zero else f"a[{tile}:{tile + 3}]"
         self.emit(f"v_mfma_f32_16x16x32_bf16 a[{tile}:{tile + 3}], {self.reg(a)}, {self.reg(b)}, {c}")
 
 
 def epilogue_ops(rbs, bias):
+    # (the bias is in the accumulators already: a tile's first MFMA takes it as its C operand)
     ops, k = [], 0
     for bi, rb in enumerate(rbs):
-        bq = T_BIAS[bi & 1]
-        if bias:
-            ops.append(("biasrd", (bq, rb * 64)))
         for pb in range(4):
             t = 4 * (4 * rb + pb)
-            rd, out = T_RD[k & 1], T_OUT[k & 3]
+            rd, out = T_RD[0], T_OUT[k & 1]
             for i in range(4):
                 ops.append(("v", f"v_accvgpr_read_b32 v{rd[i]}, a{t + i}"))
-            if bias:
-                for i in range(4):
-                    ops.append(("vb", (f"v_add_f32 v{rd[i]}, v{rd[i]}, v{bq[i]}", bq)))
             ops.append(("v", f"v_cvt_pk_bf16_f32 v{out[0]}, v{rd[0]}, v{rd[1]}"))
             ops.append(("v", f"v_cvt_pk_bf16_f32 v{out[1]}, v{rd[2]}, v{rd[3]}"))
             ops.append(("w", (out, (rb & 3) * 2048 + pb * 256)))
@@ -155,14 +155,14 @@ def tail_ops(kind):
         # (behind the period's last B read the address registers are free: the mailbox row of this lane -- 4 pixel-block units -- lands in
         #  v[32:35], {there is a next tile, row pitch, bytes of a channel block} in v[36:39]; turned into the next tile's addresses behind the drain)
         return [("v", f"v_readfirstlane_b32 {S_HAS}, v{V_P}"), ("v", f"v_readfirstlane_b32 {S_LW}, v{V_P + 1}"), ("v", f"v_readfirstlane_b32 {S_PERKB}, v{V_P + 2}"),
-                ("v", f"v_and_b32 v104, {S_PERKB}, %[kmask]"), ("v", "v_add_u32 v104, v104, %[kconst]")] + \
-               [("v", f"v_add_u32 v{V_PBL + i}, v{V_PBL + i}, v104") for i in range(4)] + [("v", f"v_mov_b32 v{V_P + i}, v{V_PBL + i}") for i in range(4)]
+                ("v", f"v_and_b32 v{T_RD[0][0]}, {S_PERKB}, %[kmask]"), ("v", f"v_add_u32 v{T_RD[0][0]}, v{T_RD[0][0]}, %[kconst]")] + \
+               [("v", f"v_add_u32 v{V_PBL + i}, v{V_PBL + i}, v{T_RD[0][0]}") for i in range(4)] + [("v", f"v_mov_b32 v{V_P + i}, v{V_PBL + i}") for i in range(4)]
     return [("v", f"v_add_u32 v{V_P + i}, v{V_PBL + i}, {S_IO}") for i in range(4)]
 
 
 def gen(kind, bias, par=0, wslot=0):
     group_major = kind != "M"
-    st = Stream(par, wslot)
+    st = Stream(par, wslot, bias)
     passes, flat = slots_of(group_major)
     zero_first = kind in ("F", "F0")
 
@@ -303,6 +303,10 @@ def role(bias):
     L = []
     # entry: the tile's pixel-block addresses, the row pitch; (s_P, s_R) = the period FOLLOWING the one whose text comes next
     L += [f"v_mov_b32 v{V_PBL + i}, %[q{i}]" for i in range(4)] + [f"v_mov_b32 v{V_P + i}, %[q{i}]" for i in range(4)]
+    if bias:   # this lane's bias (channels 16 rb + 4 g + 0..3: a float4 per row block at %[eb] + 64 rb) -> a[128:159], once
+        for rb in range(8):
+            L += [f"ds_read_b128 v[{T_RD[0][0]}:{T_RD[0][3]}], %[eb] offset:{rb * 64}", "s_waitcnt lgkmcnt(0)"]
+            L += [f"v_accvgpr_write_b32 a{A_BIAS + 4 * rb + i}, v{T_RD[0][i]}" for i in range(4)]
     L += [f"s_mov_b32 {S_LW}, %[lw16]", f"s_mov_b32 {S_P}, 0", f"s_mov_b32 {S_R}, 1"] + set_io()
     L += gen("F0", bias, 0, 0)
     L += ["s_branch Lw16_mid%="]
