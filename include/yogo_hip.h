@@ -295,6 +295,18 @@ int yogo_conv_first_bn_wgrad_finalize_xs(const float* sums, const float* gram, c
                                          const float* gamma, const float* w_oihw, float* dw, float* dgamma, float* dbeta, int B,
                                          int Cin, int Cout, int IH, int IW, int stride, int training, float clip,
                                          yogo_stream_t stream);
+/* Layer 1's data gradient and the sweep of yogo_conv_first_bn_wgrad_bf16_xs in ONE launch (ABI 7): the gradient w.r.t. layer 0's output
+ * is folded into layer 0's backward sums tile by tile and never written (layer 0 has no data gradient of its own).  g = gradient
+ * w.r.t. layer 1's conv output, bf16 NCHW8c [B][Cout1 / 8][H][W]; packed = layer 1's yogo_conv_bf16_pack mode-1 packing; image = uint8
+ * [B][2H][2W]; signs as above (NULL with ACT_NONE); part: rows (yogo_conv2d_dgrad_first_bwd_rows, on the current device) x cols
+ * (yogo_conv_first_bn_wgrad_cols) floats; finish with yogo_partials_reduce and yogo_conv_first_bn_wgrad_finalize_xs exactly as after the
+ * unfused sweep.  _supported: 3x3 stride-1 layer 1 with 16 -> 32 channels, even W.  Results agree with yogo_conv2d_dgrad_bf16 followed by
+ * yogo_conv_first_bn_wgrad_bf16_xs to fp32 rounding of the sums (every element is rounded to bf16 as the stored gradient would have been).
+ * Replaces autograd of yogo/model_defns.py:34-41 (the backward of the first two blocks of base_model). */
+int yogo_conv2d_dgrad_first_bwd_supported(int Cmid, int Cout1, int H, int W, int B, int act0);
+int yogo_conv2d_dgrad_first_bwd_rows(int B, int H, int W, int* rows);
+int yogo_conv2d_dgrad_bf16_first_bwd(const void* g, const void* packed, const void* image, const void* signs, float* part, int B, int Cmid,
+                                     int Cout1, int H, int W, int act0, yogo_stream_t stream);
 
 /* ---- data-parallel exchange over RCCL / xGMI (replaces torch DDP: init_process_group("nccl") + DistributedDataParallel,
  * yogo/train.py:155-159; gradient all-reduce overlapped with backward, buffers broadcast from rank 0).  One process per GPU.

@@ -14,7 +14,7 @@ def test_library_exports_every_declared_symbol():
 
     protos = _hip.prototypes()   # raises AttributeError if a declared symbol is missing from the .so
     assert len(protos) >= 26
-    assert _hip.lib().yogo_hip_abi_version() == 6
+    assert _hip.lib().yogo_hip_abi_version() == 7
     for name in ("yogo_conv2d_fwd_f32", "yogo_conv2d_dgrad_f32", "yogo_conv2d_wgrad_f32", "yogo_conv_first_fwd", "yogo_bn_finalize",
                  "yogo_decode_fwd", "yogo_loss_fwd_bwd", "yogo_format_preds_batched", "yogo_decode_format_preds_batched", "yogo_adamw_step"):
         assert name in protos

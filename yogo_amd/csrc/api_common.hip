@@ -12,7 +12,7 @@ void yogo_set_error(const char* fmt, ...) {
 
 extern "C" const char* yogo_hip_last_error(void) { return g_err; }
 
-extern "C" int yogo_hip_abi_version(void) { return 6; }
+extern "C" int yogo_hip_abi_version(void) { return 7; }
 
 // ---- launch log: which kernel instantiation (and planner parameters) each entry point launched -------------------------------
 // Off by default (one relaxed load per launch).  The parity tests switch it on to prove that the instantiations and tilings a

@@ -369,6 +369,7 @@ _L0_GRAM = True             # ... with the batch statistics from the exact integ
 _WGRAD_DEFER_REDUCE = True  # the per-layer split-K reductions of the weight gradients in one launch at the end of the backward pass
 _L0_NO_Z = True             # ... and without its conv output in memory: sign map + derived sums (yogo_conv_first_*_xs)
 _PACK_MULTI = True          # all weight packings of a step in one launch
+_L01_FUSE_BWD = True        # layer 1's data gradient folded into layer 0's backward sums (yogo_conv2d_dgrad_bf16_first_bwd): no dy of layer 0 in memory
 _BN_STATS_PASS = True       # BatchNorm statistics of layers > 0 by a sweep over the stored bf16 output (not the conv epilogue)
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
@@ -638,9 +639,10 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
         g = torch.empty(B, _blocks(P), Sy, Sx, 8, dtype=torch.bfloat16, device=dev)
         _hip.call("yogo_nchw_f32_to_bf16_8c", graw, g, B, P, Sy * Sx, st)
     n = len(eng.layers)
+    fused01 = None   # (part, rows) of layer 0's backward sums when layer 1's data gradient produced them (g is then None at layer 0)
     for i in range(n - 1, -1, -1):
         L, S = eng.layers[i], saved[i]
-        OH, OW = int(g.shape[2]), int(g.shape[3])
+        OH, OW = (int(g.shape[2]), int(g.shape[3])) if g is not None else fused01[2:]
         if i == 0:
             IH, IW = int(S.x_in.shape[2]), int(S.x_in.shape[3])
         else:
@@ -648,7 +650,7 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
         # layer 0 with BatchNorm and no conv bias: BatchNorm backward, activation derivative and the weight gradient share ONE
         # sweep over (image, g, z) -- dz is never written (see conv_first_bn_wgrad_kernel)
         fuse0 = _FUSE_LAYER0_BWD and i == 0 and L.bn is not None and L.conv.bias is None and L.act in (ACT_NONE, ACT_LEAKY)
-        if trace is not None:
+        if trace is not None and g is not None:
             trace[("g", i)] = g.clone()
         if L.bn is not None and not fuse0:
             bn = L.bn
@@ -680,9 +682,12 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
             beta = _f32(bn.bias.detach()) if bn.bias is not None else torch.zeros(L.cout, device=dev)
             dgamma = dst(bn.weight) if bn.weight is not None else torch.empty(L.cout, dtype=torch.float32, device=dev)
             dbeta = dst(bn.bias) if bn.bias is not None else torch.empty(L.cout, dtype=torch.float32, device=dev)
-            rows = _hip.query_ints("yogo_conv_first_wgrad_rows", 1, B, IH, IW, L.s)[0]
             cols = _hip.query_ints("yogo_conv_first_bn_wgrad_cols", 1, L.cin, L.cout)[0]
-            part = torch.empty(rows * cols, dtype=torch.float32, device=dev)
+            if fused01 is not None:
+                part, rows = fused01[:2]
+            else:
+                rows = _hip.query_ints("yogo_conv_first_wgrad_rows", 1, B, IH, IW, L.s)[0]
+                part = torch.empty(rows * cols, dtype=torch.float32, device=dev)
             sums = torch.empty(cols, dtype=torch.float32, device=dev)
             keep.extend((gamma, beta, dgamma, dbeta, part, sums))
         elif i == 0:
@@ -705,8 +710,9 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
                 xg = "_xs" if S.signs0 is not None else "_xg" if S.gram is not None else ""
                 zs = S.signs0 if S.signs0 is not None else S.z
                 keep.append(zs)
-                _hip.call("yogo_conv_first_bn_wgrad_bf16" + xg, S.x_in, xdt, g, zs, S.mean, S.invstd, gamma, beta, part, B, L.cin, L.cout,
-                          IH, IW, L.s, L.act, wst)
+                if fused01 is None:   # (else: layer 1's data gradient has filled `part`)
+                    _hip.call("yogo_conv_first_bn_wgrad_bf16" + xg, S.x_in, xdt, g, zs, S.mean, S.invstd, gamma, beta, part, B, L.cin, L.cout,
+                              IH, IW, L.s, L.act, wst)
                 _hip.call("yogo_partials_reduce", part, rows, cols, 0.0, sums, wst)
                 _hip.call("yogo_conv_first_bn_wgrad_finalize" + xg, sums, *((S.gram,) if S.gram is not None else ()), S.mean, S.invstd, gamma,
                           S.w_used if S.w_used is not None else _f32(L.conv.weight.detach()), dw, dgamma,
@@ -749,8 +755,25 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
                 act_ref = Sp.y        # sign of the output = sign of the pre-activation
             else:
                 act_ref = Sp.pre      # SiLU: the pre-activation saved by yogo_conv2d_fwd_bf16_pre
-            dx = torch.empty(B, _blocks(L.cin), IH, IW, 8, dtype=torch.bfloat16, device=dev)
             pk = _packed_bf16(eng, i, 2 if (L.s == 2 and L.k == 3) else 1)
+            # layer 1 above a matrix-core layer 0 that kept its sign map: the data gradient goes straight into layer 0's backward sums
+            # (layer 0 has no data gradient of its own, so its dy need not exist; a trace wants to see it)
+            if (_L01_FUSE_BWD and i == 1 and trace is None and _FUSE_LAYER0_BWD and Sp.signs0 is not None and Sp.x_in.dtype == torch.uint8
+                    and Lp.bn is not None and Lp.conv.bias is None and Lp.cin == 1 and Lp.s == 2 and Lp.act in (ACT_NONE, ACT_LEAKY)
+                    and L.k == 3 and L.s == 1 and Sp.mask is None
+                    and _hip.lib().yogo_conv2d_dgrad_first_bwd_supported(L.cin, L.cout, IH, IW, B, Lp.act)):
+                rows01 = _hip.query_ints("yogo_conv2d_dgrad_first_bwd_rows", 1, B, IH, IW)[0]
+                cols01 = _hip.query_ints("yogo_conv_first_bn_wgrad_cols", 1, Lp.cin, Lp.cout)[0]
+                part01 = torch.empty(rows01 * cols01, dtype=torch.float32, device=dev)
+                keep.append(part01)
+                eng._tick("dgrad", i, 2.0 * B * L.cout * L.cin * L.k * L.k * OH * OW, mw=30,
+                          nbytes=B * (16 * _blocks(L.cout) * OH * OW + 2 * IH * IW + 4 * IH * IW))
+                _hip.call("yogo_conv2d_dgrad_bf16_first_bwd", g, pk, Sp.x_in, Sp.signs0, part01, B, L.cin, L.cout, IH, IW, Lp.act, st)
+                eng._tock()
+                fused01 = (part01, rows01, IH, IW)
+                g = None
+                continue
+            dx = torch.empty(B, _blocks(L.cin), IH, IW, 8, dtype=torch.bfloat16, device=dev)
             nbytes = B * 2 * 8 * (_blocks(L.cout) * OH * OW + _blocks(L.cin) * IH * IW * (2 if act_ref is not None else 1))
             if ref_act == ACT_LEAKY and Sp.signs is not None:   # one byte per 16-byte unit in place of the reference
                 nbytes = B * (16 * _blocks(L.cout) * OH * OW + 17 * _blocks(L.cin) * IH * IW)
