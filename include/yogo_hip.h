@@ -304,9 +304,17 @@ int yogo_conv_first_bn_wgrad_finalize_xs(const float* sums, const float* gram, c
  * yogo_conv_first_bn_wgrad_bf16_xs to fp32 rounding of the sums (every element is rounded to bf16 as the stored gradient would have been).
  * Replaces autograd of yogo/model_defns.py:34-41 (the backward of the first two blocks of base_model). */
 int yogo_conv2d_dgrad_first_bwd_supported(int Cmid, int Cout1, int H, int W, int B, int act0);
-int yogo_conv2d_dgrad_first_bwd_rows(int B, int H, int W, int* rows);
+int yogo_conv2d_dgrad_first_bwd_rows(int B, int H, int W, int with_wgrad, int* rows);
 int yogo_conv2d_dgrad_bf16_first_bwd(const void* g, const void* packed, const void* image, const void* signs, float* part, int B, int Cmid,
                                      int Cout1, int H, int W, int act0, yogo_stream_t stream);
+/* ... and layer 1's WEIGHT gradient in the same sweep (it reads the same g; x = layer 1's input = layer 0's output, bf16 NCHW8c): dw (OIHW)
+ * and db (may be NULL) clamped to +-clip, as yogo_conv2d_wgrad_bf16 / _deferred deliver them (queue: NULL = reduce now, else a
+ * yogo_wgrad_reduce_queue); part rows: yogo_conv2d_dgrad_first_bwd_rows(..., 1, ...).  Replaces autograd of model_defns.py:34-41 except
+ * layer 1's own data-gradient input. */
+int yogo_conv2d_dgrad_wgrad_first_bwd_workspace_bytes(int B, int H, int W, size_t* bytes);
+int yogo_conv2d_dgrad_wgrad_bf16_first_bwd(const void* g, const void* packed, const void* x, const void* image, const void* signs, float* part,
+                                           float* dw, float* db, void* workspace, int B, int Cmid, int Cout1, int H, int W, int act0,
+                                           float clip, void* queue, yogo_stream_t stream);
 
 /* ---- data-parallel exchange over RCCL / xGMI (replaces torch DDP: init_process_group("nccl") + DistributedDataParallel,
  * yogo/train.py:155-159; gradient all-reduce overlapped with backward, buffers broadcast from rank 0).  One process per GPU.

@@ -28,9 +28,15 @@ struct DgFirstParams {
   const unsigned char* img;      // uint8 [B][2H][2W]: layer 0's input
   const unsigned short* signs;   // [B][H*W]: layer 0's sign map (yogo_conv_first_mfma_signs), or null when act is ACT_NONE
   float* part;                   // [gridDim.x * wavefronts][ncol]
+  // with layer 1's weight gradient (WG): its input = layer 0's output, and the per-wavefront partial results
+  const u32x4* x;                // bf16 NCHW8c [B][2][H][W] units
+  float* slab;                   // [gridDim.x * wavefronts][9][32][16]: dW[tap][co][ci]
+  float* bias_part;              // [gridDim.x * wavefronts][32]
   int B, H, W, Mpad, act, ncol;
-  int tiles_per_row, tiles_per_img, ntiles;
-  unsigned m_tpr, m_tpi;         // ceil(2^32 / d)
+  // a wavefront walks SEGMENTS: seg consecutive tiles of one tile column, top to bottom (the two halo rows a tile shares with the one above it
+  // were staged microseconds ago by the same wavefront: L2 hits); consecutive segments are horizontal neighbours
+  int tiles_per_row, tile_rows, seg, segs_per_img, nsegs;
+  unsigned m_tpr, m_spi;         // ceil(2^32 / d)
 };
 
 namespace {
@@ -55,6 +61,14 @@ __device__ __forceinline__ void df_dma4(i32x4 rs, unsigned lds_addr, int voff) {
                : "=&s"(keep) : "v"(voff), "s"(lds_addr), "s"(rs) : "memory");
 }
 __device__ __forceinline__ void df_wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// eight pixels of this lane's channel: two transposed reads of four pixels each, `second` bytes apart (wgrad_bf16.hip: lds_tr8)
+__device__ __forceinline__ bf16x8 df_tr8(const unsigned char* a, int second) {
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  typedef bf16x4 __attribute__((address_space(3))) * lds_v4;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(a));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(a + second));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
 }  // namespace
 
 // R: output rows of a wavefront's tile (R x 32 pixels); NWV: wavefronts per workgroup.
@@ -69,14 +83,25 @@ __device__ __forceinline__ void df_wait_dma() { asm volatile("s_waitcnt vmcnt(0)
 // gradient by its sign bit into two operands with two accumulators, A1 = D2pos + 0.01 D2neg at the end.  (A first form kept D in the usual
 // orientation and folded every value into 40 per-lane fp32 accumulators with packed FMAs: 624 vector instructions per 4 x 32-pixel tile
 // beside 72 MFMAs, VALU-bound at 502 us; profiles/r06_first_fused_bwd.log.)
-template <int R, int NWV>
-__global__ __launch_bounds__(64 * NWV) void conv_bf16_dgrad_first_bwd_kernel(const DgFirstParams p) {
+#ifndef DF_WAVES_PER_EU
+#define DF_WAVES_PER_EU 2
+#endif
+//
+// WG: layer 1's WEIGHT gradient in the same sweep -- it reads the same gradient tile (1.63 GB that wgrad_bf16_kernel would read again) and
+// layer 0's output x (the tile's own pixels, no halo).  dW[tap][co][ci] = sum over pixels p of g[co][p - tap + 1] x[ci][p], K = the 32 pixels of a
+// tile row: both operands come out of the staged channel-fastest units through ds_read_b64_tr_b16 (16 lanes read a 4 pixel x 16 channel block,
+// each lane gets 4 pixels of its channel; wgrad_bf16.hip), the tap shifts the address of the gradient's halo tile; 2 x 9 accumulator tiles
+// of 16 output x 16 input channels per wavefront for the whole launch, and a ones operand for the bias gradient.
+template <int R, int NWV, bool WG>
+__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(DF_WAVES_PER_EU))) void conv_bf16_dgrad_first_bwd_kernel(const DgFirstParams p) {
   extern __shared__ __attribute__((aligned(16))) u32x4 lds_u[];   // (the dynamic block starts at LDS address 0: LDS-DMA takes addresses)
   constexpr int OOB = (int)0x80000000u;
   constexpr int KB = 4, NR = R + 2, ROWU = 34, TU = KB * NR * ROWU, NDMA = (TU + 63) / 64;
   constexpr int IR = 2 * R + 1, IROWB = 72, IDW = IROWB / 4, IU = IR * IDW, NIDMA = (IU + 63) / 64;   // staged image: IR rows of 18 dwords = columns 2 ox0 - 4 .. 2 ox0 + 67
   constexpr int SU = R * 16, NSDMA = (SU + 63) / 64;   // staged sign words: R rows of 16 dwords (32 pixels x 2 bytes)
-  constexpr int WAVE_BYTES = NDMA * 1024 + NIDMA * 256 + NSDMA * 256;
+  static_assert(!WG || (R % 2) == 0, "a piece of the staged x tile is two whole rows");
+  constexpr int NXDMA = WG ? R : 0;   // staged x tile: [2 channel blocks][R rows][32 columns] units
+  constexpr int WAVE_BYTES = NDMA * 1024 + NIDMA * 256 + NSDMA * 256 + NXDMA * 1024;
   constexpr int CONST_BYTES = ((IR * IROWB + 15) / 16) * 16;   // an "image" of ones and one of zeros behind the wavefronts' pieces (rows 9 and 10..15 of X)
   const int tid = threadIdx.x, lane = tid & 63, c16 = lane & 15, g4 = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -84,6 +109,7 @@ __global__ __launch_bounds__(64 * NWV) void conv_bf16_dgrad_first_bwd_kernel(con
   const int kcb = H * W * 16;
   const bool leaky = p.act == ACT_LEAKY;   // uniform
   const unsigned my_addr = (unsigned)(wave * WAVE_BYTES), my_img_addr = my_addr + NDMA * 1024, my_sg_addr = my_img_addr + NIDMA * 256;
+  [[maybe_unused]] const unsigned my_x_addr = my_sg_addr + NSDMA * 256;
   const unsigned ones_addr = (unsigned)(NWV * WAVE_BYTES), zeros_addr = ones_addr + CONST_BYTES;
   const u32x4* my_tile = lds_u + wave * (WAVE_BYTES / 16);
   const unsigned char* lds8 = reinterpret_cast<const unsigned char*>(lds_u);
@@ -129,14 +155,28 @@ __global__ __launch_bounds__(64 * NWV) void conv_bf16_dgrad_first_bwd_kernel(con
   const unsigned sg_pos = (unsigned)(c16 < 4 ? c16 : c16 < 8 ? c16 + 4 : c16 < 12 ? c16 - 4 : c16);   // channel c16 in a pixel's sign word
 
   f32x4 d2p = {0.f, 0.f, 0.f, 0.f}, d2n = {0.f, 0.f, 0.f, 0.f};   // rows 4 g4 + i of D2, column c16
+  // WG: rows co = 16 cbk + 4 g4 + i, column ci = c16 of dW[tap]; the bias gradient in every column of bacc
+  f32x4 wacc[WG ? 2 : 1][WG ? 9 : 1], bacc[WG ? 2 : 1];
+#pragma unroll
+  for (int c = 0; c < (WG ? 2 : 1); ++c) {
+    bacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < (WG ? 9 : 1); ++t) wacc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // transposed reads: lane (q = (c16 >> 2), pc = c16 & 3) of a 16-lane group supplies channels 4 pc .. 4 pc + 3 of pixel 8 g4 + q (+ 4: the second read)
+  [[maybe_unused]] const unsigned tr_g = my_addr + (unsigned)((((c16 & 3) >> 1) * NR * ROWU + 8 * g4 + (c16 >> 2)) * 16 + (c16 & 1) * 8);
+  [[maybe_unused]] const unsigned tr_x = my_x_addr + (unsigned)((((c16 & 3) >> 1) * R * 32 + 8 * g4 + (c16 >> 2)) * 16 + (c16 & 1) * 8);
+  const u32x4 ones_op = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
 
-  // workgroup -> XCD -> a contiguous eighth of the tiles (conv_bf16_staged.hip)
+  // workgroup -> XCD -> a contiguous eighth of the segments (conv_bf16_staged.hip)
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
-  const int t8 = (p.ntiles + 7) >> 3, t_end = min(p.ntiles, (xcd + 1) * t8);
-  for (int tile = xcd * t8 + slot * NWV + wave; tile < t_end; tile += nslot * NWV) {
-    const int b = df_udivm1(tile, p.tiles_per_img, p.m_tpi);
-    const int t = tile - b * p.tiles_per_img;
-    const int ty = df_udivm1(t, p.tiles_per_row, p.m_tpr), ox0 = (t - ty * p.tiles_per_row) * 32;
+  const int s8 = (p.nsegs + 7) >> 3, s_end = min(p.nsegs, (xcd + 1) * s8);
+  for (int sgm = xcd * s8 + slot * NWV + wave; sgm < s_end; sgm += nslot * NWV) {
+    const int b = df_udivm1(sgm, p.segs_per_img, p.m_spi);
+    const int t = sgm - b * p.segs_per_img;
+    const int sy = df_udivm1(t, p.tiles_per_row, p.m_tpr), ox0 = (t - sy * p.tiles_per_row) * 32;
+    const int ty_end = min(p.tile_rows, (sy + 1) * p.seg);
+   for (int ty = sy * p.seg; ty < ty_end; ++ty) {
     const int oy0 = ty * R;
     // ---- stage the gradient tile (rows oy0 - 1 .. oy0 + R, columns ox0 - 1 .. ox0 + 32; zeros beyond the image), the image window and the sign words
     {
@@ -172,6 +212,18 @@ __global__ __launch_bounds__(64 * NWV) void conv_bf16_dgrad_first_bwd_kernel(con
           df_dma4(rs_s, my_sg_addr + (unsigned)i * 256u, ok ? ((oy0 + r) * W + ox0 + 2 * d) * 2 : OOB);
         }
       }
+      if constexpr (WG) {   // piece i = rows 2 i, 2 i + 1 of the flattened [channel block][row]: lanes 0-31 / 32-63, column = lane & 31
+        const i32x4 rs_x = df_rsrc(p.x + (size_t)b * 2 * H * W, (unsigned)(2 * kcb));
+        const int hi = lane >> 5, col = lane & 31;
+        const int xo = ((oy0 + hi) * W + ox0 + col) * 16;
+        const bool cok = ox0 + col < W;
+#pragma unroll
+        for (int i = 0; i < NXDMA; ++i) {
+          constexpr int dummy = 0; (void)dummy;
+          const int kb = (2 * i) / R, row0 = (2 * i) % R;
+          df_dma16(rs_x, my_x_addr + (unsigned)i * 1024u, (cok && oy0 + row0 + hi < H) ? xo + kb * kcb + row0 * W * 16 : OOB);
+        }
+      }
     }
     const bool right = ox0 + 32 > W;   // (uniform) pixel columns beyond the image: their "gradient" is the halo's, not zero
     df_wait_dma();
@@ -189,6 +241,18 @@ __global__ __launch_bounds__(64 * NWV) void conv_bf16_dgrad_first_bwd_kernel(con
           const bf16x8 bv = __builtin_bit_cast(bf16x8, bt[(rr + ky) * ROWU + 16 * pb + kx]);
           acc[pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv, wv[tp], acc[pb], 0, 0, 0);
         }
+      }
+      if constexpr (WG) {
+        const bf16x8 xt = df_tr8(lds8 + tr_x + rr * 512, 64);
+#pragma unroll
+        for (int cbk = 0; cbk < 2; ++cbk)
+#pragma unroll
+          for (int tp = 0; tp < 9; ++tp) {
+            const int ky = tp / 3, kx = tp % 3;
+            const bf16x8 gt = df_tr8(lds8 + tr_g + ((cbk * 2 * NR + rr + 2 - ky) * ROWU + 2 - kx) * 16, 64);
+            wacc[cbk][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt, xt, wacc[cbk][tp], 0, 0, 0);
+            if (tp == 4) bacc[cbk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt, __builtin_bit_cast(bf16x8, ones_op), bacc[cbk], 0, 0, 0);
+          }
       }
       // X: row j of the image window for this lane's 2 x 4 pixels, as bf16
       u32x4 xop;
@@ -230,6 +294,7 @@ __global__ __launch_bounds__(64 * NWV) void conv_bf16_dgrad_first_bwd_kernel(con
       d2p = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xo, __builtin_bit_cast(bf16x8, gpos), d2p, 0, 0, 0);
       d2n = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xo, __builtin_bit_cast(bf16x8, gneg), d2n, 0, 0, 0);
     }
+   }
   }
   // ---- the wavefront's partial row: lane (c16, g4) holds rows j = 4 g4 + i of column ci = c16: A1[ci][j] for j < 9, S1[ci] for j = 9
   float* prow = p.part + (size_t)(blockIdx.x * NWV + wave) * p.ncol;
@@ -244,6 +309,19 @@ __global__ __launch_bounds__(64 * NWV) void conv_bf16_dgrad_first_bwd_kernel(con
   // (the A2 columns come from the Gram matrix, P / G from the caller's: zeros here so that the reduced row is finite)
   for (int e = lane; e < DF_COUT * DF_NJ; e += 64) prow[(e / DF_NJ) * DF_PER + DF_NJ + e % DF_NJ] = 0.f;
   for (int e = lane; e < DF_NJ + DF_NJ * DF_NJ; e += 64) prow[DF_COUT * DF_PER + e] = 0.f;
+  if constexpr (WG) {
+    float* sl = p.slab + (size_t)(blockIdx.x * NWV + wave) * (9 * 32 * 16);
+    float* bp = p.bias_part + (size_t)(blockIdx.x * NWV + wave) * 32;
+#pragma unroll
+    for (int cbk = 0; cbk < 2; ++cbk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int co = 16 * cbk + 4 * g4 + i;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) sl[(tp * 32 + co) * 16 + c16] = wacc[cbk][tp][i];
+        if (c16 == 0) bp[co] = bacc[cbk][i];
+      }
+  }
 }
 
 // =========================================================================================================
@@ -251,15 +329,20 @@ __global__ __launch_bounds__(64 * NWV) void conv_bf16_dgrad_first_bwd_kernel(con
 // =========================================================================================================
 // tile height / wavefronts per workgroup (variant builds: build.sh variant TAG conv_first_fused_bwd -DDF_TILE_ROWS=8 ...)
 #ifndef DF_TILE_ROWS
-#define DF_TILE_ROWS 4
+#define DF_TILE_ROWS 6
+#endif
+#ifndef DF_TILE_ROWS_WG
+#define DF_TILE_ROWS_WG 4
 #endif
 #ifndef DF_WAVES
 #define DF_WAVES 4
 #endif
 namespace {
-constexpr int DF_R = DF_TILE_ROWS, DF_NWV = DF_WAVES;
-constexpr int df_lds_bytes(int R, int NWV) {   // the wavefronts' pieces (gradient tile, image window, sign words) + the two constant images
-  return NWV * (((4 * (R + 2) * 34 + 63) / 64) * 1024 + (((2 * R + 1) * 18 + 63) / 64) * 256 + ((R * 16 + 63) / 64) * 256) + 2 * ((((2 * R + 1) * 72 + 15) / 16) * 16);
+constexpr int DF_NWV = DF_WAVES;
+constexpr int df_rows(bool wg) { return wg ? DF_TILE_ROWS_WG : DF_TILE_ROWS; }
+constexpr int df_lds_bytes(int R, int NWV, bool wg) {   // the wavefronts' pieces (gradient tile, image window, sign words[, x tile]) + the two constant images
+  return NWV * (((4 * (R + 2) * 34 + 63) / 64) * 1024 + (((2 * R + 1) * 18 + 63) / 64) * 256 + ((R * 16 + 63) / 64) * 256 + (wg ? R * 1024 : 0)) +
+         2 * ((((2 * R + 1) * 72 + 15) / 16) * 16);
 }
 int df_n_cu() {
   static std::mutex mu;
@@ -273,33 +356,107 @@ int df_n_cu() {
   }
   return n_cu_of[dev];
 }
-int df_grid(int B, int H, int W, int n_cu) {
-  const int ntiles = B * cdiv(H, DF_R) * cdiv(W, 32);
-  const int lds = df_lds_bytes(DF_R, DF_NWV);
+// the launch: workgroups, and the segment length -- short enough that the wavefronts of an XCD get equal shares, long enough that few tiles
+// re-read their upper halo from memory (cost = the busiest wavefront's tiles x (1 + the halo rows a segment's first tile fetches))
+struct DfPlan { int grid, seg; };
+DfPlan df_plan(int B, int H, int W, int n_cu, bool wg) {
+  const int R = df_rows(wg);
+  const int nty = cdiv(H, R), ntx = cdiv(W, 32);
+  const int lds = df_lds_bytes(R, DF_NWV, wg);
   const int per_cu = max(1, min(16 / DF_NWV, (160 * 1024) / lds));
-  const int t8 = cdiv(ntiles, 8);
-  return 8 * max(1, min(cdiv(t8, DF_NWV), per_cu * n_cu / 8));
+#ifdef DF_SEG
+  const int seg_lo = DF_SEG, seg_hi = DF_SEG;
+#else
+  const int seg_lo = 1, seg_hi = 16;
+#endif
+  DfPlan best{8, 1};
+  double best_cost = -1.0;
+  for (int seg = seg_lo; seg <= seg_hi && (seg <= nty || seg == seg_lo); ++seg) {
+    const long long nsegs = (long long)B * cdiv(nty, seg) * ntx;
+    const int s8 = (int)((nsegs + 7) / 8);
+    const int grid = 8 * max(1, min(cdiv(s8, DF_NWV), per_cu * n_cu / 8));
+    const int waves_per_xcd = grid / 8 * DF_NWV;
+    const double cost = (double)cdiv(s8, waves_per_xcd) * min(seg, nty) * (1.0 + (2.0 / R) / min(seg, nty));
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = DfPlan{grid, seg}; }
+  }
+  return best;
+}
+bool df_shape_ok(int Cmid, int Cout1, int H, int W, int B, int act0, bool wg) {
+  if (Cmid != 16 || Cout1 != 32 || H < 1 || W < 2 || (W & 1) || B < 1 || (act0 != ACT_NONE && act0 != ACT_LEAKY)) return false;
+  const int R = df_rows(wg);
+  if ((long long)4 * H * W * 16 >= (1ll << 31) || (long long)4 * H * W >= (1ll << 31) || (long long)B * cdiv(H, R) * cdiv(W, 32) >= (1ll << 31)) return false;
+  // the kernel's divisions by multiplication (segment -> image, segment of the image -> segment row), whatever segment length the plan picks
+  const long long tpr = cdiv(W, 32);
+  for (int seg = 1; seg <= 16; ++seg) {
+    const long long spi = (long long)cdiv(cdiv(H, R), seg) * tpr;
+    if (!magic_div_exact((long long)B * spi - 1, (int)spi) || !magic_div_exact(spi, (int)tpr)) return false;
+  }
+  return true;
+}
+
+template <bool WG>
+int df_launch(DgFirstParams p, int B, int H, int W, int act0, const char* what, hipStream_t stream) {
+  const int n_cu = df_n_cu();
+  if (n_cu < 0) {
+    yogo_set_error("%s: hipGetDevice failed", what);
+    return YOGO_ERR_HIP;
+  }
+  constexpr int R = df_rows(WG);
+  p.B = B; p.H = H; p.W = W; p.Mpad = 32; p.act = act0; p.ncol = DF_COUT * DF_PER + DF_NJ + DF_NJ * DF_NJ;
+  const DfPlan pl = df_plan(B, H, W, n_cu, WG);
+  p.tiles_per_row = cdiv(W, 32); p.tile_rows = cdiv(H, R); p.seg = pl.seg;
+  p.segs_per_img = cdiv(p.tile_rows, pl.seg) * p.tiles_per_row; p.nsegs = B * p.segs_per_img;
+  auto magic = [](int d) -> unsigned { return d <= 1 ? 0xFFFFFFFFu : (unsigned)(((1ull << 32) + (unsigned)d - 1ull) / (unsigned)d); };
+  p.m_tpr = magic(p.tiles_per_row); p.m_spi = magic(p.segs_per_img);
+  const int grid = pl.grid;
+  constexpr int lds = df_lds_bytes(R, DF_NWV, WG);
+  static_assert(lds <= 160 * 1024, "LDS");
+  if (lds > 64 * 1024) {   // more than 64 KB of dynamic LDS has to be asked for: once per device and instantiation
+    static std::mutex mu;
+    static bool done[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev >= 0 && dev < 64 && !done[dev]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_dgrad_first_bwd_kernel<R, DF_NWV, WG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) {
+        yogo_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+        return YOGO_ERR_HIP;
+      }
+      done[dev] = true;
+    }
+  }
+  hipLaunchKernelGGL((conv_bf16_dgrad_first_bwd_kernel<R, DF_NWV, WG>), dim3(grid), dim3(64 * DF_NWV), lds, stream, p);
+  if (yogo_launch_log_enabled())
+    yogo_launch_log("conv_bf16_dgrad_first_bwd_kernel<%d, %d, %s> | K=32 M=16 at %dx%d segments=%d of %d tiles grid=%d lds=%d act0=%d", R, DF_NWV, WG ? "true" : "false", H, W,
+                    p.nsegs, pl.seg, grid, lds, act0);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    yogo_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return YOGO_ERR_HIP;
+  }
+  return YOGO_OK;
 }
 }  // namespace
 
+// split-K reduction shared with the weight-gradient kernels (wgrad_f32.hip)
+extern "C" int yogo_internal_wgrad_reduce_q(void* queue, const float* slab, int nslab, int T, int M, int N, int Mpad, int Npad, float clip, float* dw,
+                                            const float* bias_part, int nbias, float* db, hipStream_t stream);
+
 // 1 when the fused sweep takes (layer 1: 3x3, stride 1, Cmid -> Cout1 channels at H x W; layer 0: one uint8 channel, stride 2, Cmid outputs)
 extern "C" int yogo_conv2d_dgrad_first_bwd_supported(int Cmid, int Cout1, int H, int W, int B, int act0) {
-  if (Cmid != 16 || Cout1 != 32 || H < 1 || W < 2 || (W & 1) || B < 1 || (act0 != ACT_NONE && act0 != ACT_LEAKY)) return 0;
-  if ((long long)4 * H * W * 16 >= (1ll << 31) || (long long)4 * H * W >= (1ll << 31) || (long long)B * cdiv(H, DF_R) * cdiv(W, 32) >= (1ll << 31)) return 0;
-  const long long tpr = cdiv(W, 32), tpi = (long long)cdiv(H, DF_R) * tpr;
-  if (!magic_div_exact((long long)B * tpi - 1, (int)tpi) || !magic_div_exact(tpi, (int)tpr)) return 0;
-  return 1;
+  return (df_shape_ok(Cmid, Cout1, H, W, B, act0, false) && df_shape_ok(Cmid, Cout1, H, W, B, act0, true)) ? 1 : 0;
 }
 
-// rows of the partial buffer (cols: yogo_conv_first_bn_wgrad_cols(1, Cmid)) on the current device
-extern "C" int yogo_conv2d_dgrad_first_bwd_rows(int B, int H, int W, int* rows) {
+// rows of the partial buffer (cols: yogo_conv_first_bn_wgrad_cols(1, Cmid)) on the current device; with_wgrad: of the _wgrad form below
+extern "C" int yogo_conv2d_dgrad_first_bwd_rows(int B, int H, int W, int with_wgrad, int* rows) {
   YOGO_CHECK_ARG(rows && B > 0 && H > 0 && W > 0, "conv2d_dgrad_first_bwd_rows: bad arguments");
   const int n_cu = df_n_cu();
   if (n_cu < 0) {
     yogo_set_error("conv2d_dgrad_first_bwd_rows: hipGetDevice failed");
     return YOGO_ERR_HIP;
   }
-  *rows = df_grid(B, H, W, n_cu) * DF_NWV;
+  *rows = df_plan(B, H, W, n_cu, with_wgrad != 0).grid * DF_NWV;
   return YOGO_OK;
 }
 
@@ -311,40 +468,41 @@ extern "C" int yogo_conv2d_dgrad_bf16_first_bwd(const void* g, const void* packe
   YOGO_CHECK_ARG(g && packed && image && part, "conv2d_dgrad_bf16_first_bwd: null pointer");
   YOGO_CHECK_ARG(yogo_conv2d_dgrad_first_bwd_supported(Cmid, Cout1, H, W, B, act0), "conv2d_dgrad_bf16_first_bwd: unsupported shape");
   YOGO_CHECK_ARG(signs != nullptr || act0 == ACT_NONE, "conv2d_dgrad_bf16_first_bwd: LeakyReLU needs the sign map");
-  const int n_cu = df_n_cu();
-  if (n_cu < 0) {
-    yogo_set_error("conv2d_dgrad_bf16_first_bwd: hipGetDevice failed");
-    return YOGO_ERR_HIP;
-  }
   DgFirstParams p{};
   p.g = reinterpret_cast<const u32x4*>(g); p.wp = reinterpret_cast<const u32x4*>(packed); p.img = reinterpret_cast<const unsigned char*>(image);
   p.signs = reinterpret_cast<const unsigned short*>(signs); p.part = part;
-  p.B = B; p.H = H; p.W = W; p.Mpad = 32; p.act = act0; p.ncol = DF_COUT * DF_PER + DF_NJ + DF_NJ * DF_NJ;
-  p.tiles_per_row = cdiv(W, 32); p.tiles_per_img = cdiv(H, DF_R) * p.tiles_per_row; p.ntiles = B * p.tiles_per_img;
-  auto magic = [](int d) -> unsigned { return d <= 1 ? 0xFFFFFFFFu : (unsigned)(((1ull << 32) + (unsigned)d - 1ull) / (unsigned)d); };
-  p.m_tpr = magic(p.tiles_per_row); p.m_tpi = magic(p.tiles_per_img);
-  const int grid = df_grid(B, H, W, n_cu);
-  constexpr int lds = df_lds_bytes(DF_R, DF_NWV);
-  static_assert(lds <= 160 * 1024, "LDS");
-  if (lds > 64 * 1024) {   // more than 64 KB of dynamic LDS has to be asked for: once per device
-    static std::mutex mu;
-    static bool done[64] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> lk(mu);
-    if (dev >= 0 && dev < 64 && !done[dev]) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_dgrad_first_bwd_kernel<DF_R, DF_NWV>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      if (e != hipSuccess) {
-        yogo_set_error("conv2d_dgrad_bf16_first_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        return YOGO_ERR_HIP;
-      }
-      done[dev] = true;
-    }
+  return df_launch<false>(p, B, H, W, act0, "conv2d_dgrad_bf16_first_bwd", stream);
+}
+
+// The same sweep with layer 1's WEIGHT gradient: x = layer 1's input (= layer 0's output, bf16 NCHW8c [B][Cmid / 8][H][W]); dw (OIHW fp32
+// [Cout1][Cmid][3][3]) and db ([Cout1], may be NULL), clamped to +-clip when clip > 0, exactly as yogo_conv2d_wgrad_bf16[_deferred] delivers
+// them; workspace: yogo_conv2d_dgrad_wgrad_first_bwd_workspace_bytes; queue: NULL (reduce now) or a yogo_wgrad_reduce_queue (deferred)
+extern "C" int yogo_conv2d_dgrad_wgrad_first_bwd_workspace_bytes(int B, int H, int W, size_t* bytes) {
+  YOGO_CHECK_ARG(bytes && B > 0 && H > 0 && W > 0, "conv2d_dgrad_wgrad_first_bwd_workspace_bytes: bad arguments");
+  const int n_cu = df_n_cu();
+  if (n_cu < 0) {
+    yogo_set_error("conv2d_dgrad_wgrad_first_bwd_workspace_bytes: hipGetDevice failed");
+    return YOGO_ERR_HIP;
   }
-  hipLaunchKernelGGL((conv_bf16_dgrad_first_bwd_kernel<DF_R, DF_NWV>), dim3(grid), dim3(64 * DF_NWV), lds, stream, p);
-  if (yogo_launch_log_enabled())
-    yogo_launch_log("conv_bf16_dgrad_first_bwd_kernel<%d, %d> | K=%d M=%d at %dx%d tiles=%d grid=%d lds=%d act0=%d", DF_R, DF_NWV, Cout1, Cmid, H, W, p.ntiles, grid,
-                    lds, act0);
-  YOGO_CHECK_LAUNCH("conv2d_dgrad_bf16_first_bwd");
+  *bytes = (size_t)df_plan(B, H, W, n_cu, true).grid * DF_NWV * (9 * 32 * 16 + 32) * sizeof(float);
   return YOGO_OK;
+}
+extern "C" int yogo_conv2d_dgrad_wgrad_bf16_first_bwd(const void* g, const void* packed, const void* x, const void* image, const void* signs, float* part,
+                                                      float* dw, float* db, void* workspace, int B, int Cmid, int Cout1, int H, int W, int act0, float clip,
+                                                      void* queue, hipStream_t stream) {
+  YOGO_CHECK_ARG(g && packed && x && image && part && dw && workspace, "conv2d_dgrad_wgrad_bf16_first_bwd: null pointer");
+  YOGO_CHECK_ARG(yogo_conv2d_dgrad_first_bwd_supported(Cmid, Cout1, H, W, B, act0), "conv2d_dgrad_wgrad_bf16_first_bwd: unsupported shape");
+  YOGO_CHECK_ARG(signs != nullptr || act0 == ACT_NONE, "conv2d_dgrad_wgrad_bf16_first_bwd: LeakyReLU needs the sign map");
+  const int n_cu = df_n_cu();
+  if (n_cu < 0) {
+    yogo_set_error("conv2d_dgrad_wgrad_bf16_first_bwd: hipGetDevice failed");
+    return YOGO_ERR_HIP;
+  }
+  const int rows = df_plan(B, H, W, n_cu, true).grid * DF_NWV;
+  DgFirstParams p{};
+  p.g = reinterpret_cast<const u32x4*>(g); p.wp = reinterpret_cast<const u32x4*>(packed); p.img = reinterpret_cast<const unsigned char*>(image);
+  p.signs = reinterpret_cast<const unsigned short*>(signs); p.part = part;
+  p.x = reinterpret_cast<const u32x4*>(x); p.slab = reinterpret_cast<float*>(workspace); p.bias_part = p.slab + (size_t)rows * 9 * 32 * 16;
+  if (int e = df_launch<true>(p, B, H, W, act0, "conv2d_dgrad_wgrad_bf16_first_bwd", stream)) return e;
+  return yogo_internal_wgrad_reduce_q(queue, p.slab, rows, 9, Cout1, Cmid, 32, 16, clip, dw, p.bias_part, rows, db, stream);
 }

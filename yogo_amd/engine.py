@@ -650,6 +650,15 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
         # layer 0 with BatchNorm and no conv bias: BatchNorm backward, activation derivative and the weight gradient share ONE
         # sweep over (image, g, z) -- dz is never written (see conv_first_bn_wgrad_kernel)
         fuse0 = _FUSE_LAYER0_BWD and i == 0 and L.bn is not None and L.conv.bias is None and L.act in (ACT_NONE, ACT_LEAKY)
+        # layer 1 above a matrix-core layer 0 that kept its sign map: ONE sweep over g does layer 1's weight gradient and folds its data
+        # gradient straight into layer 0's backward sums (layer 0 has no data gradient of its own, so its dy need not exist; a trace wants
+        # to see it)
+        fuse01 = False
+        if _L01_FUSE_BWD and i == 1 and trace is None and _FUSE_LAYER0_BWD and _WGRAD_BF16_MFMA:
+            L0, S0 = eng.layers[0], saved[0]
+            fuse01 = bool(S0.signs0 is not None and S0.x_in.dtype == torch.uint8 and L0.bn is not None and L0.conv.bias is None and L0.cin == 1
+                          and L0.s == 2 and L0.act in (ACT_NONE, ACT_LEAKY) and L.k == 3 and L.s == 1 and S0.mask is None
+                          and _hip.lib().yogo_conv2d_dgrad_first_bwd_supported(L.cin, L.cout, IH, IW, B, L0.act))
         if trace is not None and g is not None:
             trace[("g", i)] = g.clone()
         if L.bn is not None and not fuse0:
@@ -696,6 +705,12 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
             part = torch.empty(rows * L.cout * nj, dtype=torch.float32, device=dev)
             red = torch.empty(L.cout, nj, dtype=torch.float32, device=dev)
             keep.extend((part, red))
+        elif fuse01:
+            ws = torch.empty(_hip.query_size("yogo_conv2d_dgrad_wgrad_first_bwd_workspace_bytes", B, IH, IW) // 4, dtype=torch.float32, device=dev)
+            rows01 = _hip.query_ints("yogo_conv2d_dgrad_first_bwd_rows", 1, B, IH, IW, 1)[0]
+            cols01 = _hip.query_ints("yogo_conv_first_bn_wgrad_cols", 1, L0.cin, L0.cout)[0]
+            part01 = torch.empty(rows01 * cols01, dtype=torch.float32, device=dev)
+            keep.extend((ws, part01))
         else:
             wname = "yogo_conv2d_wgrad_bf16_workspace_bytes" if _WGRAD_BF16_MFMA else "yogo_conv2d_wgrad_workspace_bytes"
             ws = torch.empty(_hip.query_size(wname, B, L.cin, L.cout, IH, IW, L.k, L.s) // 4, dtype=torch.float32, device=dev)
@@ -720,6 +735,13 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
                 if bn.weight is not None:
                     grads[id(bn.weight)] = dgamma
                     grads[id(bn.bias)] = dbeta
+            elif fuse01:
+                eng._tick("wgrad", i, 2.0 * B * L.cout * L.cin * L.k * L.k * OH * OW * 2, mw=30,
+                          nbytes=B * (16 * (_blocks(L.cout) + _blocks(L.cin)) * OH * OW + 2 * IH * IW + 4 * IH * IW))
+                _hip.call("yogo_conv2d_dgrad_wgrad_bf16_first_bwd", g, _packed_bf16(eng, i, 1), S.x_in, S0.x_in, S0.signs0, part01, dw, db, ws,
+                          B, L.cin, L.cout, IH, IW, L0.act, clip, wq, wst)
+                eng._tock()
+                fused01 = (part01, rows01, IH, IW)
             elif i == 0:
                 _hip.call("yogo_conv_first_wgrad_bf16g", S.x_in, xdt, g, part, B, L.cin, L.cout, IH, IW, L.s, wst)
                 _hip.call("yogo_partials_reduce", part, rows, L.cout * nj, clip, red, wst)
@@ -746,6 +768,9 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
             if wstream is not main:
                 main.wait_stream(wstream)   # the weight gradient of this layer is part of what the hook hands over
             on_layer(i)
+        if fuse01:   # (layer 1's data gradient went into layer 0's sums above)
+            g = None
+            continue
         if i > 0:
             Lp, Sp = eng.layers[i - 1], saved[i - 1]
             ref_act = Lp.act
@@ -756,23 +781,6 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
             else:
                 act_ref = Sp.pre      # SiLU: the pre-activation saved by yogo_conv2d_fwd_bf16_pre
             pk = _packed_bf16(eng, i, 2 if (L.s == 2 and L.k == 3) else 1)
-            # layer 1 above a matrix-core layer 0 that kept its sign map: the data gradient goes straight into layer 0's backward sums
-            # (layer 0 has no data gradient of its own, so its dy need not exist; a trace wants to see it)
-            if (_L01_FUSE_BWD and i == 1 and trace is None and _FUSE_LAYER0_BWD and Sp.signs0 is not None and Sp.x_in.dtype == torch.uint8
-                    and Lp.bn is not None and Lp.conv.bias is None and Lp.cin == 1 and Lp.s == 2 and Lp.act in (ACT_NONE, ACT_LEAKY)
-                    and L.k == 3 and L.s == 1 and Sp.mask is None
-                    and _hip.lib().yogo_conv2d_dgrad_first_bwd_supported(L.cin, L.cout, IH, IW, B, Lp.act)):
-                rows01 = _hip.query_ints("yogo_conv2d_dgrad_first_bwd_rows", 1, B, IH, IW)[0]
-                cols01 = _hip.query_ints("yogo_conv_first_bn_wgrad_cols", 1, Lp.cin, Lp.cout)[0]
-                part01 = torch.empty(rows01 * cols01, dtype=torch.float32, device=dev)
-                keep.append(part01)
-                eng._tick("dgrad", i, 2.0 * B * L.cout * L.cin * L.k * L.k * OH * OW, mw=30,
-                          nbytes=B * (16 * _blocks(L.cout) * OH * OW + 2 * IH * IW + 4 * IH * IW))
-                _hip.call("yogo_conv2d_dgrad_bf16_first_bwd", g, pk, Sp.x_in, Sp.signs0, part01, B, L.cin, L.cout, IH, IW, Lp.act, st)
-                eng._tock()
-                fused01 = (part01, rows01, IH, IW)
-                g = None
-                continue
             dx = torch.empty(B, _blocks(L.cin), IH, IW, 8, dtype=torch.bfloat16, device=dev)
             nbytes = B * 2 * 8 * (_blocks(L.cout) * OH * OW + _blocks(L.cin) * IH * IW * (2 if act_ref is not None else 1))
             if ref_act == ACT_LEAKY and Sp.signs is not None:   # one byte per 16-byte unit in place of the reference
