@@ -468,8 +468,9 @@ def test_fused_layer0_backward_matches_separate_passes():
     Himg, Wimg, C, B = 96, 128, 7, 4
     x = O.synthetic_images(B, Himg, Wimg, seed=41).cuda()
     out = {}
-    old = E._FUSE_LAYER0_BWD
+    old, old01 = E._FUSE_LAYER0_BWD, E._L01_FUSE_BWD
     try:
+        E._L01_FUSE_BWD = False   # (the sweep that also takes layer 1's gradients needs the fused layer-0 backward: tests/test_gpu_first_fused_bwd.py)
         for fused in (False, True):
             E._FUSE_LAYER0_BWD = fused
             torch.manual_seed(5)
@@ -485,7 +486,7 @@ def test_fused_layer0_backward_matches_separate_passes():
             sizes = [p.numel() for p in model.parameters()]
             out[fused] = (tr.flat.grad.clone().cpu(), names, sizes)
     finally:
-        E._FUSE_LAYER0_BWD = old
+        E._FUSE_LAYER0_BWD, E._L01_FUSE_BWD = old, old01
     g0, names, sizes = out[False]
     g1 = out[True][0]
     off = 0
