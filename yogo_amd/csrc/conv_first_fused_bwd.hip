@@ -15,6 +15,8 @@
 // bit (tests/test_gpu_first_fused_bwd.py: both against a CPU fp64 reference).
 #include "common.h"
 #include <mutex>
+#include <type_traits>
+#include <utility>
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -86,6 +88,18 @@ __device__ __forceinline__ bf16x8 df_tr8(const unsigned char* a, int second) {
 #ifndef DF_WAVES_PER_EU
 #define DF_WAVES_PER_EU 2
 #endif
+#ifndef DF_NPF
+#define DF_NPF 6   // operand reads in flight ahead of their MFMA
+#endif
+#ifndef DF_NPF_WG
+#define DF_NPF_WG 3   // ... with the weight gradient's 80 accumulator registers beside them
+#endif
+namespace {
+template <class F, int... I>
+__device__ __forceinline__ void df_static_for(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+}  // namespace
 //
 // WG: layer 1's WEIGHT gradient in the same sweep -- it reads the same gradient tile (1.63 GB that wgrad_bf16_kernel would read again) and
 // layer 0's output x (the tile's own pixels, no halo).  dW[tap][co][ci] = sum over pixels p of g[co][p - tap + 1] x[ci][p], K = the 32 pixels of a
@@ -231,68 +245,112 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(DF_WAV
 #pragma unroll
     for (int rr = 0; rr < R; ++rr) {
       if (oy0 + rr >= H) break;   // (uniform)
+      // A row is ONE stream of (operand read, MFMA) steps: 2 x 9 of the data gradient (pixel block, tap), then [WG] 2 x 9 of the weight
+      // gradient (output-channel block, tap).  Operands run DF_NPF steps ahead of their MFMA in a ring of registers, and a scheduling barrier
+      // behind every step keeps that order: left to itself hipcc sinks every LDS read next to its use (it has 256 registers for 130
+      // accumulator / weight registers) and each 16-cycle MFMA then waits a full LDS round trip (the first form of this loop: matrix pipes 0.35 busy).
+      // The sums over pixels of the row (X and GB operands, two MFMAs) ride in the gaps of the weight-gradient steps.
+      constexpr int NST = WG ? 36 : 18, NPF = WG ? DF_NPF_WG : DF_NPF;
       f32x4 acc[2];
-#pragma unroll
-      for (int pb = 0; pb < 2; ++pb) {
-        acc[pb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int tp = 0; tp < 9; ++tp) {
-          const int ky = tp / 3, kx = tp % 3;
-          const bf16x8 bv = __builtin_bit_cast(bf16x8, bt[(rr + ky) * ROWU + 16 * pb + kx]);
-          acc[pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv, wv[tp], acc[pb], 0, 0, 0);
+      bf16x8 ring[NPF];
+      [[maybe_unused]] bf16x8 xt;
+      auto load = [&](auto s_tag) {
+        constexpr int S = decltype(s_tag)::value;
+        if constexpr (S < 18) {
+          constexpr int pb = S / 9, tp = S % 9, ky = tp / 3, kx = tp % 3;
+          ring[S % NPF] = __builtin_bit_cast(bf16x8, bt[(rr + ky) * ROWU + 16 * pb + kx]);
+        } else {
+          constexpr int cbk = (S - 18) / 9, tp = (S - 18) % 9, ky = tp / 3, kx = tp % 3;
+          ring[S % NPF] = df_tr8(lds8 + tr_g + ((cbk * 2 * NR + rr + 2 - ky) * ROWU + 2 - kx) * 16, 64);
         }
-      }
-      if constexpr (WG) {
-        const bf16x8 xt = df_tr8(lds8 + tr_x + rr * 512, 64);
+      };
+      auto use = [&](auto s_tag) {
+        constexpr int S = decltype(s_tag)::value;
+        if constexpr (S < 18) {
+          constexpr int pb = S / 9, tp = S % 9;
+          acc[pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[S % NPF], wv[tp], tp == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[pb], 0, 0, 0);
+        } else if constexpr (WG) {
+          constexpr int cbk = (S - 18) / 9, tp = (S - 18) % 9;
+          wacc[cbk][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[S % NPF], xt, wacc[cbk][tp], 0, 0, 0);
+          if constexpr (tp == 4) bacc[cbk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[S % NPF], __builtin_bit_cast(bf16x8, ones_op), bacc[cbk], 0, 0, 0);
+        }
+      };
+      // the sums over pixels in slices: 0 = the LDS reads, 1 / 2 = the X operand of pixel block 0 / 1, 3 / 4 = GB of pixel block 0 / 1, 5 / 6 = the MFMAs
+      unsigned xr[2][3];
+      unsigned sw[2][2] = {{0xFFFFFFFFu, 0xFFFFFFFFu}, {0xFFFFFFFFu, 0xFFFFFFFFu}};
+      u32x4 xop, gpos, gneg;
+      auto p3 = [&](auto k_tag) {
+        constexpr int K = decltype(k_tag)::value;
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        if constexpr (K == 0) {
 #pragma unroll
-        for (int cbk = 0; cbk < 2; ++cbk)
-#pragma unroll
-          for (int tp = 0; tp < 9; ++tp) {
-            const int ky = tp / 3, kx = tp % 3;
-            const bf16x8 gt = df_tr8(lds8 + tr_g + ((cbk * 2 * NR + rr + 2 - ky) * ROWU + 2 - kx) * 16, 64);
-            wacc[cbk][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt, xt, wacc[cbk][tp], 0, 0, 0);
-            if (tp == 4) bacc[cbk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt, __builtin_bit_cast(bf16x8, ones_op), bacc[cbk], 0, 0, 0);
+          for (int pb = 0; pb < 2; ++pb) {
+            const unsigned char* xa = lds8 + x_addr + rr * (2 * IROWB) + 32 * pb;
+            xr[pb][0] = *reinterpret_cast<const unsigned*>(xa);
+            xr[pb][1] = *reinterpret_cast<const unsigned*>(xa + 4);
+            xr[pb][2] = *reinterpret_cast<const unsigned*>(xa + 8);
+            if (leaky) {
+              const unsigned long long s2 = *reinterpret_cast<const unsigned long long*>(lds8 + sg_addr + rr * 64 + 32 * pb);
+              sw[pb][0] = (unsigned)s2;
+              sw[pb][1] = (unsigned)(s2 >> 32);
+            }
           }
-      }
-      // X: row j of the image window for this lane's 2 x 4 pixels, as bf16
-      u32x4 xop;
+        } else if constexpr (K == 1 || K == 2) {   // X: row j of the image window for this lane's 4 pixels of the block, as bf16
+          constexpr int pb = K - 1;
+          const unsigned lo4 = __builtin_amdgcn_alignbyte(xr[pb][1], xr[pb][0], x_sh), hi4 = __builtin_amdgcn_alignbyte(xr[pb][2], xr[pb][1], x_sh);
+          const unsigned xs = __builtin_amdgcn_perm(hi4, lo4, 0x06040200u);   // bytes A, A + 2, A + 4, A + 6
+          const bf16x2 q0 = {(__bf16)(float)(xs & 0xFFu), (__bf16)(float)((xs >> 8) & 0xFFu)};
+          const bf16x2 q1 = {(__bf16)(float)((xs >> 16) & 0xFFu), (__bf16)(float)(xs >> 24)};
+          xop[2 * pb] = __builtin_bit_cast(unsigned, q0);
+          xop[2 * pb + 1] = __builtin_bit_cast(unsigned, q1);
+        } else if constexpr (K == 3 || K == 4) {   // GB: the lane's four gradients of the block as bf16, split by the sign bit of layer 0's output
+          constexpr int pb = K - 3;
 #pragma unroll
-      for (int pb = 0; pb < 2; ++pb) {
-        const unsigned char* xa = lds8 + x_addr + rr * (2 * IROWB) + 32 * pb;
-        const unsigned d0 = *reinterpret_cast<const unsigned*>(xa), d1 = *reinterpret_cast<const unsigned*>(xa + 4), d2 = *reinterpret_cast<const unsigned*>(xa + 8);
-        const unsigned lo4 = __builtin_amdgcn_alignbyte(d1, d0, x_sh), hi4 = __builtin_amdgcn_alignbyte(d2, d1, x_sh);
-        const unsigned xs = __builtin_amdgcn_perm(hi4, lo4, 0x06040200u);   // bytes A, A + 2, A + 4, A + 6
-        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-        const bf16x2 q0 = {(__bf16)(float)(xs & 0xFFu), (__bf16)(float)((xs >> 8) & 0xFFu)};
-        const bf16x2 q1 = {(__bf16)(float)((xs >> 16) & 0xFFu), (__bf16)(float)(xs >> 24)};
-        xop[2 * pb] = __builtin_bit_cast(unsigned, q0);
-        xop[2 * pb + 1] = __builtin_bit_cast(unsigned, q1);
-      }
-      // GB: the lane's eight gradients as bf16, split by the sign bit of layer 0's output
-      u32x4 gpos, gneg;
-#pragma unroll
-      for (int pb = 0; pb < 2; ++pb) {
-        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-        unsigned sw[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
-        if (leaky) {
-          const unsigned long long s2 = *reinterpret_cast<const unsigned long long*>(lds8 + sg_addr + rr * 64 + 32 * pb);
-          sw[0] = (unsigned)s2;
-          sw[1] = (unsigned)(s2 >> 32);
+          for (int q = 0; q < 2; ++q) {
+            const bf16x2 dq = {(__bf16)acc[pb][2 * q], (__bf16)acc[pb][2 * q + 1]};
+            unsigned dw = __builtin_bit_cast(unsigned, dq);
+            if (right && ox0 + 16 * pb + 4 * g4 + 2 * q >= W) dw = 0u;
+            const unsigned m = leaky ? __umul24((sw[pb][q] >> sg_pos) & 0x00010001u, 0xFFFFu) : 0xFFFFFFFFu;
+            const unsigned pos = dw & m;
+            gpos[2 * pb + q] = pos;
+            gneg[2 * pb + q] = dw ^ pos;
+          }
+        } else if constexpr (K == 5) {
+          d2p = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xop), __builtin_bit_cast(bf16x8, gpos), d2p, 0, 0, 0);
+        } else {
+          d2n = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xop), __builtin_bit_cast(bf16x8, gneg), d2n, 0, 0, 0);
         }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const bf16x2 dq = {(__bf16)acc[pb][2 * q], (__bf16)acc[pb][2 * q + 1]};
-          unsigned dw = __builtin_bit_cast(unsigned, dq);
-          if (right && ox0 + 16 * pb + 4 * g4 + 2 * q >= W) dw = 0u;
-          const unsigned m = leaky ? __umul24((sw[q] >> sg_pos) & 0x00010001u, 0xFFFFu) : 0xFFFFFFFFu;
-          const unsigned pos = dw & m;
-          gpos[2 * pb + q] = pos;
-          gneg[2 * pb + q] = dw ^ pos;
-        }
+      };
+      df_static_for([&](auto s_tag) { load(s_tag); }, std::make_integer_sequence<int, NPF>{});
+      __builtin_amdgcn_sched_barrier(0);
+      df_static_for(
+          [&](auto s_tag) {
+            constexpr int S = decltype(s_tag)::value;
+            use(s_tag);
+            if constexpr (S + NPF < NST) load(std::integral_constant<int, S + NPF>{});
+            if constexpr (WG) {
+              if constexpr (S == 10) xt = df_tr8(lds8 + tr_x + rr * 512, 64);
+              if constexpr (S == 18) p3(std::integral_constant<int, 0>{});
+              if constexpr (S == 23) p3(std::integral_constant<int, 1>{});
+              if constexpr (S == 25) p3(std::integral_constant<int, 2>{});
+              if constexpr (S == 27) p3(std::integral_constant<int, 3>{});
+              if constexpr (S == 29) p3(std::integral_constant<int, 4>{});
+              if constexpr (S == 31) p3(std::integral_constant<int, 5>{});
+              if constexpr (S == 32) p3(std::integral_constant<int, 6>{});
+            } else {
+              if constexpr (S == 12) p3(std::integral_constant<int, 0>{});   // (the reads; the rest needs the finished data gradient)
+              if constexpr (S == 15) p3(std::integral_constant<int, 1>{});
+              if constexpr (S == 16) p3(std::integral_constant<int, 2>{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          },
+          std::make_integer_sequence<int, NST>{});
+      if constexpr (!WG) {
+        p3(std::integral_constant<int, 3>{});
+        p3(std::integral_constant<int, 4>{});
+        p3(std::integral_constant<int, 5>{});
+        p3(std::integral_constant<int, 6>{});
       }
-      const bf16x8 xo = __builtin_bit_cast(bf16x8, xop);
-      d2p = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xo, __builtin_bit_cast(bf16x8, gpos), d2p, 0, 0, 0);
-      d2n = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xo, __builtin_bit_cast(bf16x8, gneg), d2n, 0, 0, 0);
     }
    }
   }
