@@ -243,6 +243,13 @@ int yogo_bn_stats_bf16(const void* z, float* part, int B, int C, int HW, yogo_st
 int yogo_bn_bwd_bf16(const void* g, const void* z, void* dz, const float* mean, const float* invstd, const float* gamma,
                      const float* beta, int act, float* dgamma, float* dbeta, float* part, float* sums, int B, int C, int HW,
                      int training, float clip, yogo_stream_t stream);
+/* ... of the block under a 1x1 convolution with P <= 16 outputs (the detection head, yogo/model.py:150-155) WITHOUT that convolution's data
+ * gradient in memory (ABI 7): gh = gradient w.r.t. the head's output (bf16 NCHW8c [B][2][HW], channels >= P zero), head_w = the head's
+ * weights [P][C]; g = bf16(sum_k gh[k] * bf16(w[k][c])) is computed inside both sweeps (one MFMA per 16 pixels x 16 channels).  C a
+ * multiple of 16; dz must not alias gh.  Replaces the head's yogo_conv2d_dgrad_bf16 + yogo_bn_bwd_bf16. */
+int yogo_bn_bwd_bf16_head(const void* gh, const float* head_w, int P, const void* z, void* dz, const float* mean, const float* invstd,
+                          const float* gamma, const float* beta, int act, float* dgamma, float* dbeta, float* part, float* sums, int B,
+                          int C, int HW, int training, float clip, yogo_stream_t stream);
 int yogo_nchw_f32_to_bf16_8c(const float* in, void* out, int B, int C, int HW, yogo_stream_t stream);
 int yogo_bf16_8c_to_nchw_f32(const void* in, float* out, int B, int C, int HW, yogo_stream_t stream);
 

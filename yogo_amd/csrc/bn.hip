@@ -576,6 +576,145 @@ extern "C" int yogo_bn_bwd_bf16(const void* g, const void* z, void* dz, const fl
   return YOGO_OK;
 }
 
+// ---- BatchNorm backward of the block UNDER a 1x1 convolution with P <= 16 outputs (the detection head, yogo/model.py:150-155) without that
+// convolution's data gradient in memory.  g[c][pixel] = sum_k gh[k][pixel] * w[k][c] is one v_mfma_f32_16x16x32_bf16 per 16 pixels x 16 channels:
+// A = the weights (row = channel, K = the head's outputs), B = the head's output gradient (column = pixel; its 16-byte units are the operand
+// as they lie in memory), so lane (c16, g4) gets channels 4 g4 .. 4 g4 + 3 of pixel c16 -- the half of a 16-byte unit of z it then works on.
+// Both sweeps compute the same g (rounded to bf16 as the data-gradient kernel's output would have been): the 128-channel gradient tensor is
+// never written or read (-0.41 GB written, -0.82 GB read per step of base_model at batch 128).
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+struct BnHeadLane {
+  bf16x8_t wop;                            // A operand: channel 16 cp + c16, head outputs 8 g4 .. 8 g4 + 7
+  float mu[4], is[4], ga[4], sh[4], sc[4];  // channels 16 cp + 4 g4 + i
+};
+__device__ __forceinline__ void bn_head_lane(BnHeadLane& L, const float* __restrict__ hw, int P, int C, int cp, int c16, int g4, const float* mean,
+                                             const float* invstd, const float* gamma, const float* beta) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = 8 * g4 + j;
+    L.wop[j] = (k < P) ? (__bf16)hw[(size_t)k * C + 16 * cp + c16] : (__bf16)0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = 16 * cp + 4 * g4 + i;
+    L.mu[i] = mean[c]; L.is[i] = invstd[c]; L.ga[i] = gamma[c]; L.sh[i] = beta[c]; L.sc[i] = invstd[c] * gamma[c];
+  }
+}
+// this lane's four gradients (bf16-rounded, widened) and pre-activations of pixel px (nothing beyond the plane: zeros)
+__device__ __forceinline__ void bn_head_fetch(const BnHeadLane& L, const u32x4_t* __restrict__ ghp, const u32x2_t* __restrict__ zp2, int HW, int px, int g4,
+                                              float (&gb)[4], float (&zf)[4]) {
+  const bool valid = px < HW;
+  u32x4_t gop = {0u, 0u, 0u, 0u};
+  if (valid && g4 < 2) gop = ghp[(size_t)g4 * HW + px];
+  u32x2_t zr = {0u, 0u};
+  if (valid) zr = zp2[(size_t)px * 2];
+  const f32x4_t d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(L.wop, __builtin_bit_cast(bf16x8_t, gop), f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+  const bf16x4_t zv = __builtin_bit_cast(bf16x4_t, zr);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    gb[i] = (float)(__bf16)d[i];
+    zf[i] = (float)zv[i];
+  }
+}
+__global__ __launch_bounds__(256) void bn_bwd_reduce_head_kernel(const u32x4_t* __restrict__ gh, const float* __restrict__ hw, int P,
+                                                                 const u32x4_t* __restrict__ z, const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, int act, float* __restrict__ part, int C, int Cb, int HW) {
+  __shared__ float sh[4][32];
+  const int cp = blockIdx.y % (Cb / 2), b = blockIdx.y / (Cb / 2);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c16 = lane & 15, g4 = lane >> 4;
+  BnHeadLane L;
+  bn_head_lane(L, hw, P, C, cp, c16, g4, mean, invstd, gamma, beta);
+  const u32x4_t* ghp = gh + (size_t)b * 2 * HW;
+  const u32x2_t* zp2 = reinterpret_cast<const u32x2_t*>(z + ((size_t)b * Cb + 2 * cp + (g4 >> 1)) * HW) + (g4 & 1);
+  float s[4] = {0.f, 0.f, 0.f, 0.f}, t[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int px0 = (blockIdx.x * 4 + wave) * 16; px0 < HW; px0 += gridDim.x * 64) {
+    float gb[4], zf[4];
+    bn_head_fetch(L, ghp, zp2, HW, px0 + c16, g4, gb, zf);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float xh = (zf[i] - L.mu[i]) * L.is[i];
+      const float ge = gb[i] * act_bwd_factor(fmaf(xh, L.ga[i], L.sh[i]), act);
+      s[i] += ge;
+      t[i] += ge * xh;
+    }
+  }
+  // sums over the 16 pixels of a lane group, then the four wavefronts
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float a = s[i], c = t[i];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      a += __shfl_xor(a, o, 64);
+      c += __shfl_xor(c, o, 64);
+    }
+    if (c16 == 0) {
+      sh[wave][2 * (4 * g4 + i)] = a;
+      sh[wave][2 * (4 * g4 + i) + 1] = c;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 32)
+    part[((size_t)(b * gridDim.x + blockIdx.x) * C + 16 * cp + (threadIdx.x >> 1)) * 2 + (threadIdx.x & 1)] =
+        sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply_head_kernel(const u32x4_t* __restrict__ gh, const float* __restrict__ hw, int P,
+                                                                const u32x4_t* __restrict__ z, u32x4_t* __restrict__ dz, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, int act, const float* __restrict__ sum_g,
+                                                                const float* __restrict__ sum_gx, float inv_count, int training, int C, int Cb, int HW) {
+  const int cp = blockIdx.y % (Cb / 2), b = blockIdx.y / (Cb / 2);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c16 = lane & 15, g4 = lane >> 4;
+  BnHeadLane L;
+  bn_head_lane(L, hw, P, C, cp, c16, g4, mean, invstd, gamma, beta);
+  float mg[4], mgx[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = 16 * cp + 4 * g4 + i;
+    mg[i] = training ? sum_g[c] * inv_count : 0.f;
+    mgx[i] = training ? sum_gx[c] * inv_count : 0.f;
+  }
+  const u32x4_t* ghp = gh + (size_t)b * 2 * HW;
+  const size_t plane_u = ((size_t)b * Cb + 2 * cp + (g4 >> 1)) * HW;
+  const u32x2_t* zp2 = reinterpret_cast<const u32x2_t*>(z + plane_u) + (g4 & 1);
+  u32x2_t* dp2 = reinterpret_cast<u32x2_t*>(dz + plane_u) + (g4 & 1);
+  for (int px0 = (blockIdx.x * 4 + wave) * 16; px0 < HW; px0 += gridDim.x * 64) {
+    const int px = px0 + c16;
+    float gb[4], zf[4];
+    bn_head_fetch(L, ghp, zp2, HW, px, g4, gb, zf);
+    bf16x4_t o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float xh = (zf[i] - L.mu[i]) * L.is[i];
+      const float ge = gb[i] * act_bwd_factor(fmaf(xh, L.ga[i], L.sh[i]), act);
+      o[i] = (__bf16)(L.sc[i] * (ge - mg[i] - xh * mgx[i]));
+    }
+    if (px < HW) dp2[(size_t)px * 2] = __builtin_bit_cast(u32x2_t, o);
+  }
+}
+// yogo_bn_bwd_bf16 with g computed from the head's output gradient gh (bf16 NCHW8c [B][2][HW], channels >= P zero) and the head's weights
+// head_w ([P][C] fp32, OIHW of a 1x1 convolution; rounded to bf16 here as the packed operand of the head's data gradient is).  C a multiple of
+// 16.  dz must not alias gh.
+extern "C" int yogo_bn_bwd_bf16_head(const void* gh, const float* head_w, int P, const void* z, void* dz, const float* mean, const float* invstd,
+                                     const float* gamma, const float* beta, int act, float* dgamma, float* dbeta, float* part, float* sums,
+                                     int B, int C, int HW, int training, float clip, hipStream_t stream) {
+  YOGO_CHECK_ARG(gh && head_w && z && dz && mean && invstd && gamma && beta && dgamma && dbeta && part && sums, "bn_bwd_bf16_head: null pointer");
+  YOGO_CHECK_ARG(B > 0 && C > 0 && (C % 16) == 0 && HW > 0 && P > 0 && P <= 16, "bn_bwd_bf16_head: bad shape");
+  const int Cb = cb_of(C), nb = plane_blocks(HW, 4);
+  YOGO_CHECK_ARG(B * Cb <= 65535, "bn_bwd_bf16_head: batch * channel blocks exceeds 65535");
+  const u32x4_t* g4 = reinterpret_cast<const u32x4_t*>(gh);
+  const u32x4_t* z4 = reinterpret_cast<const u32x4_t*>(z);
+  hipLaunchKernelGGL(bn_bwd_reduce_head_kernel, dim3(nb, B * (Cb / 2)), dim3(256), 0, stream, g4, head_w, P, z4, mean, invstd, gamma, beta, act, part, C, Cb,
+                     HW);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, stream, part, B * nb, C, clip, dgamma, dbeta, sums, sums + C);
+  hipLaunchKernelGGL(bn_bwd_apply_head_kernel, dim3(nb, B * (Cb / 2)), dim3(256), 0, stream, g4, head_w, P, z4, reinterpret_cast<u32x4_t*>(dz), mean, invstd,
+                     gamma, beta, act, sums, sums + C, 1.0f / ((float)B * (float)HW), training, C, Cb, HW);
+  YOGO_CHECK_LAUNCH("bn_bwd_bf16_head");
+  return YOGO_OK;
+}
+
 // batch statistics of a bf16 NCHW8c tensor (the stored convolution output) as partial rows for yogo_bn_finalize:
 // part [rows][C][2] with rows from yogo_bn_bwd_bf16_rows(B, HW).  Cheaper than carrying the sums through the convolution's
 // epilogue when that epilogue is on the critical path of a one-workgroup-per-CU kernel.

@@ -370,6 +370,7 @@ _WGRAD_DEFER_REDUCE = True  # the per-layer split-K reductions of the weight gra
 _L0_NO_Z = True             # ... and without its conv output in memory: sign map + derived sums (yogo_conv_first_*_xs)
 _PACK_MULTI = True          # all weight packings of a step in one launch
 _L01_FUSE_BWD = True        # layer 1's data gradient folded into layer 0's backward sums (yogo_conv2d_dgrad_bf16_first_bwd): no dy of layer 0 in memory
+_HEAD_BN_FUSE = True        # the 1x1 head's data gradient computed inside the BatchNorm backward of the block under it (yogo_bn_bwd_bf16_head)
 _BN_STATS_PASS = True       # BatchNorm statistics of layers > 0 by a sweep over the stored bf16 output (not the conv epilogue)
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
@@ -639,6 +640,7 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
         g = torch.empty(B, _blocks(P), Sy, Sx, 8, dtype=torch.bfloat16, device=dev)
         _hip.call("yogo_nchw_f32_to_bf16_8c", graw, g, B, P, Sy * Sx, st)
     n = len(eng.layers)
+    head_g = None    # (head gradient, head weights) when the head's data gradient is left to the BatchNorm backward of the block under it
     fused01 = None   # (part, rows) of layer 0's backward sums when layer 1's data gradient produced them (g is then None at layer 0)
     for i in range(n - 1, -1, -1):
         L, S = eng.layers[i], saved[i]
@@ -670,8 +672,15 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
             rows = _hip.query_ints("yogo_bn_bwd_bf16_rows", 1, B, OH * OW)[0]
             part = torch.empty(rows * L.cout * 2, dtype=torch.float32, device=dev)
             sums = torch.empty(2 * L.cout, dtype=torch.float32, device=dev)
-            _hip.call("yogo_bn_bwd_bf16", g, S.z, g, S.mean, S.invstd, gamma, beta, L.act, dgamma, dbeta, part, sums, B, L.cout, OH * OW,
-                      1 if S.bn_train else 0, clip, st)
+            if head_g is not None:   # (g is still the head's output gradient: its data gradient is computed inside both sweeps)
+                dz = torch.empty(B, _blocks(L.cout), OH, OW, 8, dtype=torch.bfloat16, device=dev)
+                _hip.call("yogo_bn_bwd_bf16_head", head_g[0], head_g[1], head_g[2], S.z, dz, S.mean, S.invstd, gamma, beta, L.act, dgamma, dbeta,
+                          part, sums, B, L.cout, OH * OW, 1 if S.bn_train else 0, clip, st)
+                keep.extend(head_g[:2])
+                g, head_g = dz, None
+            else:
+                _hip.call("yogo_bn_bwd_bf16", g, S.z, g, S.mean, S.invstd, gamma, beta, L.act, dgamma, dbeta, part, sums, B, L.cout, OH * OW,
+                          1 if S.bn_train else 0, clip, st)
             if bn.weight is not None:
                 grads[id(bn.weight)] = dgamma
                 grads[id(bn.bias)] = dbeta
@@ -773,6 +782,12 @@ def backward_bf16_train(eng: Engine, saved: List[Saved], graw: torch.Tensor,
             continue
         if i > 0:
             Lp, Sp = eng.layers[i - 1], saved[i - 1]
+            # the 1x1 head above a BatchNorm block: 12 multiply-adds per element inside that block's BatchNorm backward are cheaper than
+            # writing and twice reading its 128-channel data gradient (a trace wants to see the tensor)
+            if (_HEAD_BN_FUSE and i == n - 1 and trace is None and L.k == 1 and L.s == 1 and L.cout <= 16 and Lp.bn is not None and i - 1 > 0
+                    and Lp.cout % 16 == 0 and g.shape[1] == 2):
+                head_g = (g, _f32(L.conv.weight.detach()).reshape(L.cout, L.cin), L.cout)
+                continue
             ref_act = Lp.act
             if Lp.bn is not None or Lp.act == ACT_NONE:
                 act_ref, ref_act = None, ACT_NONE
