@@ -32,8 +32,8 @@ struct DgFirstParams {
   float* part;                   // [gridDim.x * wavefronts][ncol]
   // with layer 1's weight gradient (WG): its input = layer 0's output, and the per-wavefront partial results
   const u32x4* x;                // bf16 NCHW8c [B][2][H][W] units
-  float* slab;                   // [gridDim.x * wavefronts][9][32][16]: dW[tap][co][ci]
-  float* bias_part;              // [gridDim.x * wavefronts][32]
+  float* slab;                   // [gridDim.x][9][32][16]: dW[tap][co][ci]
+  float* bias_part;              // [gridDim.x][32]
   int B, H, W, Mpad, act, ncol;
   // a wavefront walks SEGMENTS: seg consecutive tiles of one tile column, top to bottom (the two halo rows a tile shares with the one above it
   // were staged microseconds ago by the same wavefront: L2 hits); consecutive segments are horizontal neighbours
@@ -367,18 +367,31 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(DF_WAV
   // (the A2 columns come from the Gram matrix, P / G from the caller's: zeros here so that the reduced row is finite)
   for (int e = lane; e < DF_COUT * DF_NJ; e += 64) prow[(e / DF_NJ) * DF_PER + DF_NJ + e % DF_NJ] = 0.f;
   for (int e = lane; e < DF_NJ + DF_NJ * DF_NJ; e += 64) prow[DF_COUT * DF_PER + e] = 0.f;
-  if constexpr (WG) {
-    float* sl = p.slab + (size_t)(blockIdx.x * NWV + wave) * (9 * 32 * 16);
-    float* bp = p.bias_part + (size_t)(blockIdx.x * NWV + wave) * 32;
+  if constexpr (WG) {   // one partial result per WORKGROUP: the four wavefronts' accumulators meet in LDS (the tile buffers are free now)
+    constexpr int NE = 9 * 32 * 16, STRIDE = NE + 32;
+    static_assert(NWV * STRIDE * 4 <= NWV * WAVE_BYTES + 2 * CONST_BYTES, "the reduction uses the kernel's LDS allocation");
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds_u) + wave * STRIDE;
 #pragma unroll
     for (int cbk = 0; cbk < 2; ++cbk)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int co = 16 * cbk + 4 * g4 + i;
 #pragma unroll
-        for (int tp = 0; tp < 9; ++tp) sl[(tp * 32 + co) * 16 + c16] = wacc[cbk][tp][i];
-        if (c16 == 0) bp[co] = bacc[cbk][i];
+        for (int tp = 0; tp < 9; ++tp) red[(tp * 32 + co) * 16 + c16] = wacc[cbk][tp][i];
+        if (c16 == 0) red[NE + co] = bacc[cbk][i];
       }
+    __syncthreads();
+    const float* r0 = reinterpret_cast<const float*>(lds_u);
+    float* sl = p.slab + (size_t)blockIdx.x * NE;
+    float* bp = p.bias_part + (size_t)blockIdx.x * 32;
+    for (int e = tid; e < STRIDE; e += 64 * NWV) {
+      float v = r0[e];
+#pragma unroll
+      for (int w = 1; w < NWV; ++w) v += r0[w * STRIDE + e];
+      if (e < NE) sl[e] = v;
+      else bp[e - NE] = v;
+    }
   }
 }
 
@@ -542,7 +555,7 @@ extern "C" int yogo_conv2d_dgrad_wgrad_first_bwd_workspace_bytes(int B, int H, i
     yogo_set_error("conv2d_dgrad_wgrad_first_bwd_workspace_bytes: hipGetDevice failed");
     return YOGO_ERR_HIP;
   }
-  *bytes = (size_t)df_plan(B, H, W, n_cu, true).grid * DF_NWV * (9 * 32 * 16 + 32) * sizeof(float);
+  *bytes = (size_t)df_plan(B, H, W, n_cu, true).grid * (9 * 32 * 16 + 32) * sizeof(float);
   return YOGO_OK;
 }
 extern "C" int yogo_conv2d_dgrad_wgrad_bf16_first_bwd(const void* g, const void* packed, const void* x, const void* image, const void* signs, float* part,
@@ -556,7 +569,7 @@ extern "C" int yogo_conv2d_dgrad_wgrad_bf16_first_bwd(const void* g, const void*
     yogo_set_error("conv2d_dgrad_wgrad_bf16_first_bwd: hipGetDevice failed");
     return YOGO_ERR_HIP;
   }
-  const int rows = df_plan(B, H, W, n_cu, true).grid * DF_NWV;
+  const int rows = df_plan(B, H, W, n_cu, true).grid;   // of the weight-gradient slab: one per workgroup
   DgFirstParams p{};
   p.g = reinterpret_cast<const u32x4*>(g); p.wp = reinterpret_cast<const u32x4*>(packed); p.img = reinterpret_cast<const unsigned char*>(image);
   p.signs = reinterpret_cast<const unsigned short*>(signs); p.part = part;
