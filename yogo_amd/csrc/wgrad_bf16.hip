@@ -57,6 +57,7 @@ struct WgradBf16Params {
 };
 #ifdef YOGO_DIAG
 #define WB_DIAG(BIT) (p.diag & (BIT))
+#define WB_SC S
 static int g_wb_diag = 0;
 static unsigned long long* g_wb_stamps = nullptr;
 static size_t g_wb_stamps_bytes = 0;
@@ -67,12 +68,14 @@ extern "C" int yogo_diag_wgrad_bf16_stamps(void* buf, size_t bytes) { g_wb_stamp
 #else
 // compile-time ablations of the product build (build.sh variant TAG wgrad_bf16 -DWGB_ABL=bits + tools/ab_variants.py; timings only, the
 // results are wrong): 1 = no MFMAs, 2 = no operand reads, 4 = no LDS-DMA, 8 = every DMA piece out of range (zero fill, no memory traffic),
+// 128 = the x operand's column addressing as if the stride were 1 (no bank conflicts of the stride-2 reads: -2 % / 0 % on layers 4 / 2),
 // 16 = the second ci-half workgroup zero-fills its gradient tile (what sharing it would save), 32 = the halo rows of the input tile are
 // zero-filled (what a row ring would save), 64 = BLK4: the next unit's DMA in one block behind the barrier instead of one slot per step
 #ifndef WGB_ABL
 #define WGB_ABL 0
 #endif
 #define WB_DIAG(BIT) ((WGB_ABL & (BIT)) != 0)
+#define WB_SC ((WGB_ABL & 128) ? 1 : S)   // (bit 128: the x operand's COLUMN addressing as if the stride were 1: conflict-free reads, wrong results)
 #define WB_T() 0ull
 #define WB_STAMP(ACC)
 #endif
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
   const int xbase = p.xoff * 16 + nb * NPW * xblk + (lane_ch_off & (xpb - 1)) + (PACK2 ? (gi & 1) * xpb : 0);
   // (BLK4: k = 8 (gi >> 1) + 4 j + q -> block row 2 (gi >> 1) + j (j = the first / second transposed read), block column q)
   [[maybe_unused]] const int lean_a0 = BLK4 ? gbase + ((gi >> 1) * 2 * p.wce + q4) * 64 : gbase + lane_px * 64;                                     // (xpb = 64 on this path)
-  [[maybe_unused]] const int lean_b0 = BLK4 ? xbase + (((gi >> 1) * 2 + tg) * p.xw + q4) * 64 : xbase + ((T == 1 ? 0 : tg) * p.xw + lane_px * S) * 64;
+  [[maybe_unused]] const int lean_b0 = BLK4 ? xbase + (((gi >> 1) * 2 + tg) * p.xw + q4) * 64 : xbase + ((T == 1 ? 0 : tg) * p.xw + lane_px * WB_SC) * 64;
 
 #define WB_LOAD(AV, BV, I)                                                                                      \
   {                                                                                                             \
@@ -413,7 +416,7 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
         for (int q = 0; q < NPW; ++q)
 #pragma unroll
           for (int t = 0; t < TM; ++t)
-            bvv[set][q][t] = lds_tr8(pb + q * xblk, kx * 1024 * S + t * 64, kx * 1024 * S + t * 64 + 256 * S);
+            bvv[set][q][t] = lds_tr8(pb + q * xblk, kx * 1024 * WB_SC + t * 64, kx * 1024 * WB_SC + t * 64 + 256 * WB_SC);
         if constexpr (MPW == 2) av[set][1] = lds_tr8(pa1, e * 1024, e * 1024 + 256);
       };
       if (!WB_DIAG(2)) {
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
       WB_ISSUE_PREP(nb_)
       const int rowb = S * p.xw * XPB;
       const unsigned char* pa = buf + gbase + lane_px * 64 + ks * (KR * 1024);
-      const unsigned char* pb0 = buf + xbase + ((T == 1 ? 0 : tg) * p.xw + lane_px * S) * XPB + ks * rowb;
+      const unsigned char* pb0 = buf + xbase + ((T == 1 ? 0 : tg) * p.xw + lane_px * WB_SC) * XPB + ks * rowb;
       bf16x8 av[2][MPW], bvv[2][NPW][TM];
       auto fetch = [&](auto e_tag) {
         constexpr int e = decltype(e_tag)::value, set = e & 1, j = e / KR, kx = e % KR;
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(64 * MBW * NBW * KS * (T == 1 ? 1 : 3)) void wgrad_
         const unsigned char* pb = pb0 + (j * KS) * rowb;
 #pragma unroll
         for (int t = 0; t < TM; ++t)
-          bvv[set][0][t] = lds_tr8(pb, (kx * 16 * S + (PACK2 ? 2 * t : t)) * XPB, (kx * 16 * S + (PACK2 ? 2 * t : t)) * XPB + 4 * S * XPB);
+          bvv[set][0][t] = lds_tr8(pb, (kx * 16 * WB_SC + (PACK2 ? 2 * t : t)) * XPB, (kx * 16 * WB_SC + (PACK2 ? 2 * t : t)) * XPB + 4 * WB_SC * XPB);
       };
       if (!WB_DIAG(2)) {
         fetch(std::integral_constant<int, 0>{});
