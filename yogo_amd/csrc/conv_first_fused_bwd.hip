@@ -1,4 +1,5 @@
-// Layer 1's data gradient and layer 0's backward sums in ONE sweep (base_model: yogo/model_defns.py:34-41 under autograd).
+// Layer 1's data gradient, layer 0's backward sums and (WG) layer 1's weight gradient in ONE sweep over the gradient w.r.t. layer 1's output
+// (base_model: yogo/model_defns.py:34-41 under autograd; C ABI: yogo_conv2d_dgrad[_wgrad]_bf16_first_bwd).
 //
 // Unfused, the gradient w.r.t. layer 0's output (16 channels at 386 x 516 x 128 images = 816 MB of bf16) is written by layer 1's data
 // gradient and read back once by conv_first_bn_wgrad_pk2_kernel, whose only products are SUMS over the pixels: A1[c][j] = sum gb[c] * patch_j
@@ -30,13 +31,14 @@ struct DgFirstParams {
   const unsigned char* img;      // uint8 [B][2H][2W]: layer 0's input
   const unsigned short* signs;   // [B][H*W]: layer 0's sign map (yogo_conv_first_mfma_signs), or null when act is ACT_NONE
   float* part;                   // [gridDim.x * wavefronts][ncol]
-  // with layer 1's weight gradient (WG): its input = layer 0's output, and the per-wavefront partial results
+  // with layer 1's weight gradient (WG): its input = layer 0's output, and the per-workgroup partial results
   const u32x4* x;                // bf16 NCHW8c [B][2][H][W] units
   float* slab;                   // [gridDim.x][9][32][16]: dW[tap][co][ci]
   float* bias_part;              // [gridDim.x][32]
   int B, H, W, Mpad, act, ncol;
-  // a wavefront walks SEGMENTS: seg consecutive tiles of one tile column, top to bottom (the two halo rows a tile shares with the one above it
-  // were staged microseconds ago by the same wavefront: L2 hits); consecutive segments are horizontal neighbours
+  // a wavefront walks SEGMENTS: seg consecutive tiles of one tile column, top to bottom, so that the two halo rows a tile shares with the one
+  // above it are as recent as they can be (-8 % against tile-linear order; most still come from memory: 4.6 MB pass through an XCD's 4 MB L2
+  // per round of tiles, FETCH = 1.41 x the algorithmic bytes); consecutive segments are horizontal neighbours
   int tiles_per_row, tile_rows, seg, segs_per_img, nsegs;
   unsigned m_tpr, m_spi;         // ceil(2^32 / d)
 };
